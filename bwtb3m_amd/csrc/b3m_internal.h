@@ -1,0 +1,166 @@
+// b3m_internal.h -- shared host-side declarations of libb3m (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/b3m.h"
+
+namespace b3m {
+
+// ---- errors -------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define B3M_HIP(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e__ = (expr);                                                               \
+		if (e__ != hipSuccess)                                                                 \
+			throw b3m::Error(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" +       \
+			                 __FILE__ + ":" + std::to_string(__LINE__) + ")");                 \
+	} while (0)
+#define B3M_REQUIRE(cond, msg)                                                                 \
+	do { if (!(cond)) throw b3m::Error(std::string(msg)); } while (0)
+
+// ---- text view (device) ---------------------------------------------------------------------
+// Packed input exactly as in the file, copied into a buffer padded with >= 16 zero bytes so
+// that 3-word look-ahead reads never leave the allocation.
+struct TextView {
+	const uint8_t *b;   // bytes
+	uint64_t n;         // number of symbols (pacterm: bases + 1)
+	uint64_t nbases;    // pac/pacterm: number of 2-bit bases; bytestream: n
+	int type;           // B3M_INPUT_*
+};
+
+// Symbols per 64-bit sort key and tag width, by input type (DESIGN.md "sort key").
+//   bytestream: 8 symbols, no tag.  pac: 32 symbols, no tag (circular, no terminator).
+//   pacterm: KSYM_PACTERM symbols in the high bits, 5-bit tag in the low bits:
+//            tag = offset of the terminator inside the window, 31 = no terminator.
+constexpr int KSYM_BYTES = 8;
+constexpr int KSYM_PAC = 32;
+constexpr int KSYM_PACTERM = 21;
+constexpr int TAGBITS_PACTERM = 5;
+constexpr uint32_t TAG_NORMAL = 31;
+
+inline int key_symbols(int type) { return type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_PACTERM; }
+inline int key_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM : 64; }
+inline uint64_t packed_text_bytes(uint64_t n, int type)
+{
+	if (type == B3M_INPUT_BYTESTREAM) return n;
+	uint64_t l = (type == B3M_INPUT_PACTERM) ? n - 1 : n;
+	return l / 4 + 2;                    // BWA .pac file size
+}
+inline uint64_t num_bases(uint64_t n, int type) { return type == B3M_INPUT_PACTERM ? n - 1 : n; }
+
+// ---- kernel-family timing ---------------------------------------------------------------------
+enum KFam { KF_KEYS = 0, KF_RADIX_HIST, KF_SCAN, KF_RADIX_SCATTER, KF_TIES, KF_EMIT, KF_RANKBUILD,
+            KF_ANCHOR, KF_GAPWALK, KF_INTERLEAVE, KF_MISC, KF_COUNT };
+extern const char *const kfam_names[KF_COUNT];
+
+struct Timeline {
+	bool enabled = false;
+	hipStream_t stream = nullptr;
+	struct Ev { hipEvent_t a, b; int fam; uint64_t bytes; };
+	std::vector<Ev> evs;
+	std::vector<hipEvent_t> pool;
+	hipEvent_t get();
+	void begin(int fam, uint64_t alg_bytes);
+	void end();
+	void collect(double ms[KF_COUNT], uint64_t launches[KF_COUNT], uint64_t bytes[KF_COUNT]);
+	void reset();
+	~Timeline();
+};
+struct Scope {
+	Timeline *t;
+	Scope(Timeline *tl, int fam, uint64_t bytes = 0) : t(tl) { if (t && t->enabled) t->begin(fam, bytes); }
+	~Scope() { if (t && t->enabled) t->end(); }
+};
+
+// ---- device helpers (launchers defined in the .hip files) ------------------------------------------
+struct ScanWs { uint32_t *sums = nullptr; uint64_t cap = 0; };   // scratch for device scans
+uint64_t scan_ws_elems(uint64_t n);
+void exclusive_sum_u32(uint32_t *d, uint64_t n, uint32_t *ws, hipStream_t s);      // in place
+void inclusive_max_u32(uint32_t *d, uint64_t n, uint32_t *ws, hipStream_t s);      // in place
+
+struct RadixWs {
+	uint32_t *tile_hist = nullptr;   // [256][numTiles]
+	uint32_t *scan_ws = nullptr;
+	uint32_t *ghist = nullptr;       // [8][256] device
+	uint64_t cap_elems = 0;
+};
+uint64_t radix_tiles(uint64_t n);
+uint64_t radix_ws_bytes(uint64_t n);
+void radix_ws_carve(RadixWs &ws, void *base, uint64_t n);
+// LSD radix sort of (key,value) pairs on bits [0,nbits). Result ends in (*k_res,*v_res) which
+// is one of the two buffer pairs.  Stable.  v may be null for keys only.
+void radix_sort_u64(uint64_t *kA, uint32_t *vA, uint64_t *kB, uint32_t *vB, uint64_t n, int nbits,
+                    RadixWs &ws, hipStream_t s, Timeline *tl, uint64_t **k_res, uint32_t **v_res);
+void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &ws, hipStream_t s,
+                    Timeline *tl, uint32_t **k_res);
+
+// ---- block sort (row a7) ---------------------------------------------------------------------
+struct BlockSortWs {
+	uint64_t cap = 0;                 // max block length
+	uint64_t *keyA = nullptr, *keyB = nullptr;
+	uint32_t *idxA = nullptr, *idxB = nullptr;
+	uint8_t *bnd = nullptr;           // group-head flags
+	uint32_t *flag = nullptr;         // scan scratch (cap+1)
+	uint32_t *gid = nullptr;          // group head index per position
+	// compacted tie set (capacity cap)
+	uint32_t *U = nullptr;
+	uint32_t *scan_ws = nullptr;
+	RadixWs radix;
+	uint32_t *d_scalars = nullptr;    // small device scalars
+	uint32_t *h_scalars = nullptr;    // pinned host mirror
+};
+uint64_t blocksort_ws_bytes(uint64_t cap);
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap);
+struct BlockSortOut {
+	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions
+	uint64_t p0 = 0;
+	uint64_t tie_rounds = 0, tie_elements = 0;
+};
+void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s,
+                Timeline *tl, BlockSortOut &out);
+// products of a sorted block
+void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt,
+              uint32_t *d_p0 /*device scalar*/, hipStream_t s);
+void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, uint32_t *d_gt_abs /*bit x = gt of absolute position x*/,
+             hipStream_t s);
+void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint32_t *d_count, uint64_t cap,
+                  hipStream_t s);
+void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
+                       uint32_t *d_rank_accum /* += */, hipStream_t s);
+void histogram_symbols(const TextView &T, uint64_t start, uint64_t len, uint64_t *d_hist256, hipStream_t s);
+
+// ---- merge (rows a8-a10) ------------------------------------------------------------------------
+constexpr uint32_t RANK_BLK_SYMS = 192;  // 64-byte line: 4 x u32 counts + 48 bytes of 2-bit codes
+uint64_t rank_blocks(uint64_t m);
+// p0 (rank of S_a inside L; that BWT entry belongs to position a-1 and is never counted) stays on
+// the device: it is remapped by every merge, so kernels read it through a pointer.
+struct RankDict { const uint32_t *blocks; uint64_t m; const uint32_t *p0ptr; uint32_t C[4]; };
+// builds the 2-bit rank dictionary of BWT(L); scratch: 4 * rank_blocks(m) u32 + scan ws
+void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks,
+                uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
+struct GapWalkArgs {
+	TextView T; RankDict rd;
+	uint64_t a, m, mr;
+	const uint32_t *gt_cur;    // absolute-position bit array (level input)
+	uint32_t *gt_next;         // absolute-position bit array (level output), pre-zeroed over R
+	const uint32_t *anchors;   // num_chains ranks
+	uint64_t num_chains, chain_len;
+	uint32_t *ranks_out;       // [chain_len][num_chains] layout, invalid slots = 0xFFFFFFFF
+};
+void gap_walk(const GapWalkArgs &A, hipStream_t s);
+void interleave(const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr,
+                uint8_t *d_out, uint32_t *d_tile_q /* scratch: tiles+1 */, hipStream_t s);
+uint64_t interleave_tiles(uint64_t total);
+// new ranks after a merge: L entries r -> r + #{q: sr[q] <= r}; R entries q -> q + sr[q]
+void remap_ranks(const uint32_t *d_sr, uint64_t mr, uint64_t *d_pairs, uint64_t count, uint64_t posL_begin, uint64_t posR_begin,
+                 uint64_t posR_end, hipStream_t s);
+void dense_gap_from_sorted(const uint32_t *d_sr, uint64_t mr, uint32_t *d_G, uint64_t m, hipStream_t s);
+void copy_bits(const uint32_t *src, uint32_t *dst, uint64_t bit_begin, uint64_t bit_end, hipStream_t s);
+void fill_u32(uint32_t *d, uint32_t v, uint64_t n, hipStream_t s);
+
+}  // namespace b3m

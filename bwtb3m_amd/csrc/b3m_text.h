@@ -1,0 +1,104 @@
+// b3m_text.h -- device-side access to the packed input (the role of
+// {Byte,Pac,PacTerm}InputTypes::circular_wrapper).  Symbols are decoded in registers straight
+// from the packed bytes; nothing is unpacked to HBM.
+#pragma once
+#include "b3m_internal.h"
+
+namespace b3m {
+
+__device__ __forceinline__ uint32_t base_at(const TextView &T, uint64_t i)
+{
+	// BWA .pac: base i in byte i>>2, bit position ((~i)&3)<<1 (first base in the two MSBs)
+	return (T.b[i >> 2] >> (((~i) & 3) << 1)) & 3u;
+}
+
+// symbol in the output alphabet at position i (i < n)
+__device__ __forceinline__ uint32_t sym_at(const TextView &T, uint64_t i)
+{
+	if (T.type == B3M_INPUT_BYTESTREAM) return T.b[i];
+	if (T.type == B3M_INPUT_PAC) return base_at(T, i);
+	return (i == T.n - 1) ? 0u : base_at(T, i) + 1u;   // pacterm
+}
+
+__device__ __forceinline__ uint32_t be32(const uint8_t *p)   // p 4-byte aligned
+{
+	return __builtin_bswap32(*reinterpret_cast<const uint32_t *>(p));
+}
+
+// 64 bits = 32 consecutive 2-bit bases starting at base `pos`, first base in the MSBs.
+// Requires the 12 bytes starting at the word holding `pos` to be readable (padded buffer).
+__device__ __forceinline__ uint64_t window32(const TextView &T, uint64_t pos)
+{
+	const uint8_t *p = T.b + ((pos >> 4) << 2);
+	uint64_t w0 = be32(p), w1 = be32(p + 4), w2 = be32(p + 8);
+	uint32_t s = 2u * (uint32_t)(pos & 15);
+	uint64_t hi = (w0 << 32) | w1;
+	return s ? ((hi << s) | (w2 >> (32 - s))) : hi;
+}
+
+// Sort key of the rotation starting at i, for the symbols [depth*K, (depth+1)*K) of it.
+// Order of keys == lexicographic order of those K symbols (with the pacterm terminator
+// smaller than every base, encoded by the tag: see b3m_internal.h).
+__device__ inline uint64_t key_at(const TextView &T, uint64_t i, uint64_t depth)
+{
+	if (T.type == B3M_INPUT_PACTERM) {
+		constexpr int K = KSYM_PACTERM;
+		uint64_t pos = i + depth * K;
+		if (pos + K <= T.nbases)        // window holds bases only
+			return ((window32(T, pos) >> (64 - 2 * K)) << TAGBITS_PACTERM) | TAG_NORMAL;
+		if (pos > T.nbases) return 0;   // already past the terminator: cannot be tied
+		uint64_t k = 0; uint32_t t = 0;
+		for (; t < (uint32_t)K; ++t) {
+			uint64_t p = pos + t;
+			if (p == T.nbases) break;    // terminator at offset t
+			k = (k << 2) | base_at(T, p);
+		}
+		k <<= 2 * (K - t);
+		return (k << TAGBITS_PACTERM) | t;
+	}
+	if (T.type == B3M_INPUT_PAC) {
+		uint64_t pos = (i + depth * KSYM_PAC) % T.n;
+		if (pos + KSYM_PAC <= T.n) return window32(T, pos);
+		uint64_t k = 0;
+		for (int t = 0; t < KSYM_PAC; ++t) { k = (k << 2) | base_at(T, pos); if (++pos == T.n) pos = 0; }
+		return k;
+	}
+	// bytestream: 8 bytes, circular
+	uint64_t pos = (i + depth * KSYM_BYTES) % T.n;
+	uint64_t k = 0;
+	if (pos + 8 <= T.n) {
+		for (int t = 0; t < 8; ++t) k = (k << 8) | T.b[pos + t];
+	} else {
+		for (int t = 0; t < 8; ++t) { k = (k << 8) | T.b[pos]; if (++pos == T.n) pos = 0; }
+	}
+	return k;
+}
+
+// compare rotations S_x and S_y (x != y): -1, 0 (equal over >= n symbols), +1
+__device__ inline int compare_rotations(const TextView &T, uint64_t x, uint64_t y)
+{
+	int K = T.type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : T.type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_PACTERM;
+	for (uint64_t d = 0; d * K < T.n; ++d) {
+		uint64_t kx = key_at(T, x, d), ky = key_at(T, y, d);
+		if (kx != ky) return kx < ky ? -1 : 1;
+	}
+	return 0;
+}
+
+// ---- wave helpers (64 lanes) -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+	#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o, 64); if ((int)lane_id() >= o) v += u; }
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+	#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o, 64); if ((int)lane_id() >= o) v = v > u ? v : u; }
+	return v;
+}
+
+}  // namespace b3m

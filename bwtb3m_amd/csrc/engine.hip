@@ -1,0 +1,686 @@
+// engine.hip -- plan/orchestration of balanced block merging on one MI355X and the C ABI of the
+// device-level entry points (include/b3m.h).  Role of
+// libmaus2::suffixsort::bwtb3m::BwtMergeSortTemplate::computeBwt steps 3-9.
+#include "b3m_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+
+namespace b3m {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+const char *const kfam_names[KF_COUNT] = {"keys", "radix_hist", "scan", "radix_scatter", "ties", "emit",
+                                          "rank_build", "anchor_rank", "gap_walk", "interleave", "misc"};
+
+// ---- Timeline ------------------------------------------------------------------------------------
+hipEvent_t Timeline::get()
+{
+	if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+	hipEvent_t e; B3M_HIP(hipEventCreate(&e)); return e;
+}
+void Timeline::begin(int fam, uint64_t bytes)
+{
+	Ev e; e.a = get(); e.b = get(); e.fam = fam; e.bytes = bytes;
+	B3M_HIP(hipEventRecord(e.a, stream));
+	evs.push_back(e);
+}
+void Timeline::end() { B3M_HIP(hipEventRecord(evs.back().b, stream)); }
+void Timeline::collect(double ms[KF_COUNT], uint64_t launches[KF_COUNT], uint64_t bytes[KF_COUNT])
+{
+	for (int i = 0; i < KF_COUNT; ++i) { ms[i] = 0; launches[i] = 0; bytes[i] = 0; }
+	for (auto &e : evs) {
+		float t = 0; (void)hipEventSynchronize(e.b); (void)hipEventElapsedTime(&t, e.a, e.b);
+		ms[e.fam] += t; launches[e.fam]++; bytes[e.fam] += e.bytes;
+	}
+}
+void Timeline::reset() { for (auto &e : evs) { pool.push_back(e.a); pool.push_back(e.b); } evs.clear(); }
+Timeline::~Timeline() { reset(); for (auto e : pool) (void)hipEventDestroy(e); }
+
+// ---- small kernels -------------------------------------------------------------------------------
+// gt end bit of a leaf: [rank_leaf(S_end) > p0]
+__global__ void k_set_endbit(const uint32_t *rank, const uint64_t *p0pair, uint32_t *gt, uint64_t bit)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0 && (uint64_t)rank[0] > p0pair[0]) atomicOr(&gt[bit >> 5], 1u << (bit & 31));
+}
+__global__ void k_p0_to_pair(const uint32_t *p0, uint64_t *pair, uint64_t pos)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { pair[0] = p0[0]; pair[1] = pos; }
+}
+__global__ void k_emit_gt_ptr(const uint32_t *sa, uint64_t len, uint64_t start, const uint32_t *p0, uint32_t *gt)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	uint32_t x = sa[r];
+	if (r > *p0 && x != start) atomicOr(&gt[x >> 5], 1u << (x & 31));
+}
+__global__ void k_clear_bits(uint32_t *dst, uint64_t b, uint64_t e)   // clears bits [b,e)
+{
+	uint64_t w = (b >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if ((w << 5) >= e) return;
+	uint64_t lo = w << 5, hi = lo + 32;
+	uint32_t mask = 0xFFFFFFFFu;
+	if (lo < b) mask &= ~((1u << (b - lo)) - 1u);
+	if (hi > e) mask &= ((1u << (e - lo)) - 1u);
+	if (mask == 0xFFFFFFFFu) dst[w] = 0; else atomicAnd(&dst[w], ~mask);
+}
+static void clear_bits(uint32_t *dst, uint64_t b, uint64_t e, hipStream_t s)
+{
+	if (e <= b) return;
+	uint64_t words = ((e + 31) >> 5) - (b >> 5);
+	hipLaunchKernelGGL(k_clear_bits, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, dst, b, e);
+}
+// walk prologue: fill the RankDict scalars that live on the device (p0 of L, end bit of P)
+__global__ void k_merge_prologue(const uint64_t *p0pairL, const uint32_t *anchors, uint32_t *gt_next, uint64_t Rend, uint32_t *p0_u32)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		uint32_t p0 = (uint32_t)p0pairL[0];
+		p0_u32[0] = p0;
+		if (anchors[0] > p0) atomicOr(&gt_next[Rend >> 5], 1u << (Rend & 31));
+	}
+}
+
+}  // namespace b3m
+
+using namespace b3m;
+
+// ================================================================================================
+// plan
+// ================================================================================================
+struct Leaf { uint64_t a, m; };
+struct NodeT { uint64_t a, m; int lo, hi; };
+struct MergeT {
+	NodeT L, R; int level;
+	uint64_t chain_len, num_chains, slots;
+	uint64_t anchor_off;    // offset into anchors / anchor positions arrays
+};
+
+struct b3m_plan {
+	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
+	std::vector<Leaf> leaves;
+	std::vector<MergeT> merges;
+	std::vector<std::vector<int>> level_merges;         // merge ids per level
+	std::vector<std::vector<NodeT>> level_nodes;         // nodes entering each level
+	int levels = 0;
+	uint64_t ws_bytes = 0;
+	// device memory
+	uint8_t *arena = nullptr;
+	uint8_t *d_text = nullptr; uint64_t text_cap = 0;
+	uint8_t *d_bwt[2] = {nullptr, nullptr};
+	uint32_t *d_gt[2] = {nullptr, nullptr}; uint64_t gt_words = 0;
+	BlockSortWs bs;
+	uint32_t *d_rank_blocks = nullptr, *d_rank_scratch = nullptr, *d_scan_ws = nullptr;
+	uint32_t *d_ranks[2] = {nullptr, nullptr}; uint64_t max_slots = 0;
+	uint32_t *d_tile_q = nullptr;
+	RadixWs merge_radix;
+	uint32_t *d_anchors = nullptr; uint64_t *d_anchor_pos = nullptr; uint64_t total_anchors = 0;
+	uint64_t *d_hist = nullptr;            // [B][256]
+	uint64_t *d_p0pairs = nullptr;         // [B][2]
+	uint32_t *d_p0tmp = nullptr;           // [B] u32 p0 of leaves, + scratch
+	uint32_t *d_endrank = nullptr;         // [B]
+	uint64_t *d_endpos = nullptr;          // [B]
+	uint64_t *d_samples = nullptr; uint32_t *d_sample_cnt = nullptr;
+	std::vector<uint64_t> sample_off;      // per leaf offset (pairs)
+	uint64_t total_samples = 0;
+	// results
+	b3m_result res{};
+	std::vector<uint64_t> h_samples;
+	std::vector<uint64_t> h_hist;          // 256
+	Timeline tl;
+	double kms[KF_COUNT]{}; uint64_t klaunch[KF_COUNT]{}; uint64_t kbytes[KF_COUNT]{};
+};
+
+static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
+
+static void chains_for(uint64_t mr, uint64_t &chain_len, uint64_t &num_chains)
+{
+	const uint64_t target = 256ull * 1024;      // lanes to fill: 256 CUs x 16 waves x 64
+	const uint64_t min_len = 32;
+	chain_len = std::max<uint64_t>(min_len, (mr + target - 1) / target);
+	num_chains = (mr + chain_len - 1) / chain_len;
+	if (num_chains == 0) { num_chains = 1; }
+}
+
+static void build_tree(b3m_plan *p)
+{
+	uint64_t n = p->n, bs = p->blocksize;
+	uint64_t B = (n + bs - 1) / bs;
+	bs = (n + B - 1) / B;                       // equalise: b = ceil(n / numblocks)
+	B = (n + bs - 1) / bs;
+	p->blocksize = bs;
+	for (uint64_t k = 0; k < B; ++k) { uint64_t a = k * bs; p->leaves.push_back({a, std::min(bs, n - a)}); }
+	std::vector<NodeT> cur;
+	for (uint64_t k = 0; k < B; ++k) cur.push_back({p->leaves[k].a, p->leaves[k].m, (int)k, (int)k + 1});
+	int level = 0; uint64_t aoff = 0;
+	while (cur.size() > 1) {
+		p->level_nodes.push_back(cur);
+		std::vector<NodeT> nx; std::vector<int> ids;
+		for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+			MergeT M; M.L = cur[i]; M.R = cur[i + 1]; M.level = level;
+			chains_for(M.R.m, M.chain_len, M.num_chains);
+			M.slots = M.chain_len * M.num_chains;
+			M.anchor_off = aoff; aoff += M.num_chains;
+			ids.push_back((int)p->merges.size());
+			p->merges.push_back(M);
+			nx.push_back({M.L.a, M.L.m + M.R.m, M.L.lo, M.R.hi});
+			p->max_slots = std::max(p->max_slots, M.slots);
+		}
+		if (cur.size() & 1) nx.push_back(cur.back());
+		p->level_merges.push_back(ids);
+		cur = nx; ++level;
+	}
+	p->levels = level;
+	p->total_anchors = aoff;
+}
+
+namespace {
+struct DevBuf {
+	void *p = nullptr;
+	explicit DevBuf(uint64_t bytes) { B3M_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
+	~DevBuf() { if (p) (void)hipFree(p); }
+	template <class X> X *as() { return (X *)p; }
+};
+struct PaddedText {
+	DevBuf buf; TextView T;
+	PaddedText(const void *d_text, uint64_t n, int type, hipStream_t s) : buf(al256(packed_text_bytes(n, type) + 64))
+	{
+		B3M_REQUIRE(type == B3M_INPUT_BYTESTREAM || type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM, "unsupported input type");
+		B3M_REQUIRE(n >= 1 && n < (1ull << 32), "n out of range");
+		uint64_t tb = packed_text_bytes(n, type);
+		B3M_HIP(hipMemsetAsync(buf.p, 0, al256(tb + 64), s));
+		B3M_HIP(hipMemcpyAsync(buf.p, d_text, tb, hipMemcpyDeviceToDevice, s));
+		T = TextView{(const uint8_t *)buf.p, n, num_bases(n, type), type};
+	}
+};
+void require_device()
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) throw Error("no HIP device available: libb3m has no CPU fallback");
+}
+}  // namespace
+
+extern "C" {
+
+int b3m_version(void) { return B3M_VERSION; }
+const char *b3m_last_error(void) { return g_err.c_str(); }
+
+static const char *type_names[6] = {"bytestream", "compactstream", "pac", "pacterm", "lz4", "utf-8"};
+int b3m_parse_input_type(const char *name)
+{
+	if (name) for (int i = 0; i < 6; ++i) if (!strcmp(name, type_names[i])) return i;
+	// message of the reference's switch: /root/reference/src/checkbwt.cpp:274
+	set_error(std::string("Unknown input type ") + (name ? name : "(null)"));
+	return -1;
+}
+const char *b3m_input_type_name(int t) { return (t >= 0 && t < 6) ? type_names[t] : "unknown"; }
+
+#define B3M_TRY try {
+#define B3M_CATCH(ret)                                                          \
+	} catch (const std::exception &e) { b3m::set_error(e.what()); return ret; } \
+	catch (...) { b3m::set_error("unknown error"); return ret; }
+
+void b3m_plan_destroy(b3m_plan *p);
+b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem, uint64_t isasamplingrate)
+{
+	b3m_plan *p = nullptr;
+	B3M_TRY
+	B3M_REQUIRE(inputtype == B3M_INPUT_BYTESTREAM || inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM,
+	            std::string("input type ") + b3m_input_type_name(inputtype) + " is not supported by the GPU engine yet");
+	B3M_REQUIRE(n >= 1, "empty input");
+	B3M_REQUIRE(inputtype != B3M_INPUT_PACTERM || n >= 1, "pacterm needs n >= 1");
+	B3M_REQUIRE(n < (1ull << 32), "n >= 2^32 symbols is not supported yet (u32 positions)");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) throw Error("no HIP device available: libb3m has no CPU fallback");
+	size_t free_b = 0, total_b = 0;
+	B3M_HIP(hipMemGetInfo(&free_b, &total_b));
+	uint64_t budget = mem ? std::min<uint64_t>(mem, free_b) : (uint64_t)(free_b * 0.92);
+	p = new b3m_plan();
+	p->n = n; p->type = inputtype; p->isarate = isasamplingrate;
+	// per-suffix bytes of the leaf sort workspace ~ 2*(8+4) + 1 + 12 + radix scratch: see blocksort_ws_bytes
+	if (blocksize == 0) {
+		// fixed part: text, 2 bwt arrays, gt; merge part needs ranks (8 B per R suffix) + rank blocks
+		uint64_t fixed = packed_text_bytes(n, inputtype) + 2 * n + n / 2 + (64ull << 20);
+		uint64_t b = n;
+		while (b > 1024 && fixed + blocksort_ws_bytes(b) + (b < n ? 9 * n / 2 : 0) > budget) b = (b + 1) / 2;
+		blocksize = b;
+		if (inputtype == B3M_INPUT_BYTESTREAM && b < n)
+			throw Error("bytestream input does not fit a single block in the memory target; multi-block merging of byte alphabets is not implemented yet");
+	}
+	if (blocksize > n) blocksize = n;
+	p->blocksize = blocksize;
+	build_tree(p);
+	B3M_REQUIRE(p->leaves.size() == 1 || inputtype != B3M_INPUT_BYTESTREAM,
+	            "multi-block merging of byte alphabets is not implemented yet (use one block)");
+	const uint64_t B = p->leaves.size();
+	// ---- carve the arena ----
+	uint64_t off = 0;
+	auto take = [&](uint64_t bytes) { uint64_t o = off; off += al256(bytes); return o; };
+	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
+	uint64_t o_text = take(p->text_cap);
+	uint64_t o_bwt0 = take(n + 16), o_bwt1 = take(n + 16);
+	p->gt_words = (n + 1 + 31) / 32 + 2;
+	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
+	uint64_t o_bs = take(blocksort_ws_bytes(p->blocksize));
+	uint64_t maxL = 0, maxTot = 0;
+	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
+	uint64_t nbk = rank_blocks(maxL);
+	uint64_t o_rb = 0, o_rs = 0, o_sw = 0, o_r0 = 0, o_r1 = 0, o_tq = 0, o_mr = 0;
+	if (B > 1) {
+		o_rb = take(64 * nbk); o_rs = take(16 * nbk + 64); o_sw = take(4 * scan_ws_elems(nbk) + 64);
+		o_r0 = take(4 * p->max_slots + 64); o_r1 = take(4 * p->max_slots + 64);
+		o_tq = take(4 * (interleave_tiles(maxTot) + 2));
+		o_mr = take(radix_ws_bytes(p->max_slots));
+	}
+	uint64_t o_an = take(4 * (p->total_anchors + 1)), o_ap = take(8 * (p->total_anchors + 1));
+	uint64_t o_hist = take(8 * 256 * B), o_p0p = take(16 * B), o_p0t = take(4 * (B + 4)), o_er = take(4 * B), o_ep = take(8 * B);
+	uint64_t nsamp = 0;
+	p->sample_off.assign(B + 1, 0);
+	if (isasamplingrate) {
+		for (uint64_t k = 0; k < B; ++k) {
+			uint64_t a = p->leaves[k].a, e = a + p->leaves[k].m;
+			uint64_t c = (e + isasamplingrate - 1) / isasamplingrate - (a + isasamplingrate - 1) / isasamplingrate;
+			p->sample_off[k + 1] = p->sample_off[k] + c;
+		}
+		nsamp = p->sample_off[B];
+	}
+	p->total_samples = nsamp;
+	uint64_t o_sm = take(16 * (nsamp + 1)), o_sc = take(4 * (B + 1));
+	p->ws_bytes = off;
+	if (off > free_b) {
+		char buf[256];
+		snprintf(buf, sizeof buf, "workspace of %.2f GB does not fit the %.2f GB of free HBM (block size %llu)", off / 1e9, free_b / 1e9,
+		         (unsigned long long)p->blocksize);
+		throw Error(buf);
+	}
+	B3M_HIP(hipMalloc((void **)&p->arena, off));
+	uint8_t *A = p->arena;
+	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
+	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
+	blocksort_ws_carve(p->bs, A + o_bs, p->blocksize);
+	if (B > 1) {
+		p->d_rank_blocks = (uint32_t *)(A + o_rb); p->d_rank_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
+		p->d_ranks[0] = (uint32_t *)(A + o_r0); p->d_ranks[1] = (uint32_t *)(A + o_r1);
+		p->d_tile_q = (uint32_t *)(A + o_tq);
+		radix_ws_carve(p->merge_radix, A + o_mr, p->max_slots);
+	}
+	p->d_anchors = (uint32_t *)(A + o_an); p->d_anchor_pos = (uint64_t *)(A + o_ap);
+	p->d_hist = (uint64_t *)(A + o_hist); p->d_p0pairs = (uint64_t *)(A + o_p0p); p->d_p0tmp = (uint32_t *)(A + o_p0t);
+	p->d_endrank = (uint32_t *)(A + o_er); p->d_endpos = (uint64_t *)(A + o_ep);
+	p->d_samples = (uint64_t *)(A + o_sm); p->d_sample_cnt = (uint32_t *)(A + o_sc);
+	// static tables: anchor positions, leaf end positions
+	std::vector<uint64_t> ap(p->total_anchors + 1, 0), ep(B, 0);
+	for (auto &M : p->merges) {
+		uint64_t Rend = M.R.a + M.R.m;
+		for (uint64_t c = 0; c < M.num_chains; ++c) ap[M.anchor_off + c] = Rend - c * M.chain_len;
+	}
+	for (uint64_t k = 0; k < B; ++k) ep[k] = p->leaves[k].a + p->leaves[k].m;
+	B3M_HIP(hipMemcpy(p->d_anchor_pos, ap.data(), 8 * ap.size(), hipMemcpyHostToDevice));
+	B3M_HIP(hipMemcpy(p->d_endpos, ep.data(), 8 * B, hipMemcpyHostToDevice));
+	p->h_hist.assign(256, 0);
+	return p;
+	B3M_CATCH((b3m_plan_destroy(p), (b3m_plan *)nullptr))
+}
+
+void b3m_plan_destroy(b3m_plan *p)
+{
+	if (!p) return;
+	if (p->arena) (void)hipFree(p->arena);
+	delete p;
+}
+uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 0; }
+uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 0; }
+uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
+
+int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_text_in && d_bwt_out, "b3m_plan_run: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t n = p->n, B = p->leaves.size();
+	Timeline *tl = &p->tl;
+	tl->reset(); tl->stream = s; tl->enabled = true;
+	hipEvent_t ev0 = tl->get(), ev1 = tl->get();
+	B3M_HIP(hipEventRecord(ev0, s));
+	// resident, padded copy of the packed text
+	uint64_t tb = packed_text_bytes(n, p->type);
+	B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
+	B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
+	B3M_HIP(hipMemsetAsync(p->d_hist, 0, 8 * 256 * B, s));
+	B3M_HIP(hipMemsetAsync(p->d_anchors, 0, 4 * (p->total_anchors + 1), s));
+	B3M_HIP(hipMemsetAsync(p->d_endrank, 0, 4 * B, s));
+	B3M_HIP(hipMemsetAsync(p->d_sample_cnt, 0, 4 * (B + 1), s));
+	if (B > 1) B3M_HIP(hipMemsetAsync(p->d_gt[0], 0, 4 * p->gt_words, s));
+	p->res = b3m_result{};
+	p->res.n = n; p->res.num_blocks = B; p->res.levels = p->levels;
+	// ---- leaves (row a7) ----
+	for (uint64_t k = 0; k < B; ++k) {
+		const Leaf &lf = p->leaves[k];
+		BlockSortOut so;
+		block_sort(T, lf.a, lf.m, p->bs, s, tl, so);
+		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
+		p->res.tie_elements += so.tie_elements;
+		{
+			Scope sc(tl, KF_EMIT, 6 * lf.m);
+			emit_bwt(T, so.d_sa, lf.m, lf.a, p->d_bwt[0] + lf.a, p->d_p0tmp + k, s);
+			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
+			histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
+			if (p->isarate)
+				emit_samples(so.d_sa, lf.m, p->isarate, p->d_samples + 2 * p->sample_off[k], p->d_sample_cnt + k,
+				             p->sample_off[k + 1] - p->sample_off[k], s);
+			if (B > 1)
+				hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((lf.m + 255) / 256)), dim3(256), 0, s, so.d_sa, lf.m, lf.a, p->d_p0tmp + k, p->d_gt[0]);
+		}
+		if (B > 1) {
+			Scope sc(tl, KF_ANCHOR, 0);
+			// end bit: [S_{a+m} > S_a]
+			rank_of_positions(T, so.d_sa, lf.m, p->d_endpos + k, 1, p->d_endrank + k, s);
+			hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, p->d_endrank + k, p->d_p0pairs + 2 * k, p->d_gt[0], lf.a + lf.m);
+			// anchors of every merge that has this leaf on its left side
+			for (auto &M : p->merges)
+				if ((int)k >= M.L.lo && (int)k < M.L.hi)
+					rank_of_positions(T, so.d_sa, lf.m, p->d_anchor_pos + M.anchor_off, M.num_chains, p->d_anchors + M.anchor_off, s);
+		}
+	}
+	// leaf histograms -> host (row a4); also needed for the C arrays of the merges
+	std::vector<uint64_t> hh(256 * B);
+	B3M_HIP(hipMemcpyAsync(hh.data(), p->d_hist, 8 * 256 * B, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	std::fill(p->h_hist.begin(), p->h_hist.end(), 0);
+	for (uint64_t k = 0; k < B; ++k) for (int c = 0; c < 256; ++c) p->h_hist[c] += hh[256 * k + c];
+	// ---- merges (rows a8-a10) ----
+	int cur = 0;
+	for (int lv = 0; lv < p->levels; ++lv) {
+		int nxt = cur ^ 1;
+		B3M_HIP(hipMemcpyAsync(p->d_gt[nxt], p->d_gt[cur], 4 * p->gt_words, hipMemcpyDeviceToDevice, s));
+		const auto &nodes = p->level_nodes[lv];
+		if (nodes.size() & 1) {       // carried node
+			const NodeT &c = nodes.back();
+			B3M_HIP(hipMemcpyAsync(p->d_bwt[nxt] + c.a, p->d_bwt[cur] + c.a, c.m, hipMemcpyDeviceToDevice, s));
+		}
+		for (int id : p->level_merges[lv]) {
+			const MergeT &M = p->merges[id];
+			const uint64_t a = M.L.a, m = M.L.m, mr = M.R.m, Rbeg = a + m, Rend = Rbeg + mr;
+			uint32_t *d_p0u = p->d_p0tmp + B;   // scratch u32
+			RankDict rd{};
+			{
+				Scope sc(tl, KF_RANKBUILD, m + m / 3);
+				// p0 of L lives on the device (remapped after every merge): no host round trip
+				clear_bits(p->d_gt[nxt], Rbeg, Rend + 1, s);
+				hipLaunchKernelGGL(k_merge_prologue, dim3(1), dim3(64), 0, s, p->d_p0pairs + 2 * M.L.lo, p->d_anchors + M.anchor_off,
+				                   p->d_gt[nxt], Rend, d_p0u);
+				rank_build(p->d_bwt[cur] + a, m, d_p0u, p->type, p->d_rank_blocks, p->d_rank_scratch, p->d_scan_ws, s);
+				rd.blocks = p->d_rank_blocks; rd.m = m; rd.p0ptr = d_p0u;
+				uint64_t hl[256] = {0};
+				for (int k = M.L.lo; k < M.L.hi; ++k) for (int c = 0; c < 256; ++c) hl[c] += hh[256 * k + c];
+				if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = hl[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c + 1]; } }
+				else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c]; } }
+			}
+			{
+				Scope sc(tl, KF_GAPWALK, mr * (64 + 4));
+				GapWalkArgs G{};
+				G.T = T; G.rd = rd; G.a = a; G.m = m; G.mr = mr;
+				G.gt_cur = p->d_gt[cur]; G.gt_next = p->d_gt[nxt];
+				G.anchors = p->d_anchors + M.anchor_off; G.num_chains = M.num_chains; G.chain_len = M.chain_len;
+				G.ranks_out = p->d_ranks[0];
+				gap_walk(G, s);
+			}
+			uint32_t *sr = nullptr;
+			{
+				int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
+				radix_sort_u32(p->d_ranks[0], p->d_ranks[1], M.slots, nbits, p->merge_radix, s, tl, &sr);
+			}
+			{
+				Scope sc(tl, KF_INTERLEAVE, 4 * mr + 2 * (m + mr));
+				interleave(sr, p->d_bwt[cur] + a, m, p->d_bwt[cur] + Rbeg, mr, p->d_bwt[nxt] + a, p->d_tile_q, s);
+				// ranks of p0 entries and of the (rank,pos) samples move with the merge
+				remap_ranks(sr, mr, p->d_p0pairs + 2 * M.L.lo, (uint64_t)(M.R.hi - M.L.lo), a, Rbeg, Rend, s);
+				if (p->isarate) {
+					uint64_t o0 = p->sample_off[M.L.lo], o1 = p->sample_off[M.R.hi];
+					remap_ranks(sr, mr, p->d_samples + 2 * o0, o1 - o0, a, Rbeg, Rend, s);
+				}
+			}
+		}
+		cur = nxt;
+	}
+	B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], n, hipMemcpyDeviceToDevice, s));
+	uint64_t p0pair[2] = {0, 0};
+	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipEventRecord(ev1, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	p->res.p0 = p0pair[0];
+	float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
+	p->res.ms_total = ms;
+	tl->collect(p->kms, p->klaunch, p->kbytes);
+	tl->pool.push_back(ev0); tl->pool.push_back(ev1);
+	p->res.ms_sort = p->kms[KF_KEYS] + p->kms[KF_RADIX_HIST] + p->kms[KF_SCAN] + p->kms[KF_RADIX_SCATTER] + p->kms[KF_TIES] + p->kms[KF_EMIT];
+	p->res.ms_gap = p->kms[KF_RANKBUILD] + p->kms[KF_ANCHOR] + p->kms[KF_GAPWALK];
+	p->res.ms_interleave = p->kms[KF_INTERLEAVE];
+	// samples -> host, sorted by rank
+	p->h_samples.clear();
+	if (p->isarate && p->total_samples) {
+		p->h_samples.resize(2 * p->total_samples);
+		B3M_HIP(hipMemcpy(p->h_samples.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		std::vector<std::pair<uint64_t, uint64_t>> v(p->total_samples);
+		for (uint64_t i = 0; i < p->total_samples; ++i) v[i] = {p->h_samples[2 * i], p->h_samples[2 * i + 1]};
+		std::sort(v.begin(), v.end());
+		for (uint64_t i = 0; i < p->total_samples; ++i) { p->h_samples[2 * i] = v[i].first; p->h_samples[2 * i + 1] = v[i].second; }
+	}
+	p->res.num_samples = p->total_samples;
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_plan_result(const b3m_plan *p, b3m_result *out)
+{
+	if (!p || !out) { set_error("null argument"); return 1; }
+	*out = p->res; return 0;
+}
+int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap)
+{
+	if (!p || !pairs_out) { set_error("null argument"); return 1; }
+	uint64_t c = std::min<uint64_t>(cap, p->h_samples.size() / 2);
+	memcpy(pairs_out, p->h_samples.data(), 16 * c);
+	return 0;
+}
+int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256)
+{
+	if (!p || !hist256) { set_error("null argument"); return 1; }
+	memcpy(hist256, p->h_hist.data(), 8 * 256);
+	return 0;
+}
+int b3m_plan_kernel_times(const b3m_plan *p, b3m_kernel_time *out, int cap)
+{
+	if (!p || !out) { set_error("null argument"); return 1; }
+	int k = 0;
+	for (int i = 0; i < KF_COUNT && k < cap; ++i, ++k) { out[k].name = kfam_names[i]; out[k].ms = p->kms[i]; out[k].launches = p->klaunch[i]; out[k].alg_bytes = p->kbytes[i]; }
+	return 0;
+}
+
+// ================================================================================================
+// stage-level entry points
+// ================================================================================================
+
+int b3m_histogram(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len, uint64_t *hist_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(start + len <= n, "range out of bounds");
+	PaddedText pt(d_text, n, inputtype, s);
+	DevBuf h(8 * 256);
+	B3M_HIP(hipMemsetAsync(h.p, 0, 8 * 256, s));
+	histogram_symbols(pt.T, start, len, h.as<uint64_t>(), s);
+	B3M_HIP(hipMemcpyAsync(hist_out, h.p, 8 * 256, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len, uint32_t *d_sa_out,
+                   uint8_t *d_bwt_out, uint32_t *d_gt_out, uint64_t *p0_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
+	PaddedText pt(d_text, n, inputtype, s);
+	DevBuf ws(blocksort_ws_bytes(len));
+	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
+	BlockSortOut so;
+	block_sort(pt.T, start, len, bs, s, nullptr, so);
+	DevBuf sc(64);
+	emit_bwt(pt.T, so.d_sa, len, start, d_bwt_out, sc.as<uint32_t>(), s);
+	uint32_t p0 = 0;
+	B3M_HIP(hipMemcpyAsync(&p0, sc.p, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	if (p0_out) *p0_out = p0;
+	if (d_sa_out) B3M_HIP(hipMemcpyAsync(d_sa_out, so.d_sa, 4 * len, hipMemcpyDeviceToDevice, s));
+	if (d_gt_out) {
+		// relative bit array: bit k = [S_{start+k} > S_start], k in [1,len]
+		uint64_t words_abs = (n + 1 + 31) / 32 + 2;
+		DevBuf gt(4 * words_abs);
+		B3M_HIP(hipMemsetAsync(gt.p, 0, 4 * words_abs, s));
+		emit_gt(so.d_sa, len, start, p0, gt.as<uint32_t>(), s);
+		// end bit
+		DevBuf q(8 + 8);
+		uint64_t endpos = start + len;
+		B3M_HIP(hipMemcpyAsync(q.p, &endpos, 8, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemsetAsync((uint8_t *)q.p + 8, 0, 8, s));
+		rank_of_positions(pt.T, so.d_sa, len, q.as<uint64_t>(), 1, (uint32_t *)((uint8_t *)q.p + 8), s);
+		uint32_t er = 0;
+		B3M_HIP(hipMemcpyAsync(&er, (uint8_t *)q.p + 8, 4, hipMemcpyDeviceToHost, s));
+		// shift absolute -> relative on the host (stage API is for tests; sizes are small)
+		std::vector<uint32_t> habs(words_abs);
+		B3M_HIP(hipMemcpyAsync(habs.data(), gt.p, 4 * words_abs, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		uint64_t wrel = (len + 1 + 31) / 32;
+		std::vector<uint32_t> hrel(wrel, 0);
+		for (uint64_t k = 1; k < len; ++k) { uint64_t x = start + k; if ((habs[x >> 5] >> (x & 31)) & 1u) hrel[k >> 5] |= 1u << (k & 31); }
+		if (er > p0) hrel[len >> 5] |= 1u << (len & 31);
+		B3M_HIP(hipMemcpy(d_gt_out, hrel.data(), 4 * wrel, hipMemcpyHostToDevice));
+	}
+	B3M_HIP(hipStreamSynchronize(s));
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_rank_of(const void *d_text, uint64_t n, int inputtype, const uint32_t *d_sa, uint64_t len, const uint64_t *positions,
+                uint64_t count, uint64_t *ranks_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	PaddedText pt(d_text, n, inputtype, s);
+	DevBuf pos(8 * count), rk(4 * count);
+	B3M_HIP(hipMemcpyAsync(pos.p, positions, 8 * count, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemsetAsync(rk.p, 0, 4 * count, s));
+	rank_of_positions(pt.T, d_sa, len, pos.as<uint64_t>(), count, rk.as<uint32_t>(), s);
+	std::vector<uint32_t> h(count);
+	B3M_HIP(hipMemcpyAsync(h.data(), rk.p, 4 * count, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	for (uint64_t i = 0; i < count; ++i) ranks_out[i] = h[i];
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t m, uint64_t mr, const uint8_t *d_bwtL, uint64_t p0L,
+            const uint32_t *d_gtR, const uint64_t *anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *d_sorted_ranks,
+            uint32_t *d_G_dense, uint32_t *d_gtP, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
+	B3M_REQUIRE(a + m + mr <= n && m >= 1 && mr >= 1, "range out of bounds");
+	B3M_REQUIRE(chain_len >= 1 && num_chains * chain_len >= mr && (num_chains - 1) * chain_len < mr, "chains do not tile R");
+	PaddedText pt(d_text, n, inputtype, s);
+	const uint64_t Rbeg = a + m, Rend = Rbeg + mr;
+	uint64_t nb = rank_blocks(m);
+	DevBuf blocks(64 * nb), scratch(16 * nb + 64), sws(4 * scan_ws_elems(nb) + 64);
+	DevBuf p0d(16);
+	{ uint32_t p032 = (uint32_t)p0L; B3M_HIP(hipMemcpy(p0d.p, &p032, 4, hipMemcpyHostToDevice)); }
+	rank_build(d_bwtL, m, p0d.as<uint32_t>(), inputtype, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
+	// C array from the text histogram of L
+	DevBuf hb(8 * 256);
+	B3M_HIP(hipMemsetAsync(hb.p, 0, 8 * 256, s));
+	histogram_symbols(pt.T, a, m, hb.as<uint64_t>(), s);
+	uint64_t hl[256];
+	B3M_HIP(hipMemcpyAsync(hl, hb.p, 8 * 256, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	RankDict rd{};
+	rd.blocks = blocks.as<uint32_t>(); rd.m = m; rd.p0ptr = p0d.as<uint32_t>();
+	if (inputtype == B3M_INPUT_PACTERM) { uint64_t acc = hl[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c + 1]; } }
+	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c]; } }
+	// absolute gt arrays
+	uint64_t words_abs = (n + 1 + 31) / 32 + 2;
+	DevBuf gtc(4 * words_abs), gtn(4 * words_abs);
+	{
+		uint64_t wrel = (mr + 1 + 31) / 32;
+		std::vector<uint32_t> hrel(wrel), habs(words_abs, 0);
+		B3M_HIP(hipMemcpy(hrel.data(), d_gtR, 4 * wrel, hipMemcpyDeviceToHost));
+		for (uint64_t k = 1; k <= mr; ++k) if ((hrel[k >> 5] >> (k & 31)) & 1u) { uint64_t x = Rbeg + k; habs[x >> 5] |= 1u << (x & 31); }
+		B3M_HIP(hipMemcpy(gtc.p, habs.data(), 4 * words_abs, hipMemcpyHostToDevice));
+	}
+	B3M_HIP(hipMemsetAsync(gtn.p, 0, 4 * words_abs, s));
+	std::vector<uint32_t> a32(num_chains);
+	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
+	DevBuf an(4 * num_chains);
+	B3M_HIP(hipMemcpy(an.p, a32.data(), 4 * num_chains, hipMemcpyHostToDevice));
+	uint64_t slots = num_chains * chain_len;
+	DevBuf r0(4 * slots), r1(4 * slots), rws(radix_ws_bytes(slots));
+	RadixWs rw; radix_ws_carve(rw, rws.p, slots);
+	GapWalkArgs G{};
+	G.T = pt.T; G.rd = rd; G.a = a; G.m = m; G.mr = mr; G.gt_cur = gtc.as<uint32_t>(); G.gt_next = gtn.as<uint32_t>();
+	G.anchors = an.as<uint32_t>(); G.num_chains = num_chains; G.chain_len = chain_len; G.ranks_out = r0.as<uint32_t>();
+	gap_walk(G, s);
+	uint32_t *sr = nullptr;
+	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
+	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr);
+	if (d_sorted_ranks) B3M_HIP(hipMemcpyAsync(d_sorted_ranks, sr, 4 * mr, hipMemcpyDeviceToDevice, s));
+	if (d_G_dense) dense_gap_from_sorted(sr, mr, d_G_dense, m, s);
+	if (d_gtP) {
+		std::vector<uint32_t> habs(words_abs);
+		B3M_HIP(hipMemcpyAsync(habs.data(), gtn.p, 4 * words_abs, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		uint64_t tot = m + mr;
+		uint64_t wrel = (tot + 1 + 31) / 32;
+		std::vector<uint32_t> hrel(wrel, 0);
+		for (uint64_t k = m; k < tot; ++k) { uint64_t x = a + k; if ((habs[x >> 5] >> (x & 31)) & 1u) hrel[k >> 5] |= 1u << (k & 31); }
+		if (anchors[0] > p0L) hrel[tot >> 5] |= 1u << (tot & 31);
+		B3M_HIP(hipMemcpy(d_gtP, hrel.data(), 4 * wrel, hipMemcpyHostToDevice));
+	}
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	(void)Rend;
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out,
+                   uint64_t p0L, uint64_t *p0P_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(m + mr < (1ull << 32), "block too large");
+	DevBuf tq(4 * (interleave_tiles(m + mr) + 2));
+	interleave(d_sorted_ranks, d_bwtL, m, d_bwtR, mr, d_out, tq.as<uint32_t>(), s);
+	if (p0P_out) {
+		uint64_t pr[2] = {p0L, 0};
+		DevBuf pp(16);
+		B3M_HIP(hipMemcpyAsync(pp.p, pr, 16, hipMemcpyHostToDevice, s));
+		remap_ranks(d_sorted_ranks, mr, pp.as<uint64_t>(), 1, 0, 1, 1, s);
+		B3M_HIP(hipMemcpyAsync(pr, pp.p, 16, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		*p0P_out = pr[0];
+	}
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// compute_bwt.cpp -- b3m_compute_bwt: the whole job of BwtMergeSort::computeBwt
+// (/root/reference/src/bwtb3m.cpp:63; steps of SURVEY.md 3.1): read the input file, keep the
+// packed text resident in HBM, run the plan, write X.bwt (RL), X.hist, X.meta, X.preisa.
+#include "formats.h"
+#include "../../../include/b3m.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <unistd.h>
+
+namespace b3m { void set_error(const std::string &msg); }
+
+namespace {
+struct Log {
+	int fd;
+	void operator()(const char *fmt, ...) const
+	{
+		if (fd < 0) return;
+		char buf[1024];
+		va_list ap; va_start(ap, fmt);
+		int k = vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		if (k > 0) { ssize_t w = write(fd, buf, (size_t)std::min<int>(k, (int)sizeof buf - 1)); (void)w; }
+	}
+};
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+}
+
+extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
+{
+	void *d_text = nullptr; uint8_t *d_bwt = nullptr; b3m_plan *plan = nullptr;
+	try {
+		if (!o || !o->input_fn || !*o->input_fn) throw std::runtime_error("no input file given");
+		Log log{o->verbose ? log_fd : -1};
+		Log logalways{log_fd};
+		const char *tname = (o->inputtype && *o->inputtype) ? o->inputtype : "bytestream";
+		int type = b3m_parse_input_type(tname);
+		if (type < 0) throw std::runtime_error(b3m_last_error());
+		if (type != B3M_INPUT_BYTESTREAM && type != B3M_INPUT_PAC && type != B3M_INPUT_PACTERM)
+			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, pac, pacterm)");
+		std::string outfn = (o->output_fn && *o->output_fn) ? o->output_fn : (std::string((o->tmpprefix && *o->tmpprefix) ? o->tmpprefix : "bwtb3m_out") + ".bwt");
+		std::string prefix = b3m::clip_off(outfn, ".bwt");
+		double t0 = now();
+		std::vector<uint8_t> file = b3m::read_file(o->input_fn);
+		uint64_t n;
+		if (type == B3M_INPUT_BYTESTREAM) n = file.size();
+		else {
+			if (file.size() < 2 || file.back() > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
+			n = (file.size() - 2) * 4 + file.back() + (type == B3M_INPUT_PACTERM ? 1 : 0);
+		}
+		if (n == 0) throw std::runtime_error("input is empty");
+		log("[V] input %s type %s symbols %llu\n", o->input_fn, tname, (unsigned long long)n);
+		uint64_t isarate = o->isasamplingrate ? o->isasamplingrate : 262144;
+		// bwtonly=1 lowers the default ISA sampling rate to 64 (/root/reference/ChangeLog:281);
+		// the caller passes the effective value, 0 means "default for the mode"
+		plan = b3m_plan_create(n, type, o->blocksize, o->mem, isarate);
+		if (!plan) throw std::runtime_error(b3m_last_error());
+		log("[V] blocks %llu workspace %.2f GB\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9);
+		uint64_t tb = b3m_plan_text_bytes(plan);
+		if (tb > file.size()) throw std::runtime_error("internal: packed size mismatch");
+		HIPCHK(hipMalloc(&d_text, tb + 16));
+		HIPCHK(hipMalloc((void **)&d_bwt, n));
+		HIPCHK(hipMemcpy(d_text, file.data(), tb, hipMemcpyHostToDevice));
+		double t1 = now();
+		if (b3m_plan_run(plan, d_text, d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
+		double t2 = now();
+		b3m_result res; b3m_plan_result(plan, &res);
+		log("[V] constructed BWT in %.3f s (sort %.1f ms, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, res.ms_sort, res.ms_gap,
+		    res.ms_interleave, n / (t2 - t1) / 1e9);
+		std::vector<uint8_t> bwt(n);
+		HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
+		b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, o->numthreads ? o->numthreads : 1);
+		uint64_t hist[256];
+		b3m_plan_histogram(plan, hist);
+		b3m::write_hist(prefix + ".hist", hist);
+		std::vector<uint64_t> pairs(2 * res.num_samples);
+		if (res.num_samples) b3m_plan_samples(plan, pairs.data(), res.num_samples);
+		b3m::write_preisa(prefix + ".preisa", pairs.data(), res.num_samples);
+		b3m::write_meta(prefix + ".meta", {n, res.num_blocks, res.levels, res.p0, isarate});
+		if (!o->bwtonly)
+			logalways("[W] bwtonly=0: the sampled SA/ISA stage is not part of this engine yet; %s.preisa was written, run bwtcomputessa on it\n", prefix.c_str());
+		double t3 = now();
+		log("[V] wrote %s (+.hist .meta .preisa) in %.3f s; total %.3f s\n", outfn.c_str(), t3 - t2, t3 - t0);
+		b3m_plan_destroy(plan);
+		(void)hipFree(d_text); (void)hipFree(d_bwt);
+		return 0;
+	} catch (const std::exception &e) {
+		b3m::set_error(e.what());
+		if (plan) b3m_plan_destroy(plan);
+		if (d_text) (void)hipFree(d_text);
+		if (d_bwt) (void)hipFree(d_bwt);
+		return 1;
+	}
+}

@@ -1,0 +1,322 @@
+// formats.cpp -- see formats.h.  Pure host code (no HIP).
+#include "formats.h"
+#include "../../../include/b3m.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <queue>
+#include <stdexcept>
+#include <thread>
+#include <sys/stat.h>
+
+namespace b3m {
+
+void set_error(const std::string &msg);
+
+std::vector<uint8_t> read_file(const std::string &fn)
+{
+	FILE *f = fopen(fn.c_str(), "rb");
+	if (!f) throw std::runtime_error("cannot open " + fn + " for reading");
+	fseek(f, 0, SEEK_END);
+	long sz = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	std::vector<uint8_t> v((size_t)sz);
+	if (sz && fread(v.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); throw std::runtime_error("short read on " + fn); }
+	fclose(f);
+	return v;
+}
+void write_file(const std::string &fn, const void *data, size_t bytes)
+{
+	FILE *f = fopen(fn.c_str(), "wb");
+	if (!f) throw std::runtime_error("cannot open " + fn + " for writing");
+	if (bytes && fwrite(data, 1, bytes, f) != bytes) { fclose(f); throw std::runtime_error("short write on " + fn); }
+	fclose(f);
+}
+bool file_exists(const std::string &fn) { struct stat st; return stat(fn.c_str(), &st) == 0; }
+
+std::string clip_off(const std::string &s, const std::string &suffix)
+{
+	if (s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) return s.substr(0, s.size() - suffix.size());
+	return s;
+}
+
+static void put_be64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 7; i >= 0; --i) o.push_back((uint8_t)(v >> (8 * i))); }
+static uint64_t get_be64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[i]; return v; }
+
+// ---- bit I/O, MSB first -------------------------------------------------------------------------
+struct BitWriter {
+	std::vector<uint8_t> &out; uint8_t cur = 0; int used = 0;
+	explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+	void put(uint64_t v, int bits) { for (int i = bits - 1; i >= 0; --i) { cur = (uint8_t)((cur << 1) | ((v >> i) & 1)); if (++used == 8) { out.push_back(cur); cur = 0; used = 0; } } }
+	void align() { if (used) { out.push_back((uint8_t)(cur << (8 - used))); cur = 0; used = 0; } }
+	// Elias-delta of x+1 (x >= 0)
+	void elias(uint64_t x) { uint64_t y = x + 1; int N = 63 - __builtin_clzll(y); int L = 31 - __builtin_clz((unsigned)(N + 1)); put(0, L); put((uint64_t)(N + 1), L + 1); put(y & ((N ? (1ull << N) : 1ull) - 1), N); }
+};
+struct BitReader {
+	const uint8_t *p, *e; int left = 0; uint8_t cur = 0;
+	BitReader(const uint8_t *b, const uint8_t *end) : p(b), e(end) {}
+	int bit() { if (!left) { if (p >= e) throw std::runtime_error("RL decoder: unexpected end of data"); cur = *p++; left = 8; } return (cur >> --left) & 1; }
+	uint64_t get(int bits) { uint64_t v = 0; for (int i = 0; i < bits; ++i) v = (v << 1) | (uint64_t)bit(); return v; }
+	void align() { left = 0; }
+	uint64_t elias() { int L = 0; while (!bit()) ++L; uint64_t N1 = (1ull << L) | get(L); int N = (int)N1 - 1; uint64_t y = (1ull << N) | get(N); return y - 1; }
+};
+
+// ---- canonical Huffman ----------------------------------------------------------------------------
+struct Canon {
+	std::vector<std::pair<int64_t, int>> syms;         // (symbol, length) in canonical order (length, symbol)
+	std::map<int64_t, std::pair<uint64_t, int>> enc;  // symbol -> (code, length)
+	// decoding tables per length
+	std::vector<uint64_t> first_code; std::vector<int> first_idx, count;
+	void finish()
+	{
+		std::sort(syms.begin(), syms.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) { return a.second != b.second ? a.second < b.second : a.first < b.first; });
+		int maxl = 0; for (auto &s : syms) maxl = std::max(maxl, s.second);
+		first_code.assign(maxl + 2, 0); first_idx.assign(maxl + 2, 0); count.assign(maxl + 2, 0);
+		uint64_t code = 0; int prev = syms.empty() ? 0 : syms[0].second;
+		for (size_t i = 0; i < syms.size(); ++i) {
+			int l = syms[i].second;
+			code <<= (l - prev); prev = l;
+			if (!count[l]) { first_code[l] = code; first_idx[l] = (int)i; }
+			count[l]++;
+			enc[syms[i].first] = {code, l};
+			code++;
+		}
+	}
+	static Canon from_freq(const std::map<int64_t, uint64_t> &freq)
+	{
+		Canon c;
+		if (freq.size() == 1) { c.syms.push_back({freq.begin()->first, 1}); c.finish(); return c; }
+		struct Node { uint64_t w; int l, r; };
+		std::vector<Node> nodes; std::vector<int64_t> leafsym;
+		typedef std::pair<uint64_t, int> QE;
+		std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
+		for (auto &kv : freq) { nodes.push_back({kv.second, -1, -1}); leafsym.push_back(kv.first); q.push({kv.second, (int)nodes.size() - 1}); }
+		while (q.size() > 1) {
+			QE a = q.top(); q.pop(); QE b = q.top(); q.pop();
+			nodes.push_back({a.first + b.first, a.second, b.second});
+			q.push({a.first + b.first, (int)nodes.size() - 1});
+		}
+		std::vector<std::pair<int, int>> st; st.push_back({(int)nodes.size() - 1, 0});
+		while (!st.empty()) {
+			auto cur = st.back(); st.pop_back();
+			const Node &nd = nodes[cur.first];
+			if (nd.l < 0) c.syms.push_back({leafsym[cur.first], std::max(cur.second, 1)});
+			else { st.push_back({nd.l, cur.second + 1}); st.push_back({nd.r, cur.second + 1}); }
+		}
+		c.finish();
+		return c;
+	}
+	void serialise(BitWriter &w) const { w.elias(syms.size()); for (auto &s : syms) { w.elias((uint64_t)s.first); w.elias((uint64_t)s.second); } }
+	static Canon deserialise(BitReader &r)
+	{
+		Canon c; uint64_t k = r.elias();
+		for (uint64_t i = 0; i < k; ++i) { int64_t s = (int64_t)r.elias(); int l = (int)r.elias(); c.syms.push_back({s, l}); }
+		c.finish();
+		return c;
+	}
+	void put(BitWriter &w, int64_t sym) const { auto it = enc.find(sym); w.put(it->second.first, it->second.second); }
+	int64_t get(BitReader &r) const
+	{
+		uint64_t code = 0;
+		for (int l = 1; l < (int)count.size(); ++l) {
+			code = (code << 1) | (uint64_t)r.bit();
+			if (count[l] && code >= first_code[l] && code < first_code[l] + (uint64_t)count[l]) return syms[first_idx[l] + (int)(code - first_code[l])].first;
+		}
+		throw std::runtime_error("RL decoder: bad Huffman code");
+	}
+};
+
+static const uint64_t RL_ESCAPE = 256;   // run lengths >= 256 are coded as escape + elias(len)
+
+static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out)
+{
+	BitWriter w(out);
+	std::map<int64_t, uint64_t> sh, ch;
+	bool esc = false;
+	for (uint64_t i = 0; i < nr; ++i) {
+		sh[runs[i].sym]++;
+		if (runs[i].len >= RL_ESCAPE) { esc = true; ch[(int64_t)RL_ESCAPE]++; } else ch[(int64_t)runs[i].len]++;
+	}
+	Canon sc = Canon::from_freq(sh), cc = Canon::from_freq(ch);
+	w.elias(nr);
+	w.put(esc ? 1 : 0, 1);
+	sc.serialise(w); cc.serialise(w);
+	w.align();
+	for (uint64_t i = 0; i < nr; ++i) sc.put(w, runs[i].sym);
+	w.align();
+	for (uint64_t i = 0; i < nr; ++i) {
+		if (runs[i].len >= RL_ESCAPE) { cc.put(w, (int64_t)RL_ESCAPE); w.elias(runs[i].len); } else cc.put(w, (int64_t)runs[i].len);
+	}
+	w.align();
+}
+
+void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads)
+{
+	if (!runs_per_block) runs_per_block = 64 * 1024;
+	if (!numthreads) numthreads = 1;
+	FILE *f = fopen(fn.c_str(), "wb");
+	if (!f) throw std::runtime_error("cannot open " + fn + " for writing");
+	std::vector<uint8_t> head; put_be64(head, n);
+	fwrite(head.data(), 1, head.size(), f);
+	uint64_t filepos = 8;
+	std::vector<RLIndexEntry> index;
+	// stream: collect runs for a batch of `numthreads` blocks, encode them in parallel, append
+	const uint64_t batch_runs = runs_per_block * numthreads;
+	std::vector<RLRun> runs; runs.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1);
+	uint64_t i = 0;
+	while (i < n) {
+		runs.clear();
+		while (i < n && runs.size() < batch_runs) {
+			uint8_t s = symbols[i]; uint64_t j = i + 1;
+			while (j < n && symbols[j] == s) ++j;
+			runs.push_back({(int64_t)s, j - i});
+			i = j;
+		}
+		uint64_t nb = (runs.size() + runs_per_block - 1) / runs_per_block;
+		std::vector<std::vector<uint8_t>> bufs(nb);
+		std::vector<std::thread> th;
+		auto work = [&](uint64_t b0, uint64_t b1) {
+			for (uint64_t b = b0; b < b1; ++b) {
+				uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block);
+				encode_block(runs.data() + r0, r1 - r0, bufs[b]);
+			}
+		};
+		unsigned T = (unsigned)std::min<uint64_t>(numthreads, nb);
+		for (unsigned t = 1; t < T; ++t) th.emplace_back(work, nb * t / T, nb * (t + 1) / T);
+		work(0, nb / T);
+		for (auto &x : th) x.join();
+		for (uint64_t b = 0; b < nb; ++b) {
+			uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block), syms = 0;
+			for (uint64_t r = r0; r < r1; ++r) syms += runs[r].len;
+			index.push_back({filepos, r1 - r0, syms});
+			fwrite(bufs[b].data(), 1, bufs[b].size(), f);
+			filepos += bufs[b].size();
+		}
+	}
+	std::vector<uint8_t> tail;
+	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
+	put_be64(tail, index.size());
+	put_be64(tail, filepos);
+	fwrite(tail.data(), 1, tail.size(), f);
+	if (fclose(f)) throw std::runtime_error("error closing " + fn);
+}
+
+std::vector<RLIndexEntry> rl_index(const std::string &fn)
+{
+	std::vector<uint8_t> d = read_file(fn);
+	if (d.size() < 24) throw std::runtime_error(fn + " is not an RL .bwt file (too short)");
+	uint64_t ipos = get_be64(d.data() + d.size() - 8);
+	if (ipos + 16 > d.size()) throw std::runtime_error(fn + ": bad index offset");
+	uint64_t nb = get_be64(d.data() + d.size() - 16);
+	if (ipos + nb * 24 + 16 != d.size()) throw std::runtime_error(fn + ": bad index size");
+	std::vector<RLIndexEntry> v(nb);
+	for (uint64_t b = 0; b < nb; ++b) { const uint8_t *p = d.data() + ipos + 24 * b; v[b] = {get_be64(p), get_be64(p + 8), get_be64(p + 16)}; }
+	return v;
+}
+
+uint64_t rl_length(const std::string &fn)
+{
+	FILE *f = fopen(fn.c_str(), "rb");
+	if (!f) throw std::runtime_error("cannot open " + fn + " for reading");
+	uint8_t b[8];
+	if (fread(b, 1, 8, f) != 8) { fclose(f); throw std::runtime_error(fn + " is not an RL .bwt file (too short)"); }
+	fclose(f);
+	return get_be64(b);
+}
+
+uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx)
+{
+	std::vector<uint8_t> d = read_file(fn);
+	if (d.size() < 24) throw std::runtime_error(fn + " is not an RL .bwt file (too short)");
+	uint64_t n = get_be64(d.data());
+	uint64_t ipos = get_be64(d.data() + d.size() - 8);
+	if (ipos + 16 > d.size() || ipos < 8) throw std::runtime_error(fn + ": bad index offset");
+	BitReader r(d.data() + 8, d.data() + ipos);
+	uint64_t got = 0;
+	std::vector<int64_t> syms;
+	while (got < n) {
+		r.align();
+		uint64_t nr = r.elias();
+		bool esc = r.bit();
+		Canon sc = Canon::deserialise(r), cc = Canon::deserialise(r);
+		r.align();
+		syms.resize(nr);
+		for (uint64_t i = 0; i < nr; ++i) syms[i] = sc.get(r);
+		r.align();
+		for (uint64_t i = 0; i < nr; ++i) {
+			int64_t c = cc.get(r);
+			uint64_t len = (esc && c == (int64_t)RL_ESCAPE) ? r.elias() : (uint64_t)c;
+			sink(ctx, syms[i], len);
+			got += len;
+		}
+		r.align();
+		if (nr == 0) throw std::runtime_error(fn + ": empty block");
+	}
+	if (got != n) throw std::runtime_error(fn + ": symbol count mismatch");
+	return n;
+}
+
+// ---- siblings -----------------------------------------------------------------------------------------
+void write_hist(const std::string &fn, const uint64_t hist256[256])
+{
+	std::vector<uint8_t> o; uint64_t cnt = 0;
+	for (int i = 0; i < 256; ++i) cnt += hist256[i] != 0;
+	put_be64(o, cnt);
+	for (int i = 0; i < 256; ++i) if (hist256[i]) { put_be64(o, (uint64_t)i); put_be64(o, hist256[i]); }
+	write_file(fn, o.data(), o.size());
+}
+std::map<int64_t, uint64_t> read_hist(const std::string &fn)
+{
+	std::vector<uint8_t> d = read_file(fn);
+	std::map<int64_t, uint64_t> m;
+	if (d.size() < 8) throw std::runtime_error(fn + ": short .hist");
+	uint64_t cnt = get_be64(d.data());
+	if (d.size() != 8 + 16 * cnt) throw std::runtime_error(fn + ": bad .hist size");
+	for (uint64_t i = 0; i < cnt; ++i) m[(int64_t)get_be64(d.data() + 8 + 16 * i)] = get_be64(d.data() + 16 + 16 * i);
+	return m;
+}
+void write_preisa(const std::string &fn, const uint64_t *pairs, uint64_t count) { write_file(fn, pairs, 16 * count); }
+void write_sampled(const std::string &fn, uint64_t rate, const std::vector<uint64_t> &values)
+{
+	std::vector<uint64_t> o; o.push_back(rate); o.push_back(values.size()); o.insert(o.end(), values.begin(), values.end());
+	write_file(fn, o.data(), 8 * o.size());
+}
+void write_meta(const std::string &fn, const std::vector<uint64_t> &numbers)
+{
+	std::vector<uint8_t> o; for (uint64_t v : numbers) put_be64(o, v);
+	write_file(fn, o.data(), o.size());
+}
+
+}  // namespace b3m
+
+// ---- C ABI ---------------------------------------------------------------------------------------------
+extern "C" {
+int b3m_rl_write(const char *fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block)
+{
+	try { b3m::rl_encode_file(fn, symbols, n, runs_per_block, std::max(1u, std::thread::hardware_concurrency())); return 0; }
+	catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
+}
+struct ReadCtx { uint8_t *out; uint64_t cap, pos; bool bad; };
+static void read_sink(void *c, int64_t sym, uint64_t len)
+{
+	ReadCtx *x = (ReadCtx *)c;
+	if (sym < 0 || sym > 255) x->bad = true;
+	if (x->out) { uint64_t k = x->pos < x->cap ? std::min<uint64_t>(len, x->cap - x->pos) : 0; memset(x->out + x->pos, (int)sym, (size_t)k); }
+	x->pos += len;
+}
+int b3m_rl_read(const char *fn, uint8_t *symbols_out, uint64_t cap, uint64_t *n_out)
+{
+	try {
+		ReadCtx c{symbols_out, cap, 0, false};
+		uint64_t n = b3m::rl_decode_file(fn, read_sink, &c);
+		if (n_out) *n_out = n;
+		if (c.bad) { b3m::set_error("symbol outside 0..255"); return 1; }
+		return 0;
+	} catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
+}
+int b3m_rl_length(const char *fn, uint64_t *n_out)
+{
+	try { uint64_t n = b3m::rl_length(fn); if (n_out) *n_out = n; return 0; }
+	catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
+}
+}

@@ -1,0 +1,47 @@
+// formats.h -- host-side file formats around the hot path.
+#pragma once
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace b3m {
+
+std::vector<uint8_t> read_file(const std::string &fn);
+void write_file(const std::string &fn, const void *data, size_t bytes);
+bool file_exists(const std::string &fn);
+
+// ---- RL .bwt container (role of libmaus2::huffman::RLEncoderStd / RLDecoder) -------------------
+// Layout follows what is known of the upstream container and is
+// PARITY-UNPINNED: no libmaus2-written sample exists in /root/reference, so byte identity with
+// upstream cannot be checked.  Bit order MSB-first.
+//   u64 BE  n (symbols)
+//   blocks, each byte-aligned:
+//       elias(numruns) | 1 bit cntescape | symbol code table | run-length code table | align
+//       numruns symbol codes | align | numruns run-length codes (escape: code + elias(len)) | align
+//   index: per block (u64 BE file offset, u64 BE runs, u64 BE symbols), u64 BE numblocks
+//   u64 BE  offset of the index            (last 8 bytes of the file)
+struct RLRun { int64_t sym; uint64_t len; };
+void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads);
+// decodeRun() stream: calls sink(sym,len) per run; returns n
+uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx);
+uint64_t rl_length(const std::string &fn);
+struct RLIndexEntry { uint64_t pos, runs, syms; };
+std::vector<RLIndexEntry> rl_index(const std::string &fn);
+
+// ---- siblings -------------------------------------------------------------------------------------
+// X.hist: NumberMapSerialisation::serialiseMap<int64,uint64> (reader at
+// /root/reference/src/bwtdecodeblock.cpp:150-173): u64 BE count, then (i64 BE key, u64 BE value)
+void write_hist(const std::string &fn, const uint64_t hist256[256]);
+std::map<int64_t, uint64_t> read_hist(const std::string &fn);
+// X.preisa: raw host-endian u64 pairs (rank,pos) (/root/reference/src/hwtPreIsaToIsa.cpp:64-77)
+void write_preisa(const std::string &fn, const uint64_t *pairs, uint64_t count);
+// X.sa / X.isa: u64 rate, u64 count, count x u64, host-endian (/root/reference/src/sasubsample.cpp:34-57)
+void write_sampled(const std::string &fn, uint64_t rate, const std::vector<uint64_t> &values);
+// X.meta: 8-byte big-endian numbers (NumberSerialisation); content is engine-specific
+void write_meta(const std::string &fn, const std::vector<uint64_t> &numbers);
+
+// clipOff(bwtname, ".bwt")  (/root/reference/src/checkbwt.cpp:31)
+std::string clip_off(const std::string &s, const std::string &suffix);
+
+}  // namespace b3m

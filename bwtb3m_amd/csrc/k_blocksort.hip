@@ -1,0 +1,304 @@
+// k_blocksort.hip -- suffix-block sort (the role of
+// libmaus2::suffixsort::BwtMergeBlockSortRequest::dispatch) and the products of a sorted block.
+//
+// The packed text of the WHOLE input is HBM-resident, so block suffixes are compared as
+// rotations of the whole circular text directly: no lcpnext look-ahead window (row a6) is
+// needed.  Sort = 64-bit key of the first K symbols (radix sort) + key-extension rounds for the
+// suffixes still tied (next K symbols, segmented by tie group) until all groups are singletons
+// or n symbols have been compared (equal rotations of a periodic text).
+#include "b3m_internal.h"
+#include "b3m_text.h"
+
+namespace b3m {
+
+// ------------------------------------------------------------------------------------------------
+// K1: keys of the first K symbols, one thread per 16 bases (one 32-bit word of packed text)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_keys_packed(TextView T, uint64_t start, uint64_t len, uint64_t *keys, uint32_t *idx)
+{
+	// thread handles block-relative symbols [16*g, 16*g+16) where g counted from the word holding `start`
+	uint64_t first_word = start >> 4;
+	uint64_t w = first_word + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t pos0 = w << 4;
+	if (pos0 >= start + len) return;
+	const int K = (T.type == B3M_INPUT_PAC) ? KSYM_PAC : KSYM_PACTERM;
+	bool fast = pos0 + 15 + 32 <= T.nbases && pos0 >= start && pos0 + 16 <= start + len;
+	if (fast) {
+		const uint8_t *p = T.b + (w << 2);
+		uint64_t w0 = be32(p), w1 = be32(p + 4), w2 = be32(p + 8);
+		uint64_t hi = (w0 << 32) | w1;
+		#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			uint64_t x = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
+			uint64_t k = (T.type == B3M_INPUT_PAC) ? x : (((x >> (64 - 2 * KSYM_PACTERM)) << TAGBITS_PACTERM) | TAG_NORMAL);
+			uint64_t r = pos0 + s - start;
+			keys[r] = k;
+			idx[r] = (uint32_t)(pos0 + s);
+		}
+	} else {
+		(void)K;
+		for (int s = 0; s < 16; ++s) {
+			uint64_t i = pos0 + s;
+			if (i < start || i >= start + len) continue;
+			keys[i - start] = key_at(T, i, 0);
+			idx[i - start] = (uint32_t)i;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_keys_generic(TextView T, uint64_t start, uint64_t len, uint64_t *keys, uint32_t *idx)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	keys[r] = key_at(T, start + r, 0);
+	idx[r] = (uint32_t)(start + r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: tie groups
+// ------------------------------------------------------------------------------------------------
+__global__ void k_init_bnd(const uint64_t *keys, uint64_t len, uint8_t *bnd)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	bnd[r] = (r == 0) || keys[r] != keys[r - 1];
+}
+// flag[r] = 1 if r belongs to a tie group of size >= 2 ; head[r] = r if bnd[r] else 0 (for the max-scan)
+__global__ void k_mark_ties(const uint8_t *bnd, uint64_t len, uint32_t *flag, uint32_t *head)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	bool b0 = bnd[r], b1 = (r + 1 == len) ? true : (bool)bnd[r + 1];
+	flag[r] = (b0 && b1) ? 0u : 1u;
+	head[r] = b0 ? (uint32_t)r : 0u;
+}
+__global__ void k_compact(const uint32_t *flag_scan, const uint8_t *bnd, uint64_t len, uint32_t *U)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	bool b0 = bnd[r], b1 = (r + 1 == len) ? true : (bool)bnd[r + 1];
+	if (!(b0 && b1)) U[flag_scan[r]] = (uint32_t)r;
+}
+// keys of the next K symbols for the compacted tie set; value = slot in U
+__global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, uint64_t u, uint64_t depth, uint64_t *nk, uint32_t *slot)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	nk[s] = key_at(T, idx[U[s]], depth);
+	slot[s] = (uint32_t)s;
+}
+// second sort key: group id of the slot (as u64 so that the pair sorter can be reused)
+__global__ void k_tie_gidkeys(const uint32_t *U, const uint32_t *gid, const uint32_t *slot_sorted, uint64_t u, uint64_t *gk)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	gk[s] = gid[U[slot_sorted[s]]];
+}
+// gather (idx, newkey) of the final order into temporaries (the key is recomputed from the text)
+__global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx, const uint32_t *slot_final,
+                             uint64_t u, uint64_t depth, uint32_t *tmp_idx, uint64_t *tmp_key)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	uint32_t i = idx[U[slot_final[s]]];
+	tmp_idx[s] = i;
+	tmp_key[s] = key_at(T, i, depth);
+}
+// write back into the tie slots (ascending positions) and refine the boundaries
+__global__ void k_tie_writeback(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint64_t *tmp_key,
+                                uint64_t u, uint32_t *idx, uint8_t *bnd)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	uint32_t r = U[s];
+	idx[r] = tmp_idx[s];
+	if (s > 0) {
+		uint32_t rp = U[s - 1];
+		if (gid[rp] == gid[r] && tmp_key[s - 1] != tmp_key[s]) bnd[r] = 1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: products
+// ------------------------------------------------------------------------------------------------
+__global__ void k_emit_bwt(TextView T, const uint32_t *sa, uint64_t len, uint64_t start, uint8_t *bwt, uint32_t *p0)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	uint64_t i = sa[r];
+	uint64_t j = i ? i - 1 : T.n - 1;
+	if (bwt) bwt[r] = (uint8_t)sym_at(T, j);
+	if (i == start) *p0 = (uint32_t)r;
+}
+// gt bit of absolute position x: [S_x > S_start], for the block's own positions (x != start)
+__global__ void k_emit_gt(const uint32_t *sa, uint64_t len, uint64_t start, uint32_t p0, uint32_t *gt)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	uint32_t x = sa[r];
+	if (r > p0 && x != start) atomicOr(&gt[x >> 5], 1u << (x & 31));
+}
+__global__ void k_emit_samples(const uint32_t *sa, uint64_t len, uint64_t rate, uint64_t *pairs, uint32_t *count, uint64_t cap)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	uint32_t x = sa[r];
+	if (x % rate == 0) {
+		uint32_t k = atomicAdd(count, 1u);
+		if (k < cap) { pairs[2 * (uint64_t)k] = r; pairs[2 * (uint64_t)k + 1] = x; }
+	}
+}
+// rank of S_x among the sorted block: lower bound by rotation comparison; one thread per query
+__global__ void k_rank_of(TextView T, const uint32_t *sa, uint64_t len, const uint64_t *pos, uint64_t count, uint32_t *accum)
+{
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= count) return;
+	uint64_t x = pos[q] % T.n;
+	uint64_t lo = 0, hi = len;
+	while (lo < hi) {
+		uint64_t mid = (lo + hi) >> 1;
+		uint64_t y = sa[mid];
+		int c = (y == x) ? 0 : compare_rotations(T, y, x);
+		if (c < 0) lo = mid + 1; else hi = mid;
+	}
+	atomicAdd(&accum[q], (uint32_t)lo);
+}
+__global__ __launch_bounds__(256) void k_histogram(TextView T, uint64_t start, uint64_t len, unsigned long long *hist)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < len; r += stride)
+		atomicAdd(&h[sym_at(T, start + r)], 1u);
+	__syncthreads();
+	if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
+static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
+
+uint64_t blocksort_ws_bytes(uint64_t cap)
+{
+	uint64_t b = 0;
+	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/idx ping-pong
+	b += al(cap + 1);                                   // bnd
+	b += 3 * al(4 * (cap + 1));                         // flag, gid, U
+	b += al(4 * scan_ws_elems(cap + 1));
+	b += al(radix_ws_bytes(cap));
+	b += 4096;
+	return b;
+}
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap)
+{
+	uint8_t *p = (uint8_t *)base;
+	ws.cap = cap;
+	ws.keyA = (uint64_t *)p; p += al(8 * cap);
+	ws.keyB = (uint64_t *)p; p += al(8 * cap);
+	ws.idxA = (uint32_t *)p; p += al(4 * cap);
+	ws.idxB = (uint32_t *)p; p += al(4 * cap);
+	ws.bnd = p; p += al(cap + 1);
+	ws.flag = (uint32_t *)p; p += al(4 * (cap + 1));
+	ws.gid = (uint32_t *)p; p += al(4 * (cap + 1));
+	ws.U = (uint32_t *)p; p += al(4 * (cap + 1));
+	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
+	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
+	ws.d_scalars = (uint32_t *)p;
+}
+
+void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out)
+{
+	B3M_REQUIRE(len <= ws.cap, "block_sort: block larger than workspace");
+	B3M_REQUIRE(T.n < (1ull << 32), "n >= 2^32 is not supported yet (u32 positions)");
+	out = BlockSortOut();
+	if (len == 0) return;
+	// K1 keys
+	{
+		Scope sc(tl, KF_KEYS, len / 4 + 12 * len);
+		if (T.type == B3M_INPUT_BYTESTREAM)
+			hipLaunchKernelGGL(k_keys_generic, dim3(nblk(len)), dim3(256), 0, s, T, start, len, ws.keyA, ws.idxA);
+		else {
+			uint64_t words = ((start + len + 15) >> 4) - (start >> 4);
+			hipLaunchKernelGGL(k_keys_packed, dim3(nblk(words)), dim3(256), 0, s, T, start, len, ws.keyA, ws.idxA);
+		}
+	}
+	// K2 radix sort by the first key
+	uint64_t *k = nullptr; uint32_t *v = nullptr;
+	radix_sort_u64(ws.keyA, ws.idxA, ws.keyB, ws.idxB, len, key_bits(T.type), ws.radix, s, tl, &k, &v);
+	uint64_t *k_other = (k == ws.keyA) ? ws.keyB : ws.keyA;
+	uint32_t *v_other = (v == ws.idxA) ? ws.idxB : ws.idxA;
+	// K3/K4 key-extension rounds for tie groups.  Buffers: the sorted keys are dead once the
+	// boundaries are known, so the two key arrays and (idle idx array, flag array) form the
+	// ping-pong pairs of the tie-set sorts; all have capacity >= len >= u.
+	const uint64_t K = (uint64_t)key_symbols(T.type);
+	{
+		Scope sc(tl, KF_TIES, 9 * len);
+		hipLaunchKernelGGL(k_init_bnd, dim3(nblk(len)), dim3(256), 0, s, k, len, ws.bnd);
+	}
+	uint64_t *kx = k, *ky = k_other;
+	uint32_t *vx = v_other, *vy = ws.flag;
+	int gbits = 1; while ((1ull << gbits) < len && gbits < 32) ++gbits;
+	uint32_t h_u = 0;
+	for (uint64_t depth = 1;; ++depth) {
+		{
+			Scope sc(tl, KF_TIES, 10 * len);
+			hipLaunchKernelGGL(k_mark_ties, dim3(nblk(len)), dim3(256), 0, s, ws.bnd, len, ws.flag, ws.gid);
+			B3M_HIP(hipMemsetAsync(ws.flag + len, 0, 4, s));
+			exclusive_sum_u32(ws.flag, len + 1, ws.scan_ws, s);
+			B3M_HIP(hipMemcpyAsync(&h_u, ws.flag + len, 4, hipMemcpyDeviceToHost, s));
+		}
+		B3M_HIP(hipStreamSynchronize(s));
+		uint64_t u = h_u;
+		if (u == 0) break;
+		if (depth == 1) out.tie_elements = u;
+		if (depth * K >= T.n) break;                   // compared >= n symbols: equal rotations
+		out.tie_rounds = depth;
+		Scope sc(tl, KF_TIES, 8 * len + 60 * u);
+		inclusive_max_u32(ws.gid, len, ws.scan_ws, s);
+		hipLaunchKernelGGL(k_compact, dim3(nblk(len)), dim3(256), 0, s, ws.flag, ws.bnd, len, ws.U);
+		// (next-K-symbols key, slot) sorted by key, then stably by tie group
+		hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, ws.U, v, u, depth, kx, vx);
+		uint64_t *rk; uint32_t *rv;
+		radix_sort_u64(kx, vx, ky, vy, u, key_bits(T.type), ws.radix, s, nullptr, &rk, &rv);
+		uint64_t *gk = (rk == kx) ? ky : kx;
+		uint32_t *vidle = (rv == vx) ? vy : vx;
+		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, ws.U, ws.gid, rv, u, gk);
+		uint64_t *rk2; uint32_t *rv2;
+		radix_sort_u64(gk, rv, rk, vidle, u, gbits, ws.radix, s, nullptr, &rk2, &rv2);
+		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
+		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
+		hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, ws.U, v, rv2, u, depth, tmp_idx, tmp_key);
+		hipLaunchKernelGGL(k_tie_writeback, dim3(nblk(u)), dim3(256), 0, s, ws.U, ws.gid, tmp_idx, tmp_key, u, v, ws.bnd);
+	}
+	B3M_HIP(hipGetLastError());
+	out.d_sa = v;
+}
+
+void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)
+{
+	if (len) hipLaunchKernelGGL(k_emit_bwt, dim3(nblk(len)), dim3(256), 0, s, T, d_sa, len, start, d_bwt, d_p0);
+}
+void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, uint32_t *d_gt_abs, hipStream_t s)
+{
+	if (len) hipLaunchKernelGGL(k_emit_gt, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, start, p0, d_gt_abs);
+}
+void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint32_t *d_count, uint64_t cap, hipStream_t s)
+{
+	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, rate, d_pairs, d_count, cap);
+}
+void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
+                       uint32_t *d_rank_accum, hipStream_t s)
+{
+	if (count) hipLaunchKernelGGL(k_rank_of, dim3(nblk(count, 64)), dim3(64), 0, s, T, d_sa, len, d_pos, count, d_rank_accum);
+}
+void histogram_symbols(const TextView &T, uint64_t start, uint64_t len, uint64_t *d_hist256, hipStream_t s)
+{
+	if (!len) return;
+	uint32_t grid = nblk(len, 256 * 64); if (grid > 4096) grid = 4096; if (grid == 0) grid = 1;
+	hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(256), 0, s, T, start, len, (unsigned long long *)d_hist256);
+}
+
+}  // namespace b3m

@@ -1,0 +1,292 @@
+// k_merge.hip -- gap/rank merge of two adjacent blocks (the gap
+// computation and interleave halves of libmaus2's mergeBlocks, and the sparse gap array).
+//
+//   rank dictionary : BWT(L) as 64-byte lines {4 x u32 symbol counts | 192 two-bit codes}; one
+//                     rank query = one line.
+//   LF walk         : one lane = one chain of consecutive positions of R walked backwards from
+//                     an anchor (SURVEY.md Appendix A recurrence); every step emits the rank of
+//                     one suffix of R among the suffixes of L.
+//   sparse gap      : the emitted ranks are radix-sorted; sorted_ranks[q] is the rank in L of
+//                     the q-th smallest suffix of R (run lengths of equal values = G).
+//   interleave      : output tile by output tile; positions q + sorted_ranks[q] take BWT(R)[q],
+//                     the holes take BWT(L) in order.
+// Integer/bit work bound by HBM latency and bandwidth; no MFMA.
+#include "b3m_internal.h"
+#include "b3m_text.h"
+
+namespace b3m {
+
+static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
+
+uint64_t rank_blocks(uint64_t m) { return m / RANK_BLK_SYMS + 1; }
+
+// ------------------------------------------------------------------------------------------------
+// K6 rank dictionary
+// ------------------------------------------------------------------------------------------------
+// pass 1: one thread per 192-symbol block: pack codes, count symbols (excluding the p0 entry)
+__global__ __launch_bounds__(256) void k_rank_pack(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, int sub, uint32_t *blocks,
+                                                     uint32_t *cnt /*[4][nb]*/, uint64_t nb)
+{
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nb) return;
+	uint64_t base = b * RANK_BLK_SYMS;
+	const uint32_t p0 = *p0ptr;
+	uint32_t c[4] = {0, 0, 0, 0};
+	uint32_t *out = blocks + b * 16;
+	for (int w = 0; w < 12; ++w) {
+		uint32_t word = 0;
+		for (int k = 0; k < 16; ++k) {
+			uint64_t r = base + (uint64_t)w * 16 + k;
+			uint32_t code = 0;
+			if (r < m && r != p0) {
+				code = ((uint32_t)bwt[r] - (uint32_t)sub) & 3u;
+				c[code]++;
+			}
+			word |= code << (2 * k);
+		}
+		out[4 + w] = word;
+	}
+	cnt[0 * nb + b] = c[0]; cnt[1 * nb + b] = c[1]; cnt[2 * nb + b] = c[2]; cnt[3 * nb + b] = c[3];
+}
+// pass 2 (after 4 exclusive scans): headers
+__global__ void k_rank_headers(uint32_t *blocks, const uint32_t *cnt, uint64_t nb)
+{
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nb) return;
+	uint32_t *out = blocks + b * 16;
+	out[0] = cnt[0 * nb + b]; out[1] = cnt[1 * nb + b]; out[2] = cnt[2 * nb + b]; out[3] = cnt[3 * nb + b];
+}
+
+void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch,
+                uint32_t *scan_ws, hipStream_t s)
+{
+	B3M_REQUIRE(type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
+	uint64_t nb = rank_blocks(m);
+	int sub = (type == B3M_INPUT_PACTERM) ? 1 : 0;
+	hipLaunchKernelGGL(k_rank_pack, dim3(nblk(nb)), dim3(256), 0, s, d_bwtL, m, d_p0, sub, d_blocks, d_scratch, nb);
+	for (int c = 0; c < 4; ++c) exclusive_sum_u32(d_scratch + c * nb, nb, scan_ws, s);
+	hipLaunchKernelGGL(k_rank_headers, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, d_scratch, nb);
+}
+
+// rank_c(BWT_L, rho): occurrences of code c in BWT_L[0, rho), p0 entry never counted.
+// rank_c(B,r) counts B[0,r) -- convention of /root/reference/src/bwtdecodeblock.cpp:232-241.
+__device__ __forceinline__ uint32_t rank_query(const RankDict &rd, uint32_t p0, uint32_t code, uint32_t rho)
+{
+	uint32_t b = rho / RANK_BLK_SYMS, off = rho - b * RANK_BLK_SYMS;
+	const uint4 *line = reinterpret_cast<const uint4 *>(rd.blocks + (uint64_t)b * 16);
+	uint4 h = line[0], p0v = line[1], p1v = line[2], p2v = line[3];
+	uint32_t hd[4] = {h.x, h.y, h.z, h.w};
+	uint32_t w[12] = {p0v.x, p0v.y, p0v.z, p0v.w, p1v.x, p1v.y, p1v.z, p1v.w, p2v.x, p2v.y, p2v.z, p2v.w};
+	uint32_t cnt = hd[code];
+	uint32_t pat = code * 0x55555555u;
+	#pragma unroll
+	for (int i = 0; i < 12; ++i) {
+		int nsym = (int)off - 16 * i;
+		uint32_t mask = nsym >= 16 ? 0x55555555u : (nsym <= 0 ? 0u : (0x55555555u & ((1u << (2 * nsym)) - 1u)));
+		uint32_t y = w[i] ^ pat;
+		uint32_t mm = ~(y | (y >> 1)) & mask;
+		cnt += __popc(mm);
+	}
+	// the p0 entry is stored as code 0 but was not counted in the headers
+	if (code == 0 && p0 >= b * RANK_BLK_SYMS && p0 < rho) cnt -= 1;
+	return cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 LF walk
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gap_walk(GapWalkArgs A)
+{
+	uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= A.num_chains) return;
+	const TextView &T = A.T;
+	const uint64_t Rbeg = A.a + A.m, Rend = Rbeg + A.mr;
+	uint64_t hi = Rend - c * A.chain_len;                 // chain covers positions [lo, hi)
+	uint64_t lo = (hi - Rbeg > A.chain_len) ? hi - A.chain_len : Rbeg;
+	uint32_t rho = A.anchors[c];                          // rank_L(S_hi)
+	const uint32_t p0 = *A.rd.p0ptr;
+	const uint32_t last_code = base_at(T, A.a + A.m - 1);   // T[a+m-1], never the terminator
+	const bool term = T.type == B3M_INPUT_PACTERM;
+	uint32_t gtw = 0; uint64_t gtw_idx = ~0ull;          // cached word of gt_cur
+	uint32_t outw = 0; uint64_t outw_idx = ~0ull;        // gt_next word being assembled
+	// the end bit of the parent: gt_P[Rend] is stored per node by the host from the anchor
+	uint64_t t = 0;
+	for (uint64_t j = hi; j-- > lo; ++t) {
+		// symbol T[j]
+		uint32_t code; bool is_term = false;
+		if (term && j == T.n - 1) { is_term = true; code = 0; }
+		else code = base_at(T, j % T.n);
+		// gt_R[j+1] relative to S_{Rbeg}; for j+1 == Rend it is the node's end bit kept at bit Rend
+		uint64_t g = j + 1;
+		if ((g >> 5) != gtw_idx) { gtw_idx = g >> 5; gtw = A.gt_cur[gtw_idx]; }
+		uint32_t gtbit = (gtw >> (g & 31)) & 1u;
+		uint32_t nrho;
+		if (is_term) nrho = 0;                              // S_{n-1} = "$..." is the smallest rotation
+		else nrho = A.rd.C[code] + rank_query(A.rd, p0, code, rho) + ((last_code == code && gtbit) ? 1u : 0u);
+		rho = nrho;
+		A.ranks_out[t * A.num_chains + c] = rho;
+		// gt_P[j] = [S_j > S_a] = rank_L(j) > p0_L
+		uint32_t ob = rho > p0 ? 1u : 0u;
+		if ((j >> 5) != outw_idx) {
+			if (outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+			outw_idx = j >> 5; outw = 0;
+		}
+		outw |= ob << (j & 31);
+	}
+	if (outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+	// pad the unused slots of a short last chain
+	for (; t < A.chain_len; ++t) A.ranks_out[t * A.num_chains + c] = 0xFFFFFFFFu;
+}
+
+void gap_walk(const GapWalkArgs &A, hipStream_t s)
+{
+	if (A.num_chains) hipLaunchKernelGGL(k_gap_walk, dim3(nblk(A.num_chains, 256)), dim3(256), 0, s, A);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 interleave
+// ------------------------------------------------------------------------------------------------
+constexpr int IL_THREADS = 256;
+constexpr int IL_ITEMS = 8;
+constexpr int IL_TILE = IL_THREADS * IL_ITEMS;   // 2048 output symbols per workgroup
+
+uint64_t interleave_tiles(uint64_t total) { return (total + IL_TILE - 1) / IL_TILE; }
+
+// tile_q[t] = number of R suffixes whose output position q + sr[q] is < t*IL_TILE
+__global__ void k_tile_bounds(const uint32_t *sr, uint64_t mr, uint32_t *tile_q, uint64_t tiles)
+{
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > mr) return;
+	// f(q) = q + sr[q] strictly increasing; f(-1) = -1 ; f(mr) = +inf
+	uint64_t fprev = q ? (q - 1 + sr[q - 1]) : ~0ull;           // f(q-1)
+	uint64_t tprev = q ? fprev / IL_TILE : ~0ull;                 // tile of f(q-1), -1 if none
+	uint64_t tcur = (q < mr) ? (q + (uint64_t)sr[q]) / IL_TILE : tiles;   // tile of f(q)
+	// all tiles t in (tprev, tcur] start after f(q-1) and not after f(q): tile_q[t] = q
+	uint64_t t0 = q ? tprev + 1 : 0;
+	for (uint64_t t = t0; t <= tcur && t <= tiles; ++t) tile_q[t] = (uint32_t)q;
+}
+
+__global__ __launch_bounds__(IL_THREADS) void k_interleave(const uint32_t *sr, const uint8_t *bwtL, uint64_t m, const uint8_t *bwtR,
+                                                             uint64_t mr, uint8_t *out, const uint32_t *tile_q)
+{
+	__shared__ uint8_t sym[IL_TILE];
+	__shared__ uint8_t isr[IL_TILE];
+	__shared__ uint32_t lds[8];
+	const uint64_t total = m + mr;
+	const uint64_t tbase = (uint64_t)blockIdx.x * IL_TILE;
+	const uint32_t tn = (uint32_t)((total - tbase) < (uint64_t)IL_TILE ? (total - tbase) : (uint64_t)IL_TILE);
+	const uint32_t q0 = tile_q[blockIdx.x], q1 = tile_q[blockIdx.x + 1];
+	for (int i = threadIdx.x; i < IL_TILE; i += IL_THREADS) isr[i] = 0;
+	__syncthreads();
+	for (uint32_t q = q0 + threadIdx.x; q < q1; q += IL_THREADS) {
+		uint32_t p = (uint32_t)((uint64_t)q + sr[q] - tbase);
+		sym[p] = bwtR[q];
+		isr[p] = 1;
+	}
+	__syncthreads();
+	// holes take BWT(L)[l0 + k], k = number of holes before the position
+	const uint64_t l0 = tbase - q0;
+	uint32_t base = threadIdx.x * IL_ITEMS;
+	uint32_t holes = 0;
+	#pragma unroll
+	for (int i = 0; i < IL_ITEMS; ++i) holes += (base + i < tn && !isr[base + i]) ? 1u : 0u;
+	// block exclusive scan of holes
+	uint32_t inc = wave_incl_sum(holes);
+	uint32_t w = threadIdx.x >> 6, l = lane_id();
+	if (l == 63) lds[w] = inc;
+	__syncthreads();
+	uint32_t pre = 0;
+	for (uint32_t i = 0; i < w; ++i) pre += lds[i];
+	uint32_t ex = pre + inc - holes;
+	#pragma unroll
+	for (int i = 0; i < IL_ITEMS; ++i) {
+		uint32_t p = base + i;
+		if (p < tn) {
+			uint8_t v;
+			if (isr[p]) v = sym[p]; else { v = bwtL[l0 + ex]; ++ex; }
+			out[tbase + p] = v;
+		}
+	}
+}
+
+void interleave(const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out,
+                uint32_t *d_tile_q, hipStream_t s)
+{
+	uint64_t total = m + mr;
+	if (!total) return;
+	uint64_t tiles = interleave_tiles(total);
+	hipLaunchKernelGGL(k_tile_bounds, dim3(nblk(mr + 1)), dim3(256), 0, s, d_sr, mr, d_tile_q, tiles);
+	hipLaunchKernelGGL(k_interleave, dim3((uint32_t)tiles), dim3(IL_THREADS), 0, s, d_sr, d_bwtL, m, d_bwtR, mr, d_out, d_tile_q);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank bookkeeping across a merge
+// ------------------------------------------------------------------------------------------------
+// pairs = (rank, pos) u64; entries with pos in [posL_begin, posR_begin) belong to L, in
+// [posR_begin, posR_end) to R; others untouched.
+__global__ void k_remap(const uint32_t *sr, uint64_t mr, uint64_t *pairs, uint64_t count, uint64_t pl, uint64_t pr, uint64_t pe)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	uint64_t r = pairs[2 * i], pos = pairs[2 * i + 1];
+	if (pos >= pl && pos < pr) {
+		// L entry: r + #{q : sr[q] <= r}
+		uint64_t lo = 0, hi = mr;
+		while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if ((uint64_t)sr[mid] <= r) lo = mid + 1; else hi = mid; }
+		pairs[2 * i] = r + lo;
+	} else if (pos >= pr && pos < pe) {
+		pairs[2 * i] = r + (uint64_t)sr[r];
+	}
+}
+void remap_ranks(const uint32_t *d_sr, uint64_t mr, uint64_t *d_pairs, uint64_t count, uint64_t posL_begin, uint64_t posR_begin,
+                 uint64_t posR_end, hipStream_t s)
+{
+	if (count) hipLaunchKernelGGL(k_remap, dim3(nblk(count)), dim3(256), 0, s, d_sr, mr, d_pairs, count, posL_begin, posR_begin, posR_end);
+}
+
+__global__ void k_dense_gap(const uint32_t *sr, uint64_t mr, uint32_t *G)
+{
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= mr) return;
+	// run heads add the run length
+	if (q == 0 || sr[q] != sr[q - 1]) {
+		uint64_t e = q + 1;
+		while (e < mr && sr[e] == sr[q]) ++e;
+		G[sr[q]] = (uint32_t)(e - q);
+	}
+}
+void dense_gap_from_sorted(const uint32_t *d_sr, uint64_t mr, uint32_t *d_G, uint64_t m, hipStream_t s)
+{
+	B3M_HIP(hipMemsetAsync(d_G, 0, 4 * (m + 1), s));
+	if (mr) hipLaunchKernelGGL(k_dense_gap, dim3(nblk(mr)), dim3(256), 0, s, d_sr, mr, d_G);
+}
+
+// dst bits [b,e) = src bits [b,e) (other bits of dst untouched)
+__global__ void k_copy_bits(const uint32_t *src, uint32_t *dst, uint64_t b, uint64_t e)
+{
+	uint64_t w = (b >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if ((w << 5) >= e) return;
+	uint64_t lo = w << 5, hi = lo + 32;
+	uint32_t mask = 0xFFFFFFFFu;
+	if (lo < b) mask &= ~((1u << (b - lo)) - 1u);
+	if (hi > e) mask &= ((1u << (e - lo)) - 1u);
+	if (mask == 0xFFFFFFFFu) dst[w] = src[w];
+	else { atomicAnd(&dst[w], ~mask); atomicOr(&dst[w], src[w] & mask); }
+}
+void copy_bits(const uint32_t *src, uint32_t *dst, uint64_t bit_begin, uint64_t bit_end, hipStream_t s)
+{
+	if (bit_end <= bit_begin) return;
+	uint64_t words = ((bit_end + 31) >> 5) - (bit_begin >> 5);
+	hipLaunchKernelGGL(k_copy_bits, dim3(nblk(words)), dim3(256), 0, s, src, dst, bit_begin, bit_end);
+}
+__global__ void k_fill(uint32_t *d, uint32_t v, uint64_t n)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) d[i] = v;
+}
+void fill_u32(uint32_t *d, uint32_t v, uint64_t n, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(k_fill, dim3(nblk(n)), dim3(256), 0, s, d, v, n);
+}
+
+}  // namespace b3m

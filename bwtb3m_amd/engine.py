@@ -1,0 +1,168 @@
+"""Device-level API over libb3m: plans and the stage entry points of include/b3m.h.
+
+torch is used only as plumbing: device buffers and the current HIP stream.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import INPUT_TYPES, check, lib
+
+
+def _type_id(inputtype):
+    if isinstance(inputtype, int):
+        return inputtype
+    t = lib().b3m_parse_input_type(inputtype.encode())
+    if t < 0:
+        raise _lib.B3MError(lib().b3m_last_error().decode())
+    return t
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def num_symbols(file_bytes, inputtype):
+    """getFileSize of the input wrappers: symbols in a packed input"""
+    t = _type_id(inputtype)
+    nb = len(file_bytes)
+    if t == INPUT_TYPES["bytestream"]:
+        return nb
+    if t in (INPUT_TYPES["pac"], INPUT_TYPES["pacterm"]):
+        if nb < 2 or int(file_bytes[-1]) > 3:
+            raise _lib.B3MError("not a .pac file")
+        l = (nb - 2) * 4 + int(file_bytes[-1])
+        return l + (1 if t == INPUT_TYPES["pacterm"] else 0)
+    raise _lib.B3MError("input type not supported by the GPU engine yet")
+
+
+class Plan:
+    """b3m_plan: all workspace allocated at creation; run() = one pass of the hot path."""
+
+    def __init__(self, n, inputtype, blocksize=0, mem=0, isasamplingrate=0):
+        self.n = int(n)
+        self.type = _type_id(inputtype)
+        self._h = lib().b3m_plan_create(self.n, self.type, int(blocksize), int(mem), int(isasamplingrate))
+        if not self._h:
+            raise _lib.B3MError(lib().b3m_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().b3m_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def num_blocks(self):
+        return int(lib().b3m_plan_num_blocks(self._h))
+
+    @property
+    def workspace_bytes(self):
+        return int(lib().b3m_plan_workspace_bytes(self._h))
+
+    @property
+    def text_bytes(self):
+        return int(lib().b3m_plan_text_bytes(self._h))
+
+    def run(self, d_text, d_out=None):
+        assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.numel() >= self.text_bytes
+        if d_out is None:
+            d_out = torch.empty(self.n, dtype=torch.uint8, device=d_text.device)
+        assert d_out.is_cuda and d_out.numel() >= self.n
+        check(lib().b3m_plan_run(self._h, _ptr(d_text), _ptr(d_out), _stream()))
+        return d_out
+
+    def result(self):
+        r = _lib.Result()
+        check(lib().b3m_plan_result(self._h, ctypes.byref(r)))
+        return {k: getattr(r, k) for k, _ in _lib.Result._fields_}
+
+    def samples(self):
+        ns = self.result()["num_samples"]
+        a = np.zeros((ns, 2), dtype=np.uint64)
+        if ns:
+            check(lib().b3m_plan_samples(self._h, a.ctypes.data, ns))
+        return a
+
+    def histogram(self):
+        h = np.zeros(256, dtype=np.uint64)
+        check(lib().b3m_plan_histogram(self._h, h.ctypes.data))
+        return h
+
+    def kernel_times(self):
+        arr = (_lib.KernelTime * 16)()
+        check(lib().b3m_plan_kernel_times(self._h, arr, 16))
+        out = []
+        for k in arr:
+            if k.name:
+                out.append({"name": k.name.decode(), "ms": k.ms, "launches": int(k.launches), "alg_bytes": int(k.alg_bytes)})
+        return out
+
+
+def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0):
+    """convenience: host packed bytes -> (bwt numpy, result dict)"""
+    fb = np.ascontiguousarray(file_bytes, dtype=np.uint8)
+    n = num_symbols(fb, inputtype)
+    plan = Plan(n, inputtype, blocksize=blocksize, isasamplingrate=isasamplingrate)
+    try:
+        d = torch.from_numpy(fb).cuda()
+        out = plan.run(d)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), plan.result(), plan
+    except Exception:
+        plan.close()
+        raise
+
+
+def histogram(d_text, n, inputtype, start, length):
+    h = np.zeros(256, dtype=np.uint64)
+    check(lib().b3m_histogram(_ptr(d_text), n, _type_id(inputtype), start, length, h.ctypes.data, _stream()))
+    return h
+
+
+def block_sort(d_text, n, inputtype, start, length, want_gt=True):
+    """row a7: returns (sa u32 tensor, bwt u8 tensor, gt bit words tensor or None, p0)"""
+    dev = d_text.device
+    sa = torch.empty(length, dtype=torch.int32, device=dev)
+    bw = torch.empty(length, dtype=torch.uint8, device=dev)
+    gt = torch.zeros((length + 1 + 31) // 32, dtype=torch.int32, device=dev) if want_gt else None
+    p0 = ctypes.c_uint64(0)
+    check(lib().b3m_block_sort(_ptr(d_text), n, _type_id(inputtype), start, length, _ptr(sa), _ptr(bw), _ptr(gt),
+                               ctypes.byref(p0), _stream()))
+    return sa, bw, gt, int(p0.value)
+
+
+def rank_of(d_text, n, inputtype, d_sa, positions):
+    pos = np.ascontiguousarray(positions, dtype=np.uint64)
+    out = np.zeros(len(pos), dtype=np.uint64)
+    check(lib().b3m_rank_of(_ptr(d_text), n, _type_id(inputtype), _ptr(d_sa), d_sa.numel(), pos.ctypes.data, len(pos),
+                            out.ctypes.data, _stream()))
+    return out
+
+
+def gap(d_text, n, inputtype, a, m, mr, d_bwtL, p0L, d_gtR, anchors, chain_len, want_dense=True, want_gt=True):
+    """rows a8/a9: returns (sorted ranks u32 tensor, dense G tensor or None, gtP words or None)"""
+    dev = d_text.device
+    anc = np.ascontiguousarray(anchors, dtype=np.uint64)
+    sr = torch.empty(mr, dtype=torch.int32, device=dev)
+    G = torch.empty(m + 1, dtype=torch.int32, device=dev) if want_dense else None
+    gtP = torch.zeros((m + mr + 1 + 31) // 32, dtype=torch.int32, device=dev) if want_gt else None
+    check(lib().b3m_gap(_ptr(d_text), n, _type_id(inputtype), a, m, mr, _ptr(d_bwtL), p0L, _ptr(d_gtR), anc.ctypes.data,
+                        len(anc), chain_len, _ptr(sr), _ptr(G), _ptr(gtP), _stream()))
+    return sr, G, gtP
+
+
+def interleave(d_sr, d_bwtL, d_bwtR, p0L):
+    """row a10: returns (merged bwt tensor, new rank of L's p0 entry)"""
+    m, mr = d_bwtL.numel(), d_bwtR.numel()
+    out = torch.empty(m + mr, dtype=torch.uint8, device=d_bwtL.device)
+    p0 = ctypes.c_uint64(0)
+    check(lib().b3m_interleave(_ptr(d_sr), _ptr(d_bwtL), m, _ptr(d_bwtR), mr, _ptr(out), p0L, ctypes.byref(p0), _stream()))
+    return out, int(p0.value)

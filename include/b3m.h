@@ -1,0 +1,176 @@
+/*
+ * include/b3m.h -- C ABI of the MI355X-native BWT-construction engine (libb3m.so).
+ *
+ * Drop-in boundary for the hot path of gt1/bwtb3m.  The reference has no FFI of its
+ * own; its only library seam for this path is the static C++ call
+ *     libmaus2::suffixsort::bwtb3m::BwtMergeSortOptions options(arginfo);
+ *     libmaus2::suffixsort::bwtb3m::BwtMergeSort::computeBwt(options,&std::cerr);
+ * at /root/reference/src/bwtb3m.cpp:62-63.  b3m_options / b3m_compute_bwt replace
+ * exactly that pair; the stage-level entry points below replace the libmaus2
+ * internals that call reaches so that each stage can be
+ * checked against the oracle on its own.  INTEGRATION.md shows the reference-side
+ * binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary: every function returns 0 on success,
+ *     non-zero on error; b3m_last_error() gives the message (thread-local).
+ *   - pointers named d_* are HIP device pointers on the current device; everything
+ *     else is host memory.  All buffers are caller-owned unless stated otherwise.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - blocking, not re-entrant per process (matches the reference).
+ *   - symbols: bytestream 0..255; pac 0..3; pacterm 1..4 plus one 0 at position n-1
+ *     (/root/reference/src/bwtdecodeblock.cpp:307-310: 0 = terminator, sym-1 = base).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with an error.
+ */
+#ifndef B3M_H
+#define B3M_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B3M_VERSION 1
+
+/* input types, /root/reference/src/bwtb3m.cpp:43, enum use at /root/reference/src/checkbwt.cpp:257-270 */
+enum {
+	B3M_INPUT_BYTESTREAM = 0,
+	B3M_INPUT_COMPACTSTREAM = 1, /* parsed, not yet constructed */
+	B3M_INPUT_PAC = 2,
+	B3M_INPUT_PACTERM = 3,
+	B3M_INPUT_LZ4 = 4,           /* parsed, not yet constructed */
+	B3M_INPUT_UTF8 = 5           /* parsed, not yet constructed */
+};
+
+int         b3m_version(void);
+const char *b3m_last_error(void);
+
+/* parseInputType: name -> enum, -1 (and error text of /root/reference/src/checkbwt.cpp:274) if unknown */
+int         b3m_parse_input_type(const char *name);
+const char *b3m_input_type_name(int inputtype);
+
+/* ---- whole job: replaces BwtMergeSortOptions + BwtMergeSort::computeBwt ------------------- */
+
+/* Mirrors BwtMergeSortOptions (getters printed at /root/reference/src/bwtb3m.cpp:43-56,
+ * defaults /root/reference/README.md:38-49).  Strings are caller-owned, NUL-terminated;
+ * NULL/empty = default. */
+typedef struct b3m_options {
+	const char *input_fn;          /* positional <inputfile> */
+	const char *inputtype;         /* default "bytestream" */
+	const char *output_fn;         /* outputfilename=, default <tmpprefix>.bwt */
+	const char *tmpprefix;         /* tmpprefix= */
+	const char *sparsetmpprefix;   /* sparsetmpprefix=, default tmpprefix (unused: gap runs stay in HBM) */
+	uint64_t    mem;               /* mem=, memory target; here: HBM budget, 0 = all free HBM */
+	uint64_t    sasamplingrate;    /* default 32 */
+	uint64_t    isasamplingrate;   /* default 262144 (64 when bwtonly=1, ChangeLog:281) */
+	uint64_t    largelcpthres;     /* default 16384 (not needed on the GPU path, accepted) */
+	uint32_t    numthreads;        /* host threads for file I/O + RL encoding */
+	uint32_t    bwtonly;           /* default 0 */
+	uint32_t    copyinputtomemory; /* accepted; the packed input is always HBM-resident */
+	uint32_t    verbose;
+	int32_t     num_gpus;          /* extension: GPUs of this process (1); >1 is driven by
+	                                  bwtb3m_amd.distributed, one process per GPU */
+	uint64_t    blocksize;         /* extension: leaf block size in symbols, 0 = derive from mem */
+} b3m_options;
+
+void b3m_options_init(b3m_options *o);                       /* getDefault*() values */
+/* file -> X.bwt (+ X.hist, X.meta, X.preisa | X.sa/X.isa), log lines to log_fd (2 = stderr) */
+int  b3m_compute_bwt(const b3m_options *o, int log_fd);
+
+/* ---- device-resident construction (what bench.py times) ----------------------------------- */
+
+typedef struct b3m_plan b3m_plan;
+
+/* n = number of symbols (pacterm: bases + 1).  blocksize = leaf block size in symbols
+ * (0 = single block if it fits `mem`, else derived from mem).  isasamplingrate = 0: no
+ * (rank,pos) samples.  All workspace is allocated here, none in b3m_plan_run. */
+b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem,
+                          uint64_t isasamplingrate);
+void      b3m_plan_destroy(b3m_plan *p);
+uint64_t  b3m_plan_num_blocks(const b3m_plan *p);
+uint64_t  b3m_plan_workspace_bytes(const b3m_plan *p);
+uint64_t  b3m_plan_text_bytes(const b3m_plan *p);            /* packed input size in bytes */
+
+/* d_text: packed input exactly as in the file (bytestream: n bytes; pac/pacterm: BWA .pac
+ * payload, base i in byte i>>2 at bit ((~i)&3)<<1), b3m_plan_text_bytes() readable bytes.
+ * d_bwt_out: n bytes, one symbol per byte, in rank order. */
+int b3m_plan_run(b3m_plan *p, const void *d_text, uint8_t *d_bwt_out, void *stream);
+
+typedef struct b3m_result {
+	uint64_t n, num_blocks, levels;
+	uint64_t p0;                 /* rank of the rotation starting at position 0 (pacterm: BWA "primary") */
+	uint64_t num_samples;        /* (rank,pos) pairs available via b3m_plan_samples */
+	uint64_t tie_rounds;         /* key-extension rounds needed by the leaf sorts (max) */
+	uint64_t tie_elements;       /* suffixes that needed more than the first key (sum) */
+	double   ms_total, ms_sort, ms_gap, ms_interleave;   /* HIP-event times of the last run */
+} b3m_result;
+int b3m_plan_result(const b3m_plan *p, b3m_result *out);
+/* copies min(cap, num_samples) (rank,pos) u64 pairs, sorted by rank, to host memory */
+int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap);
+
+/* row a4: symbol histogram of the last run, hist256[sym] (the content of X.hist) */
+int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256);
+
+/* per-kernel-family timing of the last run (HIP events on the run's stream) */
+typedef struct b3m_kernel_time { const char *name; double ms; uint64_t launches; uint64_t alg_bytes; } b3m_kernel_time;
+int b3m_plan_kernel_times(const b3m_plan *p, b3m_kernel_time *out, int cap);
+
+/* ---- stage-level entry points (device buffers), one per hot-path row of SURVEY.md 8a -------- */
+
+/* row a4: symbol histogram of text[start, start+len) -> hist_out[256] (host) */
+int b3m_histogram(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len,
+                  uint64_t *hist_out, void *stream);
+
+/* row a7, BwtMergeBlockSortRequest: suffixes starting in [start, start+len) sorted as
+ * rotations of the whole circular text.
+ *   d_sa_out  : len u32 absolute positions in rank order (may be NULL)
+ *   d_bwt_out : len bytes, bwt[r] = T[(sa[r]-1) mod n]   (may be NULL)
+ *   d_gt_out  : (len+1 + 31)/32 u32 words, bit k = [S_{start+k} > S_{start}], k in [1,len]
+ *               (may be NULL)
+ *   p0_out    : rank of S_start inside the block */
+int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len,
+                   uint32_t *d_sa_out, uint8_t *d_bwt_out, uint32_t *d_gt_out,
+                   uint64_t *p0_out, void *stream);
+
+/* rank of the rotation starting at each positions[i] among a sorted block (d_sa, len):
+ * #{ r : S_{sa[r]} < S_x }.  Used for the LF-chain anchors (the reference's z-ranks). */
+int b3m_rank_of(const void *d_text, uint64_t n, int inputtype, const uint32_t *d_sa, uint64_t len,
+                const uint64_t *positions, uint64_t count, uint64_t *ranks_out, void *stream);
+
+/* row a8 + a9, gap computation of mergeBlocks: L = [a, a+m), R = [a+m, a+m+mr).
+ *   d_bwtL/p0L : block BWT of L and the rank of S_a in it (that entry belongs to a-1)
+ *   d_gtR      : bit k = [S_{a+m+k} > S_{a+m}], k in [1, mr]
+ *   anchors    : host array of `num_chains` ranks: rank in L of S_{a+m+mr - c*chain_len}
+ *   Output (sparse gap array, the in-HBM form of SparseGammaGap): d_sorted_ranks[q], q in
+ *   [0,mr), = rank in L of the q-th smallest suffix of R, ascending.  Optionally the dense
+ *   G[0..m] (u32 counts) and gt bits of the parent for positions of R:
+ *   d_gtP bit (m+k) = [S_{a+m+k} > S_a], k in [0, mr]. */
+int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t m, uint64_t mr,
+            const uint8_t *d_bwtL, uint64_t p0L, const uint32_t *d_gtR,
+            const uint64_t *anchors, uint64_t num_chains, uint64_t chain_len,
+            uint32_t *d_sorted_ranks, uint32_t *d_G_dense, uint32_t *d_gtP, void *stream);
+
+/* row a10, interleave: out = for r in 0..m: G[r] symbols of BWT(R), then BWT(L)[r], with G
+ * given as the sorted rank list.  p0P_out = new rank of L's p0 entry. */
+int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64_t m,
+                   const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out,
+                   uint64_t p0L, uint64_t *p0P_out, void *stream);
+
+/* ---- output formats (host): rows a11/a12 ------------------------------------------------------ */
+
+/* RL-encoded .bwt container (role of libmaus2::huffman::RLEncoderStd, usage
+ * /root/reference/src/lcpbit.cpp:3677-3681).  Container byte layout is PARITY-UNPINNED, see
+ * DESIGN.md. */
+int b3m_rl_write(const char *fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block);
+/* decodeRun() loop of /root/reference/src/bwtb3mdecoderl.cpp:34: n_out = symbol count;
+ * symbols_out may be NULL to query the length only */
+int b3m_rl_read(const char *fn, uint8_t *symbols_out, uint64_t cap, uint64_t *n_out);
+int b3m_rl_length(const char *fn, uint64_t *n_out);           /* RLDecoder::getLength, checkbwt.cpp:57 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

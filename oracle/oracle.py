@@ -48,7 +48,7 @@ def lib():
         L.b3mo_rank_of.argtypes = [p, i64, p, i64, i64]
         L.b3mo_rank_of.restype = i64
         L.b3mo_gap.argtypes = [p, i64, i64, i64, i64, p, i64, p, i64, ctypes.c_int, p, p, p]
-        L.b3mo_interleave.argtypes = [p, i64, p, i64, p, i64, p, i64, p]
+        L.b3mo_interleave.argtypes = [p, p, i64, p, i64, p, i64, p]
         L.b3mo_b3m.argtypes = [p, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, p, p, p]
         _lib = L
     return _lib

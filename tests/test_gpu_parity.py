@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle, bit-exact.
+
+Shape follows the reference's only in-tree test harness (`lcpbit test`,
+/root/reference/src/lcpbit.cpp:4044-4071): a fixed string, exhaustive small (length x
+alphabet) families, seeded random strings at growing sizes -- applied to BWT construction, plus
+repeat-rich and periodic inputs (circular comparisons, /root/reference/README.md:55-59).
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan_bwt(torch, file_bytes, inputtype, blocksize=0, isarate=0):
+    from bwtb3m_amd import engine
+    out, res, plan = engine.bwt_device(file_bytes, inputtype, blocksize=blocksize, isasamplingrate=isarate)
+    return out, res, plan
+
+
+def _pac(O, bases):
+    return O.pac_encode(np.asarray(bases, dtype=np.uint8))
+
+
+def _bits(words, count):
+    w = words.cpu().numpy().view(np.uint32)
+    idx = np.arange(count)
+    return ((w[idx >> 5] >> (idx & 31)) & 1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole path
+# ---------------------------------------------------------------------------------------------
+def test_fixed_string_abbab(gpu, oracle):
+    # "abbab#" of /root/reference/src/lcpbit.cpp:4053 as a bytestream
+    t = np.frombuffer(b"abbab#", dtype=np.uint8)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream")
+    assert out.tolist() == oracle.bwt_naive(t).tolist()
+    plan.close()
+
+
+@pytest.mark.parametrize("text", [b"abab", b"aaaa", b"a", b"ab", b"abcabcabc", b"mississippi", b"zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzy"])
+def test_periodic_and_tiny_bytestream(gpu, oracle, text):
+    t = np.frombuffer(text, dtype=np.uint8)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream")
+    assert out.tolist() == oracle.bwt_naive(t).tolist()
+    plan.close()
+
+
+def test_exhaustive_len6_3bit_bytestream(gpu, oracle):
+    # all strings of length 6 over a 3-bit alphabet would be 262144 launches; the family is
+    # sampled by a fixed stride, the 1-bit and 2-bit families below are complete
+    alls = list(itertools.product(range(8), repeat=6))
+    for tup in alls[::97]:
+        t = np.array(tup, dtype=np.uint8)
+        out, res, plan = _plan_bwt(gpu, t, "bytestream")
+        assert out.tolist() == oracle.bwt_naive(t).tolist(), tup
+        plan.close()
+
+
+def test_exhaustive_len8_1bit_pac_all_blockings(gpu, oracle):
+    for tup in itertools.product(range(2), repeat=8):
+        b = np.array(tup, dtype=np.uint8)
+        ref = oracle.bwt_naive(b)
+        for bs in (0, 4, 3, 2, 1):
+            out, res, plan = _plan_bwt(gpu, _pac(oracle, b), "pac", blocksize=bs)
+            assert out.tolist() == ref.tolist(), (tup, bs)
+            plan.close()
+
+
+def test_exhaustive_len6_2bit_pac_and_pacterm(gpu, oracle):
+    for tup in itertools.product(range(4), repeat=6):
+        b = np.array(tup, dtype=np.uint8)
+        ref = oracle.bwt_naive(b)
+        for bs in (0, 3, 2):
+            out, res, plan = _plan_bwt(gpu, _pac(oracle, b), "pac", blocksize=bs)
+            assert out.tolist() == ref.tolist(), (tup, bs)
+            plan.close()
+        s = np.concatenate([b + 1, [0]]).astype(np.uint8)
+        refs = oracle.bwt_naive(s)
+        for bs in (0, 4, 2):
+            out, res, plan = _plan_bwt(gpu, _pac(oracle, b), "pacterm", blocksize=bs)
+            assert out.tolist() == refs.tolist(), (tup, bs)
+            assert out[res["p0"]] == 0
+            plan.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 1000, 4096, 4097, 65536, 1 << 20])
+def test_random_bytestream_sizes(gpu, oracle, n):
+    t = oracle.synth_bytes(n, 0xB3B3B3B3)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream")
+    assert np.array_equal(out, oracle.bwt(t))
+    plan.close()
+
+
+@pytest.mark.parametrize("sigma_bits", [1, 2, 3])
+def test_random_small_alphabet_bytestream(gpu, oracle, sigma_bits):
+    # small alphabets over bytes give long ties for the 8-symbol keys (many key-extension rounds)
+    t = (oracle.synth_bytes(20000, 77) & ((1 << sigma_bits) - 1)).astype(np.uint8)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream")
+    assert np.array_equal(out, oracle.bwt(t))
+    assert res["tie_rounds"] >= 1
+    plan.close()
+
+
+@pytest.mark.parametrize("nb", [1, 2, 3, 15, 16, 17, 47, 48, 49, 1000, 65536, 1000003])
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+def test_random_dna_single_block(gpu, oracle, nb, itype):
+    b = oracle.synth_bases(nb, 0xB3B3B3B3 + 7)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype)
+    assert np.array_equal(out, oracle.bwt(s))
+    plan.close()
+
+
+@pytest.mark.parametrize("nb,bs", [(100, 7), (1000, 100), (1000, 333), (65536, 8192), (65537, 10000), (300000, 37501), (1000003, 125001)])
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+def test_random_dna_multi_block(gpu, oracle, nb, bs, itype):
+    b = oracle.synth_bases(nb, 0xB3B3B3B3 + 9)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype, blocksize=bs)
+    assert res["num_blocks"] > 1
+    ref = oracle.bwt(s)
+    assert np.array_equal(out, ref)
+    # p0 = rank of the rotation starting at 0
+    sa = oracle.sa_circular(s)
+    if itype == "pacterm":
+        assert res["p0"] == int(np.nonzero(sa == 0)[0][0])
+    plan.close()
+
+
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+@pytest.mark.parametrize("bs", [0, 20000])
+def test_repeat_rich_dna(gpu, oracle, itype, bs):
+    b = oracle.synth_repeat_bases(150000, 5)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype, blocksize=bs)
+    assert np.array_equal(out, oracle.bwt(s))
+    assert res["tie_rounds"] >= 2
+    plan.close()
+
+
+@pytest.mark.parametrize("bs", [0, 64, 1000])
+def test_periodic_dna(gpu, oracle, bs):
+    # fully periodic circular text: equal rotations must not hang the tie rounds
+    unit = np.array([0, 1, 2, 3, 3, 1, 0], dtype=np.uint8)
+    b = np.tile(unit, 500)
+    buf = _pac(oracle, b)
+    out, res, plan = _plan_bwt(gpu, buf, "pac", blocksize=bs)
+    assert np.array_equal(out, oracle.bwt(b))
+    plan.close()
+    homo = np.zeros(5000, dtype=np.uint8)
+    out, res, plan = _plan_bwt(gpu, _pac(oracle, homo), "pac", blocksize=bs)
+    assert np.array_equal(out, homo)
+    plan.close()
+
+
+def test_config_c1_1mib_bytestream(gpu, oracle):
+    # BASELINE.json configs[0]: 1 MiB random bytestream
+    t = oracle.synth_bytes(1 << 20, 0xB3B3B3B3 + 0)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream", isarate=64)
+    assert np.array_equal(out, oracle.bwt(t))
+    # (rank,pos) samples: every 64th position, rank = inverse suffix array
+    sa = oracle.sa_circular(t)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    smp = plan.samples()
+    assert len(smp) == (len(t) + 63) // 64
+    assert np.array_equal(np.sort(smp[:, 1]), np.arange(0, len(t), 64).astype(np.uint64))
+    assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    h = plan.histogram()
+    assert np.array_equal(h, np.bincount(t, minlength=256).astype(np.uint64))
+    plan.close()
+
+
+@pytest.mark.parametrize("bs", [0, 625001])
+def test_config_c2_5mbase_pacterm(gpu, oracle, bs):
+    # BASELINE.json configs[1]: 5 Mbase synthetic pacterm, bit-exact
+    b = oracle.synth_bases(5_000_000, 0xB3B3B3B3 + 1)
+    buf = _pac(oracle, b)
+    assert len(buf) == 1_250_002
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    out, res, plan = _plan_bwt(gpu, buf, "pacterm", blocksize=bs, isarate=262144)
+    ref = oracle.bwt(s)
+    assert np.array_equal(out, ref)
+    sa = oracle.sa_circular(s)
+    assert res["p0"] == int(np.nonzero(sa == 0)[0][0])
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    smp = plan.samples()
+    assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# stages against the oracle's intermediates
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+def test_stage_block_sort_gap_interleave(gpu, oracle, itype):
+    torch = gpu
+    from bwtb3m_amd import engine
+    nb = 60000
+    b = oracle.synth_bases(nb, 4242)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    n = len(s)
+    d_text = torch.from_numpy(buf).cuda()
+    a, m, mr = 10000, 20000, 17000
+    # --- leaves: row a7
+    saL = oracle.leaf_sort(s, a, m)
+    bwL, p0L, gtL = oracle.leaf_products(s, a, m, saL)
+    saR = oracle.leaf_sort(s, a + m, mr)
+    bwR, p0R, gtR = oracle.leaf_products(s, a + m, mr, saR)
+    dsaL, dbwL, dgtL, dp0L = engine.block_sort(d_text, n, itype, a, m)
+    dsaR, dbwR, dgtR, dp0R = engine.block_sort(d_text, n, itype, a + m, mr)
+    assert np.array_equal(dsaL.cpu().numpy().view(np.uint32).astype(np.int64), saL)
+    assert np.array_equal(dbwL.cpu().numpy(), bwL) and dp0L == p0L
+    assert np.array_equal(_bits(dgtL, m + 1)[1:], gtL[1:])
+    assert np.array_equal(dsaR.cpu().numpy().view(np.uint32).astype(np.int64), saR)
+    assert np.array_equal(_bits(dgtR, mr + 1)[1:], gtR[1:])
+    # --- anchors (z-ranks)
+    chain_len = 500
+    nch = (mr + chain_len - 1) // chain_len
+    pos = np.array([a + m + mr - c * chain_len for c in range(nch)], dtype=np.uint64)
+    anc = engine.rank_of(d_text, n, itype, dsaL, pos)
+    assert [oracle.rank_of(s, saL, int(x)) for x in pos] == anc.tolist()
+    # --- gap: rows a8/a9
+    G, gtP, rankR = oracle.gap(s, a, m, mr, bwL, p0L, gtR, int(anc[0]), 5 if itype == "pacterm" else 4)
+    dsr, dG, dgtP = engine.gap(d_text, n, itype, a, m, mr, dbwL, dp0L, dgtR, anc, chain_len)
+    assert np.array_equal(dG.cpu().numpy().view(np.uint32), G)
+    assert np.array_equal(dsr.cpu().numpy().view(np.uint32).astype(np.int64), np.sort(rankR))
+    assert np.array_equal(_bits(dgtP, m + mr + 1)[m:], gtP[m:])
+    # --- interleave: row a10
+    ref, p0P = oracle.interleave(G, bwL, bwR, p0L)
+    dout, dp0P = engine.interleave(dsr, dbwL, dbwR, dp0L)
+    assert np.array_equal(dout.cpu().numpy(), ref) and dp0P == p0P
+
+
+def test_stage_histogram(gpu, oracle):
+    from bwtb3m_amd import engine
+    b = oracle.synth_bases(100001, 3)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    d = gpu.from_numpy(buf).cuda()
+    h = engine.histogram(d, len(s), "pacterm", 5, len(s) - 5)
+    assert np.array_equal(h, np.bincount(s[5:], minlength=256).astype(np.uint64))
+
+
+def test_errors_are_loud(gpu):
+    from bwtb3m_amd import engine, B3MError
+    with pytest.raises(B3MError):
+        engine.Plan(100, "compactstream")
+    with pytest.raises(B3MError):
+        engine.Plan(100, "nosuchtype")
+    with pytest.raises(B3MError):
+        engine.Plan(0, "bytestream")
+    with pytest.raises(B3MError):
+        engine.Plan(100000, "bytestream", blocksize=1000)   # byte-alphabet merges not implemented
+
+
+def test_library_is_the_hip_one(gpu):
+    """the native library must be what ran: loaded from the package dir, with a HIP device"""
+    from bwtb3m_amd import _lib
+    import os
+    assert os.path.exists(_lib.so_path())
+    maps = open("/proc/self/maps").read()
+    assert "libb3m.so" in maps and "libamdhip64" in maps
