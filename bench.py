@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the BWT-construction hot path on MI355X.
+
+A step = one pass of the hot path (packed text resident in HBM -> BWT symbols in HBM) over the
+synthetic input of BASELINE.json's metric config (C3: 3 Gbase pacterm; falls back to the largest
+size that fits).  Prints ONE JSON line (contract in the task statement), with the roofline of the
+dominant kernel family (HIP events on the launch stream, collected inside the library) and a
+CPU baseline (the oracle's restatement of balanced block merging on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", help="c1|c2|c3 (BASELINE.json configs)")
+    ap.add_argument("--size", type=float, default=0, help="override the number of bases/bytes")
+    ap.add_argument("--blocksize", type=float, default=0, help="leaf block size in symbols (0 = engine default)")
+    ap.add_argument("--blocks", type=int, default=0, help="number of leaf blocks (overrides --blocksize)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=48e6, help="symbols of the CPU-baseline sample")
+    ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
+    return ap.parse_args()
+
+
+def cpu_baseline(buf, itype, sample, blocks):
+    """oracle (kind 'port'): CPU restatement of balanced block merging on a prefix of the workload"""
+    import numpy as np
+    from oracle import oracle as O      # cpu_baseline leg: the only place bench.py touches oracle/
+    # the GPU box exposes every host core; one GPU's share is 16 (task statement)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    if itype == "bytestream":
+        sym = np.asarray(buf[:sample], dtype=np.uint8)
+        sigma = 256
+    else:
+        nb = min(sample, (len(buf) - 2) * 4 + int(buf[-1]))
+        data = np.asarray(buf[: (nb + 3) // 4], dtype=np.uint8)
+        b = np.empty(len(data) * 4, dtype=np.uint8)
+        b[0::4] = data >> 6; b[1::4] = (data >> 4) & 3; b[2::4] = (data >> 2) & 3; b[3::4] = data & 3
+        b = b[:nb]
+        sym = np.concatenate([b + 1, np.zeros(1, dtype=np.uint8)]).astype(np.uint8) if itype == "pacterm" else b
+        sigma = 5 if itype == "pacterm" else 4
+    B = max(blocks, cores)
+    t0 = time.time()
+    _, _, st = O.b3m(sym, B, cores, sigma)
+    dt = time.time() - t0
+    return {"value": len(sym) / dt / 1e9, "unit": "Gbase/s", "cores": cores, "kind": "port",
+            "sample": "first %d symbols of the workload, %d leaf blocks, %d threads, %.1f s (leaf sort %.1f s, gap %.1f s, interleave %.1f s)"
+                      % (len(sym), B, cores, dt, st[0], st[1], st[2])}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    from bwtb3m_amd import engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 or world > 1:
+        from bwtb3m_amd import distributed
+        return distributed.bench_main(a, rank, local_rank, world)
+
+    torch.cuda.set_device(0)
+    itype, nsyms_cfg, _ = synth.CONFIGS[a.config]
+    size = int(a.size) if a.size else None
+    workload_note = ""
+    # largest size that fits: the single-block workspace needs ~45 B/symbol
+    free_b, _ = torch.cuda.mem_get_info()
+    want = size or nsyms_cfg
+    while want * 50 > free_b and want > 1_000_000:
+        want //= 2
+        workload_note = " (reduced: full size does not fit free HBM)"
+    t0 = time.time()
+    itype, d_text, n = synth.config_input_device(a.config, size=want, device="cuda")   # generated in HBM
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    blocksize = int(a.blocksize)
+    if a.blocks > 0:
+        blocksize = (n + a.blocks - 1) // a.blocks
+    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=0)
+    d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for _ in range(a.warmup):
+        plan.run(d_text, d_out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fam = {}
+    for _ in range(a.steps):
+        plan.run(d_text, d_out)
+        for k in plan.kernel_times():
+            f = fam.setdefault(k["name"], {"ms": 0.0, "launches": 0, "alg_bytes": 0})
+            f["ms"] += k["ms"]; f["launches"] += k["launches"]; f["alg_bytes"] += k["alg_bytes"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = plan.result()
+    nbases = n - 1 if itype == "pacterm" else n
+    value = nbases * a.steps / dt / 1e9
+    # dominant kernel family by device time
+    dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    dname, d = dom
+    achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+    B = res["num_blocks"]
+    levels = res["levels"]
+    alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
+    roof = {
+        "bound": "hbm", "kernel": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, a.steps),
+        "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),
+        "job_alg_bytes": alg_job, "job_frac": round(alg_job / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
+        "families_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in fam.items() if v["ms"] > 0},
+    }
+    out = {
+        "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
+        "value": round(value, 4), "unit": "Gbase/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: %d-symbol synthetic %s%s" % (a.config.upper(), n, itype, workload_note),
+                   "blocks": B, "merge_levels": levels, "tie_rounds": res["tie_rounds"], "tie_elements": res["tie_elements"],
+                   "parallelism": "1 GPU", "input_gen_s": round(gen_s, 2)},
+        "roofline": roof,
+    }
+    if a.verify:
+        from oracle import oracle as O
+        sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)
+        assert np.array_equal(d_out.cpu().numpy(), O.bwt(sym)), "bench --verify: BWT differs from the oracle"
+        out["config"]["verified"] = True
+    if not a.no_cpu_baseline:
+        sample = int(min(a.cpu_sample, n))
+        # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)
+        _, buf, _ = synth.config_input(a.config, size=min(want, sample + 64))
+        out["cpu_baseline"] = cpu_baseline(buf, itype, sample, B)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
