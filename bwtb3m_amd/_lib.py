@@ -63,8 +63,12 @@ SYMBOLS = [
     ("b3m_plan_kernel_times", _i, [_p, ctypes.POINTER(KernelTime), _i]),
     ("b3m_histogram", _i, [_p, _u64, _i, _u64, _u64, _p, _p]),
     ("b3m_block_sort", _i, [_p, _u64, _i, _u64, _u64, _p, _p, _p, ctypes.POINTER(_u64), _p]),
+    ("b3m_block_sort_abs", _i, [_p, _u64, _i, _u64, _u64, _p, _p, _p, ctypes.POINTER(_u64), _p]),
     ("b3m_rank_of", _i, [_p, _u64, _i, _p, _u64, _p, _u64, _p, _p]),
     ("b3m_gap", _i, [_p, _u64, _i, _u64, _u64, _u64, _p, _u64, _p, _p, _u64, _u64, _p, _p, _p, _p]),
+    ("b3m_gap_chains", _i, [_p, _u64, _i, _u64, _u64, _u64, _p, _u64, _p, _p, _u64, _u64, _u64, _p, ctypes.POINTER(_u64), _p, _p]),
+    ("b3m_sort_u32", _i, [_p, _u64, _i, _p, _p]),
+    ("b3m_bits_place", _i, [_p, _u64, _u64, _p, _p]),
     ("b3m_interleave", _i, [_p, _p, _u64, _p, _u64, _p, _u64, ctypes.POINTER(_u64), _p]),
     ("b3m_rl_write", _i, [_cp, _p, _u64, _u64]),
     ("b3m_rl_read", _i, [_cp, _p, _u64, ctypes.POINTER(_u64)]),

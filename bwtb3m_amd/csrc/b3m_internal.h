@@ -150,6 +150,7 @@ struct GapWalkArgs {
 	uint32_t *gt_next;         // absolute-position bit array (level output), pre-zeroed over R
 	const uint32_t *anchors;   // num_chains ranks
 	uint64_t num_chains, chain_len;
+	uint64_t chain_first;     // global index of this launch's first chain (multi-GPU: each rank walks a chain range)
 	uint32_t *ranks_out;       // [chain_len][num_chains] layout, invalid slots = 0xFFFFFFFF
 };
 void gap_walk(const GapWalkArgs &A, hipStream_t s);

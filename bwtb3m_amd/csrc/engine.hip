@@ -71,6 +71,13 @@ static void clear_bits(uint32_t *dst, uint64_t b, uint64_t e, hipStream_t s)
 	uint64_t words = ((e + 31) >> 5) - (b >> 5);
 	hipLaunchKernelGGL(k_clear_bits, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, dst, b, e);
 }
+// abs bit (start+k) |= rel bit k for k in [1,count]
+__global__ void k_place_bits(const uint32_t *rel, uint64_t count, uint64_t start, uint32_t *abs)
+{
+	uint64_t k = 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > count) return;
+	if ((rel[k >> 5] >> (k & 31)) & 1u) { uint64_t x = start + k; atomicOr(&abs[x >> 5], 1u << (x & 31)); }
+}
 // walk prologue: fill the RankDict scalars that live on the device (p0 of L, end bit of P)
 __global__ void k_merge_prologue(const uint64_t *p0pairL, const uint32_t *anchors, uint32_t *gt_next, uint64_t Rend, uint32_t *p0_u32)
 {
@@ -679,6 +686,136 @@ int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64
 	}
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
+
+/* Multi-GPU form of b3m_gap (see include/b3m.h): walks only the chains [chain_first,
+ * chain_first+num_chains) of the merge's global chain table, with gt bit arrays indexed by
+ * absolute text position. */
+int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t m, uint64_t mr, const uint8_t *d_bwtL, uint64_t p0L,
+                   const uint32_t *d_gt_abs_in, const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                   uint32_t *d_sorted_ranks, uint64_t *count_out, uint32_t *d_gt_abs_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
+	B3M_REQUIRE(a + m + mr <= n && m >= 1 && mr >= 1 && chain_len >= 1, "range out of bounds");
+	uint64_t total_chains = (mr + chain_len - 1) / chain_len;
+	B3M_REQUIRE(chain_first + num_chains <= total_chains, "chain range out of bounds");
+	if (num_chains == 0) { if (count_out) *count_out = 0; return 0; }
+	PaddedText pt(d_text, n, inputtype, s);
+	uint64_t nb = rank_blocks(m);
+	DevBuf blocks(64 * nb), scratch(16 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), hb(8 * 256);
+	{ uint32_t p032 = (uint32_t)p0L; B3M_HIP(hipMemcpy(p0d.p, &p032, 4, hipMemcpyHostToDevice)); }
+	rank_build(d_bwtL, m, p0d.as<uint32_t>(), inputtype, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
+	B3M_HIP(hipMemsetAsync(hb.p, 0, 8 * 256, s));
+	histogram_symbols(pt.T, a, m, hb.as<uint64_t>(), s);
+	uint64_t hl[256];
+	B3M_HIP(hipMemcpyAsync(hl, hb.p, 8 * 256, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	RankDict rd{};
+	rd.blocks = blocks.as<uint32_t>(); rd.m = m; rd.p0ptr = p0d.as<uint32_t>();
+	if (inputtype == B3M_INPUT_PACTERM) { uint64_t acc = hl[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c + 1]; } }
+	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c]; } }
+	std::vector<uint32_t> a32(num_chains);
+	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
+	DevBuf an(4 * num_chains);
+	B3M_HIP(hipMemcpy(an.p, a32.data(), 4 * num_chains, hipMemcpyHostToDevice));
+	uint64_t slots = num_chains * chain_len;
+	DevBuf r0(4 * slots), r1(4 * slots), rws(radix_ws_bytes(slots));
+	RadixWs rw; radix_ws_carve(rw, rws.p, slots);
+	GapWalkArgs G{};
+	G.T = pt.T; G.rd = rd; G.a = a; G.m = m; G.mr = mr; G.gt_cur = d_gt_abs_in; G.gt_next = d_gt_abs_out;
+	G.anchors = an.as<uint32_t>(); G.num_chains = num_chains; G.chain_len = chain_len; G.chain_first = chain_first;
+	G.ranks_out = r0.as<uint32_t>();
+	gap_walk(G, s);
+	uint32_t *sr = nullptr;
+	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
+	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr);
+	// positions covered by this chain range
+	uint64_t hi = mr - chain_first * chain_len;
+	uint64_t last = chain_first + num_chains;
+	uint64_t lo = (last * chain_len >= mr) ? 0 : mr - last * chain_len;
+	uint64_t cnt = hi - lo;
+	B3M_HIP(hipMemcpyAsync(d_sorted_ranks, sr, 4 * cnt, hipMemcpyDeviceToDevice, s));
+	if (count_out) *count_out = cnt;
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
+
+int b3m_sort_u32(const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	if (count == 0) return 0;
+	B3M_REQUIRE(nbits >= 1 && nbits <= 32, "nbits out of range");
+	DevBuf a(4 * count), b(4 * count), rws(radix_ws_bytes(count));
+	RadixWs rw; radix_ws_carve(rw, rws.p, count);
+	B3M_HIP(hipMemcpyAsync(a.p, d_keys, 4 * count, hipMemcpyDeviceToDevice, s));
+	uint32_t *res = nullptr;
+	radix_sort_u32(a.as<uint32_t>(), b.as<uint32_t>(), count, nbits, rw, s, nullptr, &res);
+	B3M_HIP(hipMemcpyAsync(d_out, res, 4 * count, hipMemcpyDeviceToDevice, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_bits_place(const uint32_t *d_rel, uint64_t count, uint64_t start, uint32_t *d_abs, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	if (count) hipLaunchKernelGGL(k_place_bits, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, d_rel, count, start, d_abs);
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
+
+/* b3m_block_sort with the gt bits written on the device into an ABSOLUTE-position bit array
+ * (d_gt_abs, (n+1+31)/32+2 words, OR-ed in): bit x = [S_x > S_start] for x in (start, start+len].
+ * No host round trip over the block: the form the multi-GPU driver uses. */
+int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len, uint32_t *d_sa_out,
+                       uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
+	PaddedText pt(d_text, n, inputtype, s);
+	DevBuf ws(blocksort_ws_bytes(len));
+	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
+	BlockSortOut so;
+	block_sort(pt.T, start, len, bs, s, nullptr, so);
+	DevBuf sc(64);     // [0] p0 u32, [2..3] p0 pair u64, [4] end rank, [6..7] end position u64
+	uint32_t *d_p0 = sc.as<uint32_t>();
+	uint64_t *d_pair = (uint64_t *)((uint8_t *)sc.p + 8);
+	uint32_t *d_er = (uint32_t *)((uint8_t *)sc.p + 32);
+	uint64_t *d_ep = (uint64_t *)((uint8_t *)sc.p + 40);
+	B3M_HIP(hipMemsetAsync(sc.p, 0, 64, s));
+	emit_bwt(pt.T, so.d_sa, len, start, d_bwt_out, d_p0, s);
+	if (d_gt_abs) {
+		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, d_p0, d_pair, start);
+		hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, s, so.d_sa, len, start, d_p0, d_gt_abs);
+		uint64_t endpos = start + len;
+		B3M_HIP(hipMemcpyAsync(d_ep, &endpos, 8, hipMemcpyHostToDevice, s));
+		rank_of_positions(pt.T, so.d_sa, len, d_ep, 1, d_er, s);
+		hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, d_er, d_pair, d_gt_abs, start + len);
+	}
+	uint32_t p0 = 0;
+	B3M_HIP(hipMemcpyAsync(&p0, d_p0, 4, hipMemcpyDeviceToHost, s));
+	if (d_sa_out) B3M_HIP(hipMemcpyAsync(d_sa_out, so.d_sa, 4 * len, hipMemcpyDeviceToDevice, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	if (p0_out) *p0_out = p0;
 	return 0;
 	B3M_CATCH(1)
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_gap_walk(GapWalkArgs A)
 	if (c >= A.num_chains) return;
 	const TextView &T = A.T;
 	const uint64_t Rbeg = A.a + A.m, Rend = Rbeg + A.mr;
-	uint64_t hi = Rend - c * A.chain_len;                 // chain covers positions [lo, hi)
+	uint64_t hi = Rend - (A.chain_first + c) * A.chain_len;   // chain covers positions [lo, hi)
 	uint64_t lo = (hi - Rbeg > A.chain_len) ? hi - A.chain_len : Rbeg;
 	uint32_t rho = A.anchors[c];                          // rank_L(S_hi)
 	const uint32_t p0 = *A.rd.p0ptr;

@@ -1,0 +1,440 @@
+"""Multi-GPU balanced block merging: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).  SURVEY.md 8(e).
+
+Partitioning (strong scaling: the input is fixed, the work is split):
+  * the packed text is replicated on every GPU (0.75 GB at 3 Gbase);
+  * rank k sorts leaf block k (no communication);
+  * a merge (L, R) is executed by ALL ranks of both sides together:
+      - BWT(L) is broadcast inside the group (every walker needs the rank dictionary),
+      - R's text positions are cut into one chain range per rank; each rank walks its range
+        (b3m_gap_chains) and gets the ranks in L of those suffixes of R,
+      - the rank space [0, |L|] (= the gap array G) is cut into one slice per rank; every rank
+        buckets its produced ranks by owning slice: ALL-TO-ALL of gap buckets,
+      - the owner sorts what it received (its slice of the sparse gap array), pulls the
+        contiguous range of BWT(R) that falls into its slice (second all-to-all) and interleaves:
+        it then owns a contiguous slice of the merged BWT.
+    No all-reduce of data on this path (a ring would be bound by one xGMI link; the all-to-all
+    drives all links).  Small vectors (sizes, anchors, gt bit words) use all_gather/all_reduce.
+
+The compute steps go through a backend object.  The product has exactly one backend, HipBackend
+(C ABI of libb3m.so on CUDA tensors); the CPU tests inject an oracle-backed one to exercise this
+host logic under gloo -- nothing in this module can fall back to the CPU by itself.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------------
+# plan (pure host logic, identical on every rank)
+# ---------------------------------------------------------------------------------------------------
+def chains_for(mr, world_hint=1):
+    """chain table of a merge: same rule as the single-GPU engine (engine.hip: chains_for)"""
+    target = 256 * 1024 * max(1, world_hint)
+    chain_len = max(32, (mr + target - 1) // target)
+    return chain_len, (mr + chain_len - 1) // chain_len
+
+
+class Node:
+    def __init__(self, a, m, ranks):
+        self.a, self.m, self.ranks = a, m, list(ranks)
+
+
+class Merge:
+    def __init__(self, L, R, idx):
+        self.L, self.R, self.idx = L, R, idx
+        self.group = L.ranks + R.ranks
+        self.chain_len, self.num_chains = chains_for(R.m, len(self.group))
+        self.anchor_off = 0
+
+
+class TreePlan:
+    """balanced binary merge tree over one leaf per rank"""
+
+    def __init__(self, n, world):
+        assert 1 <= world <= n
+        bs = (n + world - 1) // world
+        self.n, self.world, self.bs = n, world, bs
+        self.leaves = []
+        for k in range(world):
+            a = k * bs
+            m = min(bs, n - a)
+            assert m >= 1, "more ranks than symbols"
+            self.leaves.append(Node(a, m, [k]))
+        self.levels = []
+        self.merges = []
+        cur = self.leaves
+        off = 0
+        while len(cur) > 1:
+            nxt, lv = [], []
+            for i in range(0, len(cur) - 1, 2):
+                mg = Merge(cur[i], cur[i + 1], len(self.merges))
+                mg.anchor_off = off
+                off += mg.num_chains
+                self.merges.append(mg)
+                lv.append(mg)
+                nxt.append(Node(mg.L.a, mg.L.m + mg.R.m, mg.group))
+            if len(cur) & 1:
+                nxt.append(cur[-1])
+            self.levels.append(lv)
+            cur = nxt
+        self.total_anchors = off
+
+    def anchor_positions(self, mg):
+        rend = mg.R.a + mg.R.m
+        return (rend - np.arange(mg.num_chains, dtype=np.int64) * mg.chain_len) % self.n
+
+    def merges_with_leaf_on_left(self, k):
+        return [mg for mg in self.merges if k in mg.L.ranks]
+
+
+def split_even(total, parts):
+    """boundaries of `parts` nearly equal contiguous pieces of range(total)"""
+    return [(total * i) // parts for i in range(parts + 1)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the product backend: HIP kernels through the C ABI
+# ---------------------------------------------------------------------------------------------------
+class HipBackend:
+    def __init__(self, device):
+        from . import engine  # noqa: F401  (fails loudly if libb3m.so is missing)
+        self.engine = engine
+        self.device = device
+
+    def gt_words(self, n):
+        return (n + 1 + 31) // 32 + 2
+
+    def block_sort(self, d_text, n, itype, a, m):
+        """-> (sa, bwt, gt_abs words with this leaf's bits, p0)"""
+        eng = self.engine
+        sa = torch.empty(m, dtype=torch.int32, device=self.device)
+        bw = torch.empty(m, dtype=torch.uint8, device=self.device)
+        gt_abs = torch.zeros(self.gt_words(n), dtype=torch.int32, device=self.device)
+        p0 = ctypes.c_uint64(0)
+        eng.check(eng.lib().b3m_block_sort_abs(eng._ptr(d_text), n, eng._type_id(itype), a, m, eng._ptr(sa), eng._ptr(bw),
+                                               eng._ptr(gt_abs), ctypes.byref(p0), eng._stream()))
+        return sa, bw, gt_abs, int(p0.value)
+
+    def rank_of(self, d_text, n, itype, sa, positions):
+        return self.engine.rank_of(d_text, n, itype, sa, positions).astype(np.int64)
+
+    def gap_chains(self, d_text, n, itype, a, m, mr, bwtL, p0L, gt_abs, anchors, chain_first, num_chains, chain_len):
+        """-> (ascending ranks of the walked suffixes of R (int32 tensor), gt_abs_out words)"""
+        eng = self.engine
+        cap = max(1, num_chains * chain_len)
+        sr = torch.empty(cap, dtype=torch.int32, device=self.device)
+        gt_out = torch.zeros(self.gt_words(n), dtype=torch.int32, device=self.device)
+        cnt = ctypes.c_uint64(0)
+        anc = np.ascontiguousarray(anchors, dtype=np.uint64)
+        eng.check(eng.lib().b3m_gap_chains(eng._ptr(d_text), n, eng._type_id(itype), a, m, mr, eng._ptr(bwtL), p0L, eng._ptr(gt_abs),
+                                           anc.ctypes.data, chain_first, num_chains, chain_len, eng._ptr(sr), ctypes.byref(cnt),
+                                           eng._ptr(gt_out), eng._stream()))
+        return sr[: cnt.value], gt_out
+
+    def sort_u32(self, keys, nbits):
+        eng = self.engine
+        out = torch.empty_like(keys)
+        if keys.numel():
+            eng.check(eng.lib().b3m_sort_u32(eng._ptr(keys), keys.numel(), nbits, eng._ptr(out), eng._stream()))
+        return out
+
+    def interleave(self, sr_local, bwtL, bwtR):
+        out, _ = self.engine.interleave(sr_local, bwtL, bwtR, 0)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# collectives helpers
+# ---------------------------------------------------------------------------------------------------
+def _staged(t):
+    """gloo cannot move device tensors: with a gloo process group and tensors on the GPU (the 1-GPU
+    rehearsal of the N>1 path) collectives are staged through host memory.  Transport only."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather_i64(vals, group, device):
+    """every member contributes a small int64 vector; returns a (members, len) numpy array"""
+    t = torch.tensor(vals, dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+    gs = dist.get_world_size(group)
+    out = [torch.empty_like(t) for _ in range(gs)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu().numpy()
+
+
+def _all_to_all_v(send, send_counts, recv_counts, group):
+    """variable all-to-all of a 1-D tensor; counts are python ints per group member"""
+    dev = send.device
+    st = _staged(send)
+    src = send.cpu() if st else send
+    recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=src.device)
+    dist.all_to_all_single(recv, src.contiguous(), output_split_sizes=[int(x) for x in recv_counts],
+                           input_split_sizes=[int(x) for x in send_counts], group=group)
+    return recv.to(dev) if st else recv
+
+
+def _broadcast(t, src, group):
+    if _staged(t):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+def _all_reduce_sum(t, group=None):
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def _set_bit(words, x, value):
+    w, b = x >> 5, x & 31
+    mask = (1 << b)
+    mask = mask - (1 << 32) if mask >= (1 << 31) else mask
+    if value:
+        words[w] |= mask
+    else:
+        words[w] &= ~mask
+
+
+def _m32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
+def _replace_bits_seg(dst, seg, seg_w0, b, e):
+    """dst bits [b,e) = bits [b,e) of `seg`, a word range starting at word seg_w0; int32 word
+    tensors indexed by absolute position.  Edge words are merged under a mask."""
+    if e <= b:
+        return
+    w0, w1 = b >> 5, (e - 1) >> 5
+    for w in sorted({w0, w1}):
+        lo, hi = max(b, w << 5) - (w << 5), min(e, (w + 1) << 5) - (w << 5)
+        mk = _m32(((1 << hi) - 1) & ~((1 << lo) - 1))
+        dst[w] = (dst[w] & ~mk) | (seg[w - seg_w0] & mk)
+    if w1 - w0 >= 2:
+        dst[w0 + 1:w1] = seg[w0 + 1 - seg_w0:w1 - seg_w0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the distributed hot path
+# ---------------------------------------------------------------------------------------------------
+class DistributedBwt:
+    """construct the BWT of a replicated packed text on dist.get_world_size() GPUs.
+
+    run() returns this rank's contiguous slice of the BWT, its offset, and p0 (rank of the
+    rotation starting at 0).  Groups are created once (new_group is collective over ALL ranks)."""
+
+    def __init__(self, n, itype, backend, device):
+        self.n, self.itype, self.be, self.device = n, itype, backend, device
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.plan = TreePlan(n, self.world)
+        self.groups = {}
+        for mg in self.plan.merges:          # same order on every rank
+            self.groups[mg.idx] = dist.new_group(ranks=mg.group)
+        self.timing = {}
+
+    def run(self, d_text):
+        n, itype, be, plan, me = self.n, self.itype, self.be, self.plan, self.rank
+        dev = self.device
+        tm = self.timing = {"leaf": 0.0, "anchors": 0.0, "walk": 0.0, "exchange": 0.0, "interleave": 0.0}
+        t0 = time.perf_counter()
+        leaf = plan.leaves[me]
+        sa, my_bwt, gt_cur, p0 = be.block_sort(d_text, n, itype, leaf.a, leaf.m)
+        node_p0 = {me: p0}
+        # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks -----------
+        t1 = time.perf_counter()
+        tm["leaf"] += t1 - t0
+        anchors = torch.zeros(max(1, plan.total_anchors), dtype=torch.int64, device=dev)
+        for mg in plan.merges_with_leaf_on_left(me):
+            pos = plan.anchor_positions(mg)
+            r = be.rank_of(d_text, n, itype, sa, pos)
+            anchors[mg.anchor_off:mg.anchor_off + mg.num_chains] = torch.from_numpy(r).to(dev)
+        del sa
+        if self.world > 1:
+            _all_reduce_sum(anchors)
+        h_anchors = anchors.cpu().numpy()
+        tm["anchors"] += time.perf_counter() - t1
+        # ---- merge levels ----------------------------------------------------------------------------------
+        my_off = 0                  # offset of my slice inside my current node's BWT
+        my_node = leaf              # node I currently belong to
+        for lv in plan.levels:
+            mine = [mg for mg in lv if me in mg.group]
+            if not mine:
+                continue
+            mg = mine[0]
+            my_bwt, my_off, gt_cur, p0P = self._merge(mg, d_text, my_bwt, gt_cur, node_p0[my_node.ranks[0]], h_anchors, tm)
+            my_node = Node(mg.L.a, mg.L.m + mg.R.m, mg.group)
+            node_p0[my_node.ranks[0]] = p0P
+        return my_bwt, my_off, node_p0[my_node.ranks[0]]
+
+    def _merge(self, mg, d_text, my_bwt, gt_cur, my_node_p0, h_anchors, tm):
+        n, itype, be, me, dev = self.n, self.itype, self.be, self.rank, self.device
+        grp = self.groups[mg.idx]
+        members = mg.group
+        gs = len(members)
+        gi = members.index(me)
+        nL = len(mg.L.ranks)
+        a, m, mr = mg.L.a, mg.L.m, mg.R.m
+        rbeg, rend = a + m, a + m + mr
+        t0 = time.perf_counter()
+        # 1. slice sizes and node p0 of both sides
+        info = _all_gather_i64([my_bwt.numel(), my_node_p0], grp, dev)
+        sizes = info[:, 0]
+        p0L = int(info[0, 1])
+        assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
+        offL = np.concatenate([[0], np.cumsum(sizes[:nL])])
+        offR = np.concatenate([[0], np.cumsum(sizes[nL:])])
+        # 2. BWT(L) to every member (rank dictionary input)
+        bwtL = torch.empty(m, dtype=torch.uint8, device=dev)
+        for j in range(nL):
+            part = bwtL[int(offL[j]):int(offL[j + 1])]
+            if gi == j:
+                part.copy_(my_bwt)
+            _broadcast(part, members[j], grp)
+        # 3. gt bits: L's positions (a, rbeg) are valid on L's members, R's (rbeg, rend] on R's.
+        #    Everybody gets both word ranges; partial edge words are merged bit-exactly.
+        lw0, lw1 = a >> 5, (rbeg >> 5) + 1
+        w0, w1 = rbeg >> 5, (rend >> 5) + 1
+        lseg = gt_cur[lw0:lw1].clone()
+        _broadcast(lseg, members[0], grp)
+        rseg = gt_cur[w0:w1].clone()
+        _broadcast(rseg, members[nL], grp)
+        _replace_bits_seg(gt_cur, lseg, lw0, a + 1, rbeg + 1)
+        _replace_bits_seg(gt_cur, rseg, w0, rbeg + 1, rend + 1)
+        t1 = time.perf_counter()
+        tm["exchange"] += t1 - t0
+        # 4. walk my chain range
+        cb = split_even(mg.num_chains, gs)
+        c0, c1 = cb[gi], cb[gi + 1]
+        anc = h_anchors[mg.anchor_off + c0: mg.anchor_off + c1]
+        sr_mine, gt_out = be.gap_chains(d_text, n, itype, a, m, mr, bwtL, p0L, gt_cur, anc, c0, c1 - c0, mg.chain_len)
+        t2 = time.perf_counter()
+        tm["walk"] += t2 - t1
+        # new gt bits of R's positions relative to S_a: union over walkers (disjoint positions)
+        oseg = gt_out[w0:w1].contiguous()
+        _all_reduce_sum(oseg, grp)
+        del gt_out
+        gt_new = gt_cur                               # L's bits (a, rbeg) stay; R's become relative to S_a
+        _replace_bits_seg(gt_new, oseg, w0, rbeg, rend)
+        _set_bit(gt_new, rend, 1 if int(h_anchors[mg.anchor_off]) > p0L else 0)
+        # 5. all-to-all of gap buckets by owning slice of the rank space [0, m]
+        lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
+        bounds = torch.tensor(lam, dtype=torch.int64, device=dev)
+        cut = torch.searchsorted(sr_mine, bounds.to(torch.int32)).cpu().numpy()
+        send_counts = np.diff(cut)
+        rc = _all_gather_i64(list(send_counts), grp, dev)          # rc[i][j] = i sends to j
+        recv_counts = rc[:, gi]
+        got = _all_to_all_v(sr_mine, send_counts, recv_counts, grp)
+        nbits = max(1, int(m + 1).bit_length())
+        sr_slice = be.sort_u32(got, min(32, nbits))
+        # 6. which range of BWT(R) falls into my slice
+        cj = rc.sum(axis=0)                   # cj[j] = suffixes of R owned by j
+        Q = np.concatenate([[0], np.cumsum(cj)])
+        # all-to-all of BWT(R) ranges: R member r (global slice [offR[r], offR[r+1])) sends to owner
+        # j the overlap with [Q[j], Q[j+1])
+        send2 = np.zeros(gs, dtype=np.int64)
+        recv2 = np.zeros(gs, dtype=np.int64)
+        if gi >= nL:
+            r = gi - nL
+            for j in range(gs):
+                send2[j] = max(0, min(offR[r + 1], Q[j + 1]) - max(offR[r], Q[j]))
+        for r in range(gs - nL):
+            recv2[nL + r] = max(0, min(offR[r + 1], Q[gi + 1]) - max(offR[r], Q[gi]))
+        src = my_bwt if gi >= nL else torch.empty(0, dtype=torch.uint8, device=dev)
+        bwtR_part = _all_to_all_v(src, send2, recv2, grp)
+        assert bwtR_part.numel() == int(cj[gi])
+        t3 = time.perf_counter()
+        tm["exchange"] += t3 - t2
+        # 7. interleave my slice
+        l0, l1 = lam[gi], (lam[gi + 1] if gi + 1 < gs else m)
+        l1 = min(l1, m)
+        sr_local = (sr_slice - l0) if l0 else sr_slice
+        out = be.interleave(sr_local, bwtL[l0:l1].contiguous(), bwtR_part)
+        # new rank of L's p0 entry: p0L + #{q : sr[q] <= p0L}
+        cand = -1
+        if l0 <= p0L < l1:
+            le = int(torch.searchsorted(sr_slice, torch.tensor([p0L], dtype=torch.int32, device=dev), right=True)[0])
+            cand = p0L + int(Q[gi]) + le
+        fin = _all_gather_i64([out.numel(), cand], grp, dev)
+        p0P = int(fin[:, 1].max())
+        new_off = int(fin[:gi, 0].sum())
+        tm["interleave"] += time.perf_counter() - t3
+        return out, new_off, gt_new, p0P
+
+
+def gather_result(slice_t, group=None):
+    """collect the distributed BWT on every rank (tests / verification only)"""
+    ws = dist.get_world_size(group)
+    sizes = _all_gather_i64([slice_t.numel()], group, slice_t.device)[:, 0]
+    mx = int(sizes.max())
+    pad = torch.zeros(mx, dtype=slice_t.dtype, device=slice_t.device)
+    pad[: slice_t.numel()] = slice_t
+    dev = pad.device
+    if _staged(pad):
+        pad = pad.cpu()
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: int(s)] for p, s in zip(parts, sizes)]).to(dev)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench entry (called by bench.py when WORLD_SIZE > 1)
+# ---------------------------------------------------------------------------------------------------
+def bench_main(a, rank, local_rank, world):
+    from . import synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    itype_cfg, nsyms_cfg, _ = synth.CONFIGS[a.config]
+    want = int(a.size) if a.size else nsyms_cfg
+    itype, d_text, n = synth.config_input_device(a.config, size=want, device=dev)
+    be = HipBackend(dev)
+    job = DistributedBwt(n, itype, be, dev)
+    for _ in range(a.warmup):
+        job.run(d_text)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out, off, p0 = job.run(d_text)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt[0])
+    nbases = n - 1 if itype == "pacterm" else n
+    if a.verify:
+        full = gather_result(out)
+        if rank == 0:
+            from oracle import oracle as O
+            sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)
+            assert np.array_equal(full.cpu().numpy(), O.bwt(sym)), "distributed BWT differs from the oracle"
+    if rank == 0:
+        levels = len(job.plan.levels)
+        alg_job = nbases * (9.5 + 41.0 * levels)
+        res = {
+            "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
+            "value": round(nbases * a.steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world,
+                       "merge_levels": levels, "parallelism": "%d GPUs: 1 leaf block per GPU, all-to-all gap merge" % world,
+                       "rank0_phase_s": {k: round(v, 4) for k, v in job.timing.items()}},
+            "roofline": {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / a.steps) / 1e9, 1),
+                         "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / a.steps) / 1e9 / (8000.0 * world), 5), "traffic": None},
+        }
+        print(json.dumps(res))
+    dist.destroy_process_group()

@@ -135,6 +135,12 @@ int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start
                    uint32_t *d_sa_out, uint8_t *d_bwt_out, uint32_t *d_gt_out,
                    uint64_t *p0_out, void *stream);
 
+/* same sort, gt bits written on the device into an ABSOLUTE-position bit array d_gt_abs
+ * ((n+1+31)/32+2 u32 words, OR-ed in; caller zeroes): bit x = [S_x > S_start], x in (start, start+len] */
+int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len,
+                       uint32_t *d_sa_out, uint8_t *d_bwt_out, uint32_t *d_gt_abs,
+                       uint64_t *p0_out, void *stream);
+
 /* rank of the rotation starting at each positions[i] among a sorted block (d_sa, len):
  * #{ r : S_{sa[r]} < S_x }.  Used for the LF-chain anchors (the reference's z-ranks). */
 int b3m_rank_of(const void *d_text, uint64_t n, int inputtype, const uint32_t *d_sa, uint64_t len,
@@ -152,6 +158,25 @@ int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t 
             const uint8_t *d_bwtL, uint64_t p0L, const uint32_t *d_gtR,
             const uint64_t *anchors, uint64_t num_chains, uint64_t chain_len,
             uint32_t *d_sorted_ranks, uint32_t *d_G_dense, uint32_t *d_gtP, void *stream);
+
+/* Multi-GPU form of b3m_gap: one rank walks only the chains [chain_first, chain_first+num_chains)
+ * of the merge's chain table (chain c covers R positions [a+m+mr-(c+1)*chain_len, a+m+mr-c*chain_len)
+ * clipped to R).  gt arrays are indexed by ABSOLUTE text position ((n+1+31)/32+2 u32 words):
+ *   d_gt_abs_in  bit x = [S_x > S_{a+m}] for x in (a+m, a+m+mr]
+ *   d_gt_abs_out |= bit j = [S_j > S_a] for the walked positions j (caller zeroes it)
+ * anchors[i] = rank in L of the suffix at the top end of chain chain_first+i.
+ * d_sorted_ranks (capacity num_chains*chain_len) receives *count_out ascending ranks. */
+int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t m, uint64_t mr,
+                   const uint8_t *d_bwtL, uint64_t p0L, const uint32_t *d_gt_abs_in,
+                   const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                   uint32_t *d_sorted_ranks, uint64_t *count_out, uint32_t *d_gt_abs_out, void *stream);
+
+/* row a9 helper: ascending LSD radix sort of u32 keys on bits [0,nbits) (the sparse gap array is a
+ * sorted rank list; the multi-GPU driver re-sorts the rank buckets it receives). */
+int b3m_sort_u32(const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream);
+/* abs bit (start+k) |= rel bit k, k in [1,count]: block-relative gt bits of b3m_block_sort ->
+ * the absolute-position bit array b3m_gap_chains works on. */
+int b3m_bits_place(const uint32_t *d_rel, uint64_t count, uint64_t start, uint32_t *d_abs, void *stream);
 
 /* row a10, interleave: out = for r in 0..m: G[r] symbols of BWT(R), then BWT(L)[r], with G
  * given as the sorted rank list.  p0P_out = new rank of L's p0 entry. */

@@ -345,6 +345,24 @@ EXPORT int b3mo_gap(const uint8_t *t, int64_t n64, int64_t a, int64_t m, int64_t
 	return 0;
 }
 
+/* One chain of the walk from an arbitrary anchor: positions k = k_hi-1 .. k_lo of R, rho =
+ * rank_L(S_{a+m+k_hi}).  rankR[k-k_lo] and gtP[m+k] are written for the walked positions only
+ * (what one rank of the multi-GPU driver computes for one chain). */
+EXPORT int b3mo_gap_range(const uint8_t *t, int64_t n64, int64_t a, int64_t m, int64_t mr,
+                          const uint8_t *bwtL, int64_t p0L, const uint8_t *gtR, int sigma,
+                          int64_t k_hi, int64_t k_lo, int64_t rho, int64_t *rankR, uint8_t *gtP)
+{
+	lrank_t lr;
+	(void)mr;
+	int rc = lrank_build(&lr, t, (uint32_t)n64, a, m, bwtL, p0L, sigma);
+	if (rc) return rc;
+	uint32_t *G = calloc((size_t)m + 1, 4);
+	gap_chain(t, (uint32_t)n64, a, &lr, gtR, k_hi, k_lo, rho, G, gtP, rankR ? rankR - k_lo : NULL, 0);
+	free(G);
+	lrank_free(&lr);
+	return 0;
+}
+
 /* Interleave (row a10): for r in 0..m: emit G[r] symbols of BWT(R), then BWT(L)[r].
  * p0P = new rank of L's p0 entry. */
 EXPORT int b3mo_interleave(const uint32_t *G, const uint8_t *bwtL, int64_t m,

@@ -48,6 +48,7 @@ def lib():
         L.b3mo_rank_of.argtypes = [p, i64, p, i64, i64]
         L.b3mo_rank_of.restype = i64
         L.b3mo_gap.argtypes = [p, i64, i64, i64, i64, p, i64, p, i64, ctypes.c_int, p, p, p]
+        L.b3mo_gap_range.argtypes = [p, i64, i64, i64, i64, p, i64, p, ctypes.c_int, i64, i64, i64, p, p]
         L.b3mo_interleave.argtypes = [p, p, i64, p, i64, p, i64, p]
         L.b3mo_b3m.argtypes = [p, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, p, p, p]
         _lib = L
@@ -139,6 +140,19 @@ def gap(t, a, m, mr, bwtL, p0L, gtR, rank_end, sigma):
     _check(lib().b3mo_gap(tp, len(t), a, m, mr, bp, p0L, gp, rank_end, sigma,
                           G.ctypes.data, gtP.ctypes.data, rankR.ctypes.data), "gap")
     return G, gtP, rankR
+
+
+def gap_range(t, a, m, mr, bwtL, p0L, gtR, sigma, k_hi, k_lo, rho):
+    """ranks in L of R's positions k_lo..k_hi-1 walked from the anchor rho = rank_L(S_{a+m+k_hi});
+    returns (rankR[k_hi-k_lo], gtP array of m+mr+1 with the walked positions filled)"""
+    t, tp = _u8(t)
+    bwtL, bp = _u8(bwtL)
+    gtR, gp = _u8(gtR)
+    rankR = np.zeros(max(1, k_hi - k_lo), dtype=np.int64)
+    gtP = np.zeros(m + mr + 1, dtype=np.uint8)
+    _check(lib().b3mo_gap_range(tp, len(t), a, m, mr, bp, p0L, gp, sigma, k_hi, k_lo, rho,
+                                rankR.ctypes.data, gtP.ctypes.data), "gap_range")
+    return rankR[: k_hi - k_lo], gtP
 
 
 def interleave(G, bwtL, bwtR, p0L):

@@ -1,0 +1,92 @@
+"""N>1 path of the multi-GPU driver under gloo on the CPU (world sizes 2, 3, 4): tree plan, chain
+ranges, gap-bucket all-to-all, BWT(R) range all-to-all, slice bookkeeping, gt bits, p0.  The compute
+steps are the oracle's (tests/oracle_backend.py); what is tested is bwtb3m_amd/distributed.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, itype, nb, seed, repeat, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from oracle_backend import OracleBackend
+        from bwtb3m_amd import distributed as D
+        b = O.synth_repeat_bases(nb, seed) if repeat else O.synth_bases(nb, seed)
+        buf = O.pac_encode(b)
+        sym = O.symbols_from_file_bytes(buf, itype)
+        n = len(sym)
+        job = D.DistributedBwt(n, itype, OracleBackend(sym, itype), torch.device("cpu"))
+        out, off, p0 = job.run(torch.from_numpy(buf))
+        full = D.gather_result(out).numpy()
+        ref = O.bwt(sym)
+        sa = O.sa_circular(sym)
+        ok = np.array_equal(full, ref)
+        # my slice sits at its offset
+        ok = ok and np.array_equal(ref[off: off + out.numel()], out.numpy())
+        if itype == "pacterm":
+            ok = ok and p0 == int(np.nonzero(sa == 0)[0][0])
+        q.put((rank, bool(ok), int(out.numel())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("itype,nb,repeat", [("pacterm", 5000, False), ("pac", 4097, False), ("pacterm", 6000, True)])
+def test_distributed_driver_gloo(world, itype, nb, repeat):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, itype, nb, 17 + world, repeat, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for p in procs:
+        p.join(timeout=240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("worker hung")
+        assert p.exitcode == 0
+    while not q.empty():
+        res.append(q.get())
+    assert len(res) == world and all(ok for _, ok, _ in res), res
+    n = nb + (1 if itype == "pacterm" else 0)
+    assert sum(sz for _, _, sz in res) == n
+
+
+def test_tree_plan_shapes():
+    sys.path.insert(0, ROOT)
+    from bwtb3m_amd.distributed import TreePlan, split_even, chains_for
+    p = TreePlan(3_000_000_001, 8)
+    assert len(p.leaves) == 8 and len(p.levels) == 3 and [len(l) for l in p.levels] == [4, 2, 1]
+    assert sum(l.m for l in p.leaves) == 3_000_000_001
+    top = p.levels[-1][0]
+    assert top.group == list(range(8)) and top.L.m + top.R.m == 3_000_000_001
+    # chains tile R exactly
+    for mg in p.merges:
+        assert (mg.num_chains - 1) * mg.chain_len < mg.R.m <= mg.num_chains * mg.chain_len
+    p3 = TreePlan(1000, 3)          # odd: the last leaf is carried one level
+    assert [len(l) for l in p3.levels] == [1, 1] and p3.levels[1][0].group == [0, 1, 2]
+    assert split_even(10, 3) == [0, 3, 6, 10]
+    assert chains_for(100)[0] == 32

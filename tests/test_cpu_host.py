@@ -1,0 +1,149 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, option
+grammar and defaults mirror the reference CLI, file formats round-trip, errors are loud.  No
+compute entry point is exercised successfully here (there is no CPU fallback to exercise)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from bwtb3m_amd import _lib
+    if not os.path.exists(_lib.so_path()):
+        subprocess.check_call(["make", "-C", ROOT, "-j4", "all"])
+    return _lib.lib()
+
+
+def test_header_symbols_all_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "b3m.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(b3m_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 24
+    from bwtb3m_amd import _lib
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_cpu_fallback(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert not L.b3m_plan_create(1000, 0, 0, 0, 0)
+    assert b"no CPU fallback" in L.b3m_last_error()
+    h = (ctypes.c_uint64 * 256)()
+    assert L.b3m_histogram(None, 10, 0, 0, 10, h, None) != 0
+
+
+def test_library_missing_is_loud(monkeypatch, tmp_path):
+    from bwtb3m_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.lib()
+
+
+def test_input_type_parsing(L):
+    names = ["bytestream", "compactstream", "pac", "pacterm", "lz4", "utf-8"]   # /root/reference/src/bwtb3m.cpp:43
+    for i, nme in enumerate(names):
+        assert L.b3m_parse_input_type(nme.encode()) == i
+        assert L.b3m_input_type_name(i) == nme.encode()
+    assert L.b3m_parse_input_type(b"fastq") == -1
+    assert L.b3m_last_error().startswith(b"Unknown input type")
+
+
+def test_options_defaults(L):
+    from bwtb3m_amd import _lib
+    o = _lib.Options()
+    L.b3m_options_init(ctypes.byref(o))
+    # /root/reference/README.md:38-49
+    assert o.inputtype == b"bytestream" and o.sasamplingrate == 32 and o.isasamplingrate == 262144
+    assert o.bwtonly == 0 and o.copyinputtomemory == 0 and o.largelcpthres == 16384 and o.verbose == 0
+    assert o.numthreads >= 1
+
+
+def test_python_options_mirror():
+    from bwtb3m_amd import ArgInfo, BwtMergeSortOptions, B3MError
+    ai = ArgInfo(["bwtb3m", "inputtype=pacterm", "mem=2g", "bwtonly=1", "outputfilename=x.bwt", "in.pac", "extra"])
+    assert ai.restargs == ["in.pac", "extra"] and ai.argmap["mem"] == "2g"
+    o = BwtMergeSortOptions(ai)
+    assert o.fn == "in.pac" and o.inputtype == "pacterm" and o.mem == 2 << 30 and o.outfn == "x.bwt"
+    assert o.isasamplingrate == 64 and o.sasamplingrate == 32       # ChangeLog:281: 64 when bwtonly=1
+    o2 = BwtMergeSortOptions(ArgInfo(["bwtb3m", "f"]))
+    assert o2.isasamplingrate == 262144 and o2.outfn.endswith(".bwt") and o2.sparsetmpfilenamebase == o2.tmpfilenamebase
+    assert re.match(r"bwtb3m_.+_\d+_\d+$", o2.tmpfilenamebase)
+    with pytest.raises(B3MError):
+        BwtMergeSortOptions(ArgInfo(["bwtb3m", "inputtype=fastq", "f"]))
+    with pytest.raises(B3MError):
+        BwtMergeSortOptions(ArgInfo(["bwtb3m", "mem=12x", "f"]))
+    assert ArgInfo(["p", "-h"]).helpRequested()
+
+
+def _run(args, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def test_cli_help_and_errors(L):
+    exe = os.path.join(ROOT, "bin", "bwtb3m")
+    r = _run([exe])
+    # no positional: usage thrown as an exception -> stderr, EXIT_FAILURE; stdout unused
+    assert r.returncode == 1 and r.stdout == b""
+    txt = r.stderr.decode()
+    for opt in ["inputtype=[<bytestream>] (bytestream,compactstream,pac,pacterm,lz4,utf-8)", "outputfilename=", "sasamplingrate=[32]",
+                "isasamplingrate=[262144]", "mem=", "numthreads=", "bwtonly=[0]", "tmpprefix=", "sparsetmpprefix=[tmpprefix]",
+                "copyinputtomemory=[0]", "largelcpthres=[16384]", "verbose=[0]"]:
+        assert opt in txt, opt
+    assert "usage: " in txt and "[options] <inputfile>" in txt
+    assert _run([exe, "-h"]).returncode == 1
+    r = _run([exe, "inputtype=nosuch", "/dev/null"])
+    assert r.returncode == 1 and b"Unknown input type nosuch" in r.stderr
+    r = _run([exe, "/nonexistent/file"])
+    assert r.returncode == 1 and b"cannot open" in r.stderr
+
+
+def test_rl_container_round_trip(L, tmp_path):
+    rng = np.random.default_rng(5)
+    cases = [np.zeros(1, np.uint8), np.array([7], np.uint8), rng.integers(0, 256, 100000).astype(np.uint8),
+             rng.integers(1, 5, 300000).astype(np.uint8), np.repeat(rng.integers(0, 4, 50).astype(np.uint8), 9000)]
+    for i, a in enumerate(cases):
+        fn = str(tmp_path / ("t%d.bwt" % i)).encode()
+        assert L.b3m_rl_write(fn, a.ctypes.data, len(a), 4096) == 0, L.b3m_last_error()
+        n = ctypes.c_uint64()
+        assert L.b3m_rl_length(fn, ctypes.byref(n)) == 0 and n.value == len(a)
+        out = np.zeros(len(a), np.uint8)
+        assert L.b3m_rl_read(fn, out.ctypes.data, len(a), ctypes.byref(n)) == 0, L.b3m_last_error()
+        assert np.array_equal(out, a)
+        # first 8 bytes: n, big-endian; last 8 bytes: index offset
+        raw = open(fn, "rb").read()
+        assert int.from_bytes(raw[:8], "big") == len(a)
+        assert 8 <= int.from_bytes(raw[-8:], "big") < len(raw)
+        # the named consumer decodes it (bwtb3mdecoderl, bytestream mode)
+        r = _run([os.path.join(ROOT, "bin", "bwtb3mdecoderl"), fn.decode()])
+        assert r.returncode == 0 and r.stdout == a.tobytes()
+    assert L.b3m_rl_length(b"/nonexistent", ctypes.byref(n)) != 0
+    bad = tmp_path / "bad.bwt"
+    bad.write_bytes(b"\x00" * 10)
+    assert L.b3m_rl_read(str(bad).encode(), None, 0, ctypes.byref(n)) != 0
+    r = _run([os.path.join(ROOT, "bin", "bwtb3mdecoderl")])
+    assert r.returncode == 1 and b"usage:" in r.stderr
+    r = _run([os.path.join(ROOT, "bin", "bwtb3mdecoderl"), "inputtype=pac", str(bad)])
+    assert r.returncode == 1 and b"currently not supported for bwtb3mdecode" in r.stderr
+
+
+def test_synth_generators_agree(oracle):
+    from bwtb3m_amd import synth
+    for nb in [1, 3, 4, 5, 31, 32, 33, 1000, 100003]:
+        a = synth.pac_file_bytes(nb, synth.SEED_BASE + 1)
+        assert np.array_equal(a, oracle.pac_encode(oracle.synth_bases(nb, 0xB3B3B3B3 + 1)))
+        assert np.array_equal(a, synth.pac_file_bytes_torch(nb, synth.SEED_BASE + 1, device="cpu", chunk_words=777).numpy())
+    it, buf, n = synth.config_input("c2")
+    assert it == "pacterm" and len(buf) == 1_250_002 and n == 5_000_001
+    it, buf, n = synth.config_input("c1")
+    assert it == "bytestream" and n == 1 << 20 and np.array_equal(buf, oracle.synth_bytes(1 << 20, 0xB3B3B3B3))
