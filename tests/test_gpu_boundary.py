@@ -1,0 +1,137 @@
+"""GPU tests at the drop-in boundary: the bwtb3m command line and BwtMergeSort.computeBwt produce
+the reference's file set (X.bwt RL container + X.hist + X.meta + X.preisa,
+/root/reference/src/checkbwt.cpp:39-53, /root/reference/README.md:63-67) whose decoded content equals the
+oracle; the committed golden fixtures are reproduced without the oracle."""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "bwt_golden.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _decode(L, fn):
+    n = ctypes.c_uint64()
+    assert L.b3m_rl_length(fn.encode(), ctypes.byref(n)) == 0
+    out = np.zeros(n.value, dtype=np.uint8)
+    assert L.b3m_rl_read(fn.encode(), out.ctypes.data, n.value, ctypes.byref(n)) == 0, L.b3m_last_error()
+    return out
+
+
+@pytest.mark.parametrize("extra", [[], ["blocksize=40000"]])
+def test_cli_pacterm_file_set(gpu, oracle, tmp_path, extra):
+    from bwtb3m_amd import _lib
+    L = _lib.lib()
+    b = oracle.synth_bases(200_003, 21)
+    buf = oracle.pac_encode(b)
+    inp = tmp_path / "in.pac"
+    inp.write_bytes(buf.tobytes())
+    out = str(tmp_path / "x.pac.bwt")
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=1", "outputfilename=" + out, "verbose=1"] + extra + [str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == b"" and b"[M] " in r.stderr and b" runtime " in r.stderr     # /root/reference/src/bwtb3m.cpp:65
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    ref = oracle.bwt(s)
+    assert np.array_equal(_decode(L, out), ref)
+    prefix = out[:-4]
+    for suf in (".hist", ".meta", ".preisa"):
+        assert os.path.exists(prefix + suf), suf
+    # .hist: count, then (key,value) 8-byte big-endian (bwtdecodeblock.cpp:150-173 reader)
+    raw = open(prefix + ".hist", "rb").read()
+    cnt = int.from_bytes(raw[:8], "big")
+    hist = {int.from_bytes(raw[8 + 16 * i: 16 + 16 * i], "big"): int.from_bytes(raw[16 + 16 * i: 24 + 16 * i], "big") for i in range(cnt)}
+    assert hist == {int(k): int(v) for k, v in zip(*np.unique(s, return_counts=True))}
+    # .preisa: (rank,pos) u64 pairs, every 64th position when bwtonly=1 (ChangeLog:281)
+    pre = np.fromfile(prefix + ".preisa", dtype=np.uint64).reshape(-1, 2)
+    sa = oracle.sa_circular(s)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    assert len(pre) == (len(s) + 63) // 64
+    assert np.array_equal(isa[pre[:, 1].astype(np.int64)], pre[:, 0].astype(np.int64))
+    # the named consumer decodes the container
+    d = subprocess.run([os.path.join(ROOT, "bin", "bwtb3mdecoderl"), out], stdout=subprocess.PIPE)
+    assert d.returncode == 0 and d.stdout == ref.tobytes()
+
+
+def test_python_compute_bwt_bytestream(gpu, oracle, tmp_path):
+    # BASELINE.json configs[0]: inputtype=bytestream bwtonly=1, through the mirrored interface
+    from bwtb3m_amd import ArgInfo, BwtMergeSortOptions, BwtMergeSort, B3MError, _lib
+    t = oracle.synth_bytes(1 << 20, 0xB3B3B3B3)
+    inp = tmp_path / "in.bin"
+    inp.write_bytes(t.tobytes())
+    out = str(tmp_path / "o.bwt")
+    opts = BwtMergeSortOptions(ArgInfo(["bwtb3m", "inputtype=bytestream", "bwtonly=1", "outputfilename=" + out, str(inp)]))
+    res = BwtMergeSort.computeBwt(opts)
+    assert res.bwtfn == out and os.path.exists(res.histfn) and os.path.exists(res.preisafn)
+    assert np.array_equal(_decode(_lib.lib(), out), oracle.bwt(t))
+    bad = BwtMergeSortOptions(ArgInfo(["bwtb3m", "inputtype=lz4", str(inp)]))
+    with pytest.raises(B3MError):
+        BwtMergeSort.computeBwt(bad)
+    missing = BwtMergeSortOptions(ArgInfo(["bwtb3m", str(tmp_path / "nope")]))
+    with pytest.raises(B3MError):
+        BwtMergeSort.computeBwt(missing)
+
+
+def test_golden_fixtures_without_oracle(gpu):
+    """HIP path against tests/golden (committed vectors); the oracle is not imported here"""
+    from bwtb3m_amd import engine, synth
+    for s, l in GOLD["literal"].items():
+        out, res, plan = engine.bwt_device(np.frombuffer(s.encode(), dtype=np.uint8), "bytestream")
+        assert bytes(out).decode() == l
+        plan.close()
+    for n in (1024, 65536, 1 << 20):
+        out, res, plan = engine.bwt_device(synth.byte_file_bytes(n, synth.SEED_BASE), "bytestream")
+        assert sha(out) == GOLD["random_bytestream"][str(n)]
+        plan.close()
+    for nb in (1000, 65536, 5_000_000):
+        g = GOLD["random_pacterm"][str(nb)]
+        buf = synth.pac_file_bytes(nb, synth.SEED_BASE + 1)
+        assert sha(buf) == g["pac_sha256"]
+        for bs in (0, nb // 5 + 1):
+            out, res, plan = engine.bwt_device(buf, "pacterm", blocksize=bs)
+            assert sha(out) == g["sha256"] and res["p0"] == g["zero_at"]
+            plan.close()
+        if GOLD["random_pac"][str(nb)]:
+            out, res, plan = engine.bwt_device(buf, "pac", blocksize=nb // 3 + 1)
+            assert sha(out) == GOLD["random_pac"][str(nb)]
+            plan.close()
+
+
+def test_golden_intermediates_stage_level(gpu):
+    import torch
+    from bwtb3m_amd import engine, synth
+    buf = synth.pac_file_bytes(65536, synth.SEED_BASE + 1)
+    d = torch.from_numpy(buf).cuda()
+    n = 65537
+    leaves = []
+    for k in range(4):
+        g = GOLD["intermediate"]["leaf%d" % k]
+        sa, bw, gt, p0 = engine.block_sort(d, n, "pacterm", g["a"], g["m"])
+        w = gt.cpu().numpy().view(np.uint32)
+        idx = np.arange(1, g["m"] + 1)
+        bits = ((w[idx >> 5] >> (idx & 31)) & 1).astype(np.uint8)
+        assert sha(sa.cpu().numpy().view(np.uint32)) == g["sa"] and sha(bw.cpu().numpy()) == g["bwt"] and p0 == g["p0"] and sha(bits) == g["gt"]
+        leaves.append((g["a"], g["m"], sa, bw, gt, p0))
+    for k in (0, 2):
+        g = GOLD["intermediate"]["merge%d%d" % (k, k + 1)]
+        a, m, sa, bw, gt, p0 = leaves[k]
+        a2, m2, sa2, bw2, gt2, p02 = leaves[k + 1]
+        chain_len = 1000
+        nch = (m2 + chain_len - 1) // chain_len
+        pos = np.array([(a2 + m2 - c * chain_len) % n for c in range(nch)], dtype=np.uint64)
+        anc = engine.rank_of(d, n, "pacterm", sa, pos)
+        assert int(anc[0]) == g["rank_end"]
+        sr, G, gtP = engine.gap(d, n, "pacterm", a, m, m2, bw, p0, gt2, anc, chain_len)
+        assert sha(G.cpu().numpy().view(np.uint32)) == g["G"]
+        out, p0P = engine.interleave(sr, bw, bw2, p0)
+        assert sha(out.cpu().numpy()) == g["bwt"] and p0P == g["p0"]
