@@ -55,7 +55,7 @@ inline uint64_t num_bases(uint64_t n, int type) { return type == B3M_INPUT_PACTE
 
 // ---- kernel-family timing ---------------------------------------------------------------------
 enum KFam { KF_KEYS = 0, KF_RADIX_HIST, KF_SCAN, KF_RADIX_SCATTER, KF_TIES, KF_EMIT, KF_RANKBUILD,
-            KF_ANCHOR, KF_GAPWALK, KF_INTERLEAVE, KF_MISC, KF_COUNT };
+            KF_ANCHOR, KF_GAPWALK, KF_INTERLEAVE, KF_MISC, KF_MSD_HIST, KF_MSD_SCATTER, KF_LDS_SORT, KF_COUNT };
 extern const char *const kfam_names[KF_COUNT];
 
 struct Timeline {
@@ -100,29 +100,45 @@ void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &
                     Timeline *tl, uint32_t **k_res);
 
 // ---- block sort (row a7) ---------------------------------------------------------------------
+struct MsdTile { uint32_t in_off, count, hist_base, stride; };
+struct MsdWs {
+	uint32_t *hist = nullptr; uint64_t hist_cap = 0;        // flattened [bucket][digit][tile] counts / offsets
+	MsdTile *tiles = nullptr; uint64_t tiles_cap = 0;       // tile descriptors (device)
+	uint32_t *sub_start = nullptr;                           // 2^(D1+D2)+1 final bucket offsets
+	uint32_t *bucket_tab = nullptr;                          // per A bucket: start, hist_off, ntiles (3 x 2^D1)
+	uint32_t *overflow = nullptr; uint64_t overflow_cap = 0; // [0] = count, then bucket ids
+	uint32_t *scan_ws = nullptr;
+};
+uint64_t msd_ws_bytes(uint64_t cap);
+void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap);
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
-	uint64_t *keyA = nullptr, *keyB = nullptr;
-	uint32_t *idxA = nullptr, *idxB = nullptr;
-	uint8_t *bnd = nullptr;           // group-head flags
-	uint32_t *flag = nullptr;         // scan scratch (cap+1)
-	uint32_t *gid = nullptr;          // group head index per position
-	// compacted tie set (capacity cap)
-	uint32_t *U = nullptr;
+	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
+	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
+	uint32_t *t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each)
 	uint32_t *scan_ws = nullptr;
 	RadixWs radix;
+	MsdWs msd;
 	uint32_t *d_scalars = nullptr;    // small device scalars
-	uint32_t *h_scalars = nullptr;    // pinned host mirror
 };
 uint64_t blocksort_ws_bytes(uint64_t cap);
 void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap);
 struct BlockSortOut {
 	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions
-	uint64_t p0 = 0;
 	uint64_t tie_rounds = 0, tie_elements = 0;
+	uint64_t msd_overflow_buckets = 0;
+	bool used_msd = false;
 };
+// sorts the block and writes its BWT (d_bwt, len bytes) and p0 (device u32: rank of S_start)
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s,
-                Timeline *tl, BlockSortOut &out);
+                Timeline *tl, BlockSortOut &out, uint8_t *d_bwt, uint32_t *d_p0);
+void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out);
+bool msd_applicable(const TextView &T, uint64_t len);
+void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
+                    uint8_t *d_bwt, uint32_t *d_p0);
+uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
+                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left);
+void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s);
 // products of a sorted block
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt,
               uint32_t *d_p0 /*device scalar*/, hipStream_t s);

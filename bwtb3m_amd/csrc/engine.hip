@@ -12,7 +12,8 @@ static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
 const char *const kfam_names[KF_COUNT] = {"keys", "radix_hist", "scan", "radix_scatter", "ties", "emit",
-                                          "rank_build", "anchor_rank", "gap_walk", "interleave", "misc"};
+                                          "rank_build", "anchor_rank", "gap_walk", "interleave", "misc",
+                                          "msd_hist", "msd_scatter", "lds_sort"};
 
 // ---- Timeline ------------------------------------------------------------------------------------
 hipEvent_t Timeline::get()
@@ -365,12 +366,11 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	for (uint64_t k = 0; k < B; ++k) {
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
-		block_sort(T, lf.a, lf.m, p->bs, s, tl, so);
+		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k);
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;
 		{
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
-			emit_bwt(T, so.d_sa, lf.m, lf.a, p->d_bwt[0] + lf.a, p->d_p0tmp + k, s);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
 			histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
 			if (p->isarate)
@@ -537,9 +537,9 @@ int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start
 	DevBuf ws(blocksort_ws_bytes(len));
 	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
 	BlockSortOut so;
-	block_sort(pt.T, start, len, bs, s, nullptr, so);
-	DevBuf sc(64);
-	emit_bwt(pt.T, so.d_sa, len, start, d_bwt_out, sc.as<uint32_t>(), s);
+	DevBuf sc(64), bwt_tmp(d_bwt_out ? 16 : len);
+	uint8_t *bw = d_bwt_out ? d_bwt_out : bwt_tmp.as<uint8_t>();
+	block_sort(pt.T, start, len, bs, s, nullptr, so, bw, sc.as<uint32_t>());
 	uint32_t p0 = 0;
 	B3M_HIP(hipMemcpyAsync(&p0, sc.p, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
@@ -794,14 +794,14 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
 	DevBuf ws(blocksort_ws_bytes(len));
 	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
 	BlockSortOut so;
-	block_sort(pt.T, start, len, bs, s, nullptr, so);
 	DevBuf sc(64);     // [0] p0 u32, [2..3] p0 pair u64, [4] end rank, [6..7] end position u64
 	uint32_t *d_p0 = sc.as<uint32_t>();
 	uint64_t *d_pair = (uint64_t *)((uint8_t *)sc.p + 8);
 	uint32_t *d_er = (uint32_t *)((uint8_t *)sc.p + 32);
 	uint64_t *d_ep = (uint64_t *)((uint8_t *)sc.p + 40);
 	B3M_HIP(hipMemsetAsync(sc.p, 0, 64, s));
-	emit_bwt(pt.T, so.d_sa, len, start, d_bwt_out, d_p0, s);
+	DevBuf bwt_tmp(d_bwt_out ? 16 : len);
+	block_sort(pt.T, start, len, bs, s, nullptr, so, d_bwt_out ? d_bwt_out : bwt_tmp.as<uint8_t>(), d_p0);
 	if (d_gt_abs) {
 		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, d_p0, d_pair, start);
 		hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, s, so.d_sa, len, start, d_p0, d_gt_abs);

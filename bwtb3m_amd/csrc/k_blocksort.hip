@@ -55,31 +55,39 @@ __global__ __launch_bounds__(256) void k_keys_generic(TextView T, uint64_t start
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: tie groups
+// K3/K4: tie groups and key-extension rounds, on a shrinking list
+//
+// State of a round: U[s] = positions (ascending) of the suffixes still tied, gid[s] = label of the
+// tie group of slot s (equal label <=> same group; labels ascend with s).  A round gives every
+// listed suffix the key of its next K symbols, sorts the list by (group, key), writes the suffixes
+// back into their group's slots and splits the groups where keys differ; slots whose group became
+// a singleton leave the list.  Only the list is touched, never the whole block.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init_bnd(const uint64_t *keys, uint64_t len, uint8_t *bnd)
+// head labels from the sorted first keys: hid[r] = r if keys[r] starts a new group else 0
+__global__ void k_heads_from_keys(const uint64_t *keys, uint64_t len, uint32_t *hid)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= len) return;
-	bnd[r] = (r == 0) || keys[r] != keys[r - 1];
+	hid[r] = (r == 0 || keys[r] != keys[r - 1]) ? (uint32_t)r : 0u;
 }
-// flag[r] = 1 if r belongs to a tie group of size >= 2 ; head[r] = r if bnd[r] else 0 (for the max-scan)
-__global__ void k_mark_ties(const uint8_t *bnd, uint64_t len, uint32_t *flag, uint32_t *head)
+// after the max-scan hid[s] = slot of the head of s's group.  flag[s] = 1 if the group has >= 2 members
+__global__ void k_tie_flags(const uint32_t *hid, uint64_t u, uint32_t *flag)
 {
-	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= len) return;
-	bool b0 = bnd[r], b1 = (r + 1 == len) ? true : (bool)bnd[r + 1];
-	flag[r] = (b0 && b1) ? 0u : 1u;
-	head[r] = b0 ? (uint32_t)r : 0u;
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > u) return;
+	if (s == u) { flag[s] = 0; return; }
+	bool h0 = hid[s] == (uint32_t)s, h1 = (s + 1 == u) ? true : (hid[s + 1] == (uint32_t)(s + 1));
+	flag[s] = (h0 && h1) ? 0u : 1u;
 }
-__global__ void k_compact(const uint32_t *flag_scan, const uint8_t *bnd, uint64_t len, uint32_t *U)
+// compaction: U == nullptr means the identity list (first round after the radix sort)
+__global__ void k_tie_compact(const uint32_t *flag_scan, const uint32_t *hid, const uint32_t *U, uint64_t u, uint32_t *U2, uint32_t *gid2)
 {
-	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= len) return;
-	bool b0 = bnd[r], b1 = (r + 1 == len) ? true : (bool)bnd[r + 1];
-	if (!(b0 && b1)) U[flag_scan[r]] = (uint32_t)r;
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	bool h0 = hid[s] == (uint32_t)s, h1 = (s + 1 == u) ? true : (hid[s + 1] == (uint32_t)(s + 1));
+	if (!(h0 && h1)) { uint32_t p = flag_scan[s]; U2[p] = U ? U[s] : (uint32_t)s; gid2[p] = hid[s]; }
 }
-// keys of the next K symbols for the compacted tie set; value = slot in U
+// keys of the next K symbols for the list; value = slot
 __global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, uint64_t u, uint64_t depth, uint64_t *nk, uint32_t *slot)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,14 +95,14 @@ __global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, u
 	nk[s] = key_at(T, idx[U[s]], depth);
 	slot[s] = (uint32_t)s;
 }
-// second sort key: group id of the slot (as u64 so that the pair sorter can be reused)
-__global__ void k_tie_gidkeys(const uint32_t *U, const uint32_t *gid, const uint32_t *slot_sorted, uint64_t u, uint64_t *gk)
+// second sort key: group label of the slot (as u64 so that the pair sorter can be reused)
+__global__ void k_tie_gidkeys(const uint32_t *gid, const uint32_t *slot_sorted, uint64_t u, uint64_t *gk)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
-	gk[s] = gid[U[slot_sorted[s]]];
+	gk[s] = gid[slot_sorted[s]];
 }
-// gather (idx, newkey) of the final order into temporaries (the key is recomputed from the text)
+// gather (idx, key) of the final order into temporaries (the key is recomputed from the text)
 __global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx, const uint32_t *slot_final,
                              uint64_t u, uint64_t depth, uint32_t *tmp_idx, uint64_t *tmp_key)
 {
@@ -104,18 +112,26 @@ __global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx,
 	tmp_idx[s] = i;
 	tmp_key[s] = key_at(T, i, depth);
 }
-// write back into the tie slots (ascending positions) and refine the boundaries
-__global__ void k_tie_writeback(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint64_t *tmp_key,
-                                uint64_t u, uint32_t *idx, uint8_t *bnd)
+// write back into the tie slots (the sorted group labels equal the old ones slot by slot) and
+// mark the new group heads
+__global__ void k_tie_apply(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint64_t *tmp_key,
+                            uint64_t u, uint32_t *idx, uint32_t *hid)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	idx[U[s]] = tmp_idx[s];
+	bool head = (s == 0) || gid[s] != gid[s - 1] || tmp_key[s] != tmp_key[s - 1];
+	hid[s] = head ? (uint32_t)s : 0u;
+}
+__global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, uint64_t start, uint8_t *bwt, uint32_t *p0)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	uint32_t r = U[s];
-	idx[r] = tmp_idx[s];
-	if (s > 0) {
-		uint32_t rp = U[s - 1];
-		if (gid[rp] == gid[r] && tmp_key[s - 1] != tmp_key[s]) bnd[r] = 1;
-	}
+	uint64_t i = sa[r];
+	uint64_t j = i ? i - 1 : T.n - 1;
+	bwt[r] = (uint8_t)sym_at(T, j);
+	if (i == start) *p0 = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,11 +200,11 @@ static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 uint64_t blocksort_ws_bytes(uint64_t cap)
 {
 	uint64_t b = 0;
-	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/idx ping-pong
-	b += al(cap + 1);                                   // bnd
-	b += 3 * al(4 * (cap + 1));                         // flag, gid, U
+	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
+	b += 5 * al(4 * (cap + 1));                         // tie-list buffers
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
+	b += al(msd_ws_bytes(cap));
 	b += 4096;
 	return b;
 }
@@ -200,21 +216,57 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap)
 	ws.keyB = (uint64_t *)p; p += al(8 * cap);
 	ws.idxA = (uint32_t *)p; p += al(4 * cap);
 	ws.idxB = (uint32_t *)p; p += al(4 * cap);
-	ws.bnd = p; p += al(cap + 1);
-	ws.flag = (uint32_t *)p; p += al(4 * (cap + 1));
-	ws.gid = (uint32_t *)p; p += al(4 * (cap + 1));
-	ws.U = (uint32_t *)p; p += al(4 * (cap + 1));
+	for (int i = 0; i < 5; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
+	msd_ws_carve(ws.msd, p, cap); p += al(msd_ws_bytes(cap));
 	ws.d_scalars = (uint32_t *)p;
 }
 
-void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out)
+// Key-extension rounds on the list (U, gid) of u tied slots, starting with symbols
+// [depth0*K, ...).  idx = the suffix array being built.  Buffers: kx/ky (u64, cap >= u) and six
+// u32 buffers of cap+1: B[0]=U, B[1]=gid, B[2..3] sort values, B[4]=hid, B[5]=flag.
+// Returns the number of rounds run; *left = tied slots remaining (equal rotations) .
+uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
+                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left)
 {
-	B3M_REQUIRE(len <= ws.cap, "block_sort: block larger than workspace");
-	B3M_REQUIRE(T.n < (1ull << 32), "n >= 2^32 is not supported yet (u32 positions)");
-	out = BlockSortOut();
-	if (len == 0) return;
+	const uint64_t K = (uint64_t)key_symbols(T.type);
+	int gbits = 1; while ((1ull << gbits) < len_for_labels + 1 && gbits < 32) ++gbits;
+	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
+	uint64_t rounds = 0;
+	uint32_t h_u = 0;
+	for (uint64_t depth = depth0; u > 0; ++depth) {
+		if (depth * K >= T.n) break;                   // compared >= n symbols: equal rotations
+		++rounds;
+		hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, depth, kx, vx);
+		uint64_t *rk; uint32_t *rv;
+		radix_sort_u64(kx, vx, ky, vy, u, key_bits(T.type), radix, s, nullptr, &rk, &rv);
+		uint64_t *gk = (rk == kx) ? ky : kx;
+		uint32_t *vidle = (rv == vx) ? vy : vx;
+		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, gid, rv, u, gk);
+		uint64_t *rk2; uint32_t *rv2;
+		radix_sort_u64(gk, rv, rk, vidle, u, gbits, radix, s, nullptr, &rk2, &rv2);
+		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
+		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
+		hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, rv2, u, depth, tmp_idx, tmp_key);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, tmp_key, u, idx, hid);
+		inclusive_max_u32(hid, u, scan_ws, s);
+		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
+		exclusive_sum_u32(flag, u + 1, scan_ws, s);
+		B3M_HIP(hipMemcpyAsync(&h_u, flag + u, 4, hipMemcpyDeviceToHost, s));
+		// the two value buffers are free now: the compacted list goes there, then the pairs swap
+		uint32_t *U2 = vx, *gid2 = vy;
+		hipLaunchKernelGGL(k_tie_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, U, u, U2, gid2);
+		B3M_HIP(hipStreamSynchronize(s));
+		vx = U; vy = gid; U = U2; gid = gid2;
+		u = h_u;
+	}
+	if (left) *left = u;
+	return rounds;
+}
+
+void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out)
+{
 	// K1 keys
 	{
 		Scope sc(tl, KF_KEYS, len / 4 + 12 * len);
@@ -230,51 +282,50 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	radix_sort_u64(ws.keyA, ws.idxA, ws.keyB, ws.idxB, len, key_bits(T.type), ws.radix, s, tl, &k, &v);
 	uint64_t *k_other = (k == ws.keyA) ? ws.keyB : ws.keyA;
 	uint32_t *v_other = (v == ws.idxA) ? ws.idxB : ws.idxA;
-	// K3/K4 key-extension rounds for tie groups.  Buffers: the sorted keys are dead once the
-	// boundaries are known, so the two key arrays and (idle idx array, flag array) form the
-	// ping-pong pairs of the tie-set sorts; all have capacity >= len >= u.
-	const uint64_t K = (uint64_t)key_symbols(T.type);
-	{
-		Scope sc(tl, KF_TIES, 9 * len);
-		hipLaunchKernelGGL(k_init_bnd, dim3(nblk(len)), dim3(256), 0, s, k, len, ws.bnd);
-	}
-	uint64_t *kx = k, *ky = k_other;
-	uint32_t *vx = v_other, *vy = ws.flag;
-	int gbits = 1; while ((1ull << gbits) < len && gbits < 32) ++gbits;
+	// K3 tie groups of the sorted keys -> list
+	uint32_t *hid = ws.t[3], *flag = ws.t[4];
 	uint32_t h_u = 0;
-	for (uint64_t depth = 1;; ++depth) {
-		{
-			Scope sc(tl, KF_TIES, 10 * len);
-			hipLaunchKernelGGL(k_mark_ties, dim3(nblk(len)), dim3(256), 0, s, ws.bnd, len, ws.flag, ws.gid);
-			B3M_HIP(hipMemsetAsync(ws.flag + len, 0, 4, s));
-			exclusive_sum_u32(ws.flag, len + 1, ws.scan_ws, s);
-			B3M_HIP(hipMemcpyAsync(&h_u, ws.flag + len, 4, hipMemcpyDeviceToHost, s));
-		}
+	{
+		Scope sc(tl, KF_TIES, 24 * len);
+		hipLaunchKernelGGL(k_heads_from_keys, dim3(nblk(len)), dim3(256), 0, s, k, len, hid);
+		inclusive_max_u32(hid, len, ws.scan_ws, s);
+		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(len + 1)), dim3(256), 0, s, hid, len, flag);
+		exclusive_sum_u32(flag, len + 1, ws.scan_ws, s);
+		B3M_HIP(hipMemcpyAsync(&h_u, flag + len, 4, hipMemcpyDeviceToHost, s));
+		hipLaunchKernelGGL(k_tie_compact, dim3(nblk(len)), dim3(256), 0, s, flag, hid, (const uint32_t *)nullptr, len, ws.t[0], ws.t[1]);
 		B3M_HIP(hipStreamSynchronize(s));
-		uint64_t u = h_u;
-		if (u == 0) break;
-		if (depth == 1) out.tie_elements = u;
-		if (depth * K >= T.n) break;                   // compared >= n symbols: equal rotations
-		out.tie_rounds = depth;
-		Scope sc(tl, KF_TIES, 8 * len + 60 * u);
-		inclusive_max_u32(ws.gid, len, ws.scan_ws, s);
-		hipLaunchKernelGGL(k_compact, dim3(nblk(len)), dim3(256), 0, s, ws.flag, ws.bnd, len, ws.U);
-		// (next-K-symbols key, slot) sorted by key, then stably by tie group
-		hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, ws.U, v, u, depth, kx, vx);
-		uint64_t *rk; uint32_t *rv;
-		radix_sort_u64(kx, vx, ky, vy, u, key_bits(T.type), ws.radix, s, nullptr, &rk, &rv);
-		uint64_t *gk = (rk == kx) ? ky : kx;
-		uint32_t *vidle = (rv == vx) ? vy : vx;
-		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, ws.U, ws.gid, rv, u, gk);
-		uint64_t *rk2; uint32_t *rv2;
-		radix_sort_u64(gk, rv, rk, vidle, u, gbits, ws.radix, s, nullptr, &rk2, &rv2);
-		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
-		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
-		hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, ws.U, v, rv2, u, depth, tmp_idx, tmp_key);
-		hipLaunchKernelGGL(k_tie_writeback, dim3(nblk(u)), dim3(256), 0, s, ws.U, ws.gid, tmp_idx, tmp_key, u, v, ws.bnd);
+	}
+	out.tie_elements = h_u;
+	if (h_u) {
+		// K4 rounds; the sorted keys are dead, so both key arrays serve as sort buffers
+		Scope sc(tl, KF_TIES, 60ull * h_u);
+		uint32_t *B[6] = {ws.t[0], ws.t[1], v_other, ws.t[2], ws.t[3], ws.t[4]};
+		uint64_t left = 0;
+		out.tie_rounds = tie_rounds(T, v, h_u, 1, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left);
 	}
 	B3M_HIP(hipGetLastError());
 	out.d_sa = v;
+}
+
+void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
+                uint8_t *d_bwt, uint32_t *d_p0)
+{
+	B3M_REQUIRE(len <= ws.cap, "block_sort: block larger than workspace");
+	B3M_REQUIRE(T.n < (1ull << 32), "n >= 2^32 is not supported yet (u32 positions)");
+	out = BlockSortOut();
+	if (len == 0) return;
+	if (msd_applicable(T, len)) {
+		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0);
+		return;
+	}
+	block_sort_lsd(T, start, len, ws, s, tl, out);
+	Scope sc(tl, KF_EMIT, 6 * len);
+	emit_bwt(T, out.d_sa, len, start, d_bwt, d_p0, s);
+}
+
+void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)
+{
+	if (u) hipLaunchKernelGGL(k_emit_bwt_list, dim3(nblk(u)), dim3(256), 0, s, T, U, u, d_sa, start, d_bwt, d_p0);
 }
 
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)

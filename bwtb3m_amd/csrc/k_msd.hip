@@ -1,0 +1,474 @@
+// k_msd.hip -- the fast block sort for 2-bit inputs (pac/pacterm): two MSD partition passes of
+// 8-byte records followed by an in-LDS sort of every final bucket.
+//
+// Why: an LSD radix sort of (u64 key, u32 position) pairs moves ~24 B per suffix per pass plus a
+// gather for the BWT symbol (~240 B/suffix in all).  Here a suffix is ONE 8-byte record
+//        [ 29 key bits | 3 bits predecessor symbol | 32 bits position ]
+// built straight from the packed text, partitioned twice by the leading bits of its rotation
+// (D1 then D2 bits, ~2^21 final buckets of 1-2 K suffixes), and each final bucket is sorted inside
+// the LDS of one workgroup, ties resolved exactly against the text, and written as BWT symbol +
+// suffix-array entry.  HBM traffic: 0.5 (text, twice) + 8 + 8 + 16 + 8 + 5 = ~46 B per suffix.
+//
+//   pass A (k_msd_pass<true,*>)  : text -> records, partitioned by the first D1 bits
+//   pass B (k_msd_pass<false,*>) : records of every A bucket partitioned by the next D2 bits
+//   pass C (k_lds_sort)          : one workgroup per final bucket: stable LDS radix sort on the
+//                                  remaining 29-D2 key bits (64-lane ballot match-any ranking),
+//                                  exact tie resolution, emit
+// Partition order inside a bucket is irrelevant (the next level re-sorts), so slots come from LDS
+// atomics; each workgroup owns a "super tile" of 64 Ki records processed in 4 Ki chunks through
+// LDS so that every digit's run leaves the CU as one contiguous segment, and the histogram matrix
+// has only len*bins/65536 entries.
+// Buckets larger than the LDS capacity, or tie groups deeper than the in-kernel limit (skewed or
+// repetitive input), are finished by the list-based key-extension rounds of k_blocksort.hip.
+// pacterm: the terminator and everything behind it read as base 0 for bucketing; the exact tie
+// resolution (key_at with terminator tags) restores "terminator < A" where it matters.
+#include "b3m_internal.h"
+#include "b3m_text.h"
+#include <algorithm>
+#include <vector>
+
+namespace b3m {
+
+constexpr int MSD_THREADS = 256;
+constexpr int MSD_ITEMS = 16;
+constexpr int MSD_CHUNK = MSD_THREADS * MSD_ITEMS;     // 4096 records staged through LDS at a time
+constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per workgroup
+constexpr int MSD_MAXBINS = 2048;
+constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
+constexpr int LS_CAP = 3072;                           // final bucket capacity of the LDS sort
+constexpr int LS_ROUNDS = LS_CAP / MSD_THREADS;        // 12 rounds of 64 per wave
+constexpr int LS_TIE_CAP = 24;                         // tie groups up to this size are resolved in-kernel
+constexpr int REC_KEY_SHIFT = 35;
+constexpr int REC_KEY_BITS = 29;
+
+static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
+static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
+
+struct MsdDigits { int D1, D2; };
+static MsdDigits msd_digits(uint64_t len)
+{
+	int t = 0; while ((len >> (t + 1)) >= 1024) ++t;     // t = floor(log2(len/1024)): buckets of 1-2 K
+	t = std::max(8, std::min(22, t));
+	MsdDigits d; d.D1 = (t + 1) / 2; d.D2 = t - d.D1;
+	return d;
+}
+
+bool msd_applicable(const TextView &T, uint64_t len)
+{
+	return (T.type == B3M_INPUT_PAC || T.type == B3M_INPUT_PACTERM) && len >= MSD_MIN_LEN;
+}
+
+uint64_t msd_ws_bytes(uint64_t cap)
+{
+	if (cap < MSD_MIN_LEN) return 4096;
+	uint64_t tiles = cap / MSD_SUPER + MSD_MAXBINS + 2;
+	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
+	uint64_t nb = (1ull << 22) + 2;
+	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * nb) + al(4 * 3 * MSD_MAXBINS) + al(4 * (nb + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
+}
+void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
+{
+	if (cap < MSD_MIN_LEN) { ws = MsdWs(); return; }
+	uint8_t *p = (uint8_t *)base;
+	uint64_t tiles = cap / MSD_SUPER + MSD_MAXBINS + 2;
+	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
+	uint64_t nb = (1ull << 22) + 2;
+	ws.hist = (uint32_t *)p; ws.hist_cap = hist; p += al(4 * hist);
+	ws.tiles = (MsdTile *)p; ws.tiles_cap = tiles; p += al(sizeof(MsdTile) * tiles);
+	ws.sub_start = (uint32_t *)p; p += al(4 * nb);
+	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_MAXBINS);
+	ws.overflow = (uint32_t *)p; ws.overflow_cap = nb; p += al(4 * (nb + 1));
+	ws.scan_ws = (uint32_t *)p;
+}
+
+// 64 bits = the 32 bases from `pos` on, with the bucketing convention for the end of the text:
+// pacterm: the terminator and everything behind it read as 0; pac: circular.
+__device__ __forceinline__ uint64_t window_safe(const TextView &T, uint64_t pos)
+{
+	if (pos + 32 <= T.nbases) return window32(T, pos);
+	uint64_t x = 0;
+	if (T.type == B3M_INPUT_PAC) {
+		uint64_t p = pos % T.n;
+		for (int t = 0; t < 32; ++t) { x = (x << 2) | base_at(T, p); if (++p == T.n) p = 0; }
+	} else {
+		for (int t = 0; t < 32; ++t) { uint64_t p = pos + t; x = (x << 2) | (p < T.nbases ? base_at(T, p) : 0u); }
+	}
+	return x;
+}
+// output symbol preceding position i (the BWT symbol of the rotation starting at i)
+__device__ __forceinline__ uint32_t pred_sym(const TextView &T, uint64_t i)
+{
+	if (T.type == B3M_INPUT_PACTERM) return i == 0 ? 0u : base_at(T, i - 1) + 1u;     // T[n-1] is the terminator
+	return base_at(T, i ? i - 1 : T.n - 1);
+}
+__device__ __forceinline__ uint64_t make_rec(uint64_t x, int D1, uint32_t pred, uint32_t idx, uint32_t *dig)
+{
+	*dig = (uint32_t)(x >> (64 - D1));
+	uint64_t kf = (x >> (64 - D1 - REC_KEY_BITS)) & ((1ull << REC_KEY_BITS) - 1);
+	return (kf << REC_KEY_SHIFT) | ((uint64_t)pred << 32) | idx;
+}
+
+struct MsdArgs {
+	TextView T; uint64_t start, len;
+	uint64_t P0;                 // FROM_TEXT: absolute position of item 0 of tile 0 (multiple of 16)
+	const uint64_t *rec_in;      // !FROM_TEXT
+	uint64_t *rec_out;
+	const MsdTile *tiles;        // null: regular tiling (pass A)
+	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
+	int D;                       // digit bits of this pass
+};
+
+template <bool FROM_TEXT, bool COUNT_ONLY>
+__global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
+{
+	__shared__ uint32_t cnt[MSD_MAXBINS];
+	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
+	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
+	__shared__ uint64_t srec[COUNT_ONLY ? 1 : MSD_CHUNK];
+	__shared__ uint16_t sdig[COUNT_ONLY ? 1 : MSD_CHUNK];
+	__shared__ uint32_t wsum[8];
+	const uint32_t tid = threadIdx.x;
+	const int bins = 1 << A.D;
+	MsdTile tile;
+	if (A.tiles) tile = A.tiles[blockIdx.x];
+	else { tile.in_off = blockIdx.x * (uint32_t)MSD_SUPER; tile.count = MSD_SUPER; tile.hist_base = blockIdx.x; tile.stride = gridDim.x; }
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; }
+	else { for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
+	__syncthreads();
+	const uint32_t nchunks = (tile.count + MSD_CHUNK - 1) / MSD_CHUNK;
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const uint32_t cbase = c * MSD_CHUNK;
+		const uint32_t cn = tile.count - cbase < (uint32_t)MSD_CHUNK ? tile.count - cbase : (uint32_t)MSD_CHUNK;
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; __syncthreads(); }
+		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS]; uint32_t vmask = 0;
+		if (FROM_TEXT) {
+			// thread = one 32-bit word of packed text = 16 consecutive positions
+			uint64_t pos0 = A.P0 + tile.in_off + cbase + (uint64_t)tid * 16;
+			const uint64_t end = A.start + A.len;
+			if (pos0 < end && pos0 + 16 > A.start) {
+				bool fast = pos0 + 16 + 32 <= A.T.nbases;
+				uint64_t w0 = 0, w1 = 0, w2 = 0;
+				if (fast) { const uint8_t *p = A.T.b + ((pos0 >> 4) << 2); w0 = be32(p); w1 = be32(p + 4); w2 = be32(p + 8); }
+				uint64_t hi = (w0 << 32) | w1;
+				#pragma unroll
+				for (int s = 0; s < MSD_ITEMS; ++s) {
+					uint64_t i = pos0 + s;
+					if (i >= A.start && i < end) {
+						uint64_t x = fast ? (s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi) : window_safe(A.T, i);
+						uint32_t pr;
+						if (fast && s > 0) { pr = (uint32_t)(w0 >> (32 - 2 * s)) & 3u; if (A.T.type == B3M_INPUT_PACTERM) pr += 1; }
+						else pr = pred_sym(A.T, i);
+						rec[s] = make_rec(x, A.D, pr, (uint32_t)i, &dg[s]);
+						vmask |= 1u << s;
+					}
+				}
+			}
+		} else {
+			#pragma unroll
+			for (int s = 0; s < MSD_ITEMS; ++s) {
+				uint32_t e = cbase + s * MSD_THREADS + tid;
+				if (e < tile.count) {
+					rec[s] = A.rec_in[(uint64_t)tile.in_off + e];
+					dg[s] = (uint32_t)(rec[s] >> (64 - A.D));
+					vmask |= 1u << s;
+				}
+			}
+		}
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
+		if (COUNT_ONLY) continue;
+		__syncthreads();
+		// exclusive scan of cnt over the bins -> start of every digit run inside the chunk
+		{
+			const int per = MSD_MAXBINS / MSD_THREADS;        // 8 consecutive bins per thread
+			uint32_t loc[per]; uint32_t sum = 0;
+			#pragma unroll
+			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cnt[b] : 0; sum += loc[k]; }
+			uint32_t inc = wave_incl_sum(sum);
+			uint32_t w = tid >> 6, l = tid & 63;
+			if (l == 63) wsum[w] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
+			uint32_t run = pre + inc - sum;
+			#pragma unroll
+			for (int k = 0; k < per; ++k) { int b = tid * per + k; if (b < bins) binstart[b] = run; run += loc[k]; }
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; sdig[p] = (uint16_t)dg[s]; }
+		__syncthreads();
+		// number of valid records of this chunk = binstart[last] + cnt[last]; copy out run by run
+		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
+		(void)cn;
+		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) {
+			uint32_t d = sdig[p];
+			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = srec[p];
+		}
+		__syncthreads();
+		for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] += cnt[b];
+		__syncthreads();
+	}
+	if (COUNT_ONLY) {
+		__syncthreads();
+		for (int b = tid; b < bins; b += MSD_THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
+	}
+}
+
+// out[b] = scanned[b * stride] : start of A bucket b
+__global__ void k_gather_strided(const uint32_t *src, uint32_t stride, uint32_t count, uint32_t *out)
+{
+	uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < count) out[b] = src[(uint64_t)b * stride];
+}
+// final bucket offsets: bucket_tab = {start[bins1], hist_off[bins1], ntiles[bins1]}
+__global__ void k_sub_starts(const uint32_t *scanned, const uint32_t *bucket_tab, int D1, int D2, uint32_t len, uint32_t *sub_start)
+{
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t nb = 1u << (D1 + D2);
+	if (g > nb) return;
+	if (g == nb) { sub_start[g] = len; return; }
+	uint32_t b = g >> D2, d = g & ((1u << D2) - 1), bins1 = 1u << D1;
+	uint32_t nt = bucket_tab[2 * bins1 + b];
+	sub_start[g] = nt ? scanned[bucket_tab[bins1 + b] + (uint64_t)d * nt] : bucket_tab[b];
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass C: in-LDS sort of one final bucket per workgroup
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, int sortbits,
+                                                            uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0, uint32_t *overflow,
+                                                            uint32_t overflow_cap)
+{
+	__shared__ uint64_t bufA[LS_CAP];
+	__shared__ uint64_t bufB[LS_CAP];
+	__shared__ uint32_t whist[MSD_THREADS / 64][256];
+	__shared__ uint32_t wsum[8];
+	__shared__ int ovf;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t b0 = sub_start[blockIdx.x], b1 = sub_start[blockIdx.x + 1];
+	const uint32_t m = b1 - b0;
+	if (m == 0) return;
+	if (m > (uint32_t)LS_CAP) {
+		if (tid == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = blockIdx.x; }
+		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)rec[b0 + e];
+		return;
+	}
+	for (uint32_t e = tid; e < m; e += MSD_THREADS) bufA[e] = rec[b0 + e];
+	if (tid == 0) ovf = 0;
+	uint64_t *src = bufA, *dst = bufB;
+	// each wave owns a contiguous range, processed in rounds of 64 (keeps the passes stable)
+	const uint32_t per_wave = ((m + MSD_THREADS - 1) / MSD_THREADS) * 64;
+	const uint32_t wbeg = wave * per_wave, wend = (wbeg + per_wave < m) ? wbeg + per_wave : m;
+	for (int done = 0; done < sortbits; done += 8) {
+		const int bits = sortbits - done < 8 ? sortbits - done : 8;
+		const int shift = REC_KEY_SHIFT + done;
+		const uint32_t mask = (1u << bits) - 1;
+		for (int i = tid; i < (MSD_THREADS / 64) * 256; i += MSD_THREADS) ((uint32_t *)whist)[i] = 0;
+		__syncthreads();
+		uint32_t rnk[LS_ROUNDS];
+		volatile uint32_t *wh = whist[wave];
+		#pragma unroll
+		for (int t = 0; t < LS_ROUNDS; ++t) {
+			uint32_t e = wbeg + t * 64 + lane;
+			bool valid = e < wend;
+			uint32_t d = valid ? ((uint32_t)(src[e] >> shift) & mask) : 0u;
+			uint64_t mm = __ballot(valid);
+			#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				if (b < bits) { uint64_t bal = __ballot((d >> b) & 1u); mm &= ((d >> b) & 1u) ? bal : ~bal; }
+			}
+			uint32_t below = __popcll(mm & ((1ull << lane) - 1ull));
+			uint32_t cntm = __popcll(mm);
+			uint32_t old = 0;
+			if (valid && below == 0) { old = wh[d]; wh[d] = old + cntm; }
+			int leader = mm ? (__ffsll((long long)mm) - 1) : 0;
+			old = __shfl(old, leader, 64);
+			rnk[t] = old + below;
+		}
+		__syncthreads();
+		{
+			uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
+			uint32_t tot = c0 + c1 + c2 + c3;
+			uint32_t inc = wave_incl_sum(tot);
+			if (lane == 63) wsum[wave] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+			uint32_t ex = pre + inc - tot;
+			whist[0][tid] = ex; whist[1][tid] = ex + c0; whist[2][tid] = ex + c0 + c1; whist[3][tid] = ex + c0 + c1 + c2;
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int t = 0; t < LS_ROUNDS; ++t) {
+			uint32_t e = wbeg + t * 64 + lane;
+			if (e < wend) { uint64_t k = src[e]; uint32_t d = (uint32_t)(k >> shift) & mask; dst[whist[wave][d] + rnk[t]] = k; }
+		}
+		__syncthreads();
+		uint64_t *tmp = src; src = dst; dst = tmp;
+	}
+	if (sortbits <= 0) __syncthreads();
+	// exact resolution of groups with equal key bits (rare on random text): the head's thread
+	// insertion-sorts its group in place by full rotation comparison
+	for (uint32_t e = tid; e < m; e += MSD_THREADS) {
+		uint64_t kf = src[e] >> REC_KEY_SHIFT;
+		bool same_next = (e + 1 < m) && (src[e + 1] >> REC_KEY_SHIFT) == kf;
+		bool same_prev = (e > 0) && (src[e - 1] >> REC_KEY_SHIFT) == kf;
+		if (same_next && !same_prev) {
+			uint32_t g = 2;
+			while (e + g < m && (src[e + g] >> REC_KEY_SHIFT) == kf && g <= (uint32_t)LS_TIE_CAP) ++g;
+			if (g > (uint32_t)LS_TIE_CAP) { ovf = 1; }
+			else {
+				for (uint32_t i = 1; i < g; ++i) {
+					uint64_t x = src[e + i]; uint32_t j = i;
+					while (j > 0) {
+						uint64_t y = src[e + j - 1];
+						if (compare_rotations(T, (uint32_t)y, (uint32_t)x) <= 0) break;
+						src[e + j] = y; --j;
+					}
+					src[e + j] = x;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (ovf) {
+		if (tid == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = blockIdx.x; }
+		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)src[e];
+		return;
+	}
+	for (uint32_t e = tid; e < m; e += MSD_THREADS) {
+		uint64_t r = src[e];
+		uint32_t i = (uint32_t)r;
+		sa[b0 + e] = i;
+		bwt[b0 + e] = (uint8_t)((r >> 32) & 7u);
+		if (i == (uint32_t)start) *p0 = b0 + e;
+	}
+}
+
+// list of the suffix-array slots of the overflow buckets: U[s] = slot, gid[s] = bucket start
+__global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, uint32_t nov, uint64_t total, uint32_t *U, uint32_t *gid)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= total) return;
+	uint32_t lo = 0, hi = nov;          // last j with off[j] <= s
+	while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= s) lo = mid; else hi = mid; }
+	U[s] = b0[lo] + (uint32_t)(s - off[lo]);
+	if (gid) gid[s] = b0[lo];
+}
+
+void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
+                    uint8_t *d_bwt, uint32_t *d_p0)
+{
+	MsdWs &M = ws.msd;
+	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
+	const MsdDigits dg = msd_digits(len);
+	const int D1 = dg.D1, D2 = dg.D2;
+	const uint32_t bins1 = 1u << D1, bins2 = 1u << D2;
+	uint64_t *recA = ws.keyA, *recB = ws.keyB;
+	uint32_t *sa = ws.idxA;
+	out.used_msd = true;
+	// ---- pass A ----
+	const uint64_t P0 = start & ~15ull;
+	const uint64_t span = start + len - P0;
+	const uint32_t ntA = (uint32_t)((span + MSD_SUPER - 1) / MSD_SUPER);
+	B3M_REQUIRE((uint64_t)bins1 * ntA <= M.hist_cap, "MSD histogram workspace too small");
+	MsdArgs A{};
+	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_in = nullptr; A.rec_out = recA; A.tiles = nullptr; A.hist = M.hist; A.D = D1;
+	{
+		Scope sc(tl, KF_MSD_HIST, span / 4);
+		hipLaunchKernelGGL((k_msd_pass<true, true>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
+	}
+	{
+		Scope sc(tl, KF_SCAN, 8ull * bins1 * ntA);
+		exclusive_sum_u32(M.hist, (uint64_t)bins1 * ntA, M.scan_ws, s);
+	}
+	{
+		Scope sc(tl, KF_MSD_SCATTER, span / 4 + 8 * len);
+		hipLaunchKernelGGL((k_msd_pass<true, false>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
+	}
+	// ---- A bucket sizes -> tiles of pass B (host) ----
+	std::vector<uint32_t> bstart(bins1 + 1);
+	hipLaunchKernelGGL(k_gather_strided, dim3(nblk(bins1)), dim3(256), 0, s, M.hist, ntA, bins1, M.bucket_tab);
+	B3M_HIP(hipMemcpyAsync(bstart.data(), M.bucket_tab, 4 * bins1, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	bstart[bins1] = (uint32_t)len;
+	std::vector<MsdTile> tiles;
+	std::vector<uint32_t> tab(3 * bins1);
+	uint64_t hoff = 0;
+	for (uint32_t b = 0; b < bins1; ++b) {
+		uint32_t sz = bstart[b + 1] - bstart[b];
+		uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
+		tab[b] = bstart[b]; tab[bins1 + b] = (uint32_t)hoff; tab[2 * bins1 + b] = nt;
+		for (uint32_t j = 0; j < nt; ++j) {
+			MsdTile t; t.in_off = bstart[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
+			t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
+			tiles.push_back(t);
+		}
+		hoff += (uint64_t)bins2 * nt;
+	}
+	B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32), "MSD workspace too small for pass B");
+	B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipStreamSynchronize(s));      // tiles/tab are stack vectors: the copies must finish before they die
+	// ---- pass B ----
+	MsdArgs Bq{};
+	Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = recA; Bq.rec_out = recB; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = D2;
+	const uint32_t ntB = (uint32_t)tiles.size();
+	{
+		Scope sc(tl, KF_MSD_HIST, 8 * len);
+		hipLaunchKernelGGL((k_msd_pass<false, true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+	}
+	{
+		Scope sc(tl, KF_SCAN, 8ull * hoff);
+		exclusive_sum_u32(M.hist, hoff, M.scan_ws, s);
+	}
+	{
+		Scope sc(tl, KF_MSD_SCATTER, 16 * len);
+		hipLaunchKernelGGL((k_msd_pass<false, false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+	}
+	// ---- pass C ----
+	const uint32_t nfinal = 1u << (D1 + D2);
+	{
+		Scope sc(tl, KF_LDS_SORT, 13 * len);
+		hipLaunchKernelGGL(k_sub_starts, dim3(nblk((uint64_t)nfinal + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, D1, D2, (uint32_t)len, M.sub_start);
+		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
+		hipLaunchKernelGGL(k_lds_sort, dim3(nfinal), dim3(MSD_THREADS), 0, s, T, recB, M.sub_start, REC_KEY_BITS - D2, sa, d_bwt, start, d_p0,
+		                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap, nfinal));
+	}
+	uint32_t nov = 0;
+	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	out.msd_overflow_buckets = nov;
+	if (nov) {
+		// ---- fallback: oversized / deeply tied buckets go through the key-extension rounds ----
+		Scope sc(tl, KF_TIES, 0);
+		std::vector<uint32_t> ids(nov), sub(nfinal + 1);
+		B3M_HIP(hipMemcpyAsync(ids.data(), M.overflow + 1, 4ull * nov, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipMemcpyAsync(sub.data(), M.sub_start, 4ull * (nfinal + 1), hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		std::sort(ids.begin(), ids.end());
+		std::vector<uint32_t> off(nov + 1), b0(nov);
+		uint64_t total = 0;
+		for (uint32_t j = 0; j < nov; ++j) { off[j] = (uint32_t)total; b0[j] = sub[ids[j]]; total += sub[ids[j] + 1] - sub[ids[j]]; }
+		off[nov] = (uint32_t)total;
+		// the overflow table is dead now: reuse it for (off, b0)
+		B3M_REQUIRE(2ull * nov + 2 <= M.overflow_cap, "overflow table too small");
+		uint32_t *d_off = M.overflow, *d_b0 = M.overflow + nov + 1;
+		B3M_HIP(hipMemcpyAsync(d_off, off.data(), 4ull * (nov + 1), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(d_b0, b0.data(), 4ull * nov, hipMemcpyHostToDevice, s));
+		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
+		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[0], Bf[1]);
+		B3M_HIP(hipStreamSynchronize(s));
+		uint64_t left = 0;
+		out.tie_elements = total;
+		out.tie_rounds = tie_rounds(T, sa, total, 0, recA, recB, Bf, ws.scan_ws, ws.radix, len, s, &left);
+		// BWT symbols (and p0) of the slots finished here
+		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, ws.t[0], (uint32_t *)nullptr);
+		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
+	}
+	B3M_HIP(hipGetLastError());
+	out.d_sa = sa;
+}
+
+}  // namespace b3m

@@ -321,3 +321,48 @@ def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
         assert p.exitcode == 0
     res = [q.get() for _ in range(world)]
     assert all(ok for _, ok in res), res
+
+
+# ---------------------------------------------------------------------------------------------
+# the MSD block sort (blocks >= 2^18 symbols): oversized buckets and deep ties must fall back to
+# the key-extension rounds and still be exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+@pytest.mark.parametrize("kind", ["uniform", "repeat", "polyA", "periodic", "twosym"])
+def test_msd_block_sort_paths(gpu, oracle, itype, kind):
+    nb = (1 << 19) + 12345
+    if kind == "uniform":
+        b = oracle.synth_bases(nb, 31)
+    elif kind == "repeat":
+        b = oracle.synth_repeat_bases(nb, 32, unit=23, copies=3)
+    elif kind == "polyA":
+        b = oracle.synth_bases(nb, 33).copy()
+        b[1000:200000] = 0                       # one huge bucket + very deep ties
+        b[-40:] = 0                              # poly-A right before the terminator / wrap point
+    elif kind == "periodic":
+        b = np.tile(np.array([0, 1, 2, 3, 3, 1, 0, 2, 2, 1, 3], dtype=np.uint8), nb // 11 + 1)[:nb]
+    else:
+        b = (oracle.synth_bases(nb, 34) & 1).astype(np.uint8)   # only A/C: half-empty bucket space
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype)
+    assert np.array_equal(out, oracle.bwt(s)), kind
+    if itype == "pacterm":
+        assert out[res["p0"]] == 0
+    plan.close()
+
+
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+def test_msd_leaves_then_merges(gpu, oracle, itype):
+    nb = 3 * (1 << 18) + 777
+    b = oracle.synth_repeat_bases(nb, 35)
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype, blocksize=(1 << 18) + 300, isarate=4096)
+    assert res["num_blocks"] == 3
+    assert np.array_equal(out, oracle.bwt(s))
+    sa = oracle.sa_circular(s)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    smp = plan.samples()
+    assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    plan.close()
