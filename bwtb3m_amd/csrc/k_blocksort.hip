@@ -345,9 +345,49 @@ void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, co
 {
 	if (count) hipLaunchKernelGGL(k_rank_of, dim3(nblk(count, 64)), dim3(64), 0, s, T, d_sa, len, d_pos, count, d_rank_accum);
 }
+// 2-bit inputs: 16 bases per 32-bit word counted with popcounts, per-thread counters, one
+// atomic per wave and symbol at the end (no LDS-atomic contention on 4 hot counters)
+__global__ __launch_bounds__(256) void k_histogram_packed(TextView T, uint64_t start, uint64_t len, unsigned long long *hist)
+{
+	const uint64_t e = start + len;
+	uint64_t w0 = (start + 15) >> 4, w1 = e >> 4;                  // whole words inside the range ...
+	uint64_t wl = T.nbases >> 4; if (wl > w1) wl = w1;             // ... and inside the bases
+	if (wl < w0) wl = w0;
+	uint32_t c1 = 0, c2 = 0, c3 = 0; uint64_t nb = 0;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < wl; w += stride) {
+		uint32_t x = *reinterpret_cast<const uint32_t *>(T.b + (w << 2));   // byte order is irrelevant for counting
+		uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+		c1 += __popc(lo & ~hi); c2 += __popc(hi & ~lo); c3 += __popc(lo & hi); nb += 16;
+	}
+	uint64_t c0 = nb - c1 - c2 - c3;
+	uint64_t d1 = c1, d2 = c2, d3 = c3;
+	for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_down(c0, o, 64); d1 += __shfl_down(d1, o, 64); d2 += __shfl_down(d2, o, 64); d3 += __shfl_down(d3, o, 64); }
+	int off = T.type == B3M_INPUT_PACTERM ? 1 : 0;
+	if ((threadIdx.x & 63) == 0) {
+		if (c0) atomicAdd(&hist[off + 0], (unsigned long long)c0);
+		if (d1) atomicAdd(&hist[off + 1], (unsigned long long)d1);
+		if (d2) atomicAdd(&hist[off + 2], (unsigned long long)d2);
+		if (d3) atomicAdd(&hist[off + 3], (unsigned long long)d3);
+	}
+	// ragged ends, one symbol at a time: [start, head_end) and [tail_beg, e)
+	if (blockIdx.x == 0) {
+		uint64_t head_end = (w0 << 4) < e ? (w0 << 4) : e;
+		if (wl <= w0) head_end = e;                                // no bulk word at all
+		uint64_t tail_beg = (wl << 4) > head_end ? (wl << 4) : head_end;
+		for (uint64_t i = start + threadIdx.x; i < head_end; i += blockDim.x) atomicAdd(&hist[sym_at(T, i)], 1ull);
+		for (uint64_t i = tail_beg + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&hist[sym_at(T, i)], 1ull);
+	}
+}
+
 void histogram_symbols(const TextView &T, uint64_t start, uint64_t len, uint64_t *d_hist256, hipStream_t s)
 {
 	if (!len) return;
+	if (T.type != B3M_INPUT_BYTESTREAM && len >= 4096) {
+		uint32_t grid = nblk(len / 16, 256 * 8); if (grid > 2048) grid = 2048; if (grid == 0) grid = 1;
+		hipLaunchKernelGGL(k_histogram_packed, dim3(grid), dim3(256), 0, s, T, start, len, (unsigned long long *)d_hist256);
+		return;
+	}
 	uint32_t grid = nblk(len, 256 * 64); if (grid > 4096) grid = 4096; if (grid == 0) grid = 1;
 	hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(256), 0, s, T, start, len, (unsigned long long *)d_hist256);
 }

@@ -33,23 +33,29 @@ constexpr int MSD_THREADS = 256;
 constexpr int MSD_ITEMS = 16;
 constexpr int MSD_CHUNK = MSD_THREADS * MSD_ITEMS;     // 4096 records staged through LDS at a time
 constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per workgroup
-constexpr int MSD_MAXBINS = 2048;
+constexpr int MSD_MAXBITS = 8;                         // fan-out per pass: full 128-byte runs per chunk
+constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
+constexpr int MSD_MAXLEVELS = 3;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
-constexpr int LS_CAP = 3072;                           // final bucket capacity of the LDS sort
-constexpr int LS_ROUNDS = LS_CAP / MSD_THREADS;        // 12 rounds of 64 per wave
-constexpr int LS_TIE_CAP = 24;                         // tie groups up to this size are resolved in-kernel
+constexpr int LS_CAP = 2048;                           // final bucket capacity of the LDS sort
+constexpr int LS_BINBITS = 11;
+constexpr int LS_BINS = 1 << LS_BINBITS;               // bin-scatter table of the LDS sort
+constexpr int LS_TIE_CAP = 32;                         // bins / tie groups up to this size are finished in-kernel
 constexpr int REC_KEY_SHIFT = 35;
 constexpr int REC_KEY_BITS = 29;
 
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 
-struct MsdDigits { int D1, D2; };
+// total partition bits t: final buckets of <= ~1448 suffixes on uniform input (capacity 2048);
+// split over ceil(t/8) levels as evenly as possible
+struct MsdDigits { int L; int bits[MSD_MAXLEVELS]; int total; };
 static MsdDigits msd_digits(uint64_t len)
 {
-	int t = 0; while ((len >> (t + 1)) >= 1024) ++t;     // t = floor(log2(len/1024)): buckets of 1-2 K
-	t = std::max(8, std::min(22, t));
-	MsdDigits d; d.D1 = (t + 1) / 2; d.D2 = t - d.D1;
+	int t = 0; while (((uint64_t)1448 << t) < len) ++t;
+	t = std::max(4, std::min(MSD_MAXLEVELS * MSD_MAXBITS - 2, t));
+	MsdDigits d; d.total = t; d.L = (t + MSD_MAXBITS - 1) / MSD_MAXBITS;
+	for (int l = 0; l < d.L; ++l) d.bits[l] = t / d.L + (l < t % d.L ? 1 : 0);
 	return d;
 }
 
@@ -58,34 +64,34 @@ bool msd_applicable(const TextView &T, uint64_t len)
 	return (T.type == B3M_INPUT_PAC || T.type == B3M_INPUT_PACTERM) && len >= MSD_MIN_LEN;
 }
 
+static const uint64_t MSD_NB_MAX = (1ull << (MSD_MAXLEVELS * MSD_MAXBITS - 2)) + 2;   // final buckets
+static const uint64_t MSD_TAB_MAX = (1ull << ((MSD_MAXLEVELS - 1) * MSD_MAXBITS)) + 2; // buckets entering a level
+
 uint64_t msd_ws_bytes(uint64_t cap)
 {
 	if (cap < MSD_MIN_LEN) return 4096;
-	uint64_t tiles = cap / MSD_SUPER + MSD_MAXBINS + 2;
+	uint64_t tiles = cap / MSD_SUPER + MSD_TAB_MAX + 2;
 	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
-	uint64_t nb = (1ull << 22) + 2;
-	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * nb) + al(4 * 3 * MSD_MAXBINS) + al(4 * (nb + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
+	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * MSD_NB_MAX) + al(4 * 3 * MSD_TAB_MAX) + al(4 * (MSD_NB_MAX + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
 {
 	if (cap < MSD_MIN_LEN) { ws = MsdWs(); return; }
 	uint8_t *p = (uint8_t *)base;
-	uint64_t tiles = cap / MSD_SUPER + MSD_MAXBINS + 2;
+	uint64_t tiles = cap / MSD_SUPER + MSD_TAB_MAX + 2;
 	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
-	uint64_t nb = (1ull << 22) + 2;
 	ws.hist = (uint32_t *)p; ws.hist_cap = hist; p += al(4 * hist);
 	ws.tiles = (MsdTile *)p; ws.tiles_cap = tiles; p += al(sizeof(MsdTile) * tiles);
-	ws.sub_start = (uint32_t *)p; p += al(4 * nb);
-	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_MAXBINS);
-	ws.overflow = (uint32_t *)p; ws.overflow_cap = nb; p += al(4 * (nb + 1));
+	ws.sub_start = (uint32_t *)p; p += al(4 * MSD_NB_MAX);
+	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_TAB_MAX);
+	ws.overflow = (uint32_t *)p; ws.overflow_cap = MSD_NB_MAX; p += al(4 * (MSD_NB_MAX + 1));
 	ws.scan_ws = (uint32_t *)p;
 }
 
 // 64 bits = the 32 bases from `pos` on, with the bucketing convention for the end of the text:
 // pacterm: the terminator and everything behind it read as 0; pac: circular.
-__device__ __forceinline__ uint64_t window_safe(const TextView &T, uint64_t pos)
+__device__ inline uint64_t window_tail(const TextView &T, uint64_t pos)
 {
-	if (pos + 32 <= T.nbases) return window32(T, pos);
 	uint64_t x = 0;
 	if (T.type == B3M_INPUT_PAC) {
 		uint64_t p = pos % T.n;
@@ -94,6 +100,10 @@ __device__ __forceinline__ uint64_t window_safe(const TextView &T, uint64_t pos)
 		for (int t = 0; t < 32; ++t) { uint64_t p = pos + t; x = (x << 2) | (p < T.nbases ? base_at(T, p) : 0u); }
 	}
 	return x;
+}
+__device__ __forceinline__ uint64_t window_safe(const TextView &T, uint64_t pos)
+{
+	return (pos + 32 <= T.nbases) ? window32(T, pos) : window_tail(T, pos);
 }
 // output symbol preceding position i (the BWT symbol of the rotation starting at i)
 __device__ __forceinline__ uint32_t pred_sym(const TextView &T, uint64_t i)
@@ -116,6 +126,7 @@ struct MsdArgs {
 	const MsdTile *tiles;        // null: regular tiling (pass A)
 	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
 	int D;                       // digit bits of this pass
+	int shift;                   // !FROM_TEXT: digit = (rec >> shift) & (2^D - 1)
 };
 
 template <bool FROM_TEXT, bool COUNT_ONLY>
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint64_t srec[COUNT_ONLY ? 1 : MSD_CHUNK];
-	__shared__ uint16_t sdig[COUNT_ONLY ? 1 : MSD_CHUNK];
+	__shared__ uint8_t sdig[COUNT_ONLY ? 1 : MSD_CHUNK];
 	__shared__ uint32_t wsum[8];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 				uint32_t e = cbase + s * MSD_THREADS + tid;
 				if (e < tile.count) {
 					rec[s] = A.rec_in[(uint64_t)tile.in_off + e];
-					dg[s] = (uint32_t)(rec[s] >> (64 - A.D));
+					dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
 					vmask |= 1u << s;
 				}
 			}
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		__syncthreads();
 		// exclusive scan of cnt over the bins -> start of every digit run inside the chunk
 		{
-			const int per = MSD_MAXBINS / MSD_THREADS;        // 8 consecutive bins per thread
+			const int per = MSD_MAXBINS / MSD_THREADS;        // consecutive bins per thread
 			uint32_t loc[per]; uint32_t sum = 0;
 			#pragma unroll
 			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cnt[b] : 0; sum += loc[k]; }
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; sdig[p] = (uint16_t)dg[s]; }
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; sdig[p] = (uint8_t)dg[s]; }
 		__syncthreads();
 		// number of valid records of this chunk = binstart[last] + cnt[last]; copy out run by run
 		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
@@ -215,34 +226,37 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 	}
 }
 
-// out[b] = scanned[b * stride] : start of A bucket b
-__global__ void k_gather_strided(const uint32_t *src, uint32_t stride, uint32_t count, uint32_t *out)
-{
-	uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b < count) out[b] = src[(uint64_t)b * stride];
-}
-// final bucket offsets: bucket_tab = {start[bins1], hist_off[bins1], ntiles[bins1]}
-__global__ void k_sub_starts(const uint32_t *scanned, const uint32_t *bucket_tab, int D1, int D2, uint32_t len, uint32_t *sub_start)
+// starts of the buckets leaving a level: bucket_tab = {start[nb], hist_off[nb], ntiles[nb]} of the
+// buckets entering it; out[(b << D) | d] = start of digit d inside bucket b; out[nb << D] = len
+__global__ void k_next_starts(const uint32_t *scanned, const uint32_t *bucket_tab, uint32_t nb, int D, uint32_t len, uint32_t *out)
 {
 	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t nb = 1u << (D1 + D2);
-	if (g > nb) return;
-	if (g == nb) { sub_start[g] = len; return; }
-	uint32_t b = g >> D2, d = g & ((1u << D2) - 1), bins1 = 1u << D1;
-	uint32_t nt = bucket_tab[2 * bins1 + b];
-	sub_start[g] = nt ? scanned[bucket_tab[bins1 + b] + (uint64_t)d * nt] : bucket_tab[b];
+	uint32_t total = nb << D;
+	if (g > total) return;
+	if (g == total) { out[g] = len; return; }
+	uint32_t b = g >> D, d = g & ((1u << D) - 1);
+	uint32_t nt = bucket_tab[2 * nb + b];
+	out[g] = nt ? scanned[bucket_tab[nb + b] + (uint64_t)d * nt] : bucket_tab[b];
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass C: in-LDS sort of one final bucket per workgroup
+// final level: in-LDS sort of one bucket per workgroup.  The remaining key bits of a bucket are
+// close to uniform, so one bin-scatter (LDS atomics into 2048 bins, load factor ~0.7) leaves
+// almost every record in its final bin.  Then, all in parallel per record:
+//   rank inside the bin by (key field, arrival slot)            -> exact position by key field
+//   records whose key field equals a neighbour's fetch the next 32 bases of their rotation (one
+//   independent gather each, all in flight together)            -> deep key in LDS
+//   the first record of every tie group insertion-sorts its group on the deep keys (LDS only;
+//   the text is consulted again only if 32 more bases still tie or the text end is near).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, int sortbits,
+__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, int sortbits, uint32_t eq_syms,
                                                             uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0, uint32_t *overflow,
                                                             uint32_t overflow_cap)
 {
-	__shared__ uint64_t bufA[LS_CAP];
-	__shared__ uint64_t bufB[LS_CAP];
-	__shared__ uint32_t whist[MSD_THREADS / 64][256];
+	__shared__ uint64_t outb[LS_CAP];                 // records: bin-scattered, then ranked in place
+	__shared__ __attribute__((aligned(16))) uint32_t cb[2 * LS_BINS];   // bin counts | bin starts; later the deep keys
+	uint32_t *cnt = cb, *bst = cb + LS_BINS;
+	uint64_t *buf = reinterpret_cast<uint64_t *>(cb);   // LS_CAP deep keys once the bins are dead
 	__shared__ uint32_t wsum[8];
 	__shared__ int ovf;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -254,94 +268,130 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)rec[b0 + e];
 		return;
 	}
-	for (uint32_t e = tid; e < m; e += MSD_THREADS) bufA[e] = rec[b0 + e];
+	for (int i = tid; i < LS_BINS; i += MSD_THREADS) cnt[i] = 0;
 	if (tid == 0) ovf = 0;
-	uint64_t *src = bufA, *dst = bufB;
-	// each wave owns a contiguous range, processed in rounds of 64 (keeps the passes stable)
-	const uint32_t per_wave = ((m + MSD_THREADS - 1) / MSD_THREADS) * 64;
-	const uint32_t wbeg = wave * per_wave, wend = (wbeg + per_wave < m) ? wbeg + per_wave : m;
-	for (int done = 0; done < sortbits; done += 8) {
-		const int bits = sortbits - done < 8 ? sortbits - done : 8;
-		const int shift = REC_KEY_SHIFT + done;
-		const uint32_t mask = (1u << bits) - 1;
-		for (int i = tid; i < (MSD_THREADS / 64) * 256; i += MSD_THREADS) ((uint32_t *)whist)[i] = 0;
-		__syncthreads();
-		uint32_t rnk[LS_ROUNDS];
-		volatile uint32_t *wh = whist[wave];
-		#pragma unroll
-		for (int t = 0; t < LS_ROUNDS; ++t) {
-			uint32_t e = wbeg + t * 64 + lane;
-			bool valid = e < wend;
-			uint32_t d = valid ? ((uint32_t)(src[e] >> shift) & mask) : 0u;
-			uint64_t mm = __ballot(valid);
-			#pragma unroll
-			for (int b = 0; b < 8; ++b) {
-				if (b < bits) { uint64_t bal = __ballot((d >> b) & 1u); mm &= ((d >> b) & 1u) ? bal : ~bal; }
-			}
-			uint32_t below = __popcll(mm & ((1ull << lane) - 1ull));
-			uint32_t cntm = __popcll(mm);
-			uint32_t old = 0;
-			if (valid && below == 0) { old = wh[d]; wh[d] = old + cntm; }
-			int leader = mm ? (__ffsll((long long)mm) - 1) : 0;
-			old = __shfl(old, leader, 64);
-			rnk[t] = old + below;
-		}
-		__syncthreads();
-		{
-			uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
-			uint32_t tot = c0 + c1 + c2 + c3;
-			uint32_t inc = wave_incl_sum(tot);
-			if (lane == 63) wsum[wave] = inc;
-			__syncthreads();
-			uint32_t pre = 0;
-			for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
-			uint32_t ex = pre + inc - tot;
-			whist[0][tid] = ex; whist[1][tid] = ex + c0; whist[2][tid] = ex + c0 + c1; whist[3][tid] = ex + c0 + c1 + c2;
-		}
-		__syncthreads();
-		#pragma unroll
-		for (int t = 0; t < LS_ROUNDS; ++t) {
-			uint32_t e = wbeg + t * 64 + lane;
-			if (e < wend) { uint64_t k = src[e]; uint32_t d = (uint32_t)(k >> shift) & mask; dst[whist[wave][d] + rnk[t]] = k; }
-		}
-		__syncthreads();
-		uint64_t *tmp = src; src = dst; dst = tmp;
+	__syncthreads();
+	const int binbits = sortbits < LS_BINBITS ? (sortbits > 0 ? sortbits : 0) : LS_BINBITS;
+	const int bshift = REC_KEY_SHIFT + sortbits - binbits;
+	const uint32_t bmask = (1u << binbits) - 1;
+	constexpr int PER = LS_CAP / MSD_THREADS;      // 8 records per thread
+	uint64_t r[PER]; uint32_t sl[PER];
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * MSD_THREADS + tid;
+		if (e < m) { r[t] = rec[b0 + e]; sl[t] = atomicAdd(&cnt[(uint32_t)(r[t] >> bshift) & bmask], 1u); }
 	}
-	if (sortbits <= 0) __syncthreads();
-	// exact resolution of groups with equal key bits (rare on random text): the head's thread
-	// insertion-sorts its group in place by full rotation comparison
-	for (uint32_t e = tid; e < m; e += MSD_THREADS) {
-		uint64_t kf = src[e] >> REC_KEY_SHIFT;
-		bool same_next = (e + 1 < m) && (src[e + 1] >> REC_KEY_SHIFT) == kf;
-		bool same_prev = (e > 0) && (src[e - 1] >> REC_KEY_SHIFT) == kf;
-		if (same_next && !same_prev) {
-			uint32_t g = 2;
-			while (e + g < m && (src[e + g] >> REC_KEY_SHIFT) == kf && g <= (uint32_t)LS_TIE_CAP) ++g;
-			if (g > (uint32_t)LS_TIE_CAP) { ovf = 1; }
-			else {
-				for (uint32_t i = 1; i < g; ++i) {
-					uint64_t x = src[e + i]; uint32_t j = i;
-					while (j > 0) {
-						uint64_t y = src[e + j - 1];
-						if (compare_rotations(T, (uint32_t)y, (uint32_t)x) <= 0) break;
-						src[e + j] = y; --j;
+	__syncthreads();
+	{
+		constexpr int per = LS_BINS / MSD_THREADS;  // 8 consecutive bins per thread
+		uint32_t loc[per]; uint32_t sum = 0;
+		#pragma unroll
+		for (int k = 0; k < per; ++k) { loc[k] = cnt[tid * per + k]; sum += loc[k]; }
+		uint32_t inc = wave_incl_sum(sum);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t pre = 0;
+		for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+		uint32_t run = pre + inc - sum;
+		#pragma unroll
+		for (int k = 0; k < per; ++k) { bst[tid * per + k] = run; run += loc[k]; }
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * MSD_THREADS + tid;
+		if (e < m) outb[bst[(uint32_t)(r[t] >> bshift) & bmask] + sl[t]] = r[t];
+	}
+	__syncthreads();
+	// rank inside the bin: position by (key field, slot).  Bins of <= 4 records (all but ~0.1 %)
+	// are handled without a loop.  Ranks go to registers, then the bins are permuted in place.
+	uint32_t dest[PER];
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * MSD_THREADS + tid;
+		dest[t] = 0;
+		if (e < m) {
+			uint32_t bin = (uint32_t)(r[t] >> bshift) & bmask;
+			uint32_t c = cnt[bin], s0 = bst[bin], less = 0;
+			if (c > 1) {
+				const uint64_t kx = r[t] >> REC_KEY_SHIFT;
+				if (c <= 4) {
+					#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j) {
+						uint64_t ky = outb[s0 + (j < c ? j : c - 1)] >> REC_KEY_SHIFT;
+						less += (j < c && (ky < kx || (ky == kx && j < sl[t]))) ? 1u : 0u;
 					}
-					src[e + j] = x;
-				}
+				} else if (c <= (uint32_t)LS_TIE_CAP) {
+					for (uint32_t j = 0; j < c; ++j) {
+						uint64_t ky = outb[s0 + j] >> REC_KEY_SHIFT;
+						less += (ky < kx || (ky == kx && j < sl[t])) ? 1u : 0u;
+					}
+				} else { ovf = 1; less = sl[t]; }
 			}
+			dest[t] = s0 + less;
 		}
 	}
 	__syncthreads();
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) if (t * MSD_THREADS + tid < m) outb[dest[t]] = r[t];
+	__syncthreads();
+	// records whose key field equals a neighbour's: fetch the deep key (all gathers in flight at once)
+	uint32_t tiedmask = 0, headmask = 0;
+	uint64_t dk[PER];
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * MSD_THREADS + tid;
+		dk[t] = 0;
+		if (e < m) {
+			uint64_t q = outb[e], kf = q >> REC_KEY_SHIFT;
+			bool sn = (e + 1 < m) && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
+			bool sp = (e > 0) && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
+			if (sn || sp) {
+				tiedmask |= 1u << t;
+				if (sn && !sp) headmask |= 1u << t;
+				uint64_t x = (uint32_t)q;
+				// 31 bases (62 bits) + a low "exact" flag bit: 1 = the window lies inside the bases
+				if (x + eq_syms + 32 <= T.nbases) dk[t] = (window32(T, x + eq_syms) >> 2 << 2) | 1ull;
+			}
+		}
+	}
+	if (__syncthreads_or(tiedmask != 0)) {
+		#pragma unroll
+		for (int t = 0; t < PER; ++t) if (tiedmask & (1u << t)) buf[t * MSD_THREADS + tid] = dk[t];
+		__syncthreads();
+		#pragma unroll
+		for (int t = 0; t < PER; ++t) {
+			if (!(headmask & (1u << t))) continue;
+			uint32_t e = t * MSD_THREADS + tid;
+			uint64_t kf = outb[e] >> REC_KEY_SHIFT;
+			uint32_t g = 2;
+			while (e + g < m && (outb[e + g] >> REC_KEY_SHIFT) == kf && g <= (uint32_t)LS_TIE_CAP) ++g;
+			if (g > (uint32_t)LS_TIE_CAP) { ovf = 1; continue; }
+			for (uint32_t i = 1; i < g; ++i) {
+				uint64_t x = outb[e + i], dx = buf[e + i]; uint32_t j = i;
+				while (j > 0) {
+					uint64_t y = outb[e + j - 1], dy = buf[e + j - 1];
+					bool y_le_x;
+					if ((dx & 1) && (dy & 1) && (dx != dy)) y_le_x = dy < dx;
+					else y_le_x = compare_rotations(T, (uint32_t)y, (uint32_t)x) <= 0;
+					if (y_le_x) break;
+					outb[e + j] = y; buf[e + j] = dy; --j;
+				}
+				outb[e + j] = x; buf[e + j] = dx;
+			}
+		}
+		__syncthreads();
+	}
 	if (ovf) {
 		if (tid == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = blockIdx.x; }
-		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)src[e];
+		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)rec[b0 + e];
 		return;
 	}
 	for (uint32_t e = tid; e < m; e += MSD_THREADS) {
-		uint64_t r = src[e];
-		uint32_t i = (uint32_t)r;
+		uint64_t q = outb[e];
+		uint32_t i = (uint32_t)q;
 		sa[b0 + e] = i;
-		bwt[b0 + e] = (uint8_t)((r >> 32) & 7u);
+		bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
 		if (i == (uint32_t)start) *p0 = b0 + e;
 	}
 }
@@ -363,77 +413,94 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 	MsdWs &M = ws.msd;
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
 	const MsdDigits dg = msd_digits(len);
-	const int D1 = dg.D1, D2 = dg.D2;
-	const uint32_t bins1 = 1u << D1, bins2 = 1u << D2;
-	uint64_t *recA = ws.keyA, *recB = ws.keyB;
+	uint64_t *rin = ws.keyB, *rout = ws.keyA;      // level 0 writes keyA
 	uint32_t *sa = ws.idxA;
 	out.used_msd = true;
-	// ---- pass A ----
+	// ---- level 0: text -> records, partitioned by the first bits[0] bits ----
 	const uint64_t P0 = start & ~15ull;
 	const uint64_t span = start + len - P0;
 	const uint32_t ntA = (uint32_t)((span + MSD_SUPER - 1) / MSD_SUPER);
-	B3M_REQUIRE((uint64_t)bins1 * ntA <= M.hist_cap, "MSD histogram workspace too small");
+	const uint32_t bins0 = 1u << dg.bits[0];
+	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
 	MsdArgs A{};
-	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_in = nullptr; A.rec_out = recA; A.tiles = nullptr; A.hist = M.hist; A.D = D1;
+	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_in = nullptr; A.rec_out = rout; A.tiles = nullptr; A.hist = M.hist; A.D = dg.bits[0]; A.shift = 0;
 	{
 		Scope sc(tl, KF_MSD_HIST, span / 4);
 		hipLaunchKernelGGL((k_msd_pass<true, true>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
 	}
 	{
-		Scope sc(tl, KF_SCAN, 8ull * bins1 * ntA);
-		exclusive_sum_u32(M.hist, (uint64_t)bins1 * ntA, M.scan_ws, s);
+		Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
+		exclusive_sum_u32(M.hist, (uint64_t)bins0 * ntA, M.scan_ws, s);
 	}
 	{
 		Scope sc(tl, KF_MSD_SCATTER, span / 4 + 8 * len);
 		hipLaunchKernelGGL((k_msd_pass<true, false>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
 	}
-	// ---- A bucket sizes -> tiles of pass B (host) ----
-	std::vector<uint32_t> bstart(bins1 + 1);
-	hipLaunchKernelGGL(k_gather_strided, dim3(nblk(bins1)), dim3(256), 0, s, M.hist, ntA, bins1, M.bucket_tab);
-	B3M_HIP(hipMemcpyAsync(bstart.data(), M.bucket_tab, 4 * bins1, hipMemcpyDeviceToHost, s));
-	B3M_HIP(hipStreamSynchronize(s));
-	bstart[bins1] = (uint32_t)len;
-	std::vector<MsdTile> tiles;
-	std::vector<uint32_t> tab(3 * bins1);
-	uint64_t hoff = 0;
-	for (uint32_t b = 0; b < bins1; ++b) {
-		uint32_t sz = bstart[b + 1] - bstart[b];
-		uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
-		tab[b] = bstart[b]; tab[bins1 + b] = (uint32_t)hoff; tab[2 * bins1 + b] = nt;
-		for (uint32_t j = 0; j < nt; ++j) {
-			MsdTile t; t.in_off = bstart[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
-			t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
-			tiles.push_back(t);
+	// bucket starts leaving level 0: a one-bucket table {start 0, hist_off 0, ntiles ntA}
+	uint32_t nb = 1;                    // buckets entering the level just done
+	{
+		uint32_t tab0[3] = {0, 0, ntA};
+		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab0, 12, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipStreamSynchronize(s));
+	}
+	int consumed = 0;                   // key-field bits used by levels >= 1
+	for (int lv = 0; lv < dg.L; ++lv) {
+		const int D = dg.bits[lv];
+		const uint32_t nnext = nb << D;
+		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nnext + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, nb, D, (uint32_t)len, M.sub_start);
+		if (lv + 1 == dg.L) { nb = nnext; break; }
+		// ---- build the tiles of the next level on the host ----
+		std::vector<uint32_t> st(nnext + 1);
+		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (nnext + 1), hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		const int Dn = dg.bits[lv + 1];
+		std::vector<MsdTile> tiles;
+		std::vector<uint32_t> tab(3ull * nnext);
+		uint64_t hoff = 0;
+		for (uint32_t b = 0; b < nnext; ++b) {
+			uint32_t sz = st[b + 1] - st[b];
+			uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
+			tab[b] = st[b]; tab[nnext + b] = (uint32_t)hoff; tab[2ull * nnext + b] = nt;
+			for (uint32_t j = 0; j < nt; ++j) {
+				MsdTile t; t.in_off = st[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
+				t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
+				tiles.push_back(t);
+			}
+			hoff += ((uint64_t)1 << Dn) * nt;
 		}
-		hoff += (uint64_t)bins2 * nt;
+		B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32) && 3ull * nnext <= 3 * MSD_TAB_MAX, "MSD workspace too small");
+		B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
+		// ---- partition level lv+1 ----
+		std::swap(rin, rout);
+		consumed += Dn;
+		MsdArgs Bq{};
+		Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = rin; Bq.rec_out = rout; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = Dn;
+		Bq.shift = 64 - consumed;
+		const uint32_t ntB = (uint32_t)tiles.size();
+		{
+			Scope sc(tl, KF_MSD_HIST, 8 * len);
+			hipLaunchKernelGGL((k_msd_pass<false, true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+		}
+		{
+			Scope sc(tl, KF_SCAN, 8ull * hoff);
+			exclusive_sum_u32(M.hist, hoff, M.scan_ws, s);
+		}
+		{
+			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
+			hipLaunchKernelGGL((k_msd_pass<false, false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+		}
+		nb = nnext;
 	}
-	B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32), "MSD workspace too small for pass B");
-	B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
-	B3M_HIP(hipStreamSynchronize(s));      // tiles/tab are stack vectors: the copies must finish before they die
-	// ---- pass B ----
-	MsdArgs Bq{};
-	Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = recA; Bq.rec_out = recB; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = D2;
-	const uint32_t ntB = (uint32_t)tiles.size();
-	{
-		Scope sc(tl, KF_MSD_HIST, 8 * len);
-		hipLaunchKernelGGL((k_msd_pass<false, true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
-	}
-	{
-		Scope sc(tl, KF_SCAN, 8ull * hoff);
-		exclusive_sum_u32(M.hist, hoff, M.scan_ws, s);
-	}
-	{
-		Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-		hipLaunchKernelGGL((k_msd_pass<false, false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
-	}
-	// ---- pass C ----
-	const uint32_t nfinal = 1u << (D1 + D2);
+	// ---- final level: in-LDS sort of the nb buckets (M.sub_start holds nb+1 offsets) ----
+	const uint32_t nfinal = nb;
+	const int sortbits = REC_KEY_BITS - consumed;
+	const uint32_t eq_syms = (uint32_t)((dg.bits[0] + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
 	{
 		Scope sc(tl, KF_LDS_SORT, 13 * len);
-		hipLaunchKernelGGL(k_sub_starts, dim3(nblk((uint64_t)nfinal + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, D1, D2, (uint32_t)len, M.sub_start);
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
-		hipLaunchKernelGGL(k_lds_sort, dim3(nfinal), dim3(MSD_THREADS), 0, s, T, recB, M.sub_start, REC_KEY_BITS - D2, sa, d_bwt, start, d_p0,
+		hipLaunchKernelGGL(k_lds_sort, dim3(nfinal), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, sortbits, eq_syms, sa, d_bwt, start, d_p0,
 		                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap, nfinal));
 	}
 	uint32_t nov = 0;
@@ -462,7 +529,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 		B3M_HIP(hipStreamSynchronize(s));
 		uint64_t left = 0;
 		out.tie_elements = total;
-		out.tie_rounds = tie_rounds(T, sa, total, 0, recA, recB, Bf, ws.scan_ws, ws.radix, len, s, &left);
+		out.tie_rounds = tie_rounds(T, sa, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left);
 		// BWT symbols (and p0) of the slots finished here
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, ws.t[0], (uint32_t *)nullptr);
 		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
