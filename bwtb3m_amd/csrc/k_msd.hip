@@ -37,23 +37,24 @@ constexpr int MSD_MAXBITS = 8;                         // fan-out per pass: full
 constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
 constexpr int MSD_MAXLEVELS = 3;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
-constexpr int LS_CAP = 2048;                           // final bucket capacity of the LDS sort
-constexpr int LS_BINBITS = 11;
-constexpr int LS_BINS = 1 << LS_BINBITS;               // bin-scatter table of the LDS sort
+constexpr int LS_CAP = 512;                            // final bucket capacity: one WAVE sorts one bucket
+constexpr int LS_BINBITS = 9;
+constexpr int LS_BINS = 1 << LS_BINBITS;               // bin-scatter table of the wave sort
 constexpr int LS_TIE_CAP = 32;                         // bins / tie groups up to this size are finished in-kernel
+constexpr int LS_WAVES = MSD_THREADS / 64;             // independent waves (buckets) per workgroup
 constexpr int REC_KEY_SHIFT = 35;
 constexpr int REC_KEY_BITS = 29;
 
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 
-// total partition bits t: final buckets of <= ~1448 suffixes on uniform input (capacity 2048);
-// split over ceil(t/8) levels as evenly as possible
+// total partition bits t: final buckets of <= 256 suffixes on average (capacity 512, one wave
+// each); split over ceil(t/8) levels as evenly as possible
 struct MsdDigits { int L; int bits[MSD_MAXLEVELS]; int total; };
 static MsdDigits msd_digits(uint64_t len)
 {
-	int t = 0; while (((uint64_t)1448 << t) < len) ++t;
-	t = std::max(4, std::min(MSD_MAXLEVELS * MSD_MAXBITS - 2, t));
+	int t = 0; while (((uint64_t)256 << t) < len) ++t;
+	t = std::max(4, std::min(MSD_MAXLEVELS * MSD_MAXBITS, t));
 	MsdDigits d; d.total = t; d.L = (t + MSD_MAXBITS - 1) / MSD_MAXBITS;
 	for (int l = 0; l < d.L; ++l) d.bits[l] = t / d.L + (l < t % d.L ? 1 : 0);
 	return d;
@@ -64,7 +65,7 @@ bool msd_applicable(const TextView &T, uint64_t len)
 	return (T.type == B3M_INPUT_PAC || T.type == B3M_INPUT_PACTERM) && len >= MSD_MIN_LEN;
 }
 
-static const uint64_t MSD_NB_MAX = (1ull << (MSD_MAXLEVELS * MSD_MAXBITS - 2)) + 2;   // final buckets
+static const uint64_t MSD_NB_MAX = (1ull << (MSD_MAXLEVELS * MSD_MAXBITS)) + 2;       // final buckets
 static const uint64_t MSD_TAB_MAX = (1ull << ((MSD_MAXLEVELS - 1) * MSD_MAXBITS)) + 2; // buckets entering a level
 
 uint64_t msd_ws_bytes(uint64_t cap)
@@ -240,75 +241,81 @@ __global__ void k_next_starts(const uint32_t *scanned, const uint32_t *bucket_ta
 }
 
 // ------------------------------------------------------------------------------------------------
-// final level: in-LDS sort of one bucket per workgroup.  The remaining key bits of a bucket are
-// close to uniform, so one bin-scatter (LDS atomics into 2048 bins, load factor ~0.7) leaves
-// almost every record in its final bin.  Then, all in parallel per record:
-//   rank inside the bin by (key field, arrival slot)            -> exact position by key field
-//   records whose key field equals a neighbour's fetch the next 32 bases of their rotation (one
-//   independent gather each, all in flight together)            -> deep key in LDS
+// final level: one WAVE sorts one bucket (<= 512 records, ~180 on uniform input) in its own 8 KB
+// of LDS; the four waves of a workgroup are independent, so there is no workgroup barrier and a
+// CU keeps 20 buckets in flight.  The remaining key bits of a bucket are close to uniform, so one
+// bin-scatter (LDS atomics into 512 bins) leaves almost every record in its final bin.  Then:
+//   rank inside the bin by (key field, arrival slot), bins permuted in place
+//   records whose key field equals a neighbour's fetch the next 31 bases of their rotation (all
+//   gathers of the wave in flight together)                        -> deep key in LDS
 //   the first record of every tie group insertion-sorts its group on the deep keys (LDS only;
-//   the text is consulted again only if 32 more bases still tie or the text end is near).
+//   the text is consulted again only if those still tie or the text end is near).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, int sortbits, uint32_t eq_syms,
-                                                            uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0, uint32_t *overflow,
-                                                            uint32_t overflow_cap)
+__device__ __forceinline__ void wave_sync()
 {
-	__shared__ uint64_t outb[LS_CAP];                 // records: bin-scattered, then ranked in place
-	__shared__ __attribute__((aligned(16))) uint32_t cb[2 * LS_BINS];   // bin counts | bin starts; later the deep keys
-	uint32_t *cnt = cb, *bst = cb + LS_BINS;
-	uint64_t *buf = reinterpret_cast<uint64_t *>(cb);   // LS_CAP deep keys once the bins are dead
-	__shared__ uint32_t wsum[8];
-	__shared__ int ovf;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t b0 = sub_start[blockIdx.x], b1 = sub_start[blockIdx.x + 1];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, uint32_t nbuckets, int sortbits,
+                                                            uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0,
+                                                            uint32_t *overflow, uint32_t overflow_cap, uint32_t *tiebits)
+{
+	__shared__ uint64_t s_rec[LS_WAVES][LS_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t s_cb[LS_WAVES][2 * LS_BINS];   // counts | starts
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t g = blockIdx.x * LS_WAVES + wave;
+	if (g >= nbuckets) return;
+	uint64_t *outb = s_rec[wave];
+	uint32_t *cnt = s_cb[wave], *bst = s_cb[wave] + LS_BINS;
+	const uint32_t b0 = sub_start[g], b1 = sub_start[g + 1];
 	const uint32_t m = b1 - b0;
 	if (m == 0) return;
 	if (m > (uint32_t)LS_CAP) {
-		if (tid == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = blockIdx.x; }
-		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)rec[b0 + e];
+		if (lane == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = g; }
+		for (uint32_t e = lane; e < m; e += 64) sa[b0 + e] = (uint32_t)rec[b0 + e];
 		return;
 	}
-	for (int i = tid; i < LS_BINS; i += MSD_THREADS) cnt[i] = 0;
-	if (tid == 0) ovf = 0;
-	__syncthreads();
 	const int binbits = sortbits < LS_BINBITS ? (sortbits > 0 ? sortbits : 0) : LS_BINBITS;
 	const int bshift = REC_KEY_SHIFT + sortbits - binbits;
 	const uint32_t bmask = (1u << binbits) - 1;
-	constexpr int PER = LS_CAP / MSD_THREADS;      // 8 records per thread
+	constexpr int PER = LS_CAP / 64;               // 8 records per lane
 	uint64_t r[PER]; uint32_t sl[PER];
 	#pragma unroll
-	for (int t = 0; t < PER; ++t) {
-		uint32_t e = t * MSD_THREADS + tid;
-		if (e < m) { r[t] = rec[b0 + e]; sl[t] = atomicAdd(&cnt[(uint32_t)(r[t] >> bshift) & bmask], 1u); }
-	}
-	__syncthreads();
-	{
-		constexpr int per = LS_BINS / MSD_THREADS;  // 8 consecutive bins per thread
-		uint32_t loc[per]; uint32_t sum = 0;
-		#pragma unroll
-		for (int k = 0; k < per; ++k) { loc[k] = cnt[tid * per + k]; sum += loc[k]; }
-		uint32_t inc = wave_incl_sum(sum);
-		if (lane == 63) wsum[wave] = inc;
-		__syncthreads();
-		uint32_t pre = 0;
-		for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
-		uint32_t run = pre + inc - sum;
-		#pragma unroll
-		for (int k = 0; k < per; ++k) { bst[tid * per + k] = run; run += loc[k]; }
-	}
-	__syncthreads();
+	for (int t = 0; t < PER; ++t) { uint32_t e = t * 64 + lane; r[t] = e < m ? rec[b0 + e] : 0; }
+	#pragma unroll
+	for (int k = 0; k < LS_BINS / 64; ++k) cnt[k * 64 + lane] = 0;
+	wave_sync();
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
-		uint32_t e = t * MSD_THREADS + tid;
+		uint32_t e = t * 64 + lane;
+		sl[t] = 0;
+		if (e < m) sl[t] = atomicAdd(&cnt[(uint32_t)(r[t] >> bshift) & bmask], 1u);
+	}
+	wave_sync();
+	{
+		constexpr int per = LS_BINS / 64;           // 8 consecutive bins per lane
+		uint32_t loc[per]; uint32_t sum = 0;
+		#pragma unroll
+		for (int k = 0; k < per; ++k) { loc[k] = cnt[lane * per + k]; sum += loc[k]; }
+		uint32_t run = wave_incl_sum(sum) - sum;
+		#pragma unroll
+		for (int k = 0; k < per; ++k) { bst[lane * per + k] = run; run += loc[k]; }
+	}
+	wave_sync();
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * 64 + lane;
 		if (e < m) outb[bst[(uint32_t)(r[t] >> bshift) & bmask] + sl[t]] = r[t];
 	}
-	__syncthreads();
-	// rank inside the bin: position by (key field, slot).  Bins of <= 4 records (all but ~0.1 %)
-	// are handled without a loop.  Ranks go to registers, then the bins are permuted in place.
+	wave_sync();
+	// rank inside the bin: position by (key field, slot); bins of <= 4 records without a loop
+	bool ovf = false;
 	uint32_t dest[PER];
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
-		uint32_t e = t * MSD_THREADS + tid;
+		uint32_t e = t * 64 + lane;
 		dest[t] = 0;
 		if (e < m) {
 			uint32_t bin = (uint32_t)(r[t] >> bshift) & bmask;
@@ -326,73 +333,83 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 						uint64_t ky = outb[s0 + j] >> REC_KEY_SHIFT;
 						less += (ky < kx || (ky == kx && j < sl[t])) ? 1u : 0u;
 					}
-				} else { ovf = 1; less = sl[t]; }
+				} else { ovf = true; less = sl[t]; }
 			}
 			dest[t] = s0 + less;
 		}
 	}
-	__syncthreads();
+	wave_sync();
 	#pragma unroll
-	for (int t = 0; t < PER; ++t) if (t * MSD_THREADS + tid < m) outb[dest[t]] = r[t];
-	__syncthreads();
-	// records whose key field equals a neighbour's: fetch the deep key (all gathers in flight at once)
-	uint32_t tiedmask = 0, headmask = 0;
-	uint64_t dk[PER];
+	for (int t = 0; t < PER; ++t) if (t * 64 + lane < m) outb[dest[t]] = r[t];
+	wave_sync();
+	// tie groups (equal key field): bit p of the tie bitmap = "record p has the key field of
+	// record p-1"; k_tie_fix resolves the runs against the text.  Scattered single-bit atomics:
+	// no hot address.
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
-		uint32_t e = t * MSD_THREADS + tid;
-		dk[t] = 0;
-		if (e < m) {
-			uint64_t q = outb[e], kf = q >> REC_KEY_SHIFT;
-			bool sn = (e + 1 < m) && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
-			bool sp = (e > 0) && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
-			if (sn || sp) {
-				tiedmask |= 1u << t;
-				if (sn && !sp) headmask |= 1u << t;
-				uint64_t x = (uint32_t)q;
-				// 31 bases (62 bits) + a low "exact" flag bit: 1 = the window lies inside the bases
-				if (x + eq_syms + 32 <= T.nbases) dk[t] = (window32(T, x + eq_syms) >> 2 << 2) | 1ull;
-			}
-		}
-	}
-	if (__syncthreads_or(tiedmask != 0)) {
-		#pragma unroll
-		for (int t = 0; t < PER; ++t) if (tiedmask & (1u << t)) buf[t * MSD_THREADS + tid] = dk[t];
-		__syncthreads();
-		#pragma unroll
-		for (int t = 0; t < PER; ++t) {
-			if (!(headmask & (1u << t))) continue;
-			uint32_t e = t * MSD_THREADS + tid;
+		uint32_t e = t * 64 + lane;
+		if (e < m && e > 0) {
 			uint64_t kf = outb[e] >> REC_KEY_SHIFT;
-			uint32_t g = 2;
-			while (e + g < m && (outb[e + g] >> REC_KEY_SHIFT) == kf && g <= (uint32_t)LS_TIE_CAP) ++g;
-			if (g > (uint32_t)LS_TIE_CAP) { ovf = 1; continue; }
-			for (uint32_t i = 1; i < g; ++i) {
-				uint64_t x = outb[e + i], dx = buf[e + i]; uint32_t j = i;
-				while (j > 0) {
-					uint64_t y = outb[e + j - 1], dy = buf[e + j - 1];
-					bool y_le_x;
-					if ((dx & 1) && (dy & 1) && (dx != dy)) y_le_x = dy < dx;
-					else y_le_x = compare_rotations(T, (uint32_t)y, (uint32_t)x) <= 0;
-					if (y_le_x) break;
-					outb[e + j] = y; buf[e + j] = dy; --j;
-				}
-				outb[e + j] = x; buf[e + j] = dx;
-			}
+			if ((outb[e - 1] >> REC_KEY_SHIFT) == kf) { uint32_t q = b0 + e; atomicOr(&tiebits[q >> 5], 1u << (q & 31)); }
 		}
-		__syncthreads();
 	}
-	if (ovf) {
-		if (tid == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = blockIdx.x; }
-		for (uint32_t e = tid; e < m; e += MSD_THREADS) sa[b0 + e] = (uint32_t)rec[b0 + e];
+	if (__ballot(ovf)) {
+		if (lane == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = g; }
+		for (uint32_t e = lane; e < m; e += 64) sa[b0 + e] = (uint32_t)rec[b0 + e];
 		return;
 	}
-	for (uint32_t e = tid; e < m; e += MSD_THREADS) {
-		uint64_t q = outb[e];
-		uint32_t i = (uint32_t)q;
-		sa[b0 + e] = i;
-		bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
-		if (i == (uint32_t)start) *p0 = b0 + e;
+	#pragma unroll
+	for (int t = 0; t < PER; ++t) {
+		uint32_t e = t * 64 + lane;
+		if (e < m) {
+			uint64_t q = outb[e];
+			uint32_t i = (uint32_t)q;
+			sa[b0 + e] = i;
+			bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
+			if (i == (uint32_t)start) *p0 = b0 + e;
+		}
+	}
+}
+
+// one thread per word of the tie bitmap: every run of set bits starting in the word is a tie group
+// (head = the position before the run).  The group's rotations agree on their first eq_syms
+// symbols; they are ordered by the next 31 bases (one gather each), by full comparison if that
+// does not decide.  Groups longer than LS_TIE_CAP are skipped: such a group fills one bin of
+// k_lds_sort beyond LS_TIE_CAP, so its whole bucket was flagged for the overflow path.
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint32_t eq_syms, uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+{
+	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t nwords = (len + 31) >> 5;
+	if (w >= nwords) return;
+	uint32_t bits = tiebits[w];
+	if (!bits) return;
+	uint32_t prevbit = w ? (tiebits[w - 1] >> 31) : 0u;
+	uint32_t starts = bits & ~((bits << 1) | prevbit);          // set bits whose predecessor bit is clear
+	while (starts) {
+		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
+		uint64_t q = (w << 5) + k;                               // first tied record; head = q-1
+		uint64_t pos = q - 1;
+		uint32_t g = 2;
+		for (uint64_t z = q + 1; z < len && g <= (uint32_t)LS_TIE_CAP && ((tiebits[z >> 5] >> (z & 31)) & 1u); ++z) ++g;
+		if (g > (uint32_t)LS_TIE_CAP) continue;   // lies in one bin of > LS_TIE_CAP records: that bucket went to the overflow path
+		for (uint32_t a = 1; a < g; ++a) {
+			uint32_t x = sa[pos + a]; uint8_t bx = bwt[pos + a];
+			bool ex = (uint64_t)x + eq_syms + 32 <= T.nbases;
+			uint64_t dx = ex ? window32(T, (uint64_t)x + eq_syms) >> 2 : 0;
+			uint32_t j = a;
+			while (j > 0) {
+				uint32_t y = sa[pos + j - 1];
+				bool ey = (uint64_t)y + eq_syms + 32 <= T.nbases;
+				uint64_t dy = ey ? window32(T, (uint64_t)y + eq_syms) >> 2 : 0;
+				bool y_le_x;
+				if (ex && ey && dx != dy) y_le_x = dy < dx;
+				else y_le_x = compare_rotations(T, y, x) <= 0;
+				if (y_le_x) break;
+				sa[pos + j] = y; bwt[pos + j] = bwt[pos + j - 1]; --j;
+			}
+			sa[pos + j] = x; bwt[pos + j] = bx;
+		}
+		for (uint32_t a = 0; a < g; ++a) if (sa[pos + a] == (uint32_t)start) *p0 = (uint32_t)(pos + a);
 	}
 }
 
@@ -499,9 +516,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 	const uint32_t eq_syms = (uint32_t)((dg.bits[0] + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
 	{
 		Scope sc(tl, KF_LDS_SORT, 13 * len);
+		// tie bitmap: len bits in ws.t[0]
+		uint32_t *d_tiebits = ws.t[0];
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
-		hipLaunchKernelGGL(k_lds_sort, dim3(nfinal), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, sortbits, eq_syms, sa, d_bwt, start, d_p0,
-		                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap, nfinal));
+		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
+		hipLaunchKernelGGL(k_lds_sort, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
+		                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
+	}
+	{
+		Scope sc(tl, KF_TIES, len / 8);
+		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, eq_syms, sa, d_bwt, start, d_p0);
 	}
 	uint32_t nov = 0;
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
