@@ -115,12 +115,16 @@ def main():
     # dominant kernel family by device time
     dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
     dname, d = dom
+    # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
+    kernel_of = {"msd_scatter": "b3m::k_msd_pass<false, false>", "msd_scatter_text": "b3m::k_msd_pass<true, false>",
+                 "msd_hist": "b3m::k_msd_pass<*, true>", "lds_sort": "b3m::k_lds_sort", "ties": "b3m::k_tie_fix",
+                 "radix_scatter": "b3m::k_scatter<unsigned long, true>", "gap_walk": "b3m::k_gap_walk"}
     achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     B = res["num_blocks"]
     levels = res["levels"]
     alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
     roof = {
-        "bound": "hbm", "kernel": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": kernel_of.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, a.steps),
         "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),

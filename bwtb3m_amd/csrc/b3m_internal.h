@@ -55,7 +55,7 @@ inline uint64_t num_bases(uint64_t n, int type) { return type == B3M_INPUT_PACTE
 
 // ---- kernel-family timing ---------------------------------------------------------------------
 enum KFam { KF_KEYS = 0, KF_RADIX_HIST, KF_SCAN, KF_RADIX_SCATTER, KF_TIES, KF_EMIT, KF_RANKBUILD,
-            KF_ANCHOR, KF_GAPWALK, KF_INTERLEAVE, KF_MISC, KF_MSD_HIST, KF_MSD_SCATTER, KF_LDS_SORT, KF_COUNT };
+            KF_ANCHOR, KF_GAPWALK, KF_INTERLEAVE, KF_MISC, KF_MSD_HIST, KF_MSD_SCATTER, KF_LDS_SORT, KF_MSD_SCATTER_TEXT, KF_COUNT };
 extern const char *const kfam_names[KF_COUNT];
 
 struct Timeline {

@@ -450,7 +450,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 		exclusive_sum_u32(M.hist, (uint64_t)bins0 * ntA, M.scan_ws, s);
 	}
 	{
-		Scope sc(tl, KF_MSD_SCATTER, span / 4 + 8 * len);
+		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
 		hipLaunchKernelGGL((k_msd_pass<true, false>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
 	}
 	// bucket starts leaving level 0: a one-bucket table {start 0, hist_off 0, ntiles ntA}
