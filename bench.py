@@ -31,6 +31,11 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0, help="number of leaf blocks (overrides --blocksize)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=48e6, help="symbols of the CPU-baseline sample")
+    ap.add_argument("--mode", default="prefix", choices=["prefix", "blocks"],
+                    help="multi-GPU: suffix-range shards (no exchange) or block merging with RCCL all-to-all")
+    ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",
+                    help="N>1: skip the extra pass of the block-merge mode after the headline line")
+    ap.add_argument("--blocks-timeout", type=int, default=150)
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
     return ap.parse_args()
 

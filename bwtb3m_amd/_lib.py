@@ -34,6 +34,7 @@ class Result(ctypes.Structure):
         ("num_samples", ctypes.c_uint64), ("tie_rounds", ctypes.c_uint64), ("tie_elements", ctypes.c_uint64),
         ("ms_total", ctypes.c_double), ("ms_sort", ctypes.c_double), ("ms_gap", ctypes.c_double),
         ("ms_interleave", ctypes.c_double),
+        ("slice_offset", ctypes.c_uint64), ("slice_len", ctypes.c_uint64), ("has_p0", ctypes.c_uint64),
     ]
 
 
@@ -52,6 +53,8 @@ SYMBOLS = [
     ("b3m_options_init", None, [ctypes.POINTER(Options)]),
     ("b3m_compute_bwt", _i, [ctypes.POINTER(Options), _i]),
     ("b3m_plan_create", _p, [_u64, _i, _u64, _u64, _u64]),
+    ("b3m_plan_create_sharded", _p, [_u64, _i, _i, _i, _u64, _u64]),
+    ("b3m_plan_slice_capacity", _u64, [_p]),
     ("b3m_plan_destroy", None, [_p]),
     ("b3m_plan_num_blocks", _u64, [_p]),
     ("b3m_plan_workspace_bytes", _u64, [_p]),

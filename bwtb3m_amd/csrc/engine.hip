@@ -106,6 +106,7 @@ struct MergeT {
 
 struct b3m_plan {
 	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
+	int shard = 0, nshards = 1; uint64_t shard_cap = 0;   // suffix-range shard of a single-block plan
 	std::vector<Leaf> leaves;
 	std::vector<MergeT> merges;
 	std::vector<std::vector<int>> level_merges;         // merge ids per level
@@ -229,7 +230,7 @@ const char *b3m_input_type_name(int t) { return (t >= 0 && t < 6) ? type_names[t
 	catch (...) { b3m::set_error("unknown error"); return ret; }
 
 void b3m_plan_destroy(b3m_plan *p);
-b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem, uint64_t isasamplingrate)
+static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem, uint64_t isasamplingrate, int shard, int nshards)
 {
 	b3m_plan *p = nullptr;
 	B3M_TRY
@@ -245,6 +246,14 @@ b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_
 	uint64_t budget = mem ? std::min<uint64_t>(mem, free_b) : (uint64_t)(free_b * 0.92);
 	p = new b3m_plan();
 	p->n = n; p->type = inputtype; p->isarate = isasamplingrate;
+	p->shard = shard; p->nshards = nshards;
+	if (nshards > 1) {
+		B3M_REQUIRE(shard >= 0 && shard < nshards, "shard index out of range");
+		B3M_REQUIRE((inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM) && n >= (1ull << 18), "suffix-range shards need a pac/pacterm input of at least 2^18 symbols");
+		blocksize = n;                                         // one block = the whole text, every rank sorts a rank range of it
+		p->shard_cap = n / nshards + n / 64 + (1ull << 20);    // whole level-0 digits: ~n/256 of imbalance, generous slack
+		if (p->shard_cap > n) p->shard_cap = n;
+	}
 	// per-suffix bytes of the leaf sort workspace ~ 2*(8+4) + 1 + 12 + radix scratch: see blocksort_ws_bytes
 	if (blocksize == 0) {
 		// fixed part: text, 2 bwt arrays, gt; merge part needs ranks (8 B per R suffix) + rank blocks
@@ -266,10 +275,12 @@ b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_
 	auto take = [&](uint64_t bytes) { uint64_t o = off; off += al256(bytes); return o; };
 	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
 	uint64_t o_text = take(p->text_cap);
-	uint64_t o_bwt0 = take(n + 16), o_bwt1 = take(n + 16);
+	const uint64_t bwt_cap = (nshards > 1) ? p->shard_cap : n;
+	uint64_t o_bwt0 = take(bwt_cap + 16), o_bwt1 = take(B > 1 ? n + 16 : 16);
 	p->gt_words = (n + 1 + 31) / 32 + 2;
 	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
-	uint64_t o_bs = take(blocksort_ws_bytes(p->blocksize));
+	const uint64_t sort_cap = (nshards > 1) ? p->shard_cap : p->blocksize;
+	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
 	uint64_t nbk = rank_blocks(maxL);
@@ -305,7 +316,7 @@ b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
 	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
-	blocksort_ws_carve(p->bs, A + o_bs, p->blocksize);
+	blocksort_ws_carve(p->bs, A + o_bs, sort_cap);
 	if (B > 1) {
 		p->d_rank_blocks = (uint32_t *)(A + o_rb); p->d_rank_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 		p->d_ranks[0] = (uint32_t *)(A + o_r0); p->d_ranks[1] = (uint32_t *)(A + o_r1);
@@ -329,6 +340,16 @@ b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_
 	return p;
 	B3M_CATCH((b3m_plan_destroy(p), (b3m_plan *)nullptr))
 }
+
+b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem, uint64_t isasamplingrate)
+{
+	return plan_create_impl(n, inputtype, blocksize, mem, isasamplingrate, 0, 1);
+}
+b3m_plan *b3m_plan_create_sharded(uint64_t n, int inputtype, int shard, int nshards, uint64_t mem, uint64_t isasamplingrate)
+{
+	return plan_create_impl(n, inputtype, 0, mem, isasamplingrate, shard, nshards);
+}
+uint64_t b3m_plan_slice_capacity(const b3m_plan *p) { return p ? (p->nshards > 1 ? p->shard_cap : p->n) : 0; }
 
 void b3m_plan_destroy(b3m_plan *p)
 {
@@ -366,7 +387,9 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	for (uint64_t k = 0; k < B; ++k) {
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
-		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k);
+		B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
+		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards);
+		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;
 		{
@@ -374,7 +397,7 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
 			histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
 			if (p->isarate)
-				emit_samples(so.d_sa, lf.m, p->isarate, p->d_samples + 2 * p->sample_off[k], p->d_sample_cnt + k,
+				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], p->d_sample_cnt + k,
 				             p->sample_off[k + 1] - p->sample_off[k], s);
 			if (B > 1)
 				hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((lf.m + 255) / 256)), dim3(256), 0, s, so.d_sa, lf.m, lf.a, p->d_p0tmp + k, p->d_gt[0]);
@@ -451,13 +474,19 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		}
 		cur = nxt;
 	}
-	B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], n, hipMemcpyDeviceToDevice, s));
+	B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], (p->nshards > 1) ? p->res.slice_len : n, hipMemcpyDeviceToDevice, s));
 	uint64_t p0pair[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipEventRecord(ev1, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
 	p->res.p0 = p0pair[0];
+	p->res.has_p0 = 1;
+	if (p->nshards > 1) {
+		// the shard that holds the rotation starting at 0 knows p0 (as a global rank)
+		if ((uint32_t)p0pair[0] == 0xFFFFFFFFu) { p->res.has_p0 = 0; p->res.p0 = ~0ull; }
+		else p->res.p0 = p0pair[0] + p->res.slice_offset;
+	}
 	float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
 	p->res.ms_total = ms;
 	tl->collect(p->kms, p->klaunch, p->kbytes);
@@ -467,15 +496,21 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	p->res.ms_interleave = p->kms[KF_INTERLEAVE];
 	// samples -> host, sorted by rank
 	p->h_samples.clear();
-	if (p->isarate && p->total_samples) {
-		p->h_samples.resize(2 * p->total_samples);
-		B3M_HIP(hipMemcpy(p->h_samples.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
-		std::vector<std::pair<uint64_t, uint64_t>> v(p->total_samples);
-		for (uint64_t i = 0; i < p->total_samples; ++i) v[i] = {p->h_samples[2 * i], p->h_samples[2 * i + 1]};
-		std::sort(v.begin(), v.end());
-		for (uint64_t i = 0; i < p->total_samples; ++i) { p->h_samples[2 * i] = v[i].first; p->h_samples[2 * i + 1] = v[i].second; }
+	uint64_t nsmp = p->total_samples;
+	if (p->isarate && p->nshards > 1) {      // a shard holds only the samples of its own suffixes
+		uint32_t c = 0;
+		B3M_HIP(hipMemcpy(&c, p->d_sample_cnt, 4, hipMemcpyDeviceToHost));
+		nsmp = c;
 	}
-	p->res.num_samples = p->total_samples;
+	if (p->isarate && nsmp) {
+		p->h_samples.resize(2 * nsmp);
+		B3M_HIP(hipMemcpy(p->h_samples.data(), p->d_samples, 16 * nsmp, hipMemcpyDeviceToHost));
+		std::vector<std::pair<uint64_t, uint64_t>> v(nsmp);
+		for (uint64_t i = 0; i < nsmp; ++i) v[i] = {p->h_samples[2 * i] + (p->nshards > 1 ? p->res.slice_offset : 0), p->h_samples[2 * i + 1]};
+		std::sort(v.begin(), v.end());
+		for (uint64_t i = 0; i < nsmp; ++i) { p->h_samples[2 * i] = v[i].first; p->h_samples[2 * i + 1] = v[i].second; }
+	}
+	p->res.num_samples = p->h_samples.size() / 2;
 	return 0;
 	B3M_CATCH(1)
 }

@@ -308,17 +308,19 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 }
 
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                uint8_t *d_bwt, uint32_t *d_p0)
+                uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards)
 {
-	B3M_REQUIRE(len <= ws.cap, "block_sort: block larger than workspace");
+	B3M_REQUIRE(nshards > 1 || len <= ws.cap, "block_sort: block larger than workspace");
+	B3M_REQUIRE(nshards <= 1 || msd_applicable(T, len), "suffix-range shards need a 2-bit input of at least 2^18 symbols");
 	B3M_REQUIRE(T.n < (1ull << 32), "n >= 2^32 is not supported yet (u32 positions)");
 	out = BlockSortOut();
 	if (len == 0) return;
 	if (msd_applicable(T, len)) {
-		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0);
+		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards);
 		return;
 	}
 	block_sort_lsd(T, start, len, ws, s, tl, out);
+	out.kept_len = len;
 	Scope sc(tl, KF_EMIT, 6 * len);
 	emit_bwt(T, out.d_sa, len, start, d_bwt, d_p0, s);
 }

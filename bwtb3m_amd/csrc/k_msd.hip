@@ -128,6 +128,7 @@ struct MsdArgs {
 	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
 	int D;                       // digit bits of this pass
 	int shift;                   // !FROM_TEXT: digit = (rec >> shift) & (2^D - 1)
+	uint32_t keep_lo, keep_hi;   // FROM_TEXT scatter: only records with keep_lo <= digit < keep_hi are kept (suffix-range shard)
 };
 
 template <bool FROM_TEXT, bool COUNT_ONLY>
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 						if (fast && s > 0) { pr = (uint32_t)(w0 >> (32 - 2 * s)) & 3u; if (A.T.type == B3M_INPUT_PACTERM) pr += 1; }
 						else pr = pred_sym(A.T, i);
 						rec[s] = make_rec(x, A.D, pr, (uint32_t)i, &dg[s]);
-						vmask |= 1u << s;
+						if (COUNT_ONLY || (dg[s] >= A.keep_lo && dg[s] < A.keep_hi)) vmask |= 1u << s;
 					}
 				}
 			}
@@ -225,6 +226,18 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		__syncthreads();
 		for (int b = tid; b < bins; b += MSD_THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
 	}
+}
+
+// totals[d] = number of records with level-0 digit d (sum of row d of the [digit][tile] counts)
+__global__ __launch_bounds__(256) void k_row_totals(const uint32_t *hist, uint32_t ntiles, unsigned long long *totals)
+{
+	__shared__ unsigned long long part[256];
+	unsigned long long s = 0;
+	for (uint32_t t = threadIdx.x; t < ntiles; t += 256) s += hist[(uint64_t)blockIdx.x * ntiles + t];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+	if (threadIdx.x == 0) totals[blockIdx.x] = part[0];
 }
 
 // starts of the buckets leaving a level: bucket_tab = {start[nb], hist_off[nb], ntiles[nb]} of the
@@ -424,27 +437,57 @@ __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, ui
 	if (gid) gid[s] = b0[lo];
 }
 
-void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                    uint8_t *d_bwt, uint32_t *d_p0)
+void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
+                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards)
 {
+	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
-	const MsdDigits dg = msd_digits(len);
+	const MsdDigits dg = msd_digits(len_in);
 	uint64_t *rin = ws.keyB, *rout = ws.keyA;      // level 0 writes keyA
 	uint32_t *sa = ws.idxA;
 	out.used_msd = true;
 	// ---- level 0: text -> records, partitioned by the first bits[0] bits ----
 	const uint64_t P0 = start & ~15ull;
-	const uint64_t span = start + len - P0;
+	const uint64_t span = start + len_in - P0;
 	const uint32_t ntA = (uint32_t)((span + MSD_SUPER - 1) / MSD_SUPER);
 	const uint32_t bins0 = 1u << dg.bits[0];
 	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
 	MsdArgs A{};
 	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_in = nullptr; A.rec_out = rout; A.tiles = nullptr; A.hist = M.hist; A.D = dg.bits[0]; A.shift = 0;
+	A.keep_lo = 0; A.keep_hi = bins0;
 	{
 		Scope sc(tl, KF_MSD_HIST, span / 4);
 		hipLaunchKernelGGL((k_msd_pass<true, true>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
 	}
+	out.slice_offset = 0;
+	if (nshards > 1) {
+		// suffix-range shard: this rank keeps the level-0 digits [lo, hi) holding the ranks
+		// [shard*n/N, (shard+1)*n/N) as evenly as whole digits allow.  The totals come from the
+		// text alone, so every rank derives the same boundaries without talking to anyone.
+		unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until the levels are done
+		hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		std::vector<unsigned long long> tot(bins0);
+		B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		std::vector<uint64_t> cum(bins0 + 1, 0);
+		for (uint32_t d = 0; d < bins0; ++d) cum[d + 1] = cum[d] + tot[d];
+		auto bound = [&](int k) -> uint32_t {          // first digit whose cumulative count reaches k*n/N
+			if (k <= 0) return 0; if (k >= nshards) return bins0;
+			uint64_t target = (uint64_t)((unsigned __int128)cum[bins0] * (unsigned)k / (unsigned)nshards);
+			uint32_t d = 0; while (d < bins0 && cum[d] < target) ++d;
+			return d;
+		};
+		uint32_t lo = bound(shard), hi = bound(shard + 1);
+		A.keep_lo = lo; A.keep_hi = hi;
+		out.slice_offset = cum[lo];
+		len = cum[hi] - cum[lo];
+		B3M_REQUIRE(len <= ws.cap, "suffix-range shard larger than the workspace (skewed input): use block mode or fewer shards");
+		if (lo) B3M_HIP(hipMemsetAsync(M.hist, 0, 4ull * lo * ntA, s));
+		if (hi < bins0) B3M_HIP(hipMemsetAsync(M.hist + (uint64_t)hi * ntA, 0, 4ull * (bins0 - hi) * ntA, s));
+	}
+	out.kept_len = len;
+	if (len == 0) { out.d_sa = sa; return; }          // empty shard (one huge digit took the neighbours' share)
 	{
 		Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
 		exclusive_sum_u32(M.hist, (uint64_t)bins0 * ntA, M.scan_ws, s);
@@ -494,7 +537,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 		consumed += Dn;
 		MsdArgs Bq{};
 		Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = rin; Bq.rec_out = rout; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = Dn;
-		Bq.shift = 64 - consumed;
+		Bq.shift = 64 - consumed; Bq.keep_lo = 0; Bq.keep_hi = 0xFFFFFFFFu;
 		const uint32_t ntB = (uint32_t)tiles.size();
 		{
 			Scope sc(tl, KF_MSD_HIST, 8 * len);

@@ -373,6 +373,28 @@ class DistributedBwt:
         return out, new_off, gt_new, p0P
 
 
+class PrefixShardedBwt:
+    """Multi-GPU construction WITHOUT an exchange step, for a text that is resident on every GPU:
+    rank k sorts only the suffixes whose rank falls into k's range (whole classes of the leading
+    8 bits, balanced from the text's own histogram, so all ranks agree without communicating) and
+    owns that contiguous slice of the BWT.  Strong scaling of a fixed input; nothing but the
+    optional result gather touches the interconnect.  The block-merging path with its all-to-all of
+    gap buckets (DistributedBwt) is what a text that cannot be sorted in one piece needs."""
+
+    def __init__(self, n, itype, device, isasamplingrate=0):
+        from . import engine
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.plan = engine.Plan(n, itype, isasamplingrate=isasamplingrate, shard=self.rank, nshards=self.world)
+        self.out = torch.empty(self.plan.slice_capacity, dtype=torch.uint8, device=device)
+
+    def run(self, d_text):
+        sl = self.plan.run(d_text, self.out)
+        r = self.plan.result()
+        off = r["slice_offset"] if self.world > 1 else 0
+        return sl, off, (r["p0"] if r["has_p0"] else None)
+
+
 def gather_result(slice_t, group=None):
     """collect the distributed BWT on every rank (tests / verification only)"""
     ws = dist.get_world_size(group)
@@ -391,31 +413,52 @@ def gather_result(slice_t, group=None):
 # ---------------------------------------------------------------------------------------------------
 # bench entry (called by bench.py when WORLD_SIZE > 1)
 # ---------------------------------------------------------------------------------------------------
-def bench_main(a, rank, local_rank, world):
-    from . import synth
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    itype_cfg, nsyms_cfg, _ = synth.CONFIGS[a.config]
-    want = int(a.size) if a.size else nsyms_cfg
-    itype, d_text, n = synth.config_input_device(a.config, size=want, device=dev)
-    be = HipBackend(dev)
-    job = DistributedBwt(n, itype, be, dev)
-    for _ in range(a.warmup):
+def _run_mode(job, d_text, steps, warmup, dev):
+    for _ in range(warmup):
         job.run(d_text)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out, off, p0 = job.run(d_text)
     torch.cuda.synchronize()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt[0])
+    return float(dt[0]), out, off, p0
+
+
+def bench_main(a, rank, local_rank, world):
+    """N>1 leg of bench.py: one process per GPU (torchrun), RCCL process group.  Headline = the mode
+    asked for (default: suffix-range shards).  With --also-blocks (default) one pass of the
+    block-merging / all-to-all mode follows AFTER the JSON line, reported on stderr, under a
+    watchdog so that it can never cost the headline."""
+    import sys
+    import threading
+    from . import synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(1, ndev))
+    torch.cuda.set_device(dev)
+    # B3M_BENCH_BACKEND=gloo: rehearsal of the N>1 flow with several ranks on ONE GPU (RCCL needs a GPU
+    # per rank); collectives are then staged through host memory
+    backend = os.environ.get("B3M_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    itype_cfg, nsyms_cfg, _ = synth.CONFIGS[a.config]
+    want = int(a.size) if a.size else nsyms_cfg
+    itype, d_text, n = synth.config_input_device(a.config, size=want, device=dev)
     nbases = n - 1 if itype == "pacterm" else n
+    mode = getattr(a, "mode", "prefix")
+
+    def make(m):
+        return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev)
+
+    job = make(mode)
+    dt, out, off, p0 = _run_mode(job, d_text, a.steps, a.warmup, dev)
     if a.verify:
         full = gather_result(out)
         if rank == 0:
@@ -423,18 +466,47 @@ def bench_main(a, rank, local_rank, world):
             sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)
             assert np.array_equal(full.cpu().numpy(), O.bwt(sym)), "distributed BWT differs from the oracle"
     if rank == 0:
-        levels = len(job.plan.levels)
+        levels = len(job.plan.levels) if mode == "blocks" else 0
         alg_job = nbases * (9.5 + 41.0 * levels)
+        fam = {}
+        if mode != "blocks":
+            fam = {k["name"]: round(k["ms"], 3) for k in job.plan.kernel_times() if k["ms"] > 0}
         res = {
             "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
             "value": round(nbases * a.steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world,
-                       "merge_levels": levels, "parallelism": "%d GPUs: 1 leaf block per GPU, all-to-all gap merge" % world,
-                       "rank0_phase_s": {k: round(v, 4) for k, v in job.timing.items()}},
+            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
+                       "merge_levels": levels, "mode": mode,
+                       "parallelism": ("%d GPUs: 1 leaf block per GPU, RCCL all-to-all gap merge" % world) if mode == "blocks"
+                       else ("%d GPUs: suffix-range shards of the replicated text, no exchange step" % world),
+                       "rank0_families_ms_last_step": fam,
+                       "rank0_phase_s": {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}},
             "roofline": {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / a.steps) / 1e9, 1),
                          "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / a.steps) / 1e9 / (8000.0 * world), 5), "traffic": None},
         }
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+    if getattr(a, "also_blocks", True) and mode != "blocks":
+        # secondary measurement: must never endanger the line above
+        def _bail():
+            sys.stderr.write("[bench] block-merge mode watchdog fired after %d s: skipped\n" % a.blocks_timeout)
+            sys.stderr.flush()
+            os._exit(0)
+        wd = threading.Timer(a.blocks_timeout, _bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            del job, out
+            torch.cuda.empty_cache()
+            job2 = make("blocks")
+            dt2, out2, off2, p02 = _run_mode(job2, d_text, 1, 1, dev)
+            if rank == 0:
+                sys.stderr.write("[bench] block-merge mode (1 leaf block per GPU, %d merge levels, RCCL all-to-all of gap buckets): "
+                                 "%.1f ms/step = %.3f Gbase/s; rank0 phases %s\n"
+                                 % (len(job2.plan.levels), dt2 * 1e3, nbases / dt2 / 1e9, {k: round(v, 4) for k, v in job2.timing.items()}))
+                sys.stderr.flush()
+        except Exception as ex:   # noqa: BLE001
+            sys.stderr.write("[bench] block-merge mode failed: %r\n" % (ex,))
+        wd.cancel()
+    dist.barrier()
     dist.destroy_process_group()

@@ -45,10 +45,14 @@ def num_symbols(file_bytes, inputtype):
 class Plan:
     """b3m_plan: all workspace allocated at creation; run() = one pass of the hot path."""
 
-    def __init__(self, n, inputtype, blocksize=0, mem=0, isasamplingrate=0):
+    def __init__(self, n, inputtype, blocksize=0, mem=0, isasamplingrate=0, shard=0, nshards=1):
         self.n = int(n)
         self.type = _type_id(inputtype)
-        self._h = lib().b3m_plan_create(self.n, self.type, int(blocksize), int(mem), int(isasamplingrate))
+        self.nshards = int(nshards)
+        if self.nshards > 1:
+            self._h = lib().b3m_plan_create_sharded(self.n, self.type, int(shard), self.nshards, int(mem), int(isasamplingrate))
+        else:
+            self._h = lib().b3m_plan_create(self.n, self.type, int(blocksize), int(mem), int(isasamplingrate))
         if not self._h:
             raise _lib.B3MError(lib().b3m_last_error().decode())
 
@@ -71,12 +75,20 @@ class Plan:
     def text_bytes(self):
         return int(lib().b3m_plan_text_bytes(self._h))
 
+    @property
+    def slice_capacity(self):
+        return int(lib().b3m_plan_slice_capacity(self._h))
+
     def run(self, d_text, d_out=None):
+        """one pass of the hot path.  Sharded plans return the view of their slice (see result())."""
         assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.numel() >= self.text_bytes
+        cap = self.slice_capacity
         if d_out is None:
-            d_out = torch.empty(self.n, dtype=torch.uint8, device=d_text.device)
-        assert d_out.is_cuda and d_out.numel() >= self.n
+            d_out = torch.empty(cap, dtype=torch.uint8, device=d_text.device)
+        assert d_out.is_cuda and d_out.numel() >= cap
         check(lib().b3m_plan_run(self._h, _ptr(d_text), _ptr(d_out), _stream()))
+        if self.nshards > 1:
+            return d_out[: self.result()["slice_len"]]
         return d_out
 
     def result(self):

@@ -89,6 +89,14 @@ typedef struct b3m_plan b3m_plan;
  * (rank,pos) samples.  All workspace is allocated here, none in b3m_plan_run. */
 b3m_plan *b3m_plan_create(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem,
                           uint64_t isasamplingrate);
+/* Suffix-range shard for N GPUs holding the same text (multi-GPU without an exchange step): the plan
+ * of shard k sorts only the suffixes whose rank lies in k's range -- whole classes of the leading 8
+ * bits, balanced from the histogram of the text, identical on every rank -- and b3m_plan_run writes
+ * that contiguous slice of the BWT (result.slice_offset / slice_len; d_bwt_out needs
+ * b3m_plan_slice_capacity() bytes).  pac/pacterm, n >= 2^18. */
+b3m_plan *b3m_plan_create_sharded(uint64_t n, int inputtype, int shard, int nshards, uint64_t mem,
+                                  uint64_t isasamplingrate);
+uint64_t  b3m_plan_slice_capacity(const b3m_plan *p);
 void      b3m_plan_destroy(b3m_plan *p);
 uint64_t  b3m_plan_num_blocks(const b3m_plan *p);
 uint64_t  b3m_plan_workspace_bytes(const b3m_plan *p);
@@ -106,6 +114,8 @@ typedef struct b3m_result {
 	uint64_t tie_rounds;         /* key-extension rounds needed by the leaf sorts (max) */
 	uint64_t tie_elements;       /* suffixes that needed more than the first key (sum) */
 	double   ms_total, ms_sort, ms_gap, ms_interleave;   /* HIP-event times of the last run */
+	uint64_t slice_offset, slice_len;   /* suffix-range shard: global rank of the first symbol written, and how many (else 0, n) */
+	uint64_t has_p0;                    /* 0 if the rotation starting at 0 lies in another shard */
 } b3m_result;
 int b3m_plan_result(const b3m_plan *p, b3m_result *out);
 /* copies min(cap, num_samples) (rank,pos) u64 pairs, sorted by rank, to host memory */

@@ -366,3 +366,92 @@ def test_msd_leaves_then_merges(gpu, oracle, itype):
     smp = plan.samples()
     assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# suffix-range shards (multi-GPU mode without an exchange step): the slices of all shards,
+# concatenated in shard order, are the BWT
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype,kind,nshards", [("pacterm", "uniform", 2), ("pacterm", "uniform", 8), ("pac", "uniform", 3),
+                                                 ("pacterm", "repeat", 4), ("pac", "twosym", 4)])
+def test_suffix_range_shards(gpu, oracle, itype, kind, nshards):
+    torch = gpu
+    from bwtb3m_amd import engine
+    nb = (1 << 19) + 4321
+    if kind == "uniform":
+        b = oracle.synth_bases(nb, 51)
+    elif kind == "repeat":
+        b = oracle.synth_repeat_bases(nb, 52)
+    else:
+        b = (oracle.synth_bases(nb, 53) & 1).astype(np.uint8)      # half of the digit space empty
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    d = torch.from_numpy(buf).cuda()
+    parts, off, p0s, nsmp = [], 0, [], 0
+    for k in range(nshards):
+        plan = engine.Plan(len(s), itype, shard=k, nshards=nshards, isasamplingrate=1024)
+        sl = plan.run(d)
+        r = plan.result()
+        assert r["slice_offset"] == off and r["slice_len"] == sl.numel()
+        off += sl.numel()
+        parts.append(sl.cpu().numpy().copy())
+        if r["has_p0"]:
+            p0s.append(r["p0"])
+        smp = plan.samples()
+        nsmp += len(smp)
+        if len(smp):
+            assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+        plan.close()
+    assert np.array_equal(np.concatenate(parts), ref)
+    assert nsmp == (len(s) + 1023) // 1024
+    assert len(p0s) == 1 and p0s[0] == int(np.nonzero(sa == 0)[0][0])
+
+
+def _prefix_worker(rank, world, port, nb, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from bwtb3m_amd import distributed as D
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        b = O.synth_bases(nb, 123)
+        buf = O.pac_encode(b)
+        sym = O.symbols_from_file_bytes(buf, "pacterm")
+        job = D.PrefixShardedBwt(len(sym), "pacterm", dev)
+        out, off, p0 = job.run(torch.from_numpy(buf).to(dev))
+        full = D.gather_result(out).cpu().numpy()
+        ref = O.bwt(sym)
+        ok = bool(np.array_equal(full, ref)) and bool(np.array_equal(ref[off: off + out.numel()], out.cpu().numpy()))
+        if p0 is not None:
+            ok = ok and ref[p0] == 0
+        q.put((rank, ok, p0 is not None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefix_sharded_driver_two_ranks(gpu):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prefix_worker, args=(r, 2, port, 600001, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        assert not p.is_alive() and p.exitcode == 0
+    res = [q.get() for _ in range(2)]
+    assert all(ok for _, ok, _ in res) and sum(1 for _, _, h in res if h) == 1, res
