@@ -455,3 +455,52 @@ def test_prefix_sharded_driver_two_ranks(gpu):
         assert not p.is_alive() and p.exitcode == 0
     res = [q.get() for _ in range(2)]
     assert all(ok for _, ok, _ in res) and sum(1 for _, _, h in res if h) == 1, res
+
+
+# ---------------------------------------------------------------------------------------------
+# large size (too big for the CPU oracle in a test): size-independent properties.  Three different
+# algorithmic routes -- one block; 5 leaf blocks + 3 levels of gap merges; 4 suffix-range shards --
+# must give the same bytes; the BWT is a permutation of the text; the terminator sits at p0.
+# ---------------------------------------------------------------------------------------------
+def test_large_paths_agree_256mbase(gpu):
+    torch = gpu
+    import hashlib
+    from bwtb3m_amd import engine, synth
+    nb = 256_000_000
+    itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+    assert n == nb + 1
+
+    def digest(t):
+        return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+    plan = engine.Plan(n, itype)
+    one = plan.run(d_text)
+    torch.cuda.synchronize()
+    r1 = plan.result()
+    h1 = digest(one)
+    hist = plan.histogram()
+    counts = torch.bincount(one.to(torch.int64), minlength=8).cpu().numpy()
+    assert counts[0] == 1 and int(one[r1["p0"]]) == 0
+    assert np.array_equal(counts[:5], hist[:5].astype(np.int64)) and counts[:5].sum() == n
+    plan.close(); del one
+    plan = engine.Plan(n, itype, blocksize=(n + 4) // 5)
+    assert plan.num_blocks == 5
+    merged = plan.run(d_text)
+    torch.cuda.synchronize()
+    rm = plan.result()
+    assert digest(merged) == h1 and rm["p0"] == r1["p0"] and rm["levels"] == 3
+    plan.close(); del merged
+    h = hashlib.sha256()
+    off = 0
+    for k in range(4):
+        plan = engine.Plan(n, itype, shard=k, nshards=4)
+        sl = plan.run(d_text)
+        torch.cuda.synchronize()
+        r = plan.result()
+        assert r["slice_offset"] == off
+        off += sl.numel()
+        h.update(sl.cpu().numpy().tobytes())
+        if r["has_p0"]:
+            assert r["p0"] == r1["p0"]
+        plan.close(); del sl
+    assert off == n and h.hexdigest() == h1
