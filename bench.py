@@ -127,10 +127,20 @@ def main():
     achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     B = res["num_blocks"]
     levels = res["levels"]
+    # HBM traffic of the dominant kernel from the committed PMC pass (separate rocprofv3 --pmc runs,
+    # gfx950 FETCH_SIZE correction applied: see the file); only valid for the workload it was taken on
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        kn = kernel_of.get(dname, dname)
+        if tj.get("workload_n") == n and B == 1 and kn in tj["kernels"]:
+            traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
     alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
     roof = {
         "bound": "hbm", "kernel": kernel_of.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, a.steps),
         "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),
         "job_alg_bytes": alg_job, "job_frac": round(alg_job / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
