@@ -148,6 +148,8 @@ void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t st
               uint32_t *d_p0 /*device scalar*/, hipStream_t s);
 void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, uint32_t *d_gt_abs /*bit x = gt of absolute position x*/,
              hipStream_t s);
+// gt bits of the block's own positions (start, start+len) from the text alone (no SA needed)
+void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t *d_gt_abs, hipStream_t s);
 void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint32_t *d_count, uint64_t cap,
                   hipStream_t s);
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,

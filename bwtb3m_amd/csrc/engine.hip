@@ -144,7 +144,7 @@ static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
 
 static void chains_for(uint64_t mr, uint64_t &chain_len, uint64_t &num_chains)
 {
-	const uint64_t target = 256ull * 1024;      // lanes to fill: 256 CUs x 16 waves x 64
+	const uint64_t target = 512ull * 1024;      // lanes to fill: 256 CUs x 32 waves x 64
 	const uint64_t min_len = 32;
 	chain_len = std::max<uint64_t>(min_len, (mr + target - 1) / target);
 	num_chains = (mr + chain_len - 1) / chain_len;
@@ -286,7 +286,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint64_t nbk = rank_blocks(maxL);
 	uint64_t o_rb = 0, o_rs = 0, o_sw = 0, o_r0 = 0, o_r1 = 0, o_tq = 0, o_mr = 0;
 	if (B > 1) {
-		o_rb = take(64 * nbk); o_rs = take(16 * nbk + 64); o_sw = take(4 * scan_ws_elems(nbk) + 64);
+		o_rb = take(64 * nbk); o_rs = take(64 * nbk + 64); o_sw = take(4 * scan_ws_elems(nbk) + 64);
 		o_r0 = take(4 * p->max_slots + 64); o_r1 = take(4 * p->max_slots + 64);
 		o_tq = take(4 * (interleave_tiles(maxTot) + 2));
 		o_mr = take(radix_ws_bytes(p->max_slots));
@@ -399,8 +399,7 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 			if (p->isarate)
 				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], p->d_sample_cnt + k,
 				             p->sample_off[k + 1] - p->sample_off[k], s);
-			if (B > 1)
-				hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((lf.m + 255) / 256)), dim3(256), 0, s, so.d_sa, lf.m, lf.a, p->d_p0tmp + k, p->d_gt[0]);
+			if (B > 1) emit_gt_from_text(T, lf.a, lf.m, p->d_gt[0], s);
 		}
 		if (B > 1) {
 			Scope sc(tl, KF_ANCHOR, 0);
@@ -641,7 +640,7 @@ int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t 
 	PaddedText pt(d_text, n, inputtype, s);
 	const uint64_t Rbeg = a + m, Rend = Rbeg + mr;
 	uint64_t nb = rank_blocks(m);
-	DevBuf blocks(64 * nb), scratch(16 * nb + 64), sws(4 * scan_ws_elems(nb) + 64);
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64);
 	DevBuf p0d(16);
 	{ uint32_t p032 = (uint32_t)p0L; B3M_HIP(hipMemcpy(p0d.p, &p032, 4, hipMemcpyHostToDevice)); }
 	rank_build(d_bwtL, m, p0d.as<uint32_t>(), inputtype, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
@@ -743,7 +742,7 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
 	if (num_chains == 0) { if (count_out) *count_out = 0; return 0; }
 	PaddedText pt(d_text, n, inputtype, s);
 	uint64_t nb = rank_blocks(m);
-	DevBuf blocks(64 * nb), scratch(16 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), hb(8 * 256);
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), hb(8 * 256);
 	{ uint32_t p032 = (uint32_t)p0L; B3M_HIP(hipMemcpy(p0d.p, &p032, 4, hipMemcpyHostToDevice)); }
 	rank_build(d_bwtL, m, p0d.as<uint32_t>(), inputtype, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
 	B3M_HIP(hipMemsetAsync(hb.p, 0, 8 * 256, s));
@@ -839,7 +838,7 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
 	block_sort(pt.T, start, len, bs, s, nullptr, so, d_bwt_out ? d_bwt_out : bwt_tmp.as<uint8_t>(), d_p0);
 	if (d_gt_abs) {
 		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, d_p0, d_pair, start);
-		hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, s, so.d_sa, len, start, d_p0, d_gt_abs);
+		emit_gt_from_text(pt.T, start, len, d_gt_abs, s);
 		uint64_t endpos = start + len;
 		B3M_HIP(hipMemcpyAsync(d_ep, &endpos, 8, hipMemcpyHostToDevice, s));
 		rank_of_positions(pt.T, so.d_sa, len, d_ep, 1, d_er, s);

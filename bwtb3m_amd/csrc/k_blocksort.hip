@@ -154,6 +154,44 @@ __global__ void k_emit_gt(const uint32_t *sa, uint64_t len, uint64_t start, uint
 	uint32_t x = sa[r];
 	if (r > p0 && x != start) atomicOr(&gt[x >> 5], 1u << (x & 31));
 }
+// gt bits without a scatter: bit x = [S_x > S_start] is a property of the TEXT, so it is computed
+// by streaming the packed text: one thread per 16 positions compares every rotation with the
+// block's first one (first 32 bases in one window; the full comparison only if those tie).
+// Writes 16-bit halves of the absolute-position bit array: no atomics.
+__global__ __launch_bounds__(256) void k_gt_from_text(TextView T, uint64_t start, uint64_t len, uint16_t *gt16)
+{
+	uint64_t w = (start >> 4) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t pos0 = w << 4;
+	const uint64_t end = start + len;             // bits for x in (start, end) ; bit `end` is set by the caller
+	if (pos0 >= end) return;
+	const bool fast0 = start + 32 <= T.nbases;
+	const uint64_t ref = fast0 ? window32(T, start) : 0;
+	bool fast = fast0 && pos0 + 16 + 32 <= T.nbases;
+	uint64_t w0 = 0, w1 = 0, w2 = 0;
+	if (fast) { const uint8_t *p = T.b + (w << 2); w0 = be32(p); w1 = be32(p + 4); w2 = be32(p + 8); }
+	uint64_t hi = (w0 << 32) | w1;
+	uint32_t bits = 0, keep = 0;                  // keep: positions of this half-word outside (start, end)
+	#pragma unroll
+	for (int s = 0; s < 16; ++s) {
+		uint64_t x = pos0 + s;
+		if (x <= start || x >= end) { keep |= 1u << s; continue; }
+		int c;
+		if (fast) {
+			uint64_t wx = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
+			c = wx != ref ? (wx > ref ? 1 : -1) : compare_rotations(T, x, start);
+		} else c = compare_rotations(T, x, start);
+		if (c > 0) bits |= 1u << s;
+	}
+	uint16_t old = keep ? gt16[w] : (uint16_t)0;  // ragged ends of the block: keep the neighbours' bits
+	gt16[w] = (uint16_t)((old & keep) | bits);
+}
+void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t *d_gt_abs, hipStream_t s)
+{
+	if (!len) return;
+	uint64_t words = ((start + len + 15) >> 4) - (start >> 4);
+	hipLaunchKernelGGL(k_gt_from_text, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, T, start, len, reinterpret_cast<uint16_t *>(d_gt_abs));
+}
+
 __global__ void k_emit_samples(const uint32_t *sa, uint64_t len, uint64_t rate, uint64_t *pairs, uint32_t *count, uint64_t cap)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

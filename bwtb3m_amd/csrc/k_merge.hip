@@ -23,32 +23,46 @@ uint64_t rank_blocks(uint64_t m) { return m / RANK_BLK_SYMS + 1; }
 // ------------------------------------------------------------------------------------------------
 // K6 rank dictionary
 // ------------------------------------------------------------------------------------------------
-// pass 1: one thread per 192-symbol block: pack codes, count symbols (excluding the p0 entry)
-__global__ __launch_bounds__(256) void k_rank_pack(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, int sub, uint32_t *blocks,
-                                                     uint32_t *cnt /*[4][nb]*/, uint64_t nb)
+// pass 1: one thread per payload word = 16 consecutive symbols: pack the 2-bit codes, count them
+// with popcounts (the p0 entry is stored as code 0 and not counted).  wc[w] = the four counts of
+// the word, one byte each.
+__global__ __launch_bounds__(256) void k_rank_pack_words(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, int sub, uint32_t *blocks,
+                                                           uint32_t *wc, uint64_t nwords)
+{
+	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords) return;
+	const uint32_t p0 = *p0ptr;
+	uint64_t base = w * 16;
+	uint32_t word = 0, valid = 0;           // valid: bit 2k set if symbol k counts
+	if (base + 16 <= m) {
+		uint8_t v[16];
+		__builtin_memcpy(v, bwt + base, 16);
+		#pragma unroll
+		for (int k = 0; k < 16; ++k) word |= (((uint32_t)v[k] - (uint32_t)sub) & 3u) << (2 * k);
+		valid = 0x55555555u;
+	} else {
+		for (int k = 0; k < 16; ++k) if (base + k < m) { word |= (((uint32_t)bwt[base + k] - (uint32_t)sub) & 3u) << (2 * k); valid |= 1u << (2 * k); }
+	}
+	if (p0 >= base && p0 < base + 16) { uint32_t k = (uint32_t)(p0 - base); word &= ~(3u << (2 * k)); valid &= ~(1u << (2 * k)); }
+	uint32_t lo = word & 0x55555555u, hi = (word >> 1) & 0x55555555u;
+	uint32_t c1 = __popc(lo & ~hi & valid), c2 = __popc(hi & ~lo & valid), c3 = __popc(lo & hi & valid);
+	uint32_t c0 = __popc(valid) - c1 - c2 - c3;
+	uint64_t b = w / 12, j = w - b * 12;
+	blocks[b * 16 + 4 + j] = word;
+	wc[w] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+}
+// pass 2: per 64-byte line: sum of its 12 word counts -> cnt[4][nb]
+__global__ void k_rank_line_counts(const uint32_t *wc, uint64_t nb, uint32_t *cnt)
 {
 	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= nb) return;
-	uint64_t base = b * RANK_BLK_SYMS;
-	const uint32_t p0 = *p0ptr;
-	uint32_t c[4] = {0, 0, 0, 0};
-	uint32_t *out = blocks + b * 16;
-	for (int w = 0; w < 12; ++w) {
-		uint32_t word = 0;
-		for (int k = 0; k < 16; ++k) {
-			uint64_t r = base + (uint64_t)w * 16 + k;
-			uint32_t code = 0;
-			if (r < m && r != p0) {
-				code = ((uint32_t)bwt[r] - (uint32_t)sub) & 3u;
-				c[code]++;
-			}
-			word |= code << (2 * k);
-		}
-		out[4 + w] = word;
-	}
-	cnt[0 * nb + b] = c[0]; cnt[1 * nb + b] = c[1]; cnt[2 * nb + b] = c[2]; cnt[3 * nb + b] = c[3];
+	uint32_t s = 0, t = 0;                  // byte-wise sums: 12 * 16 = 192 < 256 per lane of the packed word
+	#pragma unroll
+	for (int j = 0; j < 12; ++j) { uint32_t x = wc[b * 12 + j]; s += x & 0x00FF00FFu; t += (x >> 8) & 0x00FF00FFu; }
+	cnt[0 * nb + b] = s & 0xFFFFu; cnt[2 * nb + b] = s >> 16;
+	cnt[1 * nb + b] = t & 0xFFFFu; cnt[3 * nb + b] = t >> 16;
 }
-// pass 2 (after 4 exclusive scans): headers
+// pass 3 (after 4 exclusive scans): headers
 __global__ void k_rank_headers(uint32_t *blocks, const uint32_t *cnt, uint64_t nb)
 {
 	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,15 +71,18 @@ __global__ void k_rank_headers(uint32_t *blocks, const uint32_t *cnt, uint64_t n
 	out[0] = cnt[0 * nb + b]; out[1] = cnt[1 * nb + b]; out[2] = cnt[2 * nb + b]; out[3] = cnt[3 * nb + b];
 }
 
+// d_scratch: 4*nb u32 (line counts) followed by 12*nb u32 (word counts)
 void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch,
                 uint32_t *scan_ws, hipStream_t s)
 {
 	B3M_REQUIRE(type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
 	uint64_t nb = rank_blocks(m);
 	int sub = (type == B3M_INPUT_PACTERM) ? 1 : 0;
-	hipLaunchKernelGGL(k_rank_pack, dim3(nblk(nb)), dim3(256), 0, s, d_bwtL, m, d_p0, sub, d_blocks, d_scratch, nb);
-	for (int c = 0; c < 4; ++c) exclusive_sum_u32(d_scratch + c * nb, nb, scan_ws, s);
-	hipLaunchKernelGGL(k_rank_headers, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, d_scratch, nb);
+	uint32_t *cnt = d_scratch, *wc = d_scratch + 4 * nb;
+	hipLaunchKernelGGL(k_rank_pack_words, dim3(nblk(nb * 12)), dim3(256), 0, s, d_bwtL, m, d_p0, sub, d_blocks, wc, nb * 12);
+	hipLaunchKernelGGL(k_rank_line_counts, dim3(nblk(nb)), dim3(256), 0, s, wc, nb, cnt);
+	for (int c = 0; c < 4; ++c) exclusive_sum_u32(cnt + c * nb, nb, scan_ws, s);
+	hipLaunchKernelGGL(k_rank_headers, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, cnt, nb);
 }
 
 // rank_c(BWT_L, rho): occurrences of code c in BWT_L[0, rho), p0 entry never counted.
