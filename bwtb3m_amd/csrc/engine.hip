@@ -854,4 +854,53 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
 	B3M_CATCH(1)
 }
 
+
+/* SURVEY.md 8f rows 1 + 3 on the device: LF walks over the final BWT of the plan's last run between
+ * its (rank,pos) samples.  Verifies every BWT symbol against the text and every chain against the
+ * next anchor (checkbwt), and, if sarate > 0, fills sa_out[i] = SA[i*sarate] (bwtcomputessa).
+ * pac/pacterm, unsharded plans created with isasamplingrate > 0. */
+int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out, uint64_t *mismatches_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_bwt && mismatches_out, "b3m_plan_lf_walk: null argument");
+	B3M_REQUIRE(p->type == B3M_INPUT_PAC || p->type == B3M_INPUT_PACTERM, "the LF walk needs a 2-bit alphabet (pac/pacterm)");
+	B3M_REQUIRE(p->nshards == 1, "the LF walk needs the whole BWT (unsharded plan)");
+	B3M_REQUIRE(p->isarate && !p->h_samples.empty(), "the plan has no (rank,pos) samples: create it with isasamplingrate > 0 and run it");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t n = p->n;
+	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
+	// anchors sorted by position (h_samples is sorted by rank)
+	uint64_t K = p->h_samples.size() / 2;
+	std::vector<std::pair<uint64_t, uint64_t>> bypos(K);
+	for (uint64_t i = 0; i < K; ++i) bypos[i] = {p->h_samples[2 * i + 1], p->h_samples[2 * i]};
+	std::sort(bypos.begin(), bypos.end());
+	B3M_REQUIRE(bypos[0].first == 0, "anchor at position 0 missing");
+	std::vector<uint64_t> anc(2 * K);
+	for (uint64_t i = 0; i < K; ++i) { anc[2 * i] = bypos[i].second; anc[2 * i + 1] = bypos[i].first; }
+	uint64_t nb = rank_blocks(n);
+	uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);
+	uint32_t p032 = (p->type == B3M_INPUT_PACTERM) ? (uint32_t)p->res.p0 : 0xFFFFFFFFu;   // pac: no terminator entry
+	B3M_HIP(hipMemcpyAsync(p0d.p, &p032, 4, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
+	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 4 * (nsa + 1), s));
+	rank_build(d_bwt, n, p0d.as<uint32_t>(), p->type, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
+	RankDict rd{};
+	rd.blocks = blocks.as<uint32_t>(); rd.m = n; rd.p0ptr = p0d.as<uint32_t>();
+	if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = p->h_hist[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += p->h_hist[c + 1]; } }
+	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += p->h_hist[c]; } }
+	lf_walk(T, rd, danc.as<uint64_t>(), K, sarate, dsa.as<uint32_t>(), dmis.as<unsigned long long>(), s);
+	unsigned long long mm[2] = {0, 0};
+	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
+	std::vector<uint32_t> hsa(nsa);
+	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(hsa.data(), dsa.p, 4 * nsa, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+	if (nsa && sa_out) for (uint64_t i = 0; i < nsa; ++i) sa_out[i] = hsa[i];
+	return 0;
+	B3M_CATCH(1)
+}
+
 }  // extern "C"

@@ -55,9 +55,15 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (n == 0) throw std::runtime_error("input is empty");
 		log("[V] input %s type %s symbols %llu\n", o->input_fn, tname, (unsigned long long)n);
 		uint64_t isarate = o->isasamplingrate ? o->isasamplingrate : 262144;
+		uint64_t sarate = o->sasamplingrate ? o->sasamplingrate : 32;
 		// bwtonly=1 lowers the default ISA sampling rate to 64 (/root/reference/ChangeLog:281);
 		// the caller passes the effective value, 0 means "default for the mode"
-		plan = b3m_plan_create(n, type, o->blocksize, o->mem, isarate);
+		const bool two_bit = type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM;
+		const bool want_sa = !o->bwtonly && two_bit;          // sampled SA/ISA stage
+		// anchors of the LF walks: a divisor of the output rate, dense enough to fill the GPU
+		uint64_t anchor_rate = isarate;
+		if (want_sa && isarate > 1024 && isarate % 1024 == 0) anchor_rate = 1024;
+		plan = b3m_plan_create(n, type, o->blocksize, o->mem, anchor_rate);
 		if (!plan) throw std::runtime_error(b3m_last_error());
 		log("[V] blocks %llu workspace %.2f GB\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9);
 		uint64_t tb = b3m_plan_text_bytes(plan);
@@ -79,10 +85,24 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		b3m::write_hist(prefix + ".hist", hist);
 		std::vector<uint64_t> pairs(2 * res.num_samples);
 		if (res.num_samples) b3m_plan_samples(plan, pairs.data(), res.num_samples);
-		b3m::write_preisa(prefix + ".preisa", pairs.data(), res.num_samples);
 		b3m::write_meta(prefix + ".meta", {n, res.num_blocks, res.levels, res.p0, isarate});
-		if (!o->bwtonly)
-			logalways("[W] bwtonly=0: the sampled SA/ISA stage is not part of this engine yet; %s.preisa was written, run bwtcomputessa on it\n", prefix.c_str());
+		if (want_sa) {
+			// bwtonly=0 (/root/reference/README.md:63-67): sampled suffix array and its inverse by LF
+			// walks over the final BWT, every symbol and every chain verified on the way
+			std::vector<uint64_t> sa((n + sarate - 1) / sarate);
+			uint64_t mm[2] = {0, 0};
+			if (b3m_plan_lf_walk(plan, d_bwt, sarate, sa.data(), mm, nullptr)) throw std::runtime_error(b3m_last_error());
+			if (mm[0] || mm[1]) throw std::runtime_error("internal error: the LF walk over the constructed BWT does not reproduce the text");
+			b3m::write_sampled(prefix + ".sa", sarate, sa);
+			std::vector<uint64_t> isa((n + isarate - 1) / isarate);
+			for (uint64_t i = 0; i < res.num_samples; ++i) { uint64_t pos = pairs[2 * i + 1]; if (pos % isarate == 0) isa[pos / isarate] = pairs[2 * i]; }
+			b3m::write_sampled(prefix + ".isa", isarate, isa);
+			log("[V] sampled SA (rate %llu) and ISA (rate %llu) by LF walks, BWT verified against the text\n", (unsigned long long)sarate, (unsigned long long)isarate);
+		} else {
+			b3m::write_preisa(prefix + ".preisa", pairs.data(), res.num_samples);
+			if (!o->bwtonly)
+				logalways("[W] bwtonly=0: the sampled SA/ISA stage needs a 2-bit input type in this engine; %s.preisa was written, run bwtcomputessa on it\n", prefix.c_str());
+		}
 		double t3 = now();
 		log("[V] wrote %s (+.hist .meta .preisa) in %.3f s; total %.3f s\n", outfn.c_str(), t3 - t2, t3 - t0);
 		b3m_plan_destroy(plan);

@@ -161,6 +161,62 @@ void gap_walk(const GapWalkArgs &A, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LF walks over the FINAL BWT (the sampled SA stage of bwtcomputessa,
+// /root/reference/src/bwtcomputessa.cpp:39-51, and the verification walk of checkbwt,
+// /root/reference/src/checkbwt.cpp:176-241).  Chain k starts at anchor k+1 (rank r of the rotation
+// at position p) and walks back to anchor k: at every step the BWT symbol at r must equal T[p-1]
+// (checked), lf(r) = C[c] + rank_c(BWT, r) (convention /root/reference/src/bwtdecodeblock.cpp:280-284),
+// and SA[r] = p is stored when r is a multiple of the SA sampling rate.  The rank the chain
+// arrives with must be anchor k's (checked).
+// ------------------------------------------------------------------------------------------------
+struct LfWalkArgs {
+	TextView T; RankDict rd;
+	const uint64_t *anchors;        // (rank, pos) pairs sorted by pos; pos of anchor 0 is 0
+	uint64_t nanchors;
+	uint64_t sarate;                // 0: no SA samples
+	uint32_t *sa_out;               // ceil(n / sarate) positions
+	unsigned long long *mismatch;   // [0] symbol mismatches, [1] chain closure mismatches
+};
+__global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
+{
+	uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= A.nanchors) return;
+	const TextView &T = A.T;
+	const bool term = T.type == B3M_INPUT_PACTERM;
+	const uint32_t p0 = *A.rd.p0ptr;
+	uint64_t kn = k + 1 == A.nanchors ? 0 : k + 1;
+	uint32_t r = (uint32_t)A.anchors[2 * kn];
+	uint64_t p = kn ? A.anchors[2 * kn + 1] : T.n;     // the last chain starts at position n == 0
+	const uint64_t pend = A.anchors[2 * k + 1];
+	uint32_t bad = 0;
+	while (p > pend) {
+		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (uint32_t)(p == T.n ? 0 : p);
+		uint32_t st = sym_at(T, p - 1);                 // symbol preceding the rotation at p
+		uint32_t nr;
+		if (term && r == p0) {                          // the BWT holds the terminator here
+			bad += st != 0;
+			nr = 0;                                      // the rotation starting with the terminator is the smallest
+		} else {
+			uint32_t b = r / RANK_BLK_SYMS, off = r - b * RANK_BLK_SYMS;
+			uint32_t word = A.rd.blocks[(uint64_t)b * 16 + 4 + (off >> 4)];
+			uint32_t code = (word >> (2 * (off & 15))) & 3u;
+			uint32_t sb = term ? code + 1 : code;
+			bad += sb != st;
+			nr = A.rd.C[code] + rank_query(A.rd, p0, code, r);
+		}
+		r = nr; --p;
+	}
+	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
+	if (r != (uint32_t)A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
+}
+void lf_walk(const TextView &T, const RankDict &rd, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out,
+             unsigned long long *d_mismatch, hipStream_t s)
+{
+	LfWalkArgs A{T, rd, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K9 interleave
 // ------------------------------------------------------------------------------------------------
 constexpr int IL_THREADS = 256;

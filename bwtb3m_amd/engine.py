@@ -108,6 +108,14 @@ class Plan:
         check(lib().b3m_plan_histogram(self._h, h.ctypes.data))
         return h
 
+    def lf_walk(self, d_bwt, sarate=0):
+        """checkbwt + sampled SA on the device: returns (symbol mismatches,
+        chain mismatches, SA samples SA[0], SA[sarate], ... as uint64 numpy array or None)"""
+        mm = np.zeros(2, dtype=np.uint64)
+        sa = np.zeros((self.n + sarate - 1) // sarate, dtype=np.uint64) if sarate else None
+        check(lib().b3m_plan_lf_walk(self._h, _ptr(d_bwt), int(sarate), sa.ctypes.data if sarate else None, mm.ctypes.data, _stream()))
+        return int(mm[0]), int(mm[1]), sa
+
     def kernel_times(self):
         arr = (_lib.KernelTime * 16)()
         check(lib().b3m_plan_kernel_times(self._h, arr, 16))

@@ -124,6 +124,15 @@ int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap);
 /* row a4: symbol histogram of the last run, hist256[sym] (the content of X.hist) */
 int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256);
 
+/* SURVEY.md 8f rows 1 + 3: parallel LF walks over the final BWT (d_bwt = output of the plan's last run)
+ * between the plan's (rank,pos) samples.  Role of BwtComputeSSA::computeSSA
+ * (/root/reference/src/bwtcomputessa.cpp:39-51) and of checkbwt's verification walk
+ * (/root/reference/src/checkbwt.cpp:176-243).  mismatches_out[0] = positions where the BWT symbol differs
+ * from the text, [1] = chains that did not arrive at the next anchor's rank (both 0 for a correct BWT).
+ * sarate > 0: sa_out[i] = SA[i*sarate], ceil(n/sarate) entries (host).  pac/pacterm, unsharded plans. */
+int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out,
+                     uint64_t *mismatches_out, void *stream);
+
 /* per-kernel-family timing of the last run (HIP events on the run's stream) */
 typedef struct b3m_kernel_time { const char *name; double ms; uint64_t launches; uint64_t alg_bytes; } b3m_kernel_time;
 int b3m_plan_kernel_times(const b3m_plan *p, b3m_kernel_time *out, int cap);

@@ -135,3 +135,53 @@ def test_golden_intermediates_stage_level(gpu):
         assert sha(G.cpu().numpy().view(np.uint32)) == g["G"]
         out, p0P = engine.interleave(sr, bw, bw2, p0)
         assert sha(out.cpu().numpy()) == g["bwt"] and p0P == g["p0"]
+
+
+@pytest.mark.parametrize("itype,bs", [("pacterm", 0), ("pac", 0), ("pacterm", 70001)])
+def test_lf_walk_checkbwt_and_sampled_sa(gpu, oracle, itype, bs):
+    """SURVEY.md 8f rows 1 + 3: on-device checkbwt and the sampled SA stage"""
+    torch = gpu
+    from bwtb3m_amd import engine
+    b = oracle.synth_repeat_bases(300_000, 77)
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    d = torch.from_numpy(buf).cuda()
+    plan = engine.Plan(n, itype, blocksize=bs, isasamplingrate=256)
+    out = plan.run(d)
+    assert np.array_equal(out.cpu().numpy(), oracle.bwt(s))
+    m0, m1, ssa = plan.lf_walk(out, sarate=32)
+    assert (m0, m1) == (0, 0)
+    assert np.array_equal(ssa.astype(np.int64), sa[::32])
+    # a damaged BWT must be caught: swap two different symbols
+    bad = out.clone()
+    h = out.cpu().numpy()
+    term = 0 if itype == "pacterm" else 255          # never move the terminator entry
+    i = next(k for k in range(1000, n) if h[k] != term)
+    j = next(k for k in range(i + 1, n) if h[k] != h[i] and h[k] != term)
+    bad[i], bad[j] = out[j], out[i]
+    m0, m1, _ = plan.lf_walk(bad, sarate=0)
+    assert m0 + m1 > 0
+    plan.close()
+
+
+def test_cli_bwtonly0_writes_sa_isa(gpu, oracle, tmp_path):
+    b = oracle.synth_bases(400_001, 88)
+    buf = oracle.pac_encode(b)
+    inp = tmp_path / "g.pac"
+    inp.write_bytes(buf.tobytes())
+    out = str(tmp_path / "g.pac.bwt")
+    # the README's indexing call: no bwtonly => sampled SA and ISA (/root/reference/README.md:106-108)
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "outputfilename=" + out, "isasamplingrate=4096", str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    sa = oracle.sa_circular(s)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    prefix = out[:-4]
+    assert not os.path.exists(prefix + ".preisa")
+    fsa = np.fromfile(prefix + ".sa", dtype=np.uint64)        # rate, count, values (sasubsample.cpp:34-57)
+    assert fsa[0] == 32 and fsa[1] == len(fsa) - 2 and np.array_equal(fsa[2:].astype(np.int64), sa[::32])
+    fisa = np.fromfile(prefix + ".isa", dtype=np.uint64)
+    assert fisa[0] == 4096 and fisa[1] == len(fisa) - 2 and np.array_equal(fisa[2:].astype(np.int64), isa[::4096])
