@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",
                     help="N>1: skip the extra pass of the block-merge mode after the headline line")
     ap.add_argument("--blocks-timeout", type=int, default=150)
+    ap.add_argument("--check", action="store_true",
+                    help="verify the result on the device at any size: LF walks over the BWT against the text (checkbwt)")
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
     return ap.parse_args()
 
@@ -100,7 +102,7 @@ def main():
     blocksize = int(a.blocksize)
     if a.blocks > 0:
         blocksize = (n + a.blocks - 1) // a.blocks
-    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=0)
+    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=1024 if a.check else 0)
     d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
     for _ in range(a.warmup):
         plan.run(d_text, d_out)
@@ -161,6 +163,12 @@ def main():
         sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)
         assert np.array_equal(d_out.cpu().numpy(), O.bwt(sym)), "bench --verify: BWT differs from the oracle"
         out["config"]["verified"] = True
+    if a.check:
+        t0 = time.perf_counter()
+        m0, m1, _ = plan.lf_walk(d_out, sarate=0)
+        torch.cuda.synchronize()
+        assert (m0, m1) == (0, 0), "bench --check: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
+        out["config"]["checked"] = "LF walk over all %d symbols against the text: 0 mismatches (%.0f ms)" % (n, (time.perf_counter() - t0) * 1e3)
     if not a.no_cpu_baseline:
         sample = int(min(a.cpu_sample, n))
         # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)

@@ -150,7 +150,8 @@ void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, ui
              hipStream_t s);
 // gt bits of the block's own positions (start, start+len) from the text alone (no SA needed)
 void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t *d_gt_abs, hipStream_t s);
-void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint32_t *d_count, uint64_t cap,
+// sample of position k*rate -> pairs[k - first] = (rank, pos); slots of other shards stay untouched
+void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint64_t first, uint64_t cap,
                   hipStream_t s);
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum /* += */, hipStream_t s);

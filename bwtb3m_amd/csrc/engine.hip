@@ -396,9 +396,11 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
 			histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
-			if (p->isarate)
-				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], p->d_sample_cnt + k,
+			if (p->isarate) {
+				if (p->nshards > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
+				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,
 				             p->sample_off[k + 1] - p->sample_off[k], s);
+			}
 			if (B > 1) emit_gt_from_text(T, lf.a, lf.m, p->d_gt[0], s);
 		}
 		if (B > 1) {
@@ -493,21 +495,15 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	p->res.ms_sort = p->kms[KF_KEYS] + p->kms[KF_RADIX_HIST] + p->kms[KF_SCAN] + p->kms[KF_RADIX_SCATTER] + p->kms[KF_TIES] + p->kms[KF_EMIT];
 	p->res.ms_gap = p->kms[KF_RANKBUILD] + p->kms[KF_ANCHOR] + p->kms[KF_GAPWALK];
 	p->res.ms_interleave = p->kms[KF_INTERLEAVE];
-	// samples -> host, sorted by rank
+	// samples -> host, in position order (slot k holds position k*rate); a shard keeps only its own
 	p->h_samples.clear();
-	uint64_t nsmp = p->total_samples;
-	if (p->isarate && p->nshards > 1) {      // a shard holds only the samples of its own suffixes
-		uint32_t c = 0;
-		B3M_HIP(hipMemcpy(&c, p->d_sample_cnt, 4, hipMemcpyDeviceToHost));
-		nsmp = c;
-	}
-	if (p->isarate && nsmp) {
-		p->h_samples.resize(2 * nsmp);
-		B3M_HIP(hipMemcpy(p->h_samples.data(), p->d_samples, 16 * nsmp, hipMemcpyDeviceToHost));
-		std::vector<std::pair<uint64_t, uint64_t>> v(nsmp);
-		for (uint64_t i = 0; i < nsmp; ++i) v[i] = {p->h_samples[2 * i] + (p->nshards > 1 ? p->res.slice_offset : 0), p->h_samples[2 * i + 1]};
-		std::sort(v.begin(), v.end());
-		for (uint64_t i = 0; i < nsmp; ++i) { p->h_samples[2 * i] = v[i].first; p->h_samples[2 * i + 1] = v[i].second; }
+	if (p->isarate && p->total_samples) {
+		std::vector<uint64_t> raw(2 * p->total_samples);
+		B3M_HIP(hipMemcpy(raw.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		if (p->nshards > 1) {
+			for (uint64_t i = 0; i < p->total_samples; ++i)
+				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i] + p->res.slice_offset); p->h_samples.push_back(raw[2 * i + 1]); }
+		} else p->h_samples.swap(raw);
 	}
 	p->res.num_samples = p->h_samples.size() / 2;
 	return 0;
@@ -869,14 +865,10 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	hipStream_t s = (hipStream_t)stream;
 	const uint64_t n = p->n;
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
-	// anchors sorted by position (h_samples is sorted by rank)
+	// anchors = the samples, already in position order
 	uint64_t K = p->h_samples.size() / 2;
-	std::vector<std::pair<uint64_t, uint64_t>> bypos(K);
-	for (uint64_t i = 0; i < K; ++i) bypos[i] = {p->h_samples[2 * i + 1], p->h_samples[2 * i]};
-	std::sort(bypos.begin(), bypos.end());
-	B3M_REQUIRE(bypos[0].first == 0, "anchor at position 0 missing");
-	std::vector<uint64_t> anc(2 * K);
-	for (uint64_t i = 0; i < K; ++i) { anc[2 * i] = bypos[i].second; anc[2 * i + 1] = bypos[i].first; }
+	const std::vector<uint64_t> &anc = p->h_samples;
+	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
 	uint64_t nb = rank_blocks(n);
 	uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);

@@ -192,14 +192,19 @@ void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t
 	hipLaunchKernelGGL(k_gt_from_text, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, s, T, start, len, reinterpret_cast<uint16_t *>(d_gt_abs));
 }
 
-__global__ void k_emit_samples(const uint32_t *sa, uint64_t len, uint64_t rate, uint64_t *pairs, uint32_t *count, uint64_t cap)
+// (rank,pos) samples: the sample of position x = k*rate has the fixed slot k - first: no counter
+__global__ void k_emit_samples(const uint32_t *sa, uint64_t len, uint64_t rate, uint64_t *pairs, uint64_t first, uint64_t cap)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= len) return;
 	uint32_t x = sa[r];
-	if (x % rate == 0) {
-		uint32_t k = atomicAdd(count, 1u);
-		if (k < cap) { pairs[2 * (uint64_t)k] = r; pairs[2 * (uint64_t)k + 1] = x; }
+	const uint32_t r32 = (uint32_t)rate;
+	bool hit; uint64_t q;
+	if ((r32 & (r32 - 1)) == 0) { hit = (x & (r32 - 1)) == 0; q = x >> (31 - __clz(r32)); }     // power of two: no division
+	else { q = x / r32; hit = q * r32 == x; }
+	if (hit) {
+		uint64_t k = q - first;
+		if (k < cap) { pairs[2 * k] = r; pairs[2 * k + 1] = x; }
 	}
 }
 // rank of S_x among the sorted block: lower bound by rotation comparison; one thread per query
@@ -376,9 +381,9 @@ void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, ui
 {
 	if (len) hipLaunchKernelGGL(k_emit_gt, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, start, p0, d_gt_abs);
 }
-void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint32_t *d_count, uint64_t cap, hipStream_t s)
+void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint64_t first, uint64_t cap, hipStream_t s)
 {
-	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, rate, d_pairs, d_count, cap);
+	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, rate, d_pairs, first, cap);
 }
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum, hipStream_t s)

@@ -118,7 +118,7 @@ typedef struct b3m_result {
 	uint64_t has_p0;                    /* 0 if the rotation starting at 0 lies in another shard */
 } b3m_result;
 int b3m_plan_result(const b3m_plan *p, b3m_result *out);
-/* copies min(cap, num_samples) (rank,pos) u64 pairs, sorted by rank, to host memory */
+/* copies min(cap, num_samples) (rank,pos) u64 pairs to host memory, in position order (pos = 0, rate, 2*rate, ...) */
 int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap);
 
 /* row a4: symbol histogram of the last run, hist256[sym] (the content of X.hist) */
