@@ -132,14 +132,15 @@ struct BlockSortOut {
 	uint64_t slice_offset = 0;        // global rank of the first of them
 };
 // sorts the block and writes its BWT (d_bwt, len bytes) and p0 (device u32: rank of S_start)
+// need_sa = false: the caller only wants the BWT (out.d_sa is null; saves 4 B/suffix of writes on the MSD path)
 // shard/nshards > 1: suffix-range shard of a whole-text block (MSD path only): only the suffixes whose
 // rank falls into the shard's range are sorted; out.kept_len / out.slice_offset describe the slice
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s,
-                Timeline *tl, BlockSortOut &out, uint8_t *d_bwt, uint32_t *d_p0, int shard = 0, int nshards = 1);
+                Timeline *tl, BlockSortOut &out, uint8_t *d_bwt, uint32_t *d_p0, int shard = 0, int nshards = 1, bool need_sa = true);
 void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out);
 bool msd_applicable(const TextView &T, uint64_t len);
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards);
+                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa);
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left);
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s);

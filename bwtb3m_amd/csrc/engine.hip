@@ -388,7 +388,8 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
 		B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
-		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards);
+		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
+		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
 		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;

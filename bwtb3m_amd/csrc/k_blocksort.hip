@@ -351,7 +351,7 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 }
 
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards)
+                uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa)
 {
 	B3M_REQUIRE(nshards > 1 || len <= ws.cap, "block_sort: block larger than workspace");
 	B3M_REQUIRE(nshards <= 1 || msd_applicable(T, len), "suffix-range shards need a 2-bit input of at least 2^18 symbols");
@@ -359,7 +359,7 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	out = BlockSortOut();
 	if (len == 0) return;
 	if (msd_applicable(T, len)) {
-		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards);
+		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards, need_sa);
 		return;
 	}
 	block_sort_lsd(T, start, len, ws, s, tl, out);

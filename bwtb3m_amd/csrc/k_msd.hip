@@ -271,6 +271,7 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool WRITE_SA>
 __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, uint32_t nbuckets, int sortbits,
                                                             uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0,
                                                             uint32_t *overflow, uint32_t overflow_cap, uint32_t *tiebits)
@@ -357,13 +358,17 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 	wave_sync();
 	// tie groups (equal key field): bit p of the tie bitmap = "record p has the key field of
 	// record p-1"; k_tie_fix resolves the runs against the text.  Scattered single-bit atomics:
-	// no hot address.
+	// no hot address.  tied: records that k_tie_fix will look at (they need their SA entry).
+	uint32_t tiedm = 0;
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
 		uint32_t e = t * 64 + lane;
-		if (e < m && e > 0) {
+		if (e < m) {
 			uint64_t kf = outb[e] >> REC_KEY_SHIFT;
-			if ((outb[e - 1] >> REC_KEY_SHIFT) == kf) { uint32_t q = b0 + e; atomicOr(&tiebits[q >> 5], 1u << (q & 31)); }
+			bool sp = e > 0 && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
+			bool sn = e + 1 < m && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
+			if (sp) { uint32_t q = b0 + e; atomicOr(&tiebits[q >> 5], 1u << (q & 31)); }
+			if (sp || sn) tiedm |= 1u << t;
 		}
 	}
 	if (__ballot(ovf)) {
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 		if (e < m) {
 			uint64_t q = outb[e];
 			uint32_t i = (uint32_t)q;
-			sa[b0 + e] = i;
+			if (WRITE_SA || (tiedm & (1u << t))) sa[b0 + e] = i;       // without consumers only k_tie_fix reads positions
 			bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
 			if (i == (uint32_t)start) *p0 = b0 + e;
 		}
@@ -438,7 +443,7 @@ __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, ui
 }
 
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards)
+                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa)
 {
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
@@ -563,8 +568,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		uint32_t *d_tiebits = ws.t[0];
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
-		hipLaunchKernelGGL(k_lds_sort, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
-		                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
+		if (need_sa)
+			hipLaunchKernelGGL(k_lds_sort<true>, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
+			                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
+		else
+			hipLaunchKernelGGL(k_lds_sort<false>, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
+			                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
 	}
 	{
 		Scope sc(tl, KF_TIES, len / 8);
@@ -602,7 +611,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
 	}
 	B3M_HIP(hipGetLastError());
-	out.d_sa = sa;
+	out.d_sa = need_sa ? sa : nullptr;      // without need_sa only the entries of tied / overflow records were written
 }
 
 }  // namespace b3m
