@@ -105,7 +105,8 @@ struct MsdWs {
 	uint32_t *hist = nullptr; uint64_t hist_cap = 0;        // flattened [bucket][digit][tile] counts / offsets
 	MsdTile *tiles = nullptr; uint64_t tiles_cap = 0;       // tile descriptors (device)
 	uint32_t *sub_start = nullptr;                           // 2^(D1+D2)+1 final bucket offsets
-	uint32_t *bucket_tab = nullptr;                          // per A bucket: start, hist_off, ntiles (3 x 2^D1)
+	uint32_t *bucket_tab = nullptr;                          // per bucket entering a level: start, hist_off, ntiles
+	uint32_t *lvl_start = nullptr;                           // starts of the buckets entering the last (fused) level
 	uint32_t *overflow = nullptr; uint64_t overflow_cap = 0; // [0] = count, then bucket ids
 	uint32_t *scan_ws = nullptr;
 };

@@ -13,7 +13,7 @@ void set_error(const std::string &msg) { g_err = msg; }
 
 const char *const kfam_names[KF_COUNT] = {"keys", "radix_hist", "scan", "radix_scatter", "ties", "emit",
                                           "rank_build", "anchor_rank", "gap_walk", "interleave", "misc",
-                                          "msd_hist", "msd_scatter", "lds_sort", "msd_scatter_text"};
+                                          "msd_hist", "msd_scatter", "bucket_finish", "msd_scatter_text"};
 
 // ---- Timeline ------------------------------------------------------------------------------------
 hipEvent_t Timeline::get()

@@ -55,7 +55,7 @@ static MsdDigits msd_digits(uint64_t len)
 {
 	int t = 0; while (((uint64_t)256 << t) < len) ++t;
 	t = std::max(4, std::min(MSD_MAXLEVELS * MSD_MAXBITS, t));
-	MsdDigits d; d.total = t; d.L = (t + MSD_MAXBITS - 1) / MSD_MAXBITS;
+	MsdDigits d; d.total = t; d.L = std::max(2, (t + MSD_MAXBITS - 1) / MSD_MAXBITS);
 	for (int l = 0; l < d.L; ++l) d.bits[l] = t / d.L + (l < t % d.L ? 1 : 0);
 	return d;
 }
@@ -73,7 +73,7 @@ uint64_t msd_ws_bytes(uint64_t cap)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t tiles = cap / MSD_SUPER + MSD_TAB_MAX + 2;
 	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
-	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * MSD_NB_MAX) + al(4 * 3 * MSD_TAB_MAX) + al(4 * (MSD_NB_MAX + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
+	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * MSD_NB_MAX) + al(4 * 4 * MSD_TAB_MAX) + al(4 * (MSD_NB_MAX + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
 {
@@ -84,7 +84,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
 	ws.hist = (uint32_t *)p; ws.hist_cap = hist; p += al(4 * hist);
 	ws.tiles = (MsdTile *)p; ws.tiles_cap = tiles; p += al(sizeof(MsdTile) * tiles);
 	ws.sub_start = (uint32_t *)p; p += al(4 * MSD_NB_MAX);
-	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_TAB_MAX);
+	ws.bucket_tab = (uint32_t *)p; ws.lvl_start = ws.bucket_tab + 3 * MSD_TAB_MAX; p += al(4 * 4 * MSD_TAB_MAX);
 	ws.overflow = (uint32_t *)p; ws.overflow_cap = MSD_NB_MAX; p += al(4 * (MSD_NB_MAX + 1));
 	ws.scan_ws = (uint32_t *)p;
 }
@@ -177,15 +177,17 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 				}
 			}
 		} else {
+			// all 16 loads go out back to back (clamped index, no branch around a load: a load
+			// inside its own if-block gets its own s_waitcnt and the chunk takes 16 round trips)
 			#pragma unroll
 			for (int s = 0; s < MSD_ITEMS; ++s) {
 				uint32_t e = cbase + s * MSD_THREADS + tid;
-				if (e < tile.count) {
-					rec[s] = A.rec_in[(uint64_t)tile.in_off + e];
-					dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
-					vmask |= 1u << s;
-				}
+				uint32_t ec = e < tile.count ? e : tile.count - 1;
+				rec[s] = A.rec_in[(uint64_t)tile.in_off + ec];
+				if (e < tile.count) vmask |= 1u << s;
 			}
+			#pragma unroll
+			for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
 		}
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
@@ -271,20 +273,18 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+struct SortOut { uint32_t *sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; };
+
+// one wave sorts the final bucket g = records [b0, b0+m) of `rec`; outb (LS_CAP u64) and cb
+// (2*LS_BINS u32) are this wave's private LDS
 template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, uint32_t nbuckets, int sortbits,
-                                                            uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0,
-                                                            uint32_t *overflow, uint32_t overflow_cap, uint32_t *tiebits)
+__device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64_t *rec, uint32_t g, uint32_t b0, uint32_t m, int sortbits,
+                                                  uint64_t *outb, uint32_t *cb, const SortOut &O)
 {
-	__shared__ uint64_t s_rec[LS_WAVES][LS_CAP];
-	__shared__ __attribute__((aligned(16))) uint32_t s_cb[LS_WAVES][2 * LS_BINS];   // counts | starts
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t g = blockIdx.x * LS_WAVES + wave;
-	if (g >= nbuckets) return;
-	uint64_t *outb = s_rec[wave];
-	uint32_t *cnt = s_cb[wave], *bst = s_cb[wave] + LS_BINS;
-	const uint32_t b0 = sub_start[g], b1 = sub_start[g + 1];
-	const uint32_t m = b1 - b0;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t *cnt = cb, *bst = cb + LS_BINS;
+	uint32_t *sa = O.sa; uint8_t *bwt = O.bwt; const uint64_t start = O.start; uint32_t *p0 = O.p0;
+	uint32_t *overflow = O.overflow; const uint32_t overflow_cap = O.overflow_cap; uint32_t *tiebits = O.tiebits;
 	if (m == 0) return;
 	if (m > (uint32_t)LS_CAP) {
 		if (lane == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = g; }
@@ -386,6 +386,113 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 			bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
 			if (i == (uint32_t)start) *p0 = b0 + e;
 		}
+	}
+}
+
+
+// final level as its own launch (kept for reference / experiments): one wave per final bucket
+template <bool WRITE_SA>
+__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, uint32_t nbuckets, int sortbits, SortOut O)
+{
+	__shared__ uint64_t s_rec[LS_WAVES][LS_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t s_cb[LS_WAVES][2 * LS_BINS];   // counts | starts
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t g = blockIdx.x * LS_WAVES + wave;
+	if (g >= nbuckets) return;
+	const uint32_t b0 = sub_start[g], b1 = sub_start[g + 1];
+	wave_sort_bucket<WRITE_SA>(T, rec, g, b0, b1 - b0, sortbits, s_rec[wave], s_cb[wave], O);
+}
+
+// LAST PARTITION LEVEL + FINAL SORT FUSED: one workgroup owns one bucket entering the last level
+// (~46 K records at 3 Gbase): it counts the bucket's next digit, scatters the bucket into its
+// own range of the other record buffer (chunks of 4096 through LDS, as k_msd_pass), and its four
+// waves then sort the 256 sub-buckets one after the other.  What the scatter writes is read back
+// by the same CU microseconds later: that 24 GB write + 24 GB read stay in L2 / Infinity Cache
+// instead of HBM, and the separate counting pass, scan and host round trip of the level are gone.
+template <bool WRITE_SA>
+__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, uint32_t nb,
+                                                                 int D, int shift, int sortbits, uint32_t *sub_start, SortOut O)
+{
+	constexpr int CH = MSD_THREADS * MSD_ITEMS;                 // 4096
+	__shared__ uint32_t cnt[MSD_MAXBINS];
+	__shared__ uint32_t binstart[MSD_MAXBINS];
+	__shared__ uint32_t gbase[MSD_MAXBINS];
+	__shared__ uint32_t sub[MSD_MAXBINS + 4];
+	__shared__ uint32_t wsum[8];
+	__shared__ uint8_t sdig[CH];
+	__shared__ __attribute__((aligned(16))) uint64_t big[CH];     // scatter staging, later the waves' sort buffers (32 KB)
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t b = blockIdx.x;
+	const uint32_t s0 = bstart[b], s1 = bstart[b + 1], m = s1 - s0;
+	const uint32_t bins = 1u << D, dmask = bins - 1;
+	// ---- pass 1: histogram of the next digit over the bucket ----
+	cnt[tid] = 0;
+	__syncthreads();
+	for (uint32_t e0 = 0; e0 < m; e0 += MSD_THREADS * 8) {        // 8 loads in flight per thread
+		uint64_t v[8];
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { uint32_t e = e0 + k * MSD_THREADS + tid; v[k] = rec_in[(uint64_t)s0 + (e < m ? e : m - 1)]; }
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { uint32_t e = e0 + k * MSD_THREADS + tid; if (e < m) atomicAdd(&cnt[(uint32_t)(v[k] >> shift) & dmask], 1u); }
+	}
+	__syncthreads();
+	{
+		uint32_t v = cnt[tid], inc = wave_incl_sum(v);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t pre = 0;
+		for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+		uint32_t ex = pre + inc - v;
+		sub[tid] = ex; gbase[tid] = s0 + ex;
+		if (tid == MSD_THREADS - 1) sub[MSD_MAXBINS] = ex + v;
+		if (tid < bins) sub_start[((uint64_t)b << D) + tid] = s0 + ex;
+		if (b + 1 == nb && tid == 0) sub_start[(uint64_t)nb << D] = s1;
+	}
+	__syncthreads();
+	if (m == 0) return;
+	// ---- pass 2: scatter the bucket into rec_tmp[s0, s1) ----
+	for (uint32_t cbase = 0; cbase < m; cbase += CH) {
+		cnt[tid] = 0;
+		__syncthreads();
+		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS], slot[MSD_ITEMS]; uint32_t vmask = 0;
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) {          // loads first, uses later: one wait for all 16
+			uint32_t e = cbase + s * MSD_THREADS + tid;
+			rec[s] = rec_in[(uint64_t)s0 + (e < m ? e : m - 1)];
+			if (e < m) vmask |= 1u << s;
+		}
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> shift) & dmask;
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
+		__syncthreads();
+		{
+			uint32_t v = cnt[tid], inc = wave_incl_sum(v);
+			if (lane == 63) wsum[wave] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+			binstart[tid] = pre + inc - v;
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; big[p] = rec[s]; sdig[p] = (uint8_t)dg[s]; }
+		__syncthreads();
+		const uint32_t nvalid = m - cbase < (uint32_t)CH ? m - cbase : (uint32_t)CH;
+		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) { uint32_t d = sdig[p]; rec_tmp[(uint64_t)gbase[d] + (p - binstart[d])] = big[p]; }
+		__syncthreads();
+		gbase[tid] += cnt[tid];
+		__syncthreads();
+	}
+	__threadfence_block();
+	__syncthreads();
+	// ---- pass 3: the four waves sort the sub-buckets, each wave on its own slice of LDS ----
+	uint64_t *outb = big + wave * LS_CAP;                                                  // 4 x 4 KB
+	uint32_t *cb = reinterpret_cast<uint32_t *>(big + LS_WAVES * LS_CAP) + wave * 2 * LS_BINS;   // 4 x 4 KB
+	for (uint32_t d = wave; d < bins; d += LS_WAVES) {
+		uint32_t lo = sub[d], hi = sub[d + 1];
+		wave_sort_bucket<WRITE_SA>(T, rec_tmp, (b << D) | d, s0 + lo, hi - lo, sortbits, outb, cb, O);
+		wave_sync();
 	}
 }
 
@@ -509,16 +616,36 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipStreamSynchronize(s));
 	}
 	int consumed = 0;                   // key-field bits used by levels >= 1
-	for (int lv = 0; lv < dg.L; ++lv) {
+	uint32_t nfinal = 0;
+	const uint32_t eq_syms = (uint32_t)((dg.bits[0] + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
+	uint32_t *d_tiebits = ws.t[0];      // tie bitmap: len bits
+	for (int lv = 0; lv + 1 < dg.L; ++lv) {
 		const int D = dg.bits[lv];
 		const uint32_t nnext = nb << D;
-		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nnext + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, nb, D, (uint32_t)len, M.sub_start);
-		if (lv + 1 == dg.L) { nb = nnext; break; }
+		const bool last = lv + 2 == dg.L;         // the next level is the last one: fused with the final sort
+		uint32_t *d_starts = last ? M.lvl_start : M.sub_start;
+		B3M_REQUIRE(!last || nnext + 1 <= MSD_TAB_MAX, "MSD level table too small");
+		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nnext + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, nb, D, (uint32_t)len, d_starts);
+		const int Dn = dg.bits[lv + 1];
+		consumed += Dn;
+		std::swap(rin, rout);
+		if (last) {
+			// ---- last partition level + final sort, one workgroup per bucket ----
+			Scope sc(tl, KF_LDS_SORT, 45 * len);
+			B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
+			B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
+			SortOut O{sa, d_bwt, start, d_p0, M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, (uint64_t)nnext << Dn), d_tiebits};
+			if (need_sa)
+				hipLaunchKernelGGL(k_bucket_finish<true>, dim3(nnext), dim3(MSD_THREADS), 0, s, T, rin, rout, d_starts, nnext, Dn, 64 - consumed, REC_KEY_BITS - consumed, M.sub_start, O);
+			else
+				hipLaunchKernelGGL(k_bucket_finish<false>, dim3(nnext), dim3(MSD_THREADS), 0, s, T, rin, rout, d_starts, nnext, Dn, 64 - consumed, REC_KEY_BITS - consumed, M.sub_start, O);
+			nfinal = nnext << Dn;
+			break;
+		}
 		// ---- build the tiles of the next level on the host ----
 		std::vector<uint32_t> st(nnext + 1);
 		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (nnext + 1), hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
-		const int Dn = dg.bits[lv + 1];
 		std::vector<MsdTile> tiles;
 		std::vector<uint32_t> tab(3ull * nnext);
 		uint64_t hoff = 0;
@@ -538,8 +665,6 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
 		// ---- partition level lv+1 ----
-		std::swap(rin, rout);
-		consumed += Dn;
 		MsdArgs Bq{};
 		Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = rin; Bq.rec_out = rout; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = Dn;
 		Bq.shift = 64 - consumed; Bq.keep_lo = 0; Bq.keep_hi = 0xFFFFFFFFu;
@@ -558,23 +683,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		}
 		nb = nnext;
 	}
-	// ---- final level: in-LDS sort of the nb buckets (M.sub_start holds nb+1 offsets) ----
-	const uint32_t nfinal = nb;
-	const int sortbits = REC_KEY_BITS - consumed;
-	const uint32_t eq_syms = (uint32_t)((dg.bits[0] + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
-	{
-		Scope sc(tl, KF_LDS_SORT, 13 * len);
-		// tie bitmap: len bits in ws.t[0]
-		uint32_t *d_tiebits = ws.t[0];
-		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
-		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
-		if (need_sa)
-			hipLaunchKernelGGL(k_lds_sort<true>, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
-			                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
-		else
-			hipLaunchKernelGGL(k_lds_sort<false>, dim3((nfinal + LS_WAVES - 1) / LS_WAVES), dim3(MSD_THREADS), 0, s, T, rout, M.sub_start, nfinal, sortbits, sa, d_bwt, start, d_p0,
-			                   M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, nfinal), d_tiebits);
-	}
+	B3M_REQUIRE(nfinal != 0, "internal: MSD needs at least two levels");
 	{
 		Scope sc(tl, KF_TIES, len / 8);
 		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, eq_syms, sa, d_bwt, start, d_p0);
