@@ -124,7 +124,7 @@ def main():
     dname, d = dom
     # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
     kernel_of = {"msd_scatter": "b3m::k_msd_pass<false, false>", "msd_scatter_text": "b3m::k_msd_pass<true, false>",
-                 "msd_hist": "b3m::k_msd_pass<*, true>", "bucket_finish": "b3m::k_bucket_finish", "ties": "b3m::k_tie_fix",
+                 "msd_hist": "b3m::k_msd_pass<*, true>", "bucket_finish": "b3m::k_bucket_finish<false>", "ties": "b3m::k_tie_fix",
                  "radix_scatter": "b3m::k_scatter<unsigned long, true>", "gap_walk": "b3m::k_gap_walk"}
     achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     B = res["num_blocks"]

@@ -159,20 +159,32 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 			uint64_t pos0 = A.P0 + tile.in_off + cbase + (uint64_t)tid * 16;
 			const uint64_t end = A.start + A.len;
 			if (pos0 < end && pos0 + 16 > A.start) {
-				bool fast = pos0 + 16 + 32 <= A.T.nbases;
-				uint64_t w0 = 0, w1 = 0, w2 = 0;
-				if (fast) { const uint8_t *p = A.T.b + ((pos0 >> 4) << 2); w0 = be32(p); w1 = be32(p + 4); w2 = be32(p + 8); }
-				uint64_t hi = (w0 << 32) | w1;
-				#pragma unroll
-				for (int s = 0; s < MSD_ITEMS; ++s) {
-					uint64_t i = pos0 + s;
-					if (i >= A.start && i < end) {
-						uint64_t x = fast ? (s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi) : window_safe(A.T, i);
-						uint32_t pr;
-						if (fast && s > 0) { pr = (uint32_t)(w0 >> (32 - 2 * s)) & 3u; if (A.T.type == B3M_INPUT_PACTERM) pr += 1; }
-						else pr = pred_sym(A.T, i);
-						rec[s] = make_rec(x, A.D, pr, (uint32_t)i, &dg[s]);
+				const bool fast = pos0 + 16 + 32 <= A.T.nbases && pos0 >= A.start && pos0 + 16 <= end && pos0 > 0;
+				if (fast) {
+					// the whole word lies inside the block and far from the text end: 3 words -> 16 records
+					const uint8_t *p = A.T.b + ((pos0 >> 4) << 2);
+					uint64_t wp = be32(p - 4), w0 = be32(p), w1 = be32(p + 4), w2 = be32(p + 8);
+					uint64_t hi = (w0 << 32) | w1;
+					const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
+					#pragma unroll
+					for (int s = 0; s < MSD_ITEMS; ++s) {
+						uint64_t x = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
+						uint32_t pr = (s ? (uint32_t)(w0 >> (32 - 2 * s)) & 3u : (uint32_t)wp & 3u) + padd;
+						rec[s] = make_rec(x, A.D, pr, (uint32_t)(pos0 + s), &dg[s]);
 						if (COUNT_ONLY || (dg[s] >= A.keep_lo && dg[s] < A.keep_hi)) vmask |= 1u << s;
+					}
+				} else {
+					// block edges / end of the text: one position at a time, rolled (rare: keep the code small)
+					#pragma nounroll
+					for (int s = 0; s < MSD_ITEMS; ++s) {
+						uint64_t i = pos0 + s;
+						uint64_t rr = 0; uint32_t dd = 0; bool ok = false;
+						if (i >= A.start && i < end) {
+							rr = make_rec(window_safe(A.T, i), A.D, pred_sym(A.T, i), (uint32_t)i, &dd);
+							ok = COUNT_ONLY || (dd >= A.keep_lo && dd < A.keep_hi);
+						}
+						#pragma unroll
+						for (int q = 0; q < MSD_ITEMS; ++q) if (q == s) { rec[q] = rr; dg[q] = dd; if (ok) vmask |= 1u << q; }
 					}
 				}
 			}
@@ -277,9 +289,19 @@ struct SortOut { uint32_t *sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint3
 
 // one wave sorts the final bucket g = records [b0, b0+m) of `rec`; outb (LS_CAP u64) and cb
 // (2*LS_BINS u32) are this wave's private LDS
+// the records of a bucket, 8 per lane (lane l holds records l, l+64, ...); issued early by the caller
+// so that they are in flight while the previous bucket is being sorted
+__device__ __forceinline__ void wave_load_bucket(const uint64_t *rec, uint32_t b0, uint32_t m, uint64_t (&r)[LS_CAP / 64])
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t mm = m < (uint32_t)LS_CAP ? m : (uint32_t)LS_CAP;
+	#pragma unroll
+	for (int t = 0; t < LS_CAP / 64; ++t) { uint32_t e = t * 64 + lane; r[t] = mm ? rec[(uint64_t)b0 + (e < mm ? e : mm - 1)] : 0; }
+}
+
 template <bool WRITE_SA>
 __device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64_t *rec, uint32_t g, uint32_t b0, uint32_t m, int sortbits,
-                                                  uint64_t *outb, uint32_t *cb, const SortOut &O)
+                                                  uint64_t *outb, uint32_t *cb, const SortOut &O, const uint64_t (&r)[LS_CAP / 64])
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t *cnt = cb, *bst = cb + LS_BINS;
@@ -295,9 +317,7 @@ __device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64
 	const int bshift = REC_KEY_SHIFT + sortbits - binbits;
 	const uint32_t bmask = (1u << binbits) - 1;
 	constexpr int PER = LS_CAP / 64;               // 8 records per lane
-	uint64_t r[PER]; uint32_t sl[PER];
-	#pragma unroll
-	for (int t = 0; t < PER; ++t) { uint32_t e = t * 64 + lane; r[t] = e < m ? rec[b0 + e] : 0; }
+	uint32_t sl[PER];
 	#pragma unroll
 	for (int k = 0; k < LS_BINS / 64; ++k) cnt[k * 64 + lane] = 0;
 	wave_sync();
@@ -400,7 +420,9 @@ __global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint
 	const uint32_t g = blockIdx.x * LS_WAVES + wave;
 	if (g >= nbuckets) return;
 	const uint32_t b0 = sub_start[g], b1 = sub_start[g + 1];
-	wave_sort_bucket<WRITE_SA>(T, rec, g, b0, b1 - b0, sortbits, s_rec[wave], s_cb[wave], O);
+	uint64_t r[LS_CAP / 64];
+	wave_load_bucket(rec, b0, b1 - b0, r);
+	wave_sort_bucket<WRITE_SA>(T, rec, g, b0, b1 - b0, sortbits, s_rec[wave], s_cb[wave], O, r);
 }
 
 // LAST PARTITION LEVEL + FINAL SORT FUSED: one workgroup owns one bucket entering the last level
@@ -489,9 +511,15 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 	// ---- pass 3: the four waves sort the sub-buckets, each wave on its own slice of LDS ----
 	uint64_t *outb = big + wave * LS_CAP;                                                  // 4 x 4 KB
 	uint32_t *cb = reinterpret_cast<uint32_t *>(big + LS_WAVES * LS_CAP) + wave * 2 * LS_BINS;   // 4 x 4 KB
+	uint64_t rn[LS_CAP / 64];
+	if (wave < bins) wave_load_bucket(rec_tmp, s0 + sub[wave], sub[wave + 1] - sub[wave], rn);
 	for (uint32_t d = wave; d < bins; d += LS_WAVES) {
 		uint32_t lo = sub[d], hi = sub[d + 1];
-		wave_sort_bucket<WRITE_SA>(T, rec_tmp, (b << D) | d, s0 + lo, hi - lo, sortbits, outb, cb, O);
+		uint64_t r[LS_CAP / 64];
+		#pragma unroll
+		for (int t = 0; t < LS_CAP / 64; ++t) r[t] = rn[t];
+		if (d + LS_WAVES < bins) wave_load_bucket(rec_tmp, s0 + sub[d + LS_WAVES], sub[d + LS_WAVES + 1] - sub[d + LS_WAVES], rn);   // next one flies meanwhile
+		wave_sort_bucket<WRITE_SA>(T, rec_tmp, (b << D) | d, s0 + lo, hi - lo, sortbits, outb, cb, O, r);
 		wave_sync();
 	}
 }
@@ -631,7 +659,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		std::swap(rin, rout);
 		if (last) {
 			// ---- last partition level + final sort, one workgroup per bucket ----
-			Scope sc(tl, KF_LDS_SORT, 45 * len);
+			// compulsory HBM traffic: the records once in, the BWT byte (and the SA entry) out; the
+			// scatter inside the bucket and its re-read are meant to stay in L2 / Infinity Cache
+			Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
 			B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
 			B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 			SortOut O{sa, d_bwt, start, d_p0, M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, (uint64_t)nnext << Dn), d_tiebits};
