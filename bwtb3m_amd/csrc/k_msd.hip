@@ -138,7 +138,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint64_t srec[COUNT_ONLY ? 1 : MSD_CHUNK];
-	__shared__ uint8_t sdig[COUNT_ONLY ? 1 : MSD_CHUNK];
+	__shared__ uint8_t sdig[(COUNT_ONLY || !FROM_TEXT) ? 1 : MSD_CHUNK];   // level 0 keeps its digit out of the record
 	__shared__ uint32_t wsum[8];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
@@ -223,14 +223,15 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; sdig[p] = (uint8_t)dg[s]; }
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; if (FROM_TEXT) sdig[p] = (uint8_t)dg[s]; }
 		__syncthreads();
 		// number of valid records of this chunk = binstart[last] + cnt[last]; copy out run by run
 		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
 		(void)cn;
 		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) {
-			uint32_t d = sdig[p];
-			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = srec[p];
+			uint64_t q = srec[p];
+			const uint32_t d = FROM_TEXT ? (uint32_t)sdig[p] : ((uint32_t)(q >> A.shift) & (uint32_t)(bins - 1));
+			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = q;
 		}
 		__syncthreads();
 		for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] += cnt[b];
@@ -441,7 +442,6 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 	__shared__ uint32_t gbase[MSD_MAXBINS];
 	__shared__ uint32_t sub[MSD_MAXBINS + 4];
 	__shared__ uint32_t wsum[8];
-	__shared__ uint8_t sdig[CH];
 	__shared__ __attribute__((aligned(16))) uint64_t big[CH];     // scatter staging, later the waves' sort buffers (32 KB)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t b = blockIdx.x;
@@ -498,10 +498,10 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; big[p] = rec[s]; sdig[p] = (uint8_t)dg[s]; }
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) big[binstart[dg[s]] + slot[s]] = rec[s];
 		__syncthreads();
 		const uint32_t nvalid = m - cbase < (uint32_t)CH ? m - cbase : (uint32_t)CH;
-		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) { uint32_t d = sdig[p]; rec_tmp[(uint64_t)gbase[d] + (p - binstart[d])] = big[p]; }
+		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) { uint64_t q = big[p]; uint32_t d = (uint32_t)(q >> shift) & dmask; rec_tmp[(uint64_t)gbase[d] + (p - binstart[d])] = q; }
 		__syncthreads();
 		gbase[tid] += cnt[tid];
 		__syncthreads();
