@@ -147,3 +147,44 @@ def test_synth_generators_agree(oracle):
     assert it == "pacterm" and len(buf) == 1_250_002 and n == 5_000_001
     it, buf, n = synth.config_input("c1")
     assert it == "bytestream" and n == 1 << 20 and np.array_equal(buf, oracle.synth_bytes(1 << 20, 0xB3B3B3B3))
+
+
+def test_bwtb3mtobwa_conversion(L, oracle, tmp_path):
+    """X.bwt (+X.sa) of a pacterm construction -> BWA's .bwt/.sa layout.  The inputs are
+    produced from the oracle here (no GPU needed); tests/test_gpu_boundary.py runs the real pipeline."""
+    b = oracle.synth_bases(5003, 19)
+    s = np.concatenate([b + 1, [0]]).astype(np.uint8)
+    sa = oracle.sa_circular(s)
+    bw = oracle.bwt(s)
+    n = len(s)
+    fn = str(tmp_path / "x.pac.bwt")
+    assert L.b3m_rl_write(fn.encode(), bw.ctypes.data, n, 4096) == 0
+    rate = 32
+    smp = sa[::rate].astype(np.uint64)
+    np.concatenate([np.array([rate, len(smp)], dtype=np.uint64), smp]).tofile(str(tmp_path / "x.pac.sa"))
+    ob, os_ = str(tmp_path / "o.bwt"), str(tmp_path / "o.sa")
+    r = _run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), fn, ob, os_])
+    assert r.returncode == 0, r.stderr.decode()
+    raw = np.fromfile(ob, dtype=np.uint8)
+    head = raw[:40].view(np.uint64)
+    primary = int(np.nonzero(bw == 0)[0][0])
+    assert head[0] == primary == int(np.nonzero(sa == 0)[0][0])
+    counts = np.bincount(b, minlength=4)
+    assert head[1:5].tolist() == np.cumsum(counts).tolist()           # L2[1..4]
+    words = raw[40:].view(np.uint32)
+    sym = ((words[:, None] >> np.arange(30, -2, -2, dtype=np.uint32)[None, :]) & 3).astype(np.uint8).reshape(-1)[: n - 1]
+    assert np.array_equal(sym, np.delete(bw, primary) - 1)           # BWT without the terminator entry, first symbol in the MSBs
+    fsa = np.fromfile(os_, dtype=np.uint64)
+    assert fsa[0] == primary and fsa[1:5].tolist() == np.cumsum(counts).tolist() and fsa[5] == rate and fsa[6] == n - 1
+    n_sa = (n - 1 + rate) // rate
+    assert np.array_equal(fsa[7:].astype(np.int64), sa[rate::rate][: n_sa - 1])
+    # errors: usage, missing .sa, wrong alphabet
+    assert _run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), fn]).returncode == 1
+    os.remove(str(tmp_path / "x.pac.sa"))
+    r = _run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), fn, ob, os_])
+    assert r.returncode == 1 and b"cannot open" in r.stderr
+    bad = np.full(10, 7, dtype=np.uint8)
+    fb = str(tmp_path / "bad.bwt")
+    assert L.b3m_rl_write(fb.encode(), bad.ctypes.data, 10, 4096) == 0
+    r = _run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), fb, ob, os_])
+    assert r.returncode == 1 and b"not the BWT of a pacterm text" in r.stderr

@@ -185,3 +185,28 @@ def test_cli_bwtonly0_writes_sa_isa(gpu, oracle, tmp_path):
     assert fsa[0] == 32 and fsa[1] == len(fsa) - 2 and np.array_equal(fsa[2:].astype(np.int64), sa[::32])
     fisa = np.fromfile(prefix + ".isa", dtype=np.uint64)
     assert fisa[0] == 4096 and fisa[1] == len(fisa) - 2 and np.array_equal(fisa[2:].astype(np.int64), isa[::4096])
+
+
+def test_readme_bwa_index_pipeline(gpu, oracle, tmp_path):
+    """the reference's indexing script (/root/reference/README.md:106-111) minus bwa itself:
+    bwtb3m inputtype=pacterm -> bwtb3mtobwa"""
+    b = oracle.synth_bases(300_007, 91)
+    buf = oracle.pac_encode(b)
+    pac = tmp_path / "ref.fa.pac"
+    pac.write_bytes(buf.tobytes())
+    out = str(pac) + ".bwt"
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "mem=2g", "outputfilename=" + out, str(pac)], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), out, str(tmp_path / "ref.fa.bwt"), str(tmp_path / "ref.fa.sa")], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    sa = oracle.sa_circular(s)
+    bw = oracle.bwt(s)
+    primary = int(np.nonzero(sa == 0)[0][0])
+    raw = np.fromfile(str(tmp_path / "ref.fa.bwt"), dtype=np.uint8)
+    assert raw[:8].view(np.uint64)[0] == primary
+    words = raw[40:].view(np.uint32)
+    sym = ((words[:, None] >> np.arange(30, -2, -2, dtype=np.uint32)[None, :]) & 3).astype(np.uint8).reshape(-1)[: len(s) - 1]
+    assert np.array_equal(sym, np.delete(bw, primary) - 1)
+    fsa = np.fromfile(str(tmp_path / "ref.fa.sa"), dtype=np.uint64)
+    assert fsa[5] == 32 and fsa[6] == len(s) - 1 and np.array_equal(fsa[7:].astype(np.int64), sa[32::32])
