@@ -76,7 +76,7 @@ def main():
     a = parse()
     import numpy as np
     import torch
-    from bwtb3m_amd import engine, synth
+    from bwtb3m_amd import benchutil, engine, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,43 +111,15 @@ def main():
     fam = {}
     for _ in range(a.steps):
         plan.run(d_text, d_out)
-        for k in plan.kernel_times():
-            f = fam.setdefault(k["name"], {"ms": 0.0, "launches": 0, "alg_bytes": 0})
-            f["ms"] += k["ms"]; f["launches"] += k["launches"]; f["alg_bytes"] += k["alg_bytes"]
+        benchutil.add_kernel_times(fam, plan.kernel_times())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     res = plan.result()
     nbases = n - 1 if itype == "pacterm" else n
     value = nbases * a.steps / dt / 1e9
-    # dominant kernel family by device time
-    dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-    dname, d = dom
-    # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
-    kernel_of = {"msd_scatter": "b3m::k_msd_pass<false, false>", "msd_scatter_text": "b3m::k_msd_pass<true, false>",
-                 "msd_hist": "b3m::k_msd_pass<*, true>", "bucket_finish": "b3m::k_bucket_finish<false>", "ties": "b3m::k_tie_fix",
-                 "radix_scatter": "b3m::k_scatter<unsigned long, true>", "gap_walk": "b3m::k_gap_walk"}
-    achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     B = res["num_blocks"]
     levels = res["levels"]
-    # HBM traffic of the dominant kernel from the committed PMC pass (separate rocprofv3 --pmc runs,
-    # gfx950 FETCH_SIZE correction applied: see the file); only valid for the workload it was taken on
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        kn = kernel_of.get(dname, dname)
-        if tj.get("workload_n") == n and B == 1 and kn in tj["kernels"]:
-            traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        traffic = None
-    alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
-    roof = {
-        "bound": "hbm", "kernel": kernel_of.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, a.steps),
-        "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),
-        "job_alg_bytes": alg_job, "job_frac": round(alg_job / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
-        "families_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in fam.items() if v["ms"] > 0},
-    }
+    roof = benchutil.dominant_roofline(fam, a.steps, dt, nbases, levels, n if B == 1 else 0, ROOT)
     out = {
         "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
         "value": round(value, 4), "unit": "Gbase/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,

@@ -1,0 +1,43 @@
+"""Shared by bench.py (N=1) and distributed.bench_main (N>1): the `roofline` object of the bench line
+for the dominant kernel family, from the engine's own HIP-event timeline (b3m_plan_kernel_times)."""
+import json
+import os
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+# rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
+KERNEL_OF = {"msd_scatter": "b3m::k_msd_pass<false, false>", "msd_scatter_text": "b3m::k_msd_pass<true, false>",
+             "msd_hist": "b3m::k_msd_pass<*, true>", "bucket_finish": "b3m::k_bucket_finish<false>", "ties": "b3m::k_tie_fix",
+             "radix_scatter": "b3m::k_scatter<unsigned long, true>", "gap_walk": "b3m::k_gap_walk"}
+
+
+def add_kernel_times(fam, kernel_times):
+    for k in kernel_times:
+        f = fam.setdefault(k["name"], {"ms": 0.0, "launches": 0, "alg_bytes": 0})
+        f["ms"] += k["ms"]; f["launches"] += k["launches"]; f["alg_bytes"] += k["alg_bytes"]
+
+
+def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
+    """fam: accumulated over `steps` runs on this rank; dt: wall seconds of those steps; pmc_n: symbol
+    count for which the committed PMC traffic may be quoted (0 = none)."""
+    dname, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+    # HBM traffic of the dominant kernel from the committed PMC pass (separate rocprofv3 --pmc runs,
+    # gfx950 FETCH_SIZE correction applied: see the file); only valid for the workload it was taken on
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(root, "profiles", "r01_pmc_traffic.json")))
+        kn = KERNEL_OF.get(dname, dname)
+        if pmc_n and tj.get("workload_n") == pmc_n and kn in tj["kernels"]:
+            traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
+    return {
+        "bound": "hbm", "kernel": KERNEL_OF.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, steps),
+        "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),
+        "job_alg_bytes": alg_job, "job_frac": round(alg_job / (dt / steps) / 1e9 / (HBM_PEAK_GBS * peak_gpus), 5),
+        "families_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in fam.items() if v["ms"] > 0},
+    }

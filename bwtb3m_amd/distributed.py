@@ -413,19 +413,23 @@ def gather_result(slice_t, group=None):
 # ---------------------------------------------------------------------------------------------------
 # bench entry (called by bench.py when WORLD_SIZE > 1)
 # ---------------------------------------------------------------------------------------------------
-def _run_mode(job, d_text, steps, warmup, dev):
+def _run_mode(job, d_text, steps, warmup, dev, fam_of=None):
+    from . import benchutil
     for _ in range(warmup):
         job.run(d_text)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
+    fam = {}
     for _ in range(steps):
         out, off, p0 = job.run(d_text)
+        if fam_of is not None:       # reads the HIP-event timeline of the finished run (b3m_plan_run is blocking)
+            benchutil.add_kernel_times(fam, fam_of(job))
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    return float(dt[0]), out, off, p0
+    return float(dt[0]), out, off, p0, fam
 
 
 def bench_main(a, rank, local_rank, world):
@@ -435,7 +439,7 @@ def bench_main(a, rank, local_rank, world):
     watchdog so that it can never cost the headline."""
     import sys
     import threading
-    from . import synth
+    from . import benchutil, synth
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
@@ -458,7 +462,9 @@ def bench_main(a, rank, local_rank, world):
         return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev)
 
     job = make(mode)
-    dt, out, off, p0 = _run_mode(job, d_text, a.steps, a.warmup, dev)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dt, out, off, p0, fam = _run_mode(job, d_text, a.steps, a.warmup, dev,
+                                      fam_of=(lambda j: j.plan.kernel_times()) if mode != "blocks" else None)
     if a.verify:
         full = gather_result(out)
         if rank == 0:
@@ -468,9 +474,13 @@ def bench_main(a, rank, local_rank, world):
     if rank == 0:
         levels = len(job.plan.levels) if mode == "blocks" else 0
         alg_job = nbases * (9.5 + 41.0 * levels)
-        fam = {}
-        if mode != "blocks":
-            fam = {k["name"]: round(k["ms"], 3) for k in job.plan.kernel_times() if k["ms"] > 0}
+        if fam:
+            # dominant kernel of rank 0's shard (every rank runs the same kernels on its own suffix range)
+            roof = benchutil.dominant_roofline(fam, a.steps, dt, nbases, levels, 0, root, peak_gpus=world)
+            roof["rank"] = 0
+        else:
+            roof = {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / a.steps) / 1e9, 1),
+                    "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / a.steps) / 1e9 / (8000.0 * world), 5), "traffic": None}
         res = {
             "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
             "value": round(nbases * a.steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -480,10 +490,8 @@ def bench_main(a, rank, local_rank, world):
                        "merge_levels": levels, "mode": mode,
                        "parallelism": ("%d GPUs: 1 leaf block per GPU, RCCL all-to-all gap merge" % world) if mode == "blocks"
                        else ("%d GPUs: suffix-range shards of the replicated text, no exchange step" % world),
-                       "rank0_families_ms_last_step": fam,
                        "rank0_phase_s": {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}},
-            "roofline": {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / a.steps) / 1e9, 1),
-                         "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / a.steps) / 1e9 / (8000.0 * world), 5), "traffic": None},
+            "roofline": roof,
         }
         print(json.dumps(res), flush=True)
     if getattr(a, "also_blocks", True) and mode != "blocks":
@@ -499,14 +507,18 @@ def bench_main(a, rank, local_rank, world):
             del job, out
             torch.cuda.empty_cache()
             job2 = make("blocks")
-            dt2, out2, off2, p02 = _run_mode(job2, d_text, 1, 1, dev)
+            dt2, out2, off2, p02, _ = _run_mode(job2, d_text, 1, 1, dev)
             if rank == 0:
                 sys.stderr.write("[bench] block-merge mode (1 leaf block per GPU, %d merge levels, RCCL all-to-all of gap buckets): "
                                  "%.1f ms/step = %.3f Gbase/s; rank0 phases %s\n"
                                  % (len(job2.plan.levels), dt2 * 1e3, nbases / dt2 / 1e9, {k: round(v, 4) for k, v in job2.timing.items()}))
                 sys.stderr.flush()
-        except Exception as ex:   # noqa: BLE001
-            sys.stderr.write("[bench] block-merge mode failed: %r\n" % (ex,))
-        wd.cancel()
+        except BaseException as ex:   # noqa: BLE001
+            # the peers are (or will be) stuck in a collective this rank has left: no barrier, no
+            # process-group teardown -- leave at once with status 0; their watchdogs do the same
+            sys.stderr.write("[bench] block-merge mode failed on rank %d: %r\n" % (rank, ex))
+            sys.stderr.flush()
+            os._exit(0)
+        # the watchdog stays armed across the final barrier
     dist.barrier()
     dist.destroy_process_group()
