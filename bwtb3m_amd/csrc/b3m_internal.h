@@ -104,10 +104,11 @@ struct MsdTile { uint32_t in_off, count, hist_base, stride; };
 struct MsdWs {
 	uint32_t *hist = nullptr; uint64_t hist_cap = 0;        // flattened [bucket][digit][tile] counts / offsets
 	MsdTile *tiles = nullptr; uint64_t tiles_cap = 0;       // tile descriptors (device)
-	uint32_t *sub_start = nullptr;                           // 2^(D1+D2)+1 final bucket offsets
-	uint32_t *bucket_tab = nullptr;                          // per bucket entering a level: start, hist_off, ntiles
-	uint32_t *lvl_start = nullptr;                           // starts of the buckets entering the last (fused) level
-	uint32_t *overflow = nullptr; uint64_t overflow_cap = 0; // [0] = count, then bucket ids
+	uint32_t *sub_start = nullptr;                           // starts of the buckets leaving level 0
+	uint32_t *bucket_tab = nullptr;                          // per bucket entering level 1: start, hist_off, ntiles
+	uint32_t *lvl_start = nullptr;                           // starts of the final buckets
+	uint32_t *overflow = nullptr; uint64_t overflow_cap = 0; // [0] = count, then (start, size) pairs
+	uint32_t *biglist = nullptr; uint64_t big_cap = 0;       // [0] = count, then ids of final buckets above the LDS capacity
 	uint32_t *scan_ws = nullptr;
 };
 uint64_t msd_ws_bytes(uint64_t cap);

@@ -1,30 +1,35 @@
-// k_msd.hip -- the fast block sort for 2-bit inputs (pac/pacterm): two MSD partition passes of
-// 8-byte records followed by an in-LDS sort of every final bucket.
+// k_msd.hip -- the fast block sort for 2-bit inputs (pac/pacterm): MSD partition of 8-byte
+// records down to buckets that fit the LDS of one workgroup, sorted there.
 //
 // Why: an LSD radix sort of (u64 key, u32 position) pairs moves ~24 B per suffix per pass plus a
 // gather for the BWT symbol (~240 B/suffix in all).  Here a suffix is ONE 8-byte record
 //        [ 29 key bits | 3 bits predecessor symbol | 32 bits position ]
-// built straight from the packed text, partitioned twice by the leading bits of its rotation
-// (D1 then D2 bits, ~2^21 final buckets of 1-2 K suffixes), and each final bucket is sorted inside
-// the LDS of one workgroup, ties resolved exactly against the text, and written as BWT symbol +
-// suffix-array entry.  HBM traffic: 0.5 (text, twice) + 8 + 8 + 16 + 8 + 5 = ~46 B per suffix.
+// and the passes are (C3: 3 Gbase, D0 = 11, D1 = 8, 2^19 final buckets of ~5.7 K records):
 //
-//   pass A (k_msd_pass<true,*>)  : text -> records, partitioned by the first D1 bits
-//   pass B (k_msd_pass<false,*>) : records of every A bucket partitioned by the next D2 bits
-//   pass C (k_lds_sort)          : one workgroup per final bucket: stable LDS radix sort on the
-//                                  remaining 29-D2 key bits (64-lane ballot match-any ranking),
-//                                  exact tie resolution, emit
-// Partition order inside a bucket is irrelevant (the next level re-sorts), so slots come from LDS
-// atomics; each workgroup owns a "super tile" of 64 Ki records processed in 4 Ki chunks through
-// LDS so that every digit's run leaves the CU as one contiguous segment, and the histogram matrix
-// has only len*bins/65536 entries.
-// Buckets larger than the LDS capacity, or tie groups deeper than the in-kernel limit (skewed or
-// repetitive input), are finished by the list-based key-extension rounds of k_blocksort.hip.
+//   level 0 (k_l0_pass)       : text -> records, partitioned by the first D0 <= 12 bits.  The
+//                               records do not exist yet, so a wide fan-out is cheap: a chunk of
+//                               32 Ki POSITIONS is counting-sorted as 16-bit indices inside LDS
+//                               (text of the chunk: 8 KB) and the records are generated in
+//                               bucket order, every digit leaving the CU as one contiguous run.
+//   level 1 (k_msd_pass)      : records of every level-0 bucket partitioned by the next D1 <= 8
+//                               bits (chunks of 4096 records through LDS; wider fan-outs break
+//                               the 128-byte runs and halve the write bandwidth).
+//   finish  (k_finish_lds)    : one workgroup per final bucket: read ONCE into LDS, split by 5
+//                               more bits, each wave sorts sub-buckets (bin-scatter on the free key
+//                               bits + rank-in-bin), emits BWT byte (+ SA entry), marks key ties.
+//   ties    (k_tie_fix)       : runs of equal 29+D0 known bits ordered from the text.
+//
+// HBM traffic per suffix: 0.5 (text, twice) + 8 | 8 + 16 | 8 + 1 (+4) = ~41 B.
+// Buckets above the LDS capacity (skewed input) take k_bucket_finish: one more 8-bit partition
+// through HBM, then the same wave sort.  Sub-buckets above 512 records, and bins / tie groups
+// above 32 (repetitive input), are finished by the list-based key-extension rounds of
+// k_blocksort.hip, started at depth 0 inside their bucket.
 // pacterm: the terminator and everything behind it read as base 0 for bucketing; the exact tie
 // resolution (key_at with terminator tags) restores "terminator < A" where it matters.
 #include "b3m_internal.h"
 #include "b3m_text.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace b3m {
@@ -33,30 +38,44 @@ constexpr int MSD_THREADS = 256;
 constexpr int MSD_ITEMS = 16;
 constexpr int MSD_CHUNK = MSD_THREADS * MSD_ITEMS;     // 4096 records staged through LDS at a time
 constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per workgroup
-constexpr int MSD_MAXBITS = 8;                         // fan-out per pass: full 128-byte runs per chunk
+constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass: full 128-byte runs per chunk
 constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
-constexpr int MSD_MAXLEVELS = 3;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
-constexpr int LS_CAP = 512;                            // final bucket capacity: one WAVE sorts one bucket
-constexpr int LS_BINBITS = 9;
+// level 0
+constexpr int W0_THREADS = 1024;
+constexpr int W0_CHUNK = 32768;                        // positions counting-sorted in LDS at a time
+constexpr int W0_WORDS = W0_CHUNK / 16;                // 32-bit words of packed text per chunk
+constexpr int W0_TILE_CHUNKS = 8;
+constexpr int W0_TILE = W0_TILE_CHUNKS * W0_CHUNK;     // positions per workgroup (one row of the histogram matrix)
+constexpr int W0_MAXBITS = 12;
+constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
+// finish
+constexpr int F_THREADS = 512;
+constexpr int F_WAVES = F_THREADS / 64;
+constexpr int F_CAP = 7168;                            // records of a final bucket held in LDS (56 KB)
+constexpr int F_PER = F_CAP / F_THREADS;               // 14 records per thread
+constexpr int F_AVG = 6000;                            // target average bucket size
+constexpr int F_BINBITS = 13;
+constexpr int F_BINS = 1 << F_BINBITS;                 // counting-sort bins of the finish (16-bit counters)
+constexpr int LS_CAP = 512;                            // sub-bucket capacity of the wave sort
+constexpr int LS_BINBITS = 8;
 constexpr int LS_BINS = 1 << LS_BINBITS;               // bin-scatter table of the wave sort
 constexpr int LS_TIE_CAP = 32;                         // bins / tie groups up to this size are finished in-kernel
-constexpr int LS_WAVES = MSD_THREADS / 64;             // independent waves (buckets) per workgroup
+constexpr int LS_WAVES = MSD_THREADS / 64;
 constexpr int REC_KEY_SHIFT = 35;
 constexpr int REC_KEY_BITS = 29;
 
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 
-// total partition bits t: final buckets of <= 256 suffixes on average (capacity 512, one wave
-// each); split over ceil(t/8) levels as evenly as possible
-struct MsdDigits { int L; int bits[MSD_MAXLEVELS]; int total; };
+// final buckets of <= F_AVG suffixes on average: t bits, D0 from the text, the rest (<= 8) from records
+struct MsdDigits { int D0, D1; };
 static MsdDigits msd_digits(uint64_t len)
 {
-	int t = 0; while (((uint64_t)256 << t) < len) ++t;
-	t = std::max(4, std::min(MSD_MAXLEVELS * MSD_MAXBITS, t));
-	MsdDigits d; d.total = t; d.L = std::max(2, (t + MSD_MAXBITS - 1) / MSD_MAXBITS);
-	for (int l = 0; l < d.L; ++l) d.bits[l] = t / d.L + (l < t % d.L ? 1 : 0);
+	int t = 0; while ((len >> t) > (uint64_t)F_AVG) ++t;
+	MsdDigits d;
+	if (t <= W0_MAXBITS) { d.D0 = std::max(t, 1); d.D1 = 0; }
+	else { d.D0 = 11; d.D1 = t - d.D0; if (d.D1 > MSD_MAXBITS) { d.D1 = MSD_MAXBITS; d.D0 = std::min(W0_MAXBITS, t - d.D1); } }
 	return d;
 }
 
@@ -65,27 +84,33 @@ bool msd_applicable(const TextView &T, uint64_t len)
 	return (T.type == B3M_INPUT_PAC || T.type == B3M_INPUT_PACTERM) && len >= MSD_MIN_LEN;
 }
 
-static const uint64_t MSD_NB_MAX = (1ull << (MSD_MAXLEVELS * MSD_MAXBITS)) + 2;       // final buckets
-static const uint64_t MSD_TAB_MAX = (1ull << ((MSD_MAXLEVELS - 1) * MSD_MAXBITS)) + 2; // buckets entering a level
+static const uint64_t MSD_L0_MAX = (uint64_t)W0_MAXBINS + 2;                            // buckets leaving level 0
+static const uint64_t MSD_TAB_MAX = ((uint64_t)W0_MAXBINS << MSD_MAXBITS) + 2;          // final buckets
+
+static uint64_t msd_hist_cap(uint64_t cap) { return cap / 64 + cap / 256 + (4ull << 20); }   // 4096*(cap/2^18+2) resp. 256*(cap/2^16+4098)
+static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
+static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 256 + 4096; }                  // (start, size) pairs
+static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
 
 uint64_t msd_ws_bytes(uint64_t cap)
 {
 	if (cap < MSD_MIN_LEN) return 4096;
-	uint64_t tiles = cap / MSD_SUPER + MSD_TAB_MAX + 2;
-	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
-	return al(4 * hist) + al(sizeof(MsdTile) * tiles) + al(4 * MSD_NB_MAX) + al(4 * 4 * MSD_TAB_MAX) + al(4 * (MSD_NB_MAX + 1)) + al(4 * scan_ws_elems(hist)) + 4096;
+	uint64_t hist = msd_hist_cap(cap);
+	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
+	     + al(4 * (2 * msd_ovf_cap(cap) + 2)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
 {
 	if (cap < MSD_MIN_LEN) { ws = MsdWs(); return; }
 	uint8_t *p = (uint8_t *)base;
-	uint64_t tiles = cap / MSD_SUPER + MSD_TAB_MAX + 2;
-	uint64_t hist = (uint64_t)MSD_MAXBINS * tiles;
+	uint64_t hist = msd_hist_cap(cap);
 	ws.hist = (uint32_t *)p; ws.hist_cap = hist; p += al(4 * hist);
-	ws.tiles = (MsdTile *)p; ws.tiles_cap = tiles; p += al(sizeof(MsdTile) * tiles);
-	ws.sub_start = (uint32_t *)p; p += al(4 * MSD_NB_MAX);
-	ws.bucket_tab = (uint32_t *)p; ws.lvl_start = ws.bucket_tab + 3 * MSD_TAB_MAX; p += al(4 * 4 * MSD_TAB_MAX);
-	ws.overflow = (uint32_t *)p; ws.overflow_cap = MSD_NB_MAX; p += al(4 * (MSD_NB_MAX + 1));
+	ws.tiles = (MsdTile *)p; ws.tiles_cap = msd_tiles_cap(cap); p += al(sizeof(MsdTile) * ws.tiles_cap);
+	ws.sub_start = (uint32_t *)p; p += al(8 * MSD_L0_MAX);          // level-0 bucket starts; first the u64 row totals
+	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_L0_MAX);
+	ws.lvl_start = (uint32_t *)p; p += al(4 * MSD_TAB_MAX);
+	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 2));
+	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
 	ws.scan_ws = (uint32_t *)p;
 }
 
@@ -119,88 +144,191 @@ __device__ __forceinline__ uint64_t make_rec(uint64_t x, int D1, uint32_t pred, 
 	return (kf << REC_KEY_SHIFT) | ((uint64_t)pred << 32) | idx;
 }
 
-struct MsdArgs {
+// ------------------------------------------------------------------------------------------------
+// level 0: text -> records
+// ------------------------------------------------------------------------------------------------
+struct L0Args {
 	TextView T; uint64_t start, len;
-	uint64_t P0;                 // FROM_TEXT: absolute position of item 0 of tile 0 (multiple of 16)
-	const uint64_t *rec_in;      // !FROM_TEXT
+	uint64_t P0;                 // absolute position of item 0 of tile 0 (multiple of 16)
 	uint64_t *rec_out;
-	const MsdTile *tiles;        // null: regular tiling (pass A)
-	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
-	int D;                       // digit bits of this pass
-	int shift;                   // !FROM_TEXT: digit = (rec >> shift) & (2^D - 1)
-	uint32_t keep_lo, keep_hi;   // FROM_TEXT scatter: only records with keep_lo <= digit < keep_hi are kept (suffix-range shard)
+	uint32_t *hist;              // COUNT_ONLY: counts out [digit][tile] ; else scanned offsets in
+	int D;                       // digit bits
+	uint32_t keep_lo, keep_hi;   // scatter: only records with keep_lo <= digit < keep_hi are kept (suffix-range shard)
 };
 
-template <bool FROM_TEXT, bool COUNT_ONLY>
+// window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
+__device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t start, uint64_t end, uint64_t *x, uint32_t *pr)
+{
+	if (i < start || i >= end) return false;
+	*x = window_safe(T, i); *pr = pred_sym(T, i);
+	return true;
+}
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
+{
+	__shared__ uint32_t cnt[W0_MAXBINS];
+	__shared__ uint32_t cur[COUNT_ONLY ? 1 : W0_MAXBINS];        // scatter cursor: exclusive start, then end of every digit run
+	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : W0_MAXBINS];
+	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : W0_CHUNK];         // chunk-local positions in digit order
+	__shared__ uint32_t stext[W0_WORDS + 4];                     // [0] = the word before the chunk
+	__shared__ uint32_t wsum[W0_THREADS / 64];
+	const uint32_t tid = threadIdx.x;
+	const int bins = 1 << A.D;
+	const int dsh = 64 - A.D;
+	const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
+	const uint64_t end = A.start + A.len;
+	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cnt[b] = 0; }
+	else { for (int b = tid; b < bins; b += W0_THREADS) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
+	__syncthreads();
+	for (int c = 0; c < W0_TILE_CHUNKS; ++c) {
+		const uint64_t cpos = A.P0 + (uint64_t)tile * W0_TILE + (uint64_t)c * W0_CHUNK;
+		if (cpos >= end) break;
+		if (cpos + W0_CHUNK <= A.start) continue;
+		// the whole chunk inside the block, every window inside the text, a word in front of it
+		const bool fast = cpos >= A.start && cpos >= 16 && cpos + W0_CHUNK <= end && cpos + W0_CHUNK + 48 <= A.T.nbases;
+		if (fast) {
+			const uint8_t *p = A.T.b + (((cpos >> 4) - 1) << 2);
+			for (int j = tid; j < W0_WORDS + 4; j += W0_THREADS) stext[j] = be32(p + 4 * j);
+		}
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cnt[b] = 0; }
+		__syncthreads();
+		// ---- count ----
+		if (fast) {
+			#pragma unroll
+			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
+				const uint32_t w = j * W0_THREADS + tid;
+				const uint64_t hi = ((uint64_t)stext[w + 1] << 32) | stext[w + 2];
+				#pragma unroll
+				for (int s = 0; s < 16; ++s) {
+					uint32_t dgt = (uint32_t)((hi << (2 * s)) >> dsh);
+					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cnt[dgt], 1u);
+				}
+			}
+		} else {
+			#pragma nounroll
+			for (uint32_t li = tid; li < (uint32_t)W0_CHUNK; li += W0_THREADS) {
+				uint64_t x; uint32_t pr;
+				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
+					uint32_t dgt = (uint32_t)(x >> dsh);
+					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cnt[dgt], 1u);
+				}
+			}
+		}
+		if (COUNT_ONLY) { __syncthreads(); continue; }
+		__syncthreads();
+		// ---- exclusive scan of cnt -> cur ----
+		{
+			constexpr int per = W0_MAXBINS / W0_THREADS;        // consecutive bins per thread
+			uint32_t loc[per]; uint32_t sum = 0;
+			#pragma unroll
+			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cnt[b] : 0; sum += loc[k]; }
+			uint32_t inc = wave_incl_sum(sum);
+			uint32_t w = tid >> 6, l = tid & 63;
+			if (l == 63) wsum[w] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
+			uint32_t run = pre + inc - sum;
+			#pragma unroll
+			for (int k = 0; k < per; ++k) { int b = tid * per + k; if (b < bins) cur[b] = run; run += loc[k]; }
+		}
+		__syncthreads();
+		// ---- place the chunk-local positions in digit order (order inside a digit is irrelevant) ----
+		if (fast) {
+			#pragma unroll
+			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
+				const uint32_t w = j * W0_THREADS + tid;
+				const uint64_t hi = ((uint64_t)stext[w + 1] << 32) | stext[w + 2];
+				#pragma unroll
+				for (int s = 0; s < 16; ++s) {
+					uint32_t dgt = (uint32_t)((hi << (2 * s)) >> dsh);
+					if (dgt >= A.keep_lo && dgt < A.keep_hi) sidx[atomicAdd(&cur[dgt], 1u)] = (uint16_t)(w * 16 + s);
+				}
+			}
+		} else {
+			#pragma nounroll
+			for (uint32_t li = tid; li < (uint32_t)W0_CHUNK; li += W0_THREADS) {
+				uint64_t x; uint32_t pr;
+				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
+					uint32_t dgt = (uint32_t)(x >> dsh);
+					if (dgt >= A.keep_lo && dgt < A.keep_hi) sidx[atomicAdd(&cur[dgt], 1u)] = (uint16_t)li;
+				}
+			}
+		}
+		__syncthreads();
+		// ---- generate the records in digit order: cur[d] is now the END of run d ----
+		const uint32_t nvalid = cur[bins - 1];
+		for (uint32_t q = tid; q < nvalid; q += W0_THREADS) {
+			const uint32_t li = sidx[q];
+			uint64_t x; uint32_t pr;
+			if (fast) {
+				const uint32_t w = li >> 4, s = li & 15u;
+				const uint64_t wp = stext[w], w0 = stext[w + 1], w1 = stext[w + 2], w2 = stext[w + 3];
+				const uint64_t hi = (w0 << 32) | w1;
+				x = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
+				pr = (s ? (uint32_t)(w0 >> (32 - 2 * s)) & 3u : (uint32_t)wp & 3u) + padd;
+			} else {
+				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
+			}
+			uint32_t dgt;
+			const uint64_t r = make_rec(x, A.D, pr, (uint32_t)(cpos + li), &dgt);
+			const uint32_t rs = dgt ? cur[dgt - 1] : 0u;          // start of run dgt
+			A.rec_out[(uint64_t)gbase[dgt] + (q - rs)] = r;
+		}
+		__syncthreads();
+		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cnt[b];
+		__syncthreads();
+	}
+	if (COUNT_ONLY) {
+		__syncthreads();
+		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tile + (uint64_t)b * ntiles] = cnt[b];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// level 1: records -> records
+// ------------------------------------------------------------------------------------------------
+struct MsdArgs {
+	const uint64_t *rec_in;
+	uint64_t *rec_out;
+	const MsdTile *tiles;
+	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
+	int D;                       // digit bits of this pass
+	int shift;                   // digit = (rec >> shift) & (2^D - 1)
+};
+
+template <bool COUNT_ONLY>
 __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 {
 	__shared__ uint32_t cnt[MSD_MAXBINS];
 	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint64_t srec[COUNT_ONLY ? 1 : MSD_CHUNK];
-	__shared__ uint8_t sdig[(COUNT_ONLY || !FROM_TEXT) ? 1 : MSD_CHUNK];   // level 0 keeps its digit out of the record
 	__shared__ uint32_t wsum[8];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
-	MsdTile tile;
-	if (A.tiles) tile = A.tiles[blockIdx.x];
-	else { tile.in_off = blockIdx.x * (uint32_t)MSD_SUPER; tile.count = MSD_SUPER; tile.hist_base = blockIdx.x; tile.stride = gridDim.x; }
+	const MsdTile tile = A.tiles[blockIdx.x];
 	if (COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; }
 	else { for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
 	__syncthreads();
 	const uint32_t nchunks = (tile.count + MSD_CHUNK - 1) / MSD_CHUNK;
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const uint32_t cbase = c * MSD_CHUNK;
-		const uint32_t cn = tile.count - cbase < (uint32_t)MSD_CHUNK ? tile.count - cbase : (uint32_t)MSD_CHUNK;
 		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; __syncthreads(); }
 		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS]; uint32_t vmask = 0;
-		if (FROM_TEXT) {
-			// thread = one 32-bit word of packed text = 16 consecutive positions
-			uint64_t pos0 = A.P0 + tile.in_off + cbase + (uint64_t)tid * 16;
-			const uint64_t end = A.start + A.len;
-			if (pos0 < end && pos0 + 16 > A.start) {
-				const bool fast = pos0 + 16 + 32 <= A.T.nbases && pos0 >= A.start && pos0 + 16 <= end && pos0 > 0;
-				if (fast) {
-					// the whole word lies inside the block and far from the text end: 3 words -> 16 records
-					const uint8_t *p = A.T.b + ((pos0 >> 4) << 2);
-					uint64_t wp = be32(p - 4), w0 = be32(p), w1 = be32(p + 4), w2 = be32(p + 8);
-					uint64_t hi = (w0 << 32) | w1;
-					const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
-					#pragma unroll
-					for (int s = 0; s < MSD_ITEMS; ++s) {
-						uint64_t x = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
-						uint32_t pr = (s ? (uint32_t)(w0 >> (32 - 2 * s)) & 3u : (uint32_t)wp & 3u) + padd;
-						rec[s] = make_rec(x, A.D, pr, (uint32_t)(pos0 + s), &dg[s]);
-						if (COUNT_ONLY || (dg[s] >= A.keep_lo && dg[s] < A.keep_hi)) vmask |= 1u << s;
-					}
-				} else {
-					// block edges / end of the text: one position at a time, rolled (rare: keep the code small)
-					#pragma nounroll
-					for (int s = 0; s < MSD_ITEMS; ++s) {
-						uint64_t i = pos0 + s;
-						uint64_t rr = 0; uint32_t dd = 0; bool ok = false;
-						if (i >= A.start && i < end) {
-							rr = make_rec(window_safe(A.T, i), A.D, pred_sym(A.T, i), (uint32_t)i, &dd);
-							ok = COUNT_ONLY || (dd >= A.keep_lo && dd < A.keep_hi);
-						}
-						#pragma unroll
-						for (int q = 0; q < MSD_ITEMS; ++q) if (q == s) { rec[q] = rr; dg[q] = dd; if (ok) vmask |= 1u << q; }
-					}
-				}
-			}
-		} else {
-			// all 16 loads go out back to back (clamped index, no branch around a load: a load
-			// inside its own if-block gets its own s_waitcnt and the chunk takes 16 round trips)
-			#pragma unroll
-			for (int s = 0; s < MSD_ITEMS; ++s) {
-				uint32_t e = cbase + s * MSD_THREADS + tid;
-				uint32_t ec = e < tile.count ? e : tile.count - 1;
-				rec[s] = A.rec_in[(uint64_t)tile.in_off + ec];
-				if (e < tile.count) vmask |= 1u << s;
-			}
-			#pragma unroll
-			for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
+		// all 16 loads go out back to back (clamped index, no branch around a load: a load
+		// inside its own if-block gets its own s_waitcnt and the chunk takes 16 round trips)
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) {
+			uint32_t e = cbase + s * MSD_THREADS + tid;
+			uint32_t ec = e < tile.count ? e : tile.count - 1;
+			rec[s] = A.rec_in[(uint64_t)tile.in_off + ec];
+			if (e < tile.count) vmask |= 1u << s;
 		}
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
 		if (COUNT_ONLY) continue;
@@ -223,14 +351,13 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) { uint32_t p = binstart[dg[s]] + slot[s]; srec[p] = rec[s]; if (FROM_TEXT) sdig[p] = (uint8_t)dg[s]; }
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) srec[binstart[dg[s]] + slot[s]] = rec[s];
 		__syncthreads();
-		// number of valid records of this chunk = binstart[last] + cnt[last]; copy out run by run
+		// copy out run by run
 		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
-		(void)cn;
 		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) {
 			uint64_t q = srec[p];
-			const uint32_t d = FROM_TEXT ? (uint32_t)sdig[p] : ((uint32_t)(q >> A.shift) & (uint32_t)(bins - 1));
+			const uint32_t d = (uint32_t)(q >> A.shift) & (uint32_t)(bins - 1);
 			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = q;
 		}
 		__syncthreads();
@@ -269,15 +396,11 @@ __global__ void k_next_starts(const uint32_t *scanned, const uint32_t *bucket_ta
 }
 
 // ------------------------------------------------------------------------------------------------
-// final level: one WAVE sorts one bucket (<= 512 records, ~180 on uniform input) in its own 8 KB
-// of LDS; the four waves of a workgroup are independent, so there is no workgroup barrier and a
-// CU keeps 20 buckets in flight.  The remaining key bits of a bucket are close to uniform, so one
-// bin-scatter (LDS atomics into 512 bins) leaves almost every record in its final bin.  Then:
-//   rank inside the bin by (key field, arrival slot), bins permuted in place
-//   records whose key field equals a neighbour's fetch the next 31 bases of their rotation (all
-//   gathers of the wave in flight together)                        -> deep key in LDS
-//   the first record of every tie group insertion-sorts its group on the deep keys (LDS only;
-//   the text is consulted again only if those still tie or the text end is near).
+// wave sort: one WAVE sorts one sub-bucket (<= 512 records, ~180 on uniform input) with wave-level
+// synchronisation only.  The remaining key bits are close to uniform, so one bin-scatter (LDS
+// atomics into 256 bins) leaves almost every record in its final bin; then rank inside the bin by
+// (key field, arrival slot) and permute in place.  Records whose whole key field ties are marked
+// in the tie bitmap for k_tie_fix.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
 {
@@ -288,36 +411,28 @@ __device__ __forceinline__ void wave_sync()
 
 struct SortOut { uint32_t *sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; };
 
-// one wave sorts the final bucket g = records [b0, b0+m) of `rec`; outb (LS_CAP u64) and cb
-// (2*LS_BINS u32) are this wave's private LDS
-// the records of a bucket, 8 per lane (lane l holds records l, l+64, ...); issued early by the caller
-// so that they are in flight while the previous bucket is being sorted
-__device__ __forceinline__ void wave_load_bucket(const uint64_t *rec, uint32_t b0, uint32_t m, uint64_t (&r)[LS_CAP / 64])
+// a sub-bucket the in-kernel sort cannot finish: (start, size) goes to the overflow list (lane 0 only)
+__device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m)
 {
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t mm = m < (uint32_t)LS_CAP ? m : (uint32_t)LS_CAP;
-	#pragma unroll
-	for (int t = 0; t < LS_CAP / 64; ++t) { uint32_t e = t * 64 + lane; r[t] = mm ? rec[(uint64_t)b0 + (e < mm ? e : mm - 1)] : 0; }
+	uint32_t k = atomicAdd(&O.overflow[0], 1u);
+	if (k < O.overflow_cap) { O.overflow[1 + 2 * k] = b0; O.overflow[2 + 2 * k] = m; }
 }
 
+// one wave sorts the m <= LS_CAP records it holds in r (lane l: records l, l+64, ...), destined
+// for the slots [b0, b0+m).  outb (>= m u64) and cb (2*LS_BINS u32) are this wave's private LDS.
 template <bool WRITE_SA>
-__device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64_t *rec, uint32_t g, uint32_t b0, uint32_t m, int sortbits,
-                                                  uint64_t *outb, uint32_t *cb, const SortOut &O, const uint64_t (&r)[LS_CAP / 64])
+__device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int sortbits, uint64_t *outb, uint32_t *cb, const SortOut &O,
+                                                  const uint64_t (&r)[LS_CAP / 64])
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t *cnt = cb, *bst = cb + LS_BINS;
 	uint32_t *sa = O.sa; uint8_t *bwt = O.bwt; const uint64_t start = O.start; uint32_t *p0 = O.p0;
-	uint32_t *overflow = O.overflow; const uint32_t overflow_cap = O.overflow_cap; uint32_t *tiebits = O.tiebits;
+	uint32_t *tiebits = O.tiebits;
 	if (m == 0) return;
-	if (m > (uint32_t)LS_CAP) {
-		if (lane == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = g; }
-		for (uint32_t e = lane; e < m; e += 64) sa[b0 + e] = (uint32_t)rec[b0 + e];
-		return;
-	}
 	const int binbits = sortbits < LS_BINBITS ? (sortbits > 0 ? sortbits : 0) : LS_BINBITS;
 	const int bshift = REC_KEY_SHIFT + sortbits - binbits;
 	const uint32_t bmask = (1u << binbits) - 1;
-	constexpr int PER = LS_CAP / 64;               // 8 records per lane
+	constexpr int PER = LS_CAP / 64;               // 8 records per lane; rounds t with t*64 >= m are skipped (m is wave-uniform)
 	uint32_t sl[PER];
 	#pragma unroll
 	for (int k = 0; k < LS_BINS / 64; ++k) cnt[k * 64 + lane] = 0;
@@ -326,11 +441,11 @@ __device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64
 	for (int t = 0; t < PER; ++t) {
 		uint32_t e = t * 64 + lane;
 		sl[t] = 0;
-		if (e < m) sl[t] = atomicAdd(&cnt[(uint32_t)(r[t] >> bshift) & bmask], 1u);
+		if (t * 64 < (int)m) { if (e < m) sl[t] = atomicAdd(&cnt[(uint32_t)(r[t] >> bshift) & bmask], 1u); }
 	}
 	wave_sync();
 	{
-		constexpr int per = LS_BINS / 64;           // 8 consecutive bins per lane
+		constexpr int per = LS_BINS / 64;           // consecutive bins per lane
 		uint32_t loc[per]; uint32_t sum = 0;
 		#pragma unroll
 		for (int k = 0; k < per; ++k) { loc[k] = cnt[lane * per + k]; sum += loc[k]; }
@@ -342,7 +457,7 @@ __device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
 		uint32_t e = t * 64 + lane;
-		if (e < m) outb[bst[(uint32_t)(r[t] >> bshift) & bmask] + sl[t]] = r[t];
+		if (t * 64 < (int)m) { if (e < m) outb[bst[(uint32_t)(r[t] >> bshift) & bmask] + sl[t]] = r[t]; }
 	}
 	wave_sync();
 	// rank inside the bin: position by (key field, slot); bins of <= 4 records without a loop
@@ -352,89 +467,206 @@ __device__ __forceinline__ void wave_sort_bucket(const TextView &T, const uint64
 	for (int t = 0; t < PER; ++t) {
 		uint32_t e = t * 64 + lane;
 		dest[t] = 0;
-		if (e < m) {
-			uint32_t bin = (uint32_t)(r[t] >> bshift) & bmask;
-			uint32_t c = cnt[bin], s0 = bst[bin], less = 0;
-			if (c > 1) {
-				const uint64_t kx = r[t] >> REC_KEY_SHIFT;
-				if (c <= 4) {
-					#pragma unroll
-					for (uint32_t j = 0; j < 4; ++j) {
-						uint64_t ky = outb[s0 + (j < c ? j : c - 1)] >> REC_KEY_SHIFT;
-						less += (j < c && (ky < kx || (ky == kx && j < sl[t]))) ? 1u : 0u;
-					}
-				} else if (c <= (uint32_t)LS_TIE_CAP) {
-					for (uint32_t j = 0; j < c; ++j) {
-						uint64_t ky = outb[s0 + j] >> REC_KEY_SHIFT;
-						less += (ky < kx || (ky == kx && j < sl[t])) ? 1u : 0u;
-					}
-				} else { ovf = true; less = sl[t]; }
+		if (t * 64 < (int)m) {
+			if (e < m) {
+				uint32_t bin = (uint32_t)(r[t] >> bshift) & bmask;
+				uint32_t c = cnt[bin], s0 = bst[bin], less = 0;
+				if (c > 1) {
+					const uint64_t kx = r[t] >> REC_KEY_SHIFT;
+					if (c <= 4) {
+						#pragma unroll
+						for (uint32_t j = 0; j < 4; ++j) {
+							uint64_t ky = outb[s0 + (j < c ? j : c - 1)] >> REC_KEY_SHIFT;
+							less += (j < c && (ky < kx || (ky == kx && j < sl[t]))) ? 1u : 0u;
+						}
+					} else if (c <= (uint32_t)LS_TIE_CAP) {
+						for (uint32_t j = 0; j < c; ++j) {
+							uint64_t ky = outb[s0 + j] >> REC_KEY_SHIFT;
+							less += (ky < kx || (ky == kx && j < sl[t])) ? 1u : 0u;
+						}
+					} else { ovf = true; less = sl[t]; }
+				}
+				dest[t] = s0 + less;
 			}
-			dest[t] = s0 + less;
 		}
 	}
 	wave_sync();
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) if (t * 64 + lane < m) outb[dest[t]] = r[t];
 	wave_sync();
+	if (__ballot(ovf)) {
+		// a bin beyond LS_TIE_CAP: the key-extension rounds sort this sub-bucket from depth 0
+		if (lane == 0) ovf_push(O, b0, m);
+		#pragma unroll
+		for (int t = 0; t < PER; ++t) if (t * 64 + lane < m) sa[b0 + t * 64 + lane] = (uint32_t)r[t];
+		return;
+	}
 	// tie groups (equal key field): bit p of the tie bitmap = "record p has the key field of
 	// record p-1"; k_tie_fix resolves the runs against the text.  Scattered single-bit atomics:
 	// no hot address.  tied: records that k_tie_fix will look at (they need their SA entry).
-	uint32_t tiedm = 0;
 	#pragma unroll
 	for (int t = 0; t < PER; ++t) {
 		uint32_t e = t * 64 + lane;
-		if (e < m) {
-			uint64_t kf = outb[e] >> REC_KEY_SHIFT;
-			bool sp = e > 0 && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
-			bool sn = e + 1 < m && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
-			if (sp) { uint32_t q = b0 + e; atomicOr(&tiebits[q >> 5], 1u << (q & 31)); }
-			if (sp || sn) tiedm |= 1u << t;
+		if (t * 64 < (int)m) {
+			if (e < m) {
+				const uint64_t q = outb[e];
+				const uint64_t kf = q >> REC_KEY_SHIFT;
+				bool sp = e > 0 && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
+				bool sn = e + 1 < m && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
+				if (sp) { uint32_t g = b0 + e; atomicOr(&tiebits[g >> 5], 1u << (g & 31)); }
+				const uint32_t i = (uint32_t)q;
+				if (WRITE_SA || sp || sn) sa[b0 + e] = i;       // without consumers only k_tie_fix reads positions
+				bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
+				if (i == (uint32_t)start) *p0 = b0 + e;
+			}
 		}
 	}
-	if (__ballot(ovf)) {
-		if (lane == 0) { uint32_t k = atomicAdd(&overflow[0], 1u); if (k < overflow_cap) overflow[1 + k] = g; }
-		for (uint32_t e = lane; e < m; e += 64) sa[b0 + e] = (uint32_t)rec[b0 + e];
+}
+
+// FINISH: one workgroup per final bucket (<= F_CAP records), read ONCE, counting-sorted inside LDS on
+// the top F_BINBITS of its free key bits (8192 bins of 16-bit counters for ~5.7 K records: almost
+// every record lands in its final place), ranked inside its bin on the remaining bits, and emitted.
+// All 512 threads hold 14 records in registers from the first load to the last store; six
+// workgroup barriers per bucket.  Buckets above F_CAP are listed for k_bucket_finish; a bucket
+// with a bin above LS_TIE_CAP (a 16-mer repeated inside the bucket) goes to the overflow list.
+template <bool WRITE_SA>
+__global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits,
+                                                               uint32_t *biglist, uint32_t big_cap, SortOut O, int exp)
+{
+	__shared__ __attribute__((aligned(16))) uint64_t buf[F_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t cw[F_BINS / 2 + 4];     // 16-bit counters, then exclusive starts, two per word
+	__shared__ uint32_t wsum[F_WAVES];
+	__shared__ uint32_t s_ovf;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t b = blockIdx.x;
+	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
+	if (m == 0) return;
+	if (m > (uint32_t)F_CAP) {
+		if (tid == 0) { uint32_t k = atomicAdd(&biglist[0], 1u); if (k < big_cap) biglist[1 + k] = b; }
+		return;
+	}
+	uint64_t r[F_PER];
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
+	if (exp == 1) { uint64_t x = 0; for (int k = 0; k < F_PER; ++k) x ^= r[k]; if (x == 0x1234567) O.bwt[s0] = 1; return; }
+	const int binbits = fbits < F_BINBITS ? fbits : F_BINBITS;
+	const int bshift = REC_KEY_SHIFT + fbits - binbits;
+	const uint32_t bmask = (1u << binbits) - 1;
+	#pragma unroll
+	for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) cw[k * F_THREADS + tid] = 0;
+	if (tid == 0) s_ovf = 0;
+	__syncthreads();
+	// ---- count: slot of every record inside its bin ----
+	uint32_t sl[F_PER];
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		uint32_t e = k * F_THREADS + tid;
+		sl[k] = 0;
+		if (e < m) {
+			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
+			uint32_t old = atomicAdd(&cw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
+			sl[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+		}
+	}
+	__syncthreads();
+	// ---- exclusive scan over the bins, in place: thread = 16 consecutive bins = 8 words ----
+	{
+		constexpr int WPT = (F_BINS / 2) / F_THREADS;       // 8
+		uint32_t w[WPT]; uint32_t sum = 0;
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { w[k] = cw[tid * WPT + k]; sum += (w[k] & 0xFFFFu) + (w[k] >> 16); }
+		uint32_t inc = wave_incl_sum(sum);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t run = inc - sum;
+		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) {
+			uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+			cw[tid * WPT + k] = run | ((run + lo) << 16);
+			run += lo + hi;
+		}
+		if (tid == F_THREADS - 1) cw[F_BINS / 2] = run;      // = m: end of the last bin
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		uint32_t e = k * F_THREADS + tid;
+		if (e < m) {
+			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
+			uint32_t st = (cw[bin >> 1] >> ((bin & 1u) * 16)) & 0xFFFFu;
+			buf[st + sl[k]] = r[k];
+		}
+	}
+	__syncthreads();
+	if (exp == 2) { if (buf[tid] == 0x1234567) O.bwt[s0] = 1; return; }
+	// ---- rank inside the bin by (key field, slot) ----
+	bool ovf = false;
+	uint32_t dest[F_PER];
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		uint32_t e = k * F_THREADS + tid;
+		dest[k] = 0;
+		if (e < m) {
+			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
+			uint32_t st = (cw[bin >> 1] >> ((bin & 1u) * 16)) & 0xFFFFu;
+			uint32_t en = (cw[(bin + 1) >> 1] >> (((bin + 1) & 1u) * 16)) & 0xFFFFu;
+			uint32_t c = en - st, less = 0;
+			if (c > 1) {
+				const uint64_t kx = r[k] >> REC_KEY_SHIFT;
+				if (c <= 4) {
+					#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j) {
+						uint64_t ky = buf[st + (j < c ? j : c - 1)] >> REC_KEY_SHIFT;
+						less += (j < c && (ky < kx || (ky == kx && j < sl[k]))) ? 1u : 0u;
+					}
+				} else if (c <= (uint32_t)LS_TIE_CAP) {
+					for (uint32_t j = 0; j < c; ++j) {
+						uint64_t ky = buf[st + j] >> REC_KEY_SHIFT;
+						less += (ky < kx || (ky == kx && j < sl[k])) ? 1u : 0u;
+					}
+				} else { ovf = true; less = sl[k]; }
+			}
+			dest[k] = st + less;
+		}
+	}
+	if (ovf) s_ovf = 1;
+	__syncthreads();
+	if (s_ovf) {
+		// a bin beyond LS_TIE_CAP: the key-extension rounds sort this bucket from depth 0
+		if (tid == 0) ovf_push(O, s0, m);
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = (uint32_t)r[k]; }
 		return;
 	}
 	#pragma unroll
-	for (int t = 0; t < PER; ++t) {
-		uint32_t e = t * 64 + lane;
+	for (int k = 0; k < F_PER; ++k) if (k * F_THREADS + tid < m) buf[dest[k]] = r[k];
+	__syncthreads();
+	// ---- emit; key-field ties are marked for k_tie_fix (they need their SA entry) ----
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
-			uint64_t q = outb[e];
-			uint32_t i = (uint32_t)q;
-			if (WRITE_SA || (tiedm & (1u << t))) sa[b0 + e] = i;       // without consumers only k_tie_fix reads positions
-			bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
-			if (i == (uint32_t)start) *p0 = b0 + e;
+			const uint64_t q = buf[e];
+			const uint64_t kf = q >> REC_KEY_SHIFT;
+			bool sp = e > 0 && (buf[e - 1] >> REC_KEY_SHIFT) == kf;
+			bool sn = e + 1 < m && (buf[e + 1] >> REC_KEY_SHIFT) == kf;
+			const uint32_t g = s0 + e;
+			if (sp) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
+			const uint32_t i = (uint32_t)q;
+			if (WRITE_SA || sp || sn) O.sa[g] = i;
+			O.bwt[g] = (uint8_t)((q >> 32) & 7u);
+			if (i == (uint32_t)O.start) *O.p0 = g;
 		}
 	}
 }
 
-
-// final level as its own launch (kept for reference / experiments): one wave per final bucket
+// BIG BUCKETS (above F_CAP; skewed input): one workgroup per listed bucket counts the bucket's next
+// 8 bits, scatters it into its own range of the other record buffer (chunks of 4096 through LDS,
+// as k_msd_pass), and its four waves then sort the 256 sub-buckets one after the other.
 template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_lds_sort(TextView T, const uint64_t *rec, const uint32_t *sub_start, uint32_t nbuckets, int sortbits, SortOut O)
-{
-	__shared__ uint64_t s_rec[LS_WAVES][LS_CAP];
-	__shared__ __attribute__((aligned(16))) uint32_t s_cb[LS_WAVES][2 * LS_BINS];   // counts | starts
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint32_t g = blockIdx.x * LS_WAVES + wave;
-	if (g >= nbuckets) return;
-	const uint32_t b0 = sub_start[g], b1 = sub_start[g + 1];
-	uint64_t r[LS_CAP / 64];
-	wave_load_bucket(rec, b0, b1 - b0, r);
-	wave_sort_bucket<WRITE_SA>(T, rec, g, b0, b1 - b0, sortbits, s_rec[wave], s_cb[wave], O, r);
-}
-
-// LAST PARTITION LEVEL + FINAL SORT FUSED: one workgroup owns one bucket entering the last level
-// (~46 K records at 3 Gbase): it counts the bucket's next digit, scatters the bucket into its
-// own range of the other record buffer (chunks of 4096 through LDS, as k_msd_pass), and its four
-// waves then sort the 256 sub-buckets one after the other.  What the scatter writes is read back
-// by the same CU microseconds later: that 24 GB write + 24 GB read stay in L2 / Infinity Cache
-// instead of HBM, and the separate counting pass, scan and host round trip of the level are gone.
-template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, uint32_t nb,
-                                                                 int D, int shift, int sortbits, uint32_t *sub_start, SortOut O)
+__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist,
+                                                                 int D, int shift, int sortbits, SortOut O)
 {
 	constexpr int CH = MSD_THREADS * MSD_ITEMS;                 // 4096
 	__shared__ uint32_t cnt[MSD_MAXBINS];
@@ -444,7 +676,8 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 	__shared__ uint32_t wsum[8];
 	__shared__ __attribute__((aligned(16))) uint64_t big[CH];     // scatter staging, later the waves' sort buffers (32 KB)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t b = blockIdx.x;
+	if (blockIdx.x >= biglist[0]) return;
+	const uint32_t b = biglist[1 + blockIdx.x];
 	const uint32_t s0 = bstart[b], s1 = bstart[b + 1], m = s1 - s0;
 	const uint32_t bins = 1u << D, dmask = bins - 1;
 	// ---- pass 1: histogram of the next digit over the bucket ----
@@ -467,11 +700,8 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 		uint32_t ex = pre + inc - v;
 		sub[tid] = ex; gbase[tid] = s0 + ex;
 		if (tid == MSD_THREADS - 1) sub[MSD_MAXBINS] = ex + v;
-		if (tid < bins) sub_start[((uint64_t)b << D) + tid] = s0 + ex;
-		if (b + 1 == nb && tid == 0) sub_start[(uint64_t)nb << D] = s1;
 	}
 	__syncthreads();
-	if (m == 0) return;
 	// ---- pass 2: scatter the bucket into rec_tmp[s0, s1) ----
 	for (uint32_t cbase = 0; cbase < m; cbase += CH) {
 		cnt[tid] = 0;
@@ -510,16 +740,19 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(TextView T, const
 	__syncthreads();
 	// ---- pass 3: the four waves sort the sub-buckets, each wave on its own slice of LDS ----
 	uint64_t *outb = big + wave * LS_CAP;                                                  // 4 x 4 KB
-	uint32_t *cb = reinterpret_cast<uint32_t *>(big + LS_WAVES * LS_CAP) + wave * 2 * LS_BINS;   // 4 x 4 KB
-	uint64_t rn[LS_CAP / 64];
-	if (wave < bins) wave_load_bucket(rec_tmp, s0 + sub[wave], sub[wave + 1] - sub[wave], rn);
+	uint32_t *cb = reinterpret_cast<uint32_t *>(big + LS_WAVES * LS_CAP) + wave * 2 * LS_BINS;
 	for (uint32_t d = wave; d < bins; d += LS_WAVES) {
-		uint32_t lo = sub[d], hi = sub[d + 1];
+		const uint32_t lo = sub[d], mm = sub[d + 1] - lo;
+		if (mm == 0) continue;
+		if (mm > (uint32_t)LS_CAP) {
+			if (lane == 0) ovf_push(O, s0 + lo, mm);
+			for (uint32_t e = lane; e < mm; e += 64) O.sa[s0 + lo + e] = (uint32_t)rec_tmp[(uint64_t)s0 + lo + e];
+			continue;
+		}
 		uint64_t r[LS_CAP / 64];
 		#pragma unroll
-		for (int t = 0; t < LS_CAP / 64; ++t) r[t] = rn[t];
-		if (d + LS_WAVES < bins) wave_load_bucket(rec_tmp, s0 + sub[d + LS_WAVES], sub[d + LS_WAVES + 1] - sub[d + LS_WAVES], rn);   // next one flies meanwhile
-		wave_sort_bucket<WRITE_SA>(T, rec_tmp, (b << D) | d, s0 + lo, hi - lo, sortbits, outb, cb, O, r);
+		for (int t = 0; t < LS_CAP / 64; ++t) { uint32_t e = t * 64 + lane; r[t] = rec_tmp[(uint64_t)s0 + lo + (e < mm ? e : mm - 1)]; }
+		wave_sort_bucket<WRITE_SA>(s0 + lo, mm, sortbits, outb, cb, O, r);
 		wave_sync();
 	}
 }
@@ -583,29 +816,30 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
-	const MsdDigits dg = msd_digits(len_in);
-	uint64_t *rin = ws.keyB, *rout = ws.keyA;      // level 0 writes keyA
+	MsdDigits dg = msd_digits(len_in);
+	if (const char *e = getenv("B3M_EXP_D0")) { int t = dg.D0 + dg.D1; dg.D0 = atoi(e); dg.D1 = t - dg.D0; }
+	B3M_REQUIRE(dg.D0 >= 1 && dg.D0 <= W0_MAXBITS && dg.D1 >= 0 && dg.D1 <= MSD_MAXBITS, "internal: MSD digit split");
 	uint32_t *sa = ws.idxA;
 	out.used_msd = true;
-	// ---- level 0: text -> records, partitioned by the first bits[0] bits ----
+	// ---- level 0: text -> records (keyA), partitioned by the first D0 bits ----
 	const uint64_t P0 = start & ~15ull;
 	const uint64_t span = start + len_in - P0;
-	const uint32_t ntA = (uint32_t)((span + MSD_SUPER - 1) / MSD_SUPER);
-	const uint32_t bins0 = 1u << dg.bits[0];
+	const uint32_t ntA = (uint32_t)((span + W0_TILE - 1) / W0_TILE);
+	const uint32_t bins0 = 1u << dg.D0;
 	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
-	MsdArgs A{};
-	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_in = nullptr; A.rec_out = rout; A.tiles = nullptr; A.hist = M.hist; A.D = dg.bits[0]; A.shift = 0;
+	L0Args A{};
+	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_out = ws.keyA; A.hist = M.hist; A.D = dg.D0;
 	A.keep_lo = 0; A.keep_hi = bins0;
 	{
 		Scope sc(tl, KF_MSD_HIST, span / 4);
-		hipLaunchKernelGGL((k_msd_pass<true, true>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
+		hipLaunchKernelGGL((k_l0_pass<true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
 	out.slice_offset = 0;
 	if (nshards > 1) {
 		// suffix-range shard: this rank keeps the level-0 digits [lo, hi) holding the ranks
 		// [shard*n/N, (shard+1)*n/N) as evenly as whole digits allow.  The totals come from the
 		// text alone, so every rank derives the same boundaries without talking to anyone.
-		unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until the levels are done
+		unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
 		hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
 		std::vector<unsigned long long> tot(bins0);
 		B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
@@ -634,74 +868,50 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	{
 		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
-		hipLaunchKernelGGL((k_msd_pass<true, false>), dim3(ntA), dim3(MSD_THREADS), 0, s, A);
+		hipLaunchKernelGGL((k_l0_pass<false>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
-	// bucket starts leaving level 0: a one-bucket table {start 0, hist_off 0, ntiles ntA}
-	uint32_t nb = 1;                    // buckets entering the level just done
 	{
-		uint32_t tab0[3] = {0, 0, ntA};
+		uint32_t tab0[3] = {0, 0, ntA};               // the one bucket entering level 0: {start, hist_off, ntiles}
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab0, 12, hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));
 	}
-	int consumed = 0;                   // key-field bits used by levels >= 1
-	uint32_t nfinal = 0;
-	const uint32_t eq_syms = (uint32_t)((dg.bits[0] + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
+	const uint32_t eq_syms = (uint32_t)((dg.D0 + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
 	uint32_t *d_tiebits = ws.t[0];      // tie bitmap: len bits
-	for (int lv = 0; lv + 1 < dg.L; ++lv) {
-		const int D = dg.bits[lv];
-		const uint32_t nnext = nb << D;
-		const bool last = lv + 2 == dg.L;         // the next level is the last one: fused with the final sort
-		uint32_t *d_starts = last ? M.lvl_start : M.sub_start;
-		B3M_REQUIRE(!last || nnext + 1 <= MSD_TAB_MAX, "MSD level table too small");
-		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nnext + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, nb, D, (uint32_t)len, d_starts);
-		const int Dn = dg.bits[lv + 1];
-		consumed += Dn;
-		std::swap(rin, rout);
-		if (last) {
-			// ---- last partition level + final sort, one workgroup per bucket ----
-			// compulsory HBM traffic: the records once in, the BWT byte (and the SA entry) out; the
-			// scatter inside the bucket and its re-read are meant to stay in L2 / Infinity Cache
-			Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
-			B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
-			B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
-			SortOut O{sa, d_bwt, start, d_p0, M.overflow, (uint32_t)std::min<uint64_t>(M.overflow_cap - 2, (uint64_t)nnext << Dn), d_tiebits};
-			if (need_sa)
-				hipLaunchKernelGGL(k_bucket_finish<true>, dim3(nnext), dim3(MSD_THREADS), 0, s, T, rin, rout, d_starts, nnext, Dn, 64 - consumed, REC_KEY_BITS - consumed, M.sub_start, O);
-			else
-				hipLaunchKernelGGL(k_bucket_finish<false>, dim3(nnext), dim3(MSD_THREADS), 0, s, T, rin, rout, d_starts, nnext, Dn, 64 - consumed, REC_KEY_BITS - consumed, M.sub_start, O);
-			nfinal = nnext << Dn;
-			break;
-		}
-		// ---- build the tiles of the next level on the host ----
-		std::vector<uint32_t> st(nnext + 1);
-		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (nnext + 1), hipMemcpyDeviceToHost, s));
+	const uint64_t *cur = ws.keyA; uint64_t *other = ws.keyB;
+	uint32_t nbF = bins0;               // final buckets
+	const int consumed = dg.D1;         // key-field bits used by level 1
+	if (dg.D1 == 0) {
+		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.lvl_start);
+	} else {
+		// ---- level 1: tiles of <= 64 Ki records inside every level-0 bucket, built on the host ----
+		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.sub_start);
+		std::vector<uint32_t> st(bins0 + 1);
+		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		std::vector<MsdTile> tiles;
-		std::vector<uint32_t> tab(3ull * nnext);
+		std::vector<uint32_t> tab(3ull * bins0);
 		uint64_t hoff = 0;
-		for (uint32_t b = 0; b < nnext; ++b) {
+		for (uint32_t b = 0; b < bins0; ++b) {
 			uint32_t sz = st[b + 1] - st[b];
 			uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
-			tab[b] = st[b]; tab[nnext + b] = (uint32_t)hoff; tab[2ull * nnext + b] = nt;
+			tab[b] = st[b]; tab[bins0 + b] = (uint32_t)hoff; tab[2ull * bins0 + b] = nt;
 			for (uint32_t j = 0; j < nt; ++j) {
 				MsdTile t; t.in_off = st[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
 				t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
 				tiles.push_back(t);
 			}
-			hoff += ((uint64_t)1 << Dn) * nt;
+			hoff += ((uint64_t)1 << dg.D1) * nt;
 		}
-		B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32) && 3ull * nnext <= 3 * MSD_TAB_MAX, "MSD workspace too small");
+		B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32), "MSD workspace too small");
 		B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
-		// ---- partition level lv+1 ----
 		MsdArgs Bq{};
-		Bq.T = T; Bq.start = start; Bq.len = len; Bq.P0 = 0; Bq.rec_in = rin; Bq.rec_out = rout; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = Dn;
-		Bq.shift = 64 - consumed; Bq.keep_lo = 0; Bq.keep_hi = 0xFFFFFFFFu;
+		Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = dg.D1; Bq.shift = 64 - dg.D1;
 		const uint32_t ntB = (uint32_t)tiles.size();
 		{
 			Scope sc(tl, KF_MSD_HIST, 8 * len);
-			hipLaunchKernelGGL((k_msd_pass<false, true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+			hipLaunchKernelGGL((k_msd_pass<true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
 		}
 		{
 			Scope sc(tl, KF_SCAN, 8ull * hoff);
@@ -709,11 +919,35 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		}
 		{
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-			hipLaunchKernelGGL((k_msd_pass<false, false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+			hipLaunchKernelGGL((k_msd_pass<false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
 		}
-		nb = nnext;
+		nbF = bins0 << dg.D1;
+		B3M_REQUIRE((uint64_t)nbF + 1 <= MSD_TAB_MAX, "MSD level table too small");
+		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nbF + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
+		cur = ws.keyB; other = ws.keyA;
 	}
-	B3M_REQUIRE(nfinal != 0, "internal: MSD needs at least two levels");
+	// ---- finish: every final bucket sorted inside LDS; compulsory traffic = records in, BWT byte (+ SA entry) out ----
+	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
+	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
+	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits};
+	const int fexp = getenv("B3M_EXP_F") ? atoi(getenv("B3M_EXP_F")) : 0;
+	{
+		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
+		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
+		B3M_HIP(hipMemsetAsync(M.biglist, 0, 4, s));
+		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
+		if (need_sa)
+			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O, fexp);
+		else
+			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O, fexp);
+		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
+		// The grid covers every bucket that could be that large; blocks beyond the list leave at once.
+		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
+		if (need_sa)
+			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+		else
+			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+	}
 	{
 		Scope sc(tl, KF_TIES, len / 8);
 		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, eq_syms, sa, d_bwt, start, d_p0);
@@ -723,19 +957,20 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	B3M_HIP(hipStreamSynchronize(s));
 	out.msd_overflow_buckets = nov;
 	if (nov) {
-		// ---- fallback: oversized / deeply tied buckets go through the key-extension rounds ----
+		// ---- fallback: oversized / deeply tied sub-buckets go through the key-extension rounds ----
 		Scope sc(tl, KF_TIES, 0);
-		std::vector<uint32_t> ids(nov), sub(nfinal + 1);
-		B3M_HIP(hipMemcpyAsync(ids.data(), M.overflow + 1, 4ull * nov, hipMemcpyDeviceToHost, s));
-		B3M_HIP(hipMemcpyAsync(sub.data(), M.sub_start, 4ull * (nfinal + 1), hipMemcpyDeviceToHost, s));
+		B3M_REQUIRE(nov <= ovf_cap, "too many overflow sub-buckets for the workspace");
+		std::vector<uint32_t> pairs(2ull * nov);
+		B3M_HIP(hipMemcpyAsync(pairs.data(), M.overflow + 1, 8ull * nov, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
-		std::sort(ids.begin(), ids.end());
+		std::vector<std::pair<uint32_t, uint32_t>> pv(nov);
+		for (uint32_t j = 0; j < nov; ++j) pv[j] = {pairs[2 * j], pairs[2 * j + 1]};
+		std::sort(pv.begin(), pv.end());
 		std::vector<uint32_t> off(nov + 1), b0(nov);
 		uint64_t total = 0;
-		for (uint32_t j = 0; j < nov; ++j) { off[j] = (uint32_t)total; b0[j] = sub[ids[j]]; total += sub[ids[j] + 1] - sub[ids[j]]; }
+		for (uint32_t j = 0; j < nov; ++j) { off[j] = (uint32_t)total; b0[j] = pv[j].first; total += pv[j].second; }
 		off[nov] = (uint32_t)total;
 		// the overflow table is dead now: reuse it for (off, b0)
-		B3M_REQUIRE(2ull * nov + 2 <= M.overflow_cap, "overflow table too small");
 		uint32_t *d_off = M.overflow, *d_b0 = M.overflow + nov + 1;
 		B3M_HIP(hipMemcpyAsync(d_off, off.data(), 4ull * (nov + 1), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipMemcpyAsync(d_b0, b0.data(), 4ull * nov, hipMemcpyHostToDevice, s));
