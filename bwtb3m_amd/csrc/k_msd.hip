@@ -52,9 +52,9 @@ constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
 // finish
 constexpr int F_THREADS = 512;
 constexpr int F_WAVES = F_THREADS / 64;
-constexpr int F_CAP = 7168;                            // records of a final bucket held in LDS (56 KB)
-constexpr int F_PER = F_CAP / F_THREADS;               // 14 records per thread
-constexpr int F_AVG = 6000;                            // target average bucket size
+constexpr int F_CAP = 6144;                            // records of a final bucket sorted in LDS
+constexpr int F_PER = F_CAP / F_THREADS;               // 12 records per thread
+constexpr int F_AVG = 5760;                            // target average bucket size
 constexpr int F_BINBITS = 13;
 constexpr int F_BINS = 1 << F_BINBITS;                 // counting-sort bins of the finish (16-bit counters)
 constexpr int LS_CAP = 512;                            // sub-bucket capacity of the wave sort
@@ -523,20 +523,25 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 	}
 }
 
-// FINISH: one workgroup per final bucket (<= F_CAP records), read ONCE, counting-sorted inside LDS on
-// the top F_BINBITS of its free key bits (8192 bins of 16-bit counters for ~5.7 K records: almost
-// every record lands in its final place), ranked inside its bin on the remaining bits, and emitted.
-// All 512 threads hold 14 records in registers from the first load to the last store; six
-// workgroup barriers per bucket.  Buckets above F_CAP are listed for k_bucket_finish; a bucket
-// with a bin above LS_TIE_CAP (a 16-mer repeated inside the bucket) goes to the overflow list.
+// FINISH: one workgroup per final bucket (<= F_CAP records), read ONCE into registers (14 per thread)
+// and counting-sorted inside LDS on the top F_BINBITS of its free key bits (8192 bins of 16-bit
+// counters for ~5.7 K records: almost every record is alone in its bin).  What moves through LDS is
+// a 4-byte entry (remaining key bits | index inside the bucket), not the record: the owner of a
+// record scans its bin, learns its final place and whether its whole key field ties with a
+// neighbour, and drops the BWT byte (and the SA entry) there; the bucket leaves as coalesced rows.
+// Buckets above F_CAP are listed for k_bucket_finish; a bucket with a bin above LS_TIE_CAP (a 16-mer
+// repeated inside the bucket) goes to the overflow list.
 template <bool WRITE_SA>
 __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits,
-                                                               uint32_t *biglist, uint32_t big_cap, SortOut O, int exp)
+                                                               uint32_t *biglist, uint32_t big_cap, SortOut O)
 {
-	__shared__ __attribute__((aligned(16))) uint64_t buf[F_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t ent[F_CAP + 4];         // (low key bits << 13) | index, in bin order
 	__shared__ __attribute__((aligned(16))) uint32_t cw[F_BINS / 2 + 4];     // 16-bit counters, then exclusive starts, two per word
+	__shared__ __attribute__((aligned(16))) uint8_t obwt[F_CAP + 8];
+	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
 	__shared__ uint32_t s_ovf;
+	static_assert(F_CAP <= (1 << 13), "index field of an entry");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t b = blockIdx.x;
 	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
@@ -548,24 +553,26 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	uint64_t r[F_PER];
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
-	if (exp == 1) { uint64_t x = 0; for (int k = 0; k < F_PER; ++k) x ^= r[k]; if (x == 0x1234567) O.bwt[s0] = 1; return; }
+	// the key field sits in the high dword (bits 3..31), the predecessor symbol in its low 3 bits
 	const int binbits = fbits < F_BINBITS ? fbits : F_BINBITS;
-	const int bshift = REC_KEY_SHIFT + fbits - binbits;
-	const uint32_t bmask = (1u << binbits) - 1;
+	const int lowbits = fbits - binbits;                      // <= 16
+	const int bsh = REC_KEY_SHIFT - 32 + lowbits;
+	const uint32_t bmask = (1u << binbits) - 1, lmask = (1u << lowbits) - 1;
+	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);   // obwt keeps the byte phase of the global address
 	#pragma unroll
 	for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) cw[k * F_THREADS + tid] = 0;
 	if (tid == 0) s_ovf = 0;
 	__syncthreads();
 	// ---- count: slot of every record inside its bin ----
-	uint32_t sl[F_PER];
+	uint32_t bs[F_PER];                                       // bin | slot << 16, later bin | start << 16
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
-		sl[k] = 0;
+		bs[k] = 0;
 		if (e < m) {
-			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
+			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
 			uint32_t old = atomicAdd(&cw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
-			sl[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+			bs[k] = bin | (((bin & 1u) ? old >> 16 : old & 0xFFFFu) << 16);
 		}
 	}
 	__syncthreads();
@@ -589,45 +596,49 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 		if (tid == F_THREADS - 1) cw[F_BINS / 2] = run;      // = m: end of the last bin
 	}
 	__syncthreads();
+	const uint16_t *cs = reinterpret_cast<const uint16_t *>(cw);       // start of bin b = cs[b], its end = cs[b + 1]
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
-			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
-			uint32_t st = (cw[bin >> 1] >> ((bin & 1u) * 16)) & 0xFFFFu;
-			buf[st + sl[k]] = r[k];
+			uint32_t bin = bs[k] & 0xFFFFu, slot = bs[k] >> 16;
+			uint32_t st = cs[bin];
+			ent[st + slot] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
+			bs[k] = bin | (st << 16);
 		}
 	}
 	__syncthreads();
-	if (exp == 2) { if (buf[tid] == 0x1234567) O.bwt[s0] = 1; return; }
-	// ---- rank inside the bin by (key field, slot) ----
+	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
+	// entries y (own entry x, xk = x without its index bits): y < x, y < xk (smaller key) and
+	// y < xk + 2^13 (key not larger) give the place, "an equal key precedes me" and "my key ties".
 	bool ovf = false;
-	uint32_t dest[F_PER];
+	uint32_t dest[F_PER];                                     // place | tied << 30 | has an equal predecessor << 31
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
 		dest[k] = 0;
 		if (e < m) {
-			uint32_t bin = (uint32_t)(r[k] >> bshift) & bmask;
-			uint32_t st = (cw[bin >> 1] >> ((bin & 1u) * 16)) & 0xFFFFu;
-			uint32_t en = (cw[(bin + 1) >> 1] >> (((bin + 1) & 1u) * 16)) & 0xFFFFu;
-			uint32_t c = en - st, less = 0;
+			const uint32_t bin = bs[k] & 0xFFFFu, st = bs[k] >> 16;
+			const uint32_t c = (uint32_t)cs[bin + 1] - st;
+			uint32_t lt = 0, ltk = 0, lek = 1;
 			if (c > 1) {
-				const uint64_t kx = r[k] >> REC_KEY_SHIFT;
+				const uint32_t xk = (((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13, x = xk | e, xn = xk + 8192u;
+				lek = 0;
 				if (c <= 4) {
 					#pragma unroll
 					for (uint32_t j = 0; j < 4; ++j) {
-						uint64_t ky = buf[st + (j < c ? j : c - 1)] >> REC_KEY_SHIFT;
-						less += (j < c && (ky < kx || (ky == kx && j < sl[k]))) ? 1u : 0u;
+						uint32_t y = ent[st + j];                 // beyond the bin: the next bin's entries (ent is padded), masked out
+						y = j < c ? y : 0xFFFFFFFFu;
+						lt += y < x ? 1u : 0u; ltk += y < xk ? 1u : 0u; lek += y < xn ? 1u : 0u;
 					}
 				} else if (c <= (uint32_t)LS_TIE_CAP) {
 					for (uint32_t j = 0; j < c; ++j) {
-						uint64_t ky = buf[st + j] >> REC_KEY_SHIFT;
-						less += (ky < kx || (ky == kx && j < sl[k])) ? 1u : 0u;
+						uint32_t y = ent[st + j];
+						lt += y < x ? 1u : 0u; ltk += y < xk ? 1u : 0u; lek += y < xn ? 1u : 0u;
 					}
-				} else { ovf = true; less = sl[k]; }
+				} else { ovf = true; }
 			}
-			dest[k] = st + less;
+			dest[k] = (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
 		}
 	}
 	if (ovf) s_ovf = 1;
@@ -639,25 +650,34 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = (uint32_t)r[k]; }
 		return;
 	}
-	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) if (k * F_THREADS + tid < m) buf[dest[k]] = r[k];
-	__syncthreads();
-	// ---- emit; key-field ties are marked for k_tie_fix (they need their SA entry) ----
+	// ---- drop BWT byte (and SA entry) at the final place; key-field ties are marked for k_tie_fix ----
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
-			const uint64_t q = buf[e];
-			const uint64_t kf = q >> REC_KEY_SHIFT;
-			bool sp = e > 0 && (buf[e - 1] >> REC_KEY_SHIFT) == kf;
-			bool sn = e + 1 < m && (buf[e + 1] >> REC_KEY_SHIFT) == kf;
-			const uint32_t g = s0 + e;
-			if (sp) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
-			const uint32_t i = (uint32_t)q;
-			if (WRITE_SA || sp || sn) O.sa[g] = i;
-			O.bwt[g] = (uint8_t)((q >> 32) & 7u);
+			const uint32_t dp = dest[k] & 0xFFFFu, g = s0 + dp;
+			const uint32_t i = (uint32_t)r[k];
+			obwt[apad + dp] = (uint8_t)((uint32_t)(r[k] >> 32) & 7u);
+			if (WRITE_SA) osa[dp] = i;
+			else if (dest[k] & (1u << 30)) O.sa[g] = i;       // without consumers only k_tie_fix reads positions
+			if (dest[k] & (1u << 31)) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
 			if (i == (uint32_t)O.start) *O.p0 = g;
 		}
+	}
+	__syncthreads();
+	// ---- the bucket leaves as rows: BWT bytes as dwords (partial first / last dword bytewise) ----
+	{
+		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);   // 4-byte aligned (may point before the block's first byte: never written)
+		const uint32_t lo = apad, hi = apad + m;               // valid bytes of obwt
+		const uint32_t ndw = (hi + 3) >> 2;
+		for (uint32_t j = tid; j < ndw; j += F_THREADS) {
+			if (4 * j >= lo && 4 * j + 4 <= hi) reinterpret_cast<uint32_t *>(gb)[j] = reinterpret_cast<const uint32_t *>(obwt)[j];
+			else { for (uint32_t q = 4 * j; q < 4 * j + 4; ++q) if (q >= lo && q < hi) gb[q] = obwt[q]; }
+		}
+	}
+	if (WRITE_SA) {
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = osa[e]; }
 	}
 }
 
@@ -930,16 +950,15 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
 	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
 	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits};
-	const int fexp = getenv("B3M_EXP_F") ? atoi(getenv("B3M_EXP_F")) : 0;
 	{
 		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(M.biglist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		if (need_sa)
-			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O, fexp);
+			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O);
 		else
-			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O, fexp);
+			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// The grid covers every bucket that could be that large; blocks beyond the list leave at once.
 		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
