@@ -29,7 +29,6 @@
 #include "b3m_internal.h"
 #include "b3m_text.h"
 #include <algorithm>
-#include <cstdlib>
 #include <vector>
 
 namespace b3m {
@@ -540,7 +539,6 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	__shared__ __attribute__((aligned(16))) uint8_t obwt[F_CAP + 8];
 	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
-	__shared__ uint32_t s_ovf;
 	static_assert(F_CAP <= (1 << 13), "index field of an entry");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t b = blockIdx.x;
@@ -561,18 +559,18 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);   // obwt keeps the byte phase of the global address
 	#pragma unroll
 	for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) cw[k * F_THREADS + tid] = 0;
-	if (tid == 0) s_ovf = 0;
 	__syncthreads();
 	// ---- count: slot of every record inside its bin ----
-	uint32_t bs[F_PER];                                       // bin | slot << 16, later bin | start << 16
+	uint32_t bs[F_PER];                                       // bin, later bin | start << 16
+	uint32_t dest[F_PER];                                     // slot, later place | flags
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
-		bs[k] = 0;
+		bs[k] = 0; dest[k] = 0;
 		if (e < m) {
 			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
 			uint32_t old = atomicAdd(&cw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
-			bs[k] = bin | (((bin & 1u) ? old >> 16 : old & 0xFFFFu) << 16);
+			bs[k] = bin; dest[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
 		}
 	}
 	__syncthreads();
@@ -601,9 +599,9 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
-			uint32_t bin = bs[k] & 0xFFFFu, slot = bs[k] >> 16;
+			uint32_t bin = bs[k];
 			uint32_t st = cs[bin];
-			ent[st + slot] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
+			ent[st + dest[k]] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
 			bs[k] = bin | (st << 16);
 		}
 	}
@@ -611,14 +609,14 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
 	// entries y (own entry x, xk = x without its index bits): y < x, y < xk (smaller key) and
 	// y < xk + 2^13 (key not larger) give the place, "an equal key precedes me" and "my key ties".
-	bool ovf = false;
-	uint32_t dest[F_PER];                                     // place | tied << 30 | has an equal predecessor << 31
+	// A bin above LS_TIE_CAP (a 16-mer repeated in the text) stays in arrival order and goes to the
+	// overflow list on its own: (start, size) pushed by its first arrival, positions into sa.
+	// dest: place | hot bin << 29 | tied << 30 | has an equal predecessor << 31
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
-		dest[k] = 0;
 		if (e < m) {
-			const uint32_t bin = bs[k] & 0xFFFFu, st = bs[k] >> 16;
+			const uint32_t bin = bs[k] & 0xFFFFu, st = bs[k] >> 16, slot = dest[k];
 			const uint32_t c = (uint32_t)cs[bin + 1] - st;
 			uint32_t lt = 0, ltk = 0, lek = 1;
 			if (c > 1) {
@@ -636,19 +634,15 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 						uint32_t y = ent[st + j];
 						lt += y < x ? 1u : 0u; ltk += y < xk ? 1u : 0u; lek += y < xn ? 1u : 0u;
 					}
-				} else { ovf = true; }
+				}
 			}
-			dest[k] = (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
+			if (c > (uint32_t)LS_TIE_CAP) {
+				dest[k] = (st + slot) | (1u << 29);
+				if (slot == 0) ovf_push(O, s0 + st, c);
+			} else {
+				dest[k] = (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
+			}
 		}
-	}
-	if (ovf) s_ovf = 1;
-	__syncthreads();
-	if (s_ovf) {
-		// a bin beyond LS_TIE_CAP: the key-extension rounds sort this bucket from depth 0
-		if (tid == 0) ovf_push(O, s0, m);
-		#pragma unroll
-		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = (uint32_t)r[k]; }
-		return;
 	}
 	// ---- drop BWT byte (and SA entry) at the final place; key-field ties are marked for k_tie_fix ----
 	#pragma unroll
@@ -657,9 +651,9 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 		if (e < m) {
 			const uint32_t dp = dest[k] & 0xFFFFu, g = s0 + dp;
 			const uint32_t i = (uint32_t)r[k];
-			obwt[apad + dp] = (uint8_t)((uint32_t)(r[k] >> 32) & 7u);
+			obwt[apad + dp] = (uint8_t)((uint32_t)(r[k] >> 32) & 7u);     // hot bins: overwritten by the fallback's emit
 			if (WRITE_SA) osa[dp] = i;
-			else if (dest[k] & (1u << 30)) O.sa[g] = i;       // without consumers only k_tie_fix reads positions
+			else if (dest[k] & (3u << 29)) O.sa[g] = i;       // without consumers only k_tie_fix / the fallback read positions
 			if (dest[k] & (1u << 31)) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
 			if (i == (uint32_t)O.start) *O.p0 = g;
 		}
@@ -836,8 +830,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
-	MsdDigits dg = msd_digits(len_in);
-	if (const char *e = getenv("B3M_EXP_D0")) { int t = dg.D0 + dg.D1; dg.D0 = atoi(e); dg.D1 = t - dg.D0; }
+	const MsdDigits dg = msd_digits(len_in);
 	B3M_REQUIRE(dg.D0 >= 1 && dg.D0 <= W0_MAXBITS && dg.D1 >= 0 && dg.D1 <= MSD_MAXBITS, "internal: MSD digit split");
 	uint32_t *sa = ws.idxA;
 	out.used_msd = true;
