@@ -117,7 +117,7 @@ struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
 	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
-	uint32_t *t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each)
+	uint32_t *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each); t[5] = ISA of the doubling rounds
 	uint32_t *scan_ws = nullptr;
 	RadixWs radix;
 	MsdWs msd;
@@ -144,7 +144,9 @@ bool msd_applicable(const TextView &T, uint64_t len);
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                     uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa);
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
-                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left);
+                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
+                    uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0);
+void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s);
 // products of a sorted block
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt,

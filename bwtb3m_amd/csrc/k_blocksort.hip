@@ -95,6 +95,43 @@ __global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, u
 	nk[s] = key_at(T, idx[U[s]], depth);
 	slot[s] = (uint32_t)s;
 }
+// prefix doubling: the key of a listed suffix is the current rank (ISA: exact for resolved suffixes,
+// first slot of the tie group for listed ones) of the suffix h symbols further on
+__global__ void k_tie_keys_isa(const uint32_t *isa, uint64_t n, uint64_t h, const uint32_t *U, const uint32_t *idx, uint64_t u, uint64_t *nk, uint32_t *slot)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	uint64_t q = (uint64_t)idx[U[s]] + h; if (q >= n) q -= n;
+	nk[s] = isa[q];
+	slot[s] = (uint32_t)s;
+}
+__global__ void k_tie_gather_isa(const uint32_t *isa, uint64_t n, uint64_t h, const uint32_t *U, const uint32_t *idx, const uint32_t *slot_final,
+                                 uint64_t u, uint32_t *tmp_idx, uint64_t *tmp_key)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	uint32_t i = idx[U[slot_final[s]]];
+	uint64_t q = (uint64_t)i + h; if (q >= n) q -= n;
+	tmp_idx[s] = i;
+	tmp_key[s] = isa[q];
+}
+__global__ void k_isa_init(const uint32_t *sa, uint64_t len, uint32_t *isa)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < len) isa[sa[r]] = (uint32_t)r;
+}
+// hid[s] = s where the label changes (heads of the listed groups), else 0
+__global__ void k_heads_from_gid(const uint32_t *gid, uint64_t u, uint32_t *hid)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) hid[s] = (s == 0 || gid[s] != gid[s - 1]) ? (uint32_t)s : 0u;
+}
+// listed suffixes: rank = first slot of their group (hid = list index of the group's head, after the max-scan)
+__global__ void k_isa_list(const uint32_t *U, const uint32_t *hid, const uint32_t *idx, uint64_t u, uint32_t *isa)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) isa[idx[U[s]]] = U[hid[s]];
+}
 // second sort key: group label of the slot (as u64 so that the pair sorter can be reused)
 __global__ void k_tie_gidkeys(const uint32_t *gid, const uint32_t *slot_sorted, uint64_t u, uint64_t *gk)
 {
@@ -244,7 +281,7 @@ uint64_t blocksort_ws_bytes(uint64_t cap)
 {
 	uint64_t b = 0;
 	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
-	b += 5 * al(4 * (cap + 1));                         // tie-list buffers
+	b += 6 * al(4 * (cap + 1));                         // tie-list buffers + inverse suffix array of the doubling rounds
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
 	b += al(msd_ws_bytes(cap));
@@ -259,31 +296,45 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap)
 	ws.keyB = (uint64_t *)p; p += al(8 * cap);
 	ws.idxA = (uint32_t *)p; p += al(4 * cap);
 	ws.idxB = (uint32_t *)p; p += al(4 * cap);
-	for (int i = 0; i < 5; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
+	for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
 	msd_ws_carve(ws.msd, p, cap); p += al(msd_ws_bytes(cap));
 	ws.d_scalars = (uint32_t *)p;
 }
 
-// Key-extension rounds on the list (U, gid) of u tied slots, starting with symbols
-// [depth0*K, ...).  idx = the suffix array being built.  Buffers: kx/ky (u64, cap >= u) and six
-// u32 buffers of cap+1: B[0]=U, B[1]=gid, B[2..3] sort values, B[4]=hid, B[5]=flag.
-// Returns the number of rounds run; *left = tied slots remaining (equal rotations) .
+// Rounds on the list (U, gid) of u tied slots.  idx = the suffix array being built.  Buffers: kx/ky
+// (u64, cap >= u) and six u32 buffers of cap+1: B[0]=U, B[1]=gid, B[2..3] sort values, B[4]=hid,
+// B[5]=flag (B is permuted in place: on return B[0]/B[1] hold the list that is left).
+//   isa == nullptr: key-extension rounds: round r sorts every group by the symbols [(depth0+r)*K, +K)
+//                   of its rotations; at most max_rounds of them (0 = until nothing is left).
+//   isa != nullptr: prefix doubling from h0 symbols (every listed group must agree on >= h0 symbols,
+//                   isa must be initialised: whole-text blocks only): round r sorts by the rank of
+//                   the suffix h0*2^r further on and refreshes the ranks of the listed suffixes.
+// Returns the number of rounds run; *left = tied slots remaining.
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
-                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left)
+                    uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
+                    uint64_t max_rounds, uint32_t *isa, uint64_t h0)
 {
 	const uint64_t K = (uint64_t)key_symbols(T.type);
 	int gbits = 1; while ((1ull << gbits) < len_for_labels + 1 && gbits < 32) ++gbits;
 	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
 	uint64_t rounds = 0;
 	uint32_t h_u = 0;
+	uint64_t h = h0;
+	if (isa && u) {
+		hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+		inclusive_max_u32(hid, u, scan_ws, s);
+		hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);
+	}
 	for (uint64_t depth = depth0; u > 0; ++depth) {
-		if (depth * K >= T.n) break;                   // compared >= n symbols: equal rotations
+		if (isa ? h >= T.n : depth * K >= T.n) break;   // compared >= n symbols: equal rotations
+		if (max_rounds && rounds >= max_rounds) break;
 		++rounds;
-		hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, depth, kx, vx);
+		if (isa) hipLaunchKernelGGL(k_tie_keys_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, u, kx, vx);
+		else hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, depth, kx, vx);
 		uint64_t *rk; uint32_t *rv;
-		radix_sort_u64(kx, vx, ky, vy, u, key_bits(T.type), radix, s, nullptr, &rk, &rv);
+		radix_sort_u64(kx, vx, ky, vy, u, isa ? gbits : key_bits(T.type), radix, s, nullptr, &rk, &rv);
 		uint64_t *gk = (rk == kx) ? ky : kx;
 		uint32_t *vidle = (rv == vx) ? vy : vx;
 		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, gid, rv, u, gk);
@@ -291,9 +342,11 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		radix_sort_u64(gk, rv, rk, vidle, u, gbits, radix, s, nullptr, &rk2, &rv2);
 		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
 		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
-		hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, rv2, u, depth, tmp_idx, tmp_key);
+		if (isa) hipLaunchKernelGGL(k_tie_gather_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, rv2, u, tmp_idx, tmp_key);
+		else hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, rv2, u, depth, tmp_idx, tmp_key);
 		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, tmp_key, u, idx, hid);
 		inclusive_max_u32(hid, u, scan_ws, s);
+		if (isa) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);   // every key of this round has been read
 		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
 		exclusive_sum_u32(flag, u + 1, scan_ws, s);
 		B3M_HIP(hipMemcpyAsync(&h_u, flag + u, 4, hipMemcpyDeviceToHost, s));
@@ -303,9 +356,15 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		B3M_HIP(hipStreamSynchronize(s));
 		vx = U; vy = gid; U = U2; gid = gid2;
 		u = h_u;
+		h *= 2;
 	}
+	B[0] = U; B[1] = gid; B[2] = vx; B[3] = vy;
 	if (left) *left = u;
 	return rounds;
+}
+void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s)
+{
+	if (len) hipLaunchKernelGGL(k_isa_init, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, d_isa);
 }
 
 void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out)
@@ -344,7 +403,15 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 		Scope sc(tl, KF_TIES, 60ull * h_u);
 		uint32_t *B[6] = {ws.t[0], ws.t[1], v_other, ws.t[2], ws.t[3], ws.t[4]};
 		uint64_t left = 0;
-		out.tie_rounds = tie_rounds(T, v, h_u, 1, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left);
+		// whole text in one block: a few key-extension rounds, then prefix doubling (see tie_rounds)
+		const bool whole = start == 0 && len == T.n;
+		const uint64_t R0 = 4;
+		out.tie_rounds = tie_rounds(T, v, h_u, 1, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
+		if (left && whole && out.tie_rounds >= R0) {
+			uint64_t h0 = 1; while (2 * h0 <= (R0 + 1) * (uint64_t)key_symbols(T.type)) h0 *= 2;
+			isa_from_sa(v, len, ws.t[5], s);
+			out.tie_rounds += tie_rounds(T, v, left, 0, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
+		}
 	}
 	B3M_HIP(hipGetLastError());
 	out.d_sa = v;

@@ -968,6 +968,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	out.msd_overflow_buckets = nov;
+	bool rerun_with_sa = false;
 	if (nov) {
 		// ---- fallback: oversized / deeply tied sub-buckets go through the key-extension rounds ----
 		Scope sc(tl, KF_TIES, 0);
@@ -991,11 +992,25 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipStreamSynchronize(s));
 		uint64_t left = 0;
 		out.tie_elements = total;
-		out.tie_rounds = tie_rounds(T, sa, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left);
+		// A block that is the whole text can rank any suffix: after a few key-extension rounds (enough for
+		// everything but long repeats) the rest is finished by prefix doubling, log2(longest repeat) rounds
+		// instead of (longest repeat)/21.  Doubling reads the rank of EVERY suffix, i.e. the complete
+		// suffix array: a run that was asked for the BWT only starts over with the array kept.
+		const bool whole = start == 0 && len_in == T.n && nshards <= 1;
+		const uint64_t R0 = 4;
+		out.tie_rounds = tie_rounds(T, sa, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
+		if (left && whole && out.tie_rounds >= R0) {
+			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
+			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
+			isa_from_sa(sa, len, ws.t[5], s);
+			out.tie_rounds += tie_rounds(T, sa, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
+		}
 		// BWT symbols (and p0) of the slots finished here
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, ws.t[0], (uint32_t *)nullptr);
 		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
+		leave_fallback:;
 	}
+	if (rerun_with_sa) { block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }
 	B3M_HIP(hipGetLastError());
 	out.d_sa = need_sa ? sa : nullptr;      // without need_sa only the entries of tied / overflow records were written
 }

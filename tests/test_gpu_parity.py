@@ -352,6 +352,32 @@ def test_msd_block_sort_paths(gpu, oracle, itype, kind):
     plan.close()
 
 
+@pytest.mark.parametrize("itype,isarate", [("pacterm", 0), ("pacterm", 4096), ("pac", 0), ("bytestream", 0)])
+def test_deep_repeats_use_prefix_doubling(gpu, oracle, itype, isarate):
+    # a block that is the whole text finishes long repeats by prefix doubling: the number of rounds
+    # is logarithmic in the longest repeat (the key-extension rounds alone would need lcp/21 of them)
+    if itype == "bytestream":
+        t = oracle.synth_bytes(150_000, 77).copy()
+        t[2000:60000] = 65                       # 58,000 x 'A': 7,250 key-extension rounds
+        t[100000:140000] = t[60000:100000]       # a 40,000-byte copy
+        buf, s = t, t
+    else:
+        nb = (1 << 19) + 4321
+        b = oracle.synth_bases(nb, 78).copy()
+        b[5000:305000] = 0                       # 300,000 x A: 14,000 key-extension rounds
+        b[400000:500000] = b[305000:405000]      # a 100,000-base copy
+        buf = _pac(oracle, b)
+        s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate)
+    assert np.array_equal(out, oracle.bwt(s))
+    assert 4 < res["tie_rounds"] <= 4 + 24, res["tie_rounds"]
+    if isarate:
+        sa = oracle.sa_circular(s)
+        smp = plan.samples()
+        assert np.array_equal(sa[smp[:, 0].astype(np.int64)], smp[:, 1].astype(sa.dtype))
+    plan.close()
+
+
 @pytest.mark.parametrize("itype", ["pac", "pacterm"])
 def test_msd_leaves_then_merges(gpu, oracle, itype):
     nb = 3 * (1 << 18) + 777
