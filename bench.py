@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--blocksize", type=float, default=0, help="leaf block size in symbols (0 = engine default)")
     ap.add_argument("--blocks", type=int, default=0, help="number of leaf blocks (overrides --blocksize)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=float, default=48e6, help="symbols of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=float, default=400e6, help="symbols of the CPU-baseline sample")
     ap.add_argument("--mode", default="prefix", choices=["prefix", "blocks"],
                     help="multi-GPU: suffix-range shards (no exchange) or block merging with RCCL all-to-all")
     ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",

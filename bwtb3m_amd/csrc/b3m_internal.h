@@ -111,8 +111,8 @@ struct MsdWs {
 	uint32_t *biglist = nullptr; uint64_t big_cap = 0;       // [0] = count, then ids of final buckets above the LDS capacity
 	uint32_t *scan_ws = nullptr;
 };
-uint64_t msd_ws_bytes(uint64_t cap);
-void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap);
+uint64_t msd_ws_bytes(uint64_t cap, uint64_t span);
+void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
@@ -123,8 +123,9 @@ struct BlockSortWs {
 	MsdWs msd;
 	uint32_t *d_scalars = nullptr;    // small device scalars
 };
-uint64_t blocksort_ws_bytes(uint64_t cap);
-void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap);
+// cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
+uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0);
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span = 0);
 struct BlockSortOut {
 	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions
 	uint64_t tie_rounds = 0, tie_elements = 0;

@@ -280,7 +280,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	p->gt_words = (n + 1 + 31) / 32 + 2;
 	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
 	const uint64_t sort_cap = (nshards > 1) ? p->shard_cap : p->blocksize;
-	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap));
+	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, p->blocksize));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
 	uint64_t nbk = rank_blocks(maxL);
@@ -316,7 +316,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
 	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
-	blocksort_ws_carve(p->bs, A + o_bs, sort_cap);
+	blocksort_ws_carve(p->bs, A + o_bs, sort_cap, p->blocksize);
 	if (B > 1) {
 		p->d_rank_blocks = (uint32_t *)(A + o_rb); p->d_rank_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 		p->d_ranks[0] = (uint32_t *)(A + o_r0); p->d_ranks[1] = (uint32_t *)(A + o_r1);

@@ -277,19 +277,21 @@ __global__ __launch_bounds__(256) void k_histogram(TextView T, uint64_t start, u
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 
-uint64_t blocksort_ws_bytes(uint64_t cap)
+uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span)
 {
+	if (span < cap) span = cap;
 	uint64_t b = 0;
 	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
 	b += 6 * al(4 * (cap + 1));                         // tie-list buffers + inverse suffix array of the doubling rounds
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
-	b += al(msd_ws_bytes(cap));
+	b += al(msd_ws_bytes(cap, span));
 	b += 4096;
 	return b;
 }
-void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap)
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span)
 {
+	if (span < cap) span = cap;
 	uint8_t *p = (uint8_t *)base;
 	ws.cap = cap;
 	ws.keyA = (uint64_t *)p; p += al(8 * cap);
@@ -299,7 +301,7 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap)
 	for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
-	msd_ws_carve(ws.msd, p, cap); p += al(msd_ws_bytes(cap));
+	msd_ws_carve(ws.msd, p, cap, span); p += al(msd_ws_bytes(cap, span));
 	ws.d_scalars = (uint32_t *)p;
 }
 

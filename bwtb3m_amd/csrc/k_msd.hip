@@ -86,23 +86,25 @@ bool msd_applicable(const TextView &T, uint64_t len)
 static const uint64_t MSD_L0_MAX = (uint64_t)W0_MAXBINS + 2;                            // buckets leaving level 0
 static const uint64_t MSD_TAB_MAX = ((uint64_t)W0_MAXBINS << MSD_MAXBITS) + 2;          // final buckets
 
-static uint64_t msd_hist_cap(uint64_t cap) { return cap / 64 + cap / 256 + (4ull << 20); }   // 4096*(cap/2^18+2) resp. 256*(cap/2^16+4098)
+// level 0: 4096 * (span/2^18 + 2) counters over the text the block spans (a suffix-range shard scans the WHOLE
+// text but keeps cap records); level 1: 256 * (cap/2^16 + 4098)
+static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap, span) / 64 + cap / 256 + (4ull << 20); }
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
 static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 256 + 4096; }                  // (start, size) pairs
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
 
-uint64_t msd_ws_bytes(uint64_t cap)
+uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 {
 	if (cap < MSD_MIN_LEN) return 4096;
-	uint64_t hist = msd_hist_cap(cap);
+	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
 	     + al(4 * (2 * msd_ovf_cap(cap) + 2)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
-void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap)
+void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
 	if (cap < MSD_MIN_LEN) { ws = MsdWs(); return; }
 	uint8_t *p = (uint8_t *)base;
-	uint64_t hist = msd_hist_cap(cap);
+	uint64_t hist = msd_hist_cap(cap, span);
 	ws.hist = (uint32_t *)p; ws.hist_cap = hist; p += al(4 * hist);
 	ws.tiles = (MsdTile *)p; ws.tiles_cap = msd_tiles_cap(cap); p += al(sizeof(MsdTile) * ws.tiles_cap);
 	ws.sub_start = (uint32_t *)p; p += al(8 * MSD_L0_MAX);          // level-0 bucket starts; first the u64 row totals
@@ -561,25 +563,29 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) cw[k * F_THREADS + tid] = 0;
 	__syncthreads();
 	// ---- count: slot of every record inside its bin ----
-	uint32_t bs[F_PER];                                       // bin, later bin | start << 16
-	uint32_t dest[F_PER];                                     // slot, later place | flags
+	uint32_t bs[F_PER];                                       // slot inside the bin, later slot | start of the bin << 16
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
-		bs[k] = 0; dest[k] = 0;
+		bs[k] = 0;
 		if (e < m) {
 			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
 			uint32_t old = atomicAdd(&cw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
-			bs[k] = bin; dest[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+			bs[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
 		}
 	}
 	__syncthreads();
 	// ---- exclusive scan over the bins, in place: thread = 16 consecutive bins = 8 words ----
+	uint32_t cmax = 0;                                        // largest of this thread's bins
 	{
 		constexpr int WPT = (F_BINS / 2) / F_THREADS;       // 8
 		uint32_t w[WPT]; uint32_t sum = 0;
 		#pragma unroll
-		for (int k = 0; k < WPT; ++k) { w[k] = cw[tid * WPT + k]; sum += (w[k] & 0xFFFFu) + (w[k] >> 16); }
+		for (int k = 0; k < WPT; ++k) {
+			w[k] = cw[tid * WPT + k];
+			uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+			sum += lo + hi; cmax = cmax > lo ? cmax : lo; cmax = cmax > hi ? cmax : hi;
+		}
 		uint32_t inc = wave_incl_sum(sum);
 		if (lane == 63) wsum[wave] = inc;
 		__syncthreads();
@@ -595,28 +601,36 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	}
 	__syncthreads();
 	const uint16_t *cs = reinterpret_cast<const uint16_t *>(cw);       // start of bin b = cs[b], its end = cs[b + 1]
+	// a bin above LS_TIE_CAP (a 16-mer repeated in the text) goes to the overflow list on its own
+	if (cmax > (uint32_t)LS_TIE_CAP) {
+		#pragma unroll 1
+		for (uint32_t bb = tid * (F_BINS / F_THREADS); bb < (tid + 1) * (F_BINS / F_THREADS); ++bb) {
+			const uint32_t st = cs[bb], c = (uint32_t)cs[bb + 1] - st;
+			if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c);
+		}
+	}
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
-			uint32_t bin = bs[k];
+			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
 			uint32_t st = cs[bin];
-			ent[st + dest[k]] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
-			bs[k] = bin | (st << 16);
+			ent[st + bs[k]] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
+			bs[k] |= st << 16;
 		}
 	}
 	__syncthreads();
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
 	// entries y (own entry x, xk = x without its index bits): y < x, y < xk (smaller key) and
 	// y < xk + 2^13 (key not larger) give the place, "an equal key precedes me" and "my key ties".
-	// A bin above LS_TIE_CAP (a 16-mer repeated in the text) stays in arrival order and goes to the
-	// overflow list on its own: (start, size) pushed by its first arrival, positions into sa.
 	// dest: place | hot bin << 29 | tied << 30 | has an equal predecessor << 31
+	uint32_t dest[F_PER];
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		uint32_t e = k * F_THREADS + tid;
+		dest[k] = 0;
 		if (e < m) {
-			const uint32_t bin = bs[k] & 0xFFFFu, st = bs[k] >> 16, slot = dest[k];
+			const uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask, st = bs[k] >> 16, slot = bs[k] & 0xFFFFu;
 			const uint32_t c = (uint32_t)cs[bin + 1] - st;
 			uint32_t lt = 0, ltk = 0, lek = 1;
 			if (c > 1) {
@@ -636,12 +650,8 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 					}
 				}
 			}
-			if (c > (uint32_t)LS_TIE_CAP) {
-				dest[k] = (st + slot) | (1u << 29);
-				if (slot == 0) ovf_push(O, s0 + st, c);
-			} else {
-				dest[k] = (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
-			}
+			dest[k] = c > (uint32_t)LS_TIE_CAP ? (st + slot) | (1u << 29)        // hot bin: arrival order, positions into sa
+			                                   : (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
 		}
 	}
 	// ---- drop BWT byte (and SA entry) at the final place; key-field ties are marked for k_tie_fix ----

@@ -530,3 +530,31 @@ def test_large_paths_agree_256mbase(gpu):
             assert r["p0"] == r1["p0"]
         plan.close(); del sl
     assert off == n and h.hexdigest() == h1
+
+
+def test_suffix_range_shards_of_a_large_text_1gbase(gpu):
+    # a shard's workspace holds n/N records but its level-0 histogram spans the whole text: at sizes
+    # where the fixed slack no longer hides it (1 Gbase, 8 shards) the slices must still tile the BWT
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    nb = 1_000_000_000
+    itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+    plan = engine.Plan(n, itype)
+    one = plan.run(d_text).clone()
+    torch.cuda.synchronize()
+    r1 = plan.result()
+    plan.close()
+    off = 0
+    for k in range(8):
+        plan = engine.Plan(n, itype, shard=k, nshards=8)
+        sl = plan.run(d_text)
+        torch.cuda.synchronize()
+        r = plan.result()
+        assert r["slice_offset"] == off
+        if k in (0, 3, 7):
+            assert torch.equal(sl, one[off:off + sl.numel()]), k
+        off += sl.numel()
+        if r["has_p0"]:
+            assert r["p0"] == r1["p0"]
+        plan.close(); del sl
+    assert off == n
