@@ -90,7 +90,7 @@ static const uint64_t MSD_TAB_MAX = ((uint64_t)W0_MAXBINS << MSD_MAXBITS) + 2;  
 // text but keeps cap records); level 1: 256 * (cap/2^16 + 4098)
 static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap, span) / 64 + cap / 256 + (4ull << 20); }
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
-static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 256 + 4096; }                  // (start, size) pairs
+static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 33 + 4096; }                   // (start, size) pairs: every listed bin holds > 32 records
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
 
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
@@ -98,7 +98,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 2)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -110,7 +110,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.sub_start = (uint32_t *)p; p += al(8 * MSD_L0_MAX);          // level-0 bucket starts; first the u64 row totals
 	ws.bucket_tab = (uint32_t *)p; p += al(4 * 3 * MSD_L0_MAX);
 	ws.lvl_start = (uint32_t *)p; p += al(4 * MSD_TAB_MAX);
-	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 2));
+	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 4));
 	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
 	ws.scan_ws = (uint32_t *)p;
 }
@@ -416,7 +416,7 @@ struct SortOut { uint32_t *sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint3
 __device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m)
 {
 	uint32_t k = atomicAdd(&O.overflow[0], 1u);
-	if (k < O.overflow_cap) { O.overflow[1 + 2 * k] = b0; O.overflow[2 + 2 * k] = m; }
+	if (k < O.overflow_cap) { O.overflow[2 + 2 * k] = b0; O.overflow[3 + 2 * k] = m; }   // 8-byte aligned pairs: u64 = size << 32 | start
 }
 
 // one wave sorts the m <= LS_CAP records it holds in r (lane l: records l, l+64, ...), destined
@@ -823,6 +823,16 @@ __global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uin
 	}
 }
 
+// sorted (size << 32 | start) pairs -> sizes (scanned into list offsets by the caller) and starts
+__global__ void k_ovf_split(const uint64_t *pairs, uint32_t nov, uint32_t *sizes, uint32_t *b0)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nov) return;
+	if (j == nov) { sizes[j] = 0; return; }
+	uint64_t p = pairs[j];
+	sizes[j] = (uint32_t)(p >> 32); b0[j] = (uint32_t)p;
+}
+
 // list of the suffix-array slots of the overflow buckets: U[s] = slot, gid[s] = bucket start
 __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, uint32_t nov, uint64_t total, uint32_t *U, uint32_t *gid)
 {
@@ -983,20 +993,19 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// ---- fallback: oversized / deeply tied sub-buckets go through the key-extension rounds ----
 		Scope sc(tl, KF_TIES, 0);
 		B3M_REQUIRE(nov <= ovf_cap, "too many overflow sub-buckets for the workspace");
-		std::vector<uint32_t> pairs(2ull * nov);
-		B3M_HIP(hipMemcpyAsync(pairs.data(), M.overflow + 1, 8ull * nov, hipMemcpyDeviceToHost, s));
-		B3M_HIP(hipStreamSynchronize(s));
-		std::vector<std::pair<uint32_t, uint32_t>> pv(nov);
-		for (uint32_t j = 0; j < nov; ++j) pv[j] = {pairs[2 * j], pairs[2 * j + 1]};
-		std::sort(pv.begin(), pv.end());
-		std::vector<uint32_t> off(nov + 1), b0(nov);
-		uint64_t total = 0;
-		for (uint32_t j = 0; j < nov; ++j) { off[j] = (uint32_t)total; b0[j] = pv[j].first; total += pv[j].second; }
-		off[nov] = (uint32_t)total;
+		// order the (start, size) pairs by start and turn the sizes into list offsets, all on the device
+		// (a repeat-rich genome lists millions of bins); the record buffers are free by now
+		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
+		radix_sort_u64(pk, nullptr, ws.keyA, nullptr, nov, 32, ws.radix, s, nullptr, &rk, nullptr);
+		if (rk == pk) { B3M_HIP(hipMemcpyAsync(ws.keyA, pk, 8ull * nov, hipMemcpyDeviceToDevice, s)); rk = ws.keyA; }
 		// the overflow table is dead now: reuse it for (off, b0)
 		uint32_t *d_off = M.overflow, *d_b0 = M.overflow + nov + 1;
-		B3M_HIP(hipMemcpyAsync(d_off, off.data(), 4ull * (nov + 1), hipMemcpyHostToDevice, s));
-		B3M_HIP(hipMemcpyAsync(d_b0, b0.data(), 4ull * nov, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_ovf_split, dim3(nblk((uint64_t)nov + 1)), dim3(256), 0, s, rk, nov, d_off, d_b0);
+		exclusive_sum_u32(d_off, (uint64_t)nov + 1, ws.scan_ws, s);
+		uint32_t total32 = 0;
+		B3M_HIP(hipMemcpyAsync(&total32, d_off + nov, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		const uint64_t total = total32;
 		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[0], Bf[1]);
 		B3M_HIP(hipStreamSynchronize(s));
