@@ -176,7 +176,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	__shared__ uint32_t wsum[W0_THREADS / 64];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
-	const int dsh = 64 - A.D;
+	const int dsh = 64 - A.D, dsh32 = 32 - A.D;
 	const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
@@ -200,10 +200,11 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			#pragma unroll
 			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
-				const uint64_t hi = ((uint64_t)stext[w + 1] << 32) | stext[w + 2];
+				// the digit needs <= 12 bits of the window: 32-bit funnel shifts of two words do
+				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					uint32_t dgt = (uint32_t)((hi << (2 * s)) >> dsh);
+					uint32_t dgt = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
 					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cnt[dgt], 1u);
 				}
 			}
@@ -241,10 +242,10 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			#pragma unroll
 			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
-				const uint64_t hi = ((uint64_t)stext[w + 1] << 32) | stext[w + 2];
+				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					uint32_t dgt = (uint32_t)((hi << (2 * s)) >> dsh);
+					uint32_t dgt = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
 					if (dgt >= A.keep_lo && dgt < A.keep_hi) sidx[atomicAdd(&cur[dgt], 1u)] = (uint16_t)(w * 16 + s);
 				}
 			}
@@ -263,18 +264,21 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		const uint32_t nvalid = cur[bins - 1];
 		for (uint32_t q = tid; q < nvalid; q += W0_THREADS) {
 			const uint32_t li = sidx[q];
-			uint64_t x; uint32_t pr;
+			uint32_t dgt; uint64_t r;
 			if (fast) {
-				const uint32_t w = li >> 4, s = li & 15u;
-				const uint64_t wp = stext[w], w0 = stext[w + 1], w1 = stext[w + 2], w2 = stext[w + 3];
-				const uint64_t hi = (w0 << 32) | w1;
-				x = s ? ((hi << (2 * s)) | (w2 >> (32 - 2 * s))) : hi;
-				pr = (s ? (uint32_t)(w0 >> (32 - 2 * s)) & 3u : (uint32_t)wp & 3u) + padd;
+				// 32-bit funnel shifts only: xh:xl = the 64-bit window at base li, key field = its 29 bits after the digit
+				const uint32_t w = li >> 4, sh = 2u * (li & 15u);
+				const uint32_t wp = stext[w], w0 = stext[w + 1], w1 = stext[w + 2], w2 = stext[w + 3];
+				const uint32_t xh = __funnelshift_l(w1, w0, sh), xl = __funnelshift_l(w2, w1, sh);
+				const uint32_t pr = (__funnelshift_l(w0, wp, sh) & 3u) + padd;
+				dgt = xh >> dsh32;
+				const uint32_t kf = __funnelshift_l(xl, xh, (uint32_t)A.D) >> (32 - REC_KEY_BITS);
+				r = ((uint64_t)((kf << 3) | pr) << 32) | (uint32_t)(cpos + li);
 			} else {
+				uint64_t x; uint32_t pr;
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
+				r = make_rec(x, A.D, pr, (uint32_t)(cpos + li), &dgt);
 			}
-			uint32_t dgt;
-			const uint64_t r = make_rec(x, A.D, pr, (uint32_t)(cpos + li), &dgt);
 			const uint32_t rs = dgt ? cur[dgt - 1] : 0u;          // start of run dgt
 			A.rec_out[(uint64_t)gbase[dgt] + (q - rs)] = r;
 		}
