@@ -389,7 +389,8 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		BlockSortOut so;
 		B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
 		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
-		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
+		// one block: its BWT is the result and goes straight to the caller's buffer
+		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out : p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
 		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;
@@ -476,7 +477,7 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		}
 		cur = nxt;
 	}
-	B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], (p->nshards > 1) ? p->res.slice_len : n, hipMemcpyDeviceToDevice, s));
+	if (B > 1) B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], n, hipMemcpyDeviceToDevice, s));
 	uint64_t p0pair[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipEventRecord(ev1, s));
