@@ -494,7 +494,8 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	p->res.ms_total = ms;
 	tl->collect(p->kms, p->klaunch, p->kbytes);
 	tl->pool.push_back(ev0); tl->pool.push_back(ev1);
-	p->res.ms_sort = p->kms[KF_KEYS] + p->kms[KF_RADIX_HIST] + p->kms[KF_SCAN] + p->kms[KF_RADIX_SCATTER] + p->kms[KF_TIES] + p->kms[KF_EMIT];
+	p->res.ms_sort = p->kms[KF_KEYS] + p->kms[KF_RADIX_HIST] + p->kms[KF_SCAN] + p->kms[KF_RADIX_SCATTER] + p->kms[KF_TIES] + p->kms[KF_EMIT]
+	               + p->kms[KF_MSD_HIST] + p->kms[KF_MSD_SCATTER] + p->kms[KF_MSD_SCATTER_TEXT] + p->kms[KF_LDS_SORT];
 	p->res.ms_gap = p->kms[KF_RANKBUILD] + p->kms[KF_ANCHOR] + p->kms[KF_GAPWALK];
 	p->res.ms_interleave = p->kms[KF_INTERLEAVE];
 	// samples -> host, in position order (slot k holds position k*rate); a shard keeps only its own

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <queue>
 #include <stdexcept>
+#include <atomic>
 #include <thread>
 #include <sys/stat.h>
 
@@ -45,10 +46,18 @@ static uint64_t get_be64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i <
 
 // ---- bit I/O, MSB first -------------------------------------------------------------------------
 struct BitWriter {
-	std::vector<uint8_t> &out; uint8_t cur = 0; int used = 0;
+	std::vector<uint8_t> &out; uint64_t acc = 0; int used = 0;      // `used` pending bits in the low end of acc
 	explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
-	void put(uint64_t v, int bits) { for (int i = bits - 1; i >= 0; --i) { cur = (uint8_t)((cur << 1) | ((v >> i) & 1)); if (++used == 8) { out.push_back(cur); cur = 0; used = 0; } } }
-	void align() { if (used) { out.push_back((uint8_t)(cur << (8 - used))); cur = 0; used = 0; } }
+	void put(uint64_t v, int bits)
+	{
+		while (bits > 0) {
+			int take = std::min(bits, 56 - used);                    // keep room for byte-wise flushing
+			acc = (acc << take) | ((v >> (bits - take)) & ((take == 64 ? 0 : (1ull << take)) - 1));
+			used += take; bits -= take;
+			while (used >= 8) { out.push_back((uint8_t)(acc >> (used - 8))); used -= 8; }
+		}
+	}
+	void align() { if (used) { out.push_back((uint8_t)(acc << (8 - used))); used = 0; } acc = 0; }
 	// Elias-delta of x+1 (x >= 0)
 	void elias(uint64_t x) { uint64_t y = x + 1; int N = 63 - __builtin_clzll(y); int L = 31 - __builtin_clz((unsigned)(N + 1)); put(0, L); put((uint64_t)(N + 1), L + 1); put(y & ((N ? (1ull << N) : 1ull) - 1), N); }
 };
@@ -131,21 +140,29 @@ static const uint64_t RL_ESCAPE = 256;   // run lengths >= 256 are coded as esca
 static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out)
 {
 	BitWriter w(out);
-	std::map<int64_t, uint64_t> sh, ch;
+	// symbols are bytes and coded lengths are 1..256 (256 = escape): flat counters and code tables
+	uint64_t sf[256] = {0}, cf[RL_ESCAPE + 1] = {0};
 	bool esc = false;
 	for (uint64_t i = 0; i < nr; ++i) {
-		sh[runs[i].sym]++;
-		if (runs[i].len >= RL_ESCAPE) { esc = true; ch[(int64_t)RL_ESCAPE]++; } else ch[(int64_t)runs[i].len]++;
+		sf[(uint8_t)runs[i].sym]++;
+		if (runs[i].len >= RL_ESCAPE) { esc = true; cf[RL_ESCAPE]++; } else cf[runs[i].len]++;
 	}
+	std::map<int64_t, uint64_t> sh, ch;
+	for (int s = 0; s < 256; ++s) if (sf[s]) sh[s] = sf[s];
+	for (uint64_t l = 0; l <= RL_ESCAPE; ++l) if (cf[l]) ch[(int64_t)l] = cf[l];
 	Canon sc = Canon::from_freq(sh), cc = Canon::from_freq(ch);
+	uint64_t scode[256]; int slen[256]; uint64_t ccode[RL_ESCAPE + 1]; int clen[RL_ESCAPE + 1];
+	for (auto &kv : sc.enc) { scode[kv.first] = kv.second.first; slen[kv.first] = kv.second.second; }
+	for (auto &kv : cc.enc) { ccode[kv.first] = kv.second.first; clen[kv.first] = kv.second.second; }
+	out.reserve(out.size() + nr / 2 + 4096);
 	w.elias(nr);
 	w.put(esc ? 1 : 0, 1);
 	sc.serialise(w); cc.serialise(w);
 	w.align();
-	for (uint64_t i = 0; i < nr; ++i) sc.put(w, runs[i].sym);
+	for (uint64_t i = 0; i < nr; ++i) { uint8_t s = (uint8_t)runs[i].sym; w.put(scode[s], slen[s]); }
 	w.align();
 	for (uint64_t i = 0; i < nr; ++i) {
-		if (runs[i].len >= RL_ESCAPE) { cc.put(w, (int64_t)RL_ESCAPE); w.elias(runs[i].len); } else cc.put(w, (int64_t)runs[i].len);
+		if (runs[i].len >= RL_ESCAPE) { w.put(ccode[RL_ESCAPE], clen[RL_ESCAPE]); w.elias(runs[i].len); } else w.put(ccode[runs[i].len], clen[runs[i].len]);
 	}
 	w.align();
 }
@@ -160,30 +177,40 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 	fwrite(head.data(), 1, head.size(), f);
 	uint64_t filepos = 8;
 	std::vector<RLIndexEntry> index;
-	// stream: collect runs for a batch of `numthreads` blocks, encode them in parallel, append
-	const uint64_t batch_runs = runs_per_block * numthreads;
-	std::vector<RLRun> runs; runs.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1);
+	// stream: the calling thread collects the runs of batch k+1 while the workers encode batch k
+	const uint64_t batch_runs = runs_per_block * numthreads * 8;
+	std::vector<RLRun> runsA, runsB;
+	runsA.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1); runsB.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1);
 	uint64_t i = 0;
-	while (i < n) {
+	auto collect = [&](std::vector<RLRun> &runs) {
 		runs.clear();
 		while (i < n && runs.size() < batch_runs) {
-			uint8_t s = symbols[i]; uint64_t j = i + 1;
+			const uint8_t s = symbols[i]; uint64_t j = i + 1;
 			while (j < n && symbols[j] == s) ++j;
 			runs.push_back({(int64_t)s, j - i});
 			i = j;
 		}
+	};
+	std::vector<RLRun> *cur = &runsA, *nxt = &runsB;
+	collect(*cur);
+	while (!cur->empty()) {
+		const std::vector<RLRun> &runs = *cur;
 		uint64_t nb = (runs.size() + runs_per_block - 1) / runs_per_block;
 		std::vector<std::vector<uint8_t>> bufs(nb);
-		std::vector<std::thread> th;
-		auto work = [&](uint64_t b0, uint64_t b1) {
-			for (uint64_t b = b0; b < b1; ++b) {
+		std::atomic<uint64_t> next_block(0);
+		auto work = [&]() {
+			for (;;) {
+				uint64_t b = next_block.fetch_add(1);
+				if (b >= nb) return;
 				uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block);
 				encode_block(runs.data() + r0, r1 - r0, bufs[b]);
 			}
 		};
+		std::vector<std::thread> th;
 		unsigned T = (unsigned)std::min<uint64_t>(numthreads, nb);
-		for (unsigned t = 1; t < T; ++t) th.emplace_back(work, nb * t / T, nb * (t + 1) / T);
-		work(0, nb / T);
+		for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+		collect(*nxt);                                   // overlaps with the encoders
+		work();
 		for (auto &x : th) x.join();
 		for (uint64_t b = 0; b < nb; ++b) {
 			uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block), syms = 0;
@@ -192,6 +219,7 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 			fwrite(bufs[b].data(), 1, bufs[b].size(), f);
 			filepos += bufs[b].size();
 		}
+		std::swap(cur, nxt);
 	}
 	std::vector<uint8_t> tail;
 	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
