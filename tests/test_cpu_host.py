@@ -188,3 +188,19 @@ def test_bwtb3mtobwa_conversion(L, oracle, tmp_path):
     assert L.b3m_rl_write(fb.encode(), bad.ctypes.data, 10, 4096) == 0
     r = _run([os.path.join(ROOT, "bin", "bwtb3mtobwa"), fb, ob, os_])
     assert r.returncode == 1 and b"not the BWT of a pacterm text" in r.stderr
+
+
+def test_bench_roofline_helper():
+    # the `roofline` object of the bench line: dominant family, achieved = algorithmic bytes / device time
+    from bwtb3m_amd import benchutil
+    fam = {}
+    kt = [{"name": "msd_scatter", "ms": 16.0, "launches": 1, "alg_bytes": 48_000_000_016},
+          {"name": "bucket_finish", "ms": 12.0, "launches": 1, "alg_bytes": 27_000_000_009},
+          {"name": "scan", "ms": 0.3, "launches": 6, "alg_bytes": 1000}]
+    benchutil.add_kernel_times(fam, kt); benchutil.add_kernel_times(fam, kt)
+    r = benchutil.dominant_roofline(fam, 2, 0.104, 3_000_000_000, 0, 0, "/nonexistent")
+    assert r["family"] == "msd_scatter" and r["kernel"] == "b3m::k_msd_pass<false>" and r["bound"] == "hbm"
+    assert abs(r["achieved"] - 3000.0) < 1.0 and abs(r["frac"] - 0.375) < 1e-3 and r["traffic"] is None
+    assert r["launches_per_step"] == 1 and r["alg_bytes_per_launch"] == 48_000_000_016
+    assert abs(r["job_frac"] - 28.5e9 / 0.052 / 1e9 / 8000.0) < 1e-4
+    assert set(r["families_ms_per_step"]) == {"msd_scatter", "bucket_finish", "scan"}
