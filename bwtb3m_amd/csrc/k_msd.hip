@@ -53,6 +53,7 @@ constexpr int F_THREADS = 512;
 constexpr int F_WAVES = F_THREADS / 64;
 constexpr int F_CAP = 6144;                            // records of a final bucket sorted in LDS
 constexpr int F_PER = F_CAP / F_THREADS;               // 12 records per thread
+constexpr uint32_t F_HUGE = 1u << 20;                      // buckets above this go to the list-based rounds directly
 constexpr int F_AVG = 5760;                            // target average bucket size
 constexpr int F_BINBITS = 13;
 constexpr int F_BINS = 1 << F_BINBITS;                 // counting-sort bins of the finish (16-bit counters)
@@ -98,7 +99,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -112,6 +113,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.lvl_start = (uint32_t *)p; p += al(4 * MSD_TAB_MAX);
 	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 4));
 	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
+	ws.hugelist = (uint32_t *)p; ws.huge_cap = cap / F_HUGE + 16; p += al(4 * (ws.huge_cap + 2));
 	ws.scan_ws = (uint32_t *)p;
 }
 
@@ -538,7 +540,7 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 // repeated inside the bucket) goes to the overflow list.
 template <bool WRITE_SA>
 __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits,
-                                                               uint32_t *biglist, uint32_t big_cap, SortOut O)
+                                                               uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t ent[F_CAP + 4];         // (low key bits << 13) | index, in bin order
 	__shared__ __attribute__((aligned(16))) uint32_t cw[F_BINS / 2 + 4];     // 16-bit counters, then exclusive starts, two per word
@@ -551,7 +553,12 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP) {
-		if (tid == 0) { uint32_t k = atomicAdd(&biglist[0], 1u); if (k < big_cap) biglist[1 + k] = b; }
+		if (tid == 0) {
+			if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
+				uint32_t k = atomicAdd(&hugelist[0], 1u); if (k < huge_cap) hugelist[1 + k] = b;
+				ovf_push(O, s0, m);
+			} else { uint32_t k = atomicAdd(&biglist[0], 1u); if (k < big_cap) biglist[1 + k] = b; }
+		}
 		return;
 	}
 	uint64_t r[F_PER];
@@ -686,6 +693,17 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	if (WRITE_SA) {
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = osa[e]; }
+	}
+}
+
+// HUGE BUCKETS (low-complexity input): every workgroup copies its share of the positions into the suffix array;
+// the bucket is already on the overflow list
+__global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *hugelist, uint32_t huge_cap, uint32_t *sa)
+{
+	uint32_t nh = hugelist[0]; if (nh > huge_cap) nh = huge_cap;
+	for (uint32_t h = 0; h < nh; ++h) {
+		const uint32_t b = hugelist[1 + h], s0 = bstart[b], m = bstart[b + 1] - s0;
+		for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) sa[s0 + e] = (uint32_t)rec[s0 + e];
 	}
 }
 
@@ -971,13 +989,15 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(M.biglist, 0, 4, s));
+		B3M_HIP(hipMemsetAsync(M.hugelist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		if (need_sa)
-			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O);
+			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
 		else
-			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, O);
+			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// The grid covers every bucket that could be that large; blocks beyond the list leave at once.
+		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
 		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
 		if (need_sa)
 			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);

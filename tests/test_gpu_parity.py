@@ -558,3 +558,17 @@ def test_suffix_range_shards_of_a_large_text_1gbase(gpu):
             assert r["p0"] == r1["p0"]
         plan.close(); del sl
     assert off == n
+
+
+def test_low_complexity_bucket_above_a_million_records(gpu, oracle):
+    # a final bucket of > 2^20 records (here 2.4 M suffixes starting AAAAAAAAAA) is not sorted by one
+    # workgroup: it goes to the overflow list whole and is finished by the (doubling) rounds
+    nb = 3_000_000
+    b = oracle.synth_bases(nb, 91).copy()
+    b[100_000:2_500_000] = 0
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    out, res, plan = _plan_bwt(gpu, buf, "pacterm")
+    assert np.array_equal(out, oracle.bwt(s))
+    assert res["tie_elements"] > (1 << 20) and res["tie_rounds"] <= 4 + 24
+    plan.close()
