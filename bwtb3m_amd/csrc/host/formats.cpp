@@ -62,11 +62,15 @@ struct BitWriter {
 	void elias(uint64_t x) { uint64_t y = x + 1; int N = 63 - __builtin_clzll(y); int L = 31 - __builtin_clz((unsigned)(N + 1)); put(0, L); put((uint64_t)(N + 1), L + 1); put(y & ((N ? (1ull << N) : 1ull) - 1), N); }
 };
 struct BitReader {
-	const uint8_t *p, *e; int left = 0; uint8_t cur = 0;
+	const uint8_t *p, *e; uint64_t buf = 0; int nb = 0;             // nb valid bits in the low end of buf
 	BitReader(const uint8_t *b, const uint8_t *end) : p(b), e(end) {}
-	int bit() { if (!left) { if (p >= e) throw std::runtime_error("RL decoder: unexpected end of data"); cur = *p++; left = 8; } return (cur >> --left) & 1; }
-	uint64_t get(int bits) { uint64_t v = 0; for (int i = 0; i < bits; ++i) v = (v << 1) | (uint64_t)bit(); return v; }
-	void align() { left = 0; }
+	void fill(int need) { while (nb < need && p < e) { buf = (buf << 8) | *p++; nb += 8; } }
+	// the next `bits` (<= 32) bits without consuming them; zero-padded past the end of the data
+	uint32_t peek(int bits) { fill(bits); return nb >= bits ? (uint32_t)((buf >> (nb - bits)) & ((1ull << bits) - 1)) : (uint32_t)((buf << (bits - nb)) & ((1ull << bits) - 1)); }
+	void skip(int bits) { fill(bits); if (nb < bits) throw std::runtime_error("RL decoder: unexpected end of data"); nb -= bits; }
+	int bit() { fill(1); if (!nb) throw std::runtime_error("RL decoder: unexpected end of data"); return (int)((buf >> --nb) & 1); }
+	uint64_t get(int bits) { uint64_t v = 0; while (bits > 0) { int t = std::min(bits, 32); v = (v << t) | peek(t); skip(t); bits -= t; } return v; }
+	void align() { nb -= nb & 7; }
 	uint64_t elias() { int L = 0; while (!bit()) ++L; uint64_t N1 = (1ull << L) | get(L); int N = (int)N1 - 1; uint64_t y = (1ull << N) | get(N); return y - 1; }
 };
 
@@ -76,6 +80,8 @@ struct Canon {
 	std::map<int64_t, std::pair<uint64_t, int>> enc;  // symbol -> (code, length)
 	// decoding tables per length
 	std::vector<uint64_t> first_code; std::vector<int> first_idx, count;
+	static const int FAST = 11;                        // codes up to this length decode with one table lookup
+	std::vector<uint32_t> fast;                        // index by the next FAST bits: (symbol index << 8) | length, 0 = longer code
 	void finish()
 	{
 		std::sort(syms.begin(), syms.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) { return a.second != b.second ? a.second < b.second : a.first < b.first; });
@@ -89,6 +95,12 @@ struct Canon {
 			count[l]++;
 			enc[syms[i].first] = {code, l};
 			code++;
+		}
+		fast.assign((size_t)1 << FAST, 0);
+		for (size_t i = 0; i < syms.size(); ++i) {
+			int l = syms[i].second; if (l > FAST) continue;
+			uint64_t c0 = enc[syms[i].first].first << (FAST - l);
+			for (uint64_t k = 0; k < (1ull << (FAST - l)); ++k) fast[(size_t)(c0 + k)] = ((uint32_t)i << 8) | (uint32_t)l;
 		}
 	}
 	static Canon from_freq(const std::map<int64_t, uint64_t> &freq)
@@ -126,6 +138,8 @@ struct Canon {
 	void put(BitWriter &w, int64_t sym) const { auto it = enc.find(sym); w.put(it->second.first, it->second.second); }
 	int64_t get(BitReader &r) const
 	{
+		uint32_t f = fast[r.peek(FAST)];
+		if (f) { r.skip((int)(f & 255u)); return syms[f >> 8].first; }
 		uint64_t code = 0;
 		for (int l = 1; l < (int)count.size(); ++l) {
 			code = (code << 1) | (uint64_t)r.bit();
@@ -229,9 +243,8 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 	if (fclose(f)) throw std::runtime_error("error closing " + fn);
 }
 
-std::vector<RLIndexEntry> rl_index(const std::string &fn)
+static std::vector<RLIndexEntry> rl_index_of(const std::vector<uint8_t> &d, const std::string &fn)
 {
-	std::vector<uint8_t> d = read_file(fn);
 	if (d.size() < 24) throw std::runtime_error(fn + " is not an RL .bwt file (too short)");
 	uint64_t ipos = get_be64(d.data() + d.size() - 8);
 	if (ipos + 16 > d.size()) throw std::runtime_error(fn + ": bad index offset");
@@ -241,6 +254,7 @@ std::vector<RLIndexEntry> rl_index(const std::string &fn)
 	for (uint64_t b = 0; b < nb; ++b) { const uint8_t *p = d.data() + ipos + 24 * b; v[b] = {get_be64(p), get_be64(p + 8), get_be64(p + 16)}; }
 	return v;
 }
+std::vector<RLIndexEntry> rl_index(const std::string &fn) { return rl_index_of(read_file(fn), fn); }
 
 uint64_t rl_length(const std::string &fn)
 {
@@ -284,6 +298,56 @@ uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uin
 	return n;
 }
 
+// decode straight into an array, the blocks in parallel (block positions and symbol counts come from the index)
+uint64_t rl_decode_array(const std::string &fn, uint8_t *out, uint64_t cap, unsigned numthreads, bool *bad_symbol)
+{
+	std::vector<uint8_t> d = read_file(fn);
+	if (d.size() < 24) throw std::runtime_error(fn + " is not an RL .bwt file (too short)");
+	const uint64_t n = get_be64(d.data());
+	std::vector<RLIndexEntry> idx = rl_index_of(d, fn);
+	std::vector<uint64_t> off(idx.size() + 1, 0);
+	for (size_t b = 0; b < idx.size(); ++b) off[b + 1] = off[b] + idx[b].syms;
+	if (off.back() != n) throw std::runtime_error(fn + ": symbol count mismatch");
+	const uint64_t ipos = get_be64(d.data() + d.size() - 8);
+	std::atomic<uint64_t> next(0); std::atomic<int> bad(0), fail(0);
+	auto work = [&]() {
+		try {
+			std::vector<int64_t> syms;
+			for (;;) {
+				uint64_t b = next.fetch_add(1);
+				if (b >= idx.size()) return;
+				if (idx[b].pos < 8 || idx[b].pos >= ipos) throw std::runtime_error("bad block position");
+				BitReader r(d.data() + idx[b].pos, d.data() + ipos);
+				uint64_t nr = r.elias(); bool esc = r.bit();
+				if (nr != idx[b].runs) throw std::runtime_error("run count mismatch");
+				Canon sc = Canon::deserialise(r), cc = Canon::deserialise(r);
+				r.align();
+				syms.resize(nr);
+				for (uint64_t i = 0; i < nr; ++i) syms[i] = sc.get(r);
+				r.align();
+				uint64_t pos = off[b];
+				for (uint64_t i = 0; i < nr; ++i) {
+					int64_t c = cc.get(r);
+					uint64_t len = (esc && c == (int64_t)RL_ESCAPE) ? r.elias() : (uint64_t)c;
+					if (syms[i] < 0 || syms[i] > 255) bad = 1;
+					if (pos + len > off[b + 1]) throw std::runtime_error("block overruns its symbol count");
+					if (out && pos < cap) memset(out + pos, (int)syms[i], (size_t)std::min<uint64_t>(len, cap - pos));
+					pos += len;
+				}
+				if (pos != off[b + 1]) throw std::runtime_error("block symbol count mismatch");
+			}
+		} catch (const std::exception &) { fail = 1; }
+	};
+	std::vector<std::thread> th;
+	unsigned T = std::max(1u, std::min<unsigned>(numthreads, (unsigned)idx.size()));
+	for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+	work();
+	for (auto &x : th) x.join();
+	if (fail) throw std::runtime_error(fn + ": corrupt RL block");
+	if (bad_symbol) *bad_symbol = bad != 0;
+	return n;
+}
+
 // ---- siblings -----------------------------------------------------------------------------------------
 void write_hist(const std::string &fn, const uint64_t hist256[256])
 {
@@ -324,21 +388,13 @@ int b3m_rl_write(const char *fn, const uint8_t *symbols, uint64_t n, uint64_t ru
 	try { b3m::rl_encode_file(fn, symbols, n, runs_per_block, std::max(1u, std::thread::hardware_concurrency())); return 0; }
 	catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
 }
-struct ReadCtx { uint8_t *out; uint64_t cap, pos; bool bad; };
-static void read_sink(void *c, int64_t sym, uint64_t len)
-{
-	ReadCtx *x = (ReadCtx *)c;
-	if (sym < 0 || sym > 255) x->bad = true;
-	if (x->out) { uint64_t k = x->pos < x->cap ? std::min<uint64_t>(len, x->cap - x->pos) : 0; memset(x->out + x->pos, (int)sym, (size_t)k); }
-	x->pos += len;
-}
 int b3m_rl_read(const char *fn, uint8_t *symbols_out, uint64_t cap, uint64_t *n_out)
 {
 	try {
-		ReadCtx c{symbols_out, cap, 0, false};
-		uint64_t n = b3m::rl_decode_file(fn, read_sink, &c);
+		bool bad = false;
+		uint64_t n = b3m::rl_decode_array(fn, symbols_out, cap, std::max(1u, std::thread::hardware_concurrency()), &bad);
 		if (n_out) *n_out = n;
-		if (c.bad) { b3m::set_error("symbol outside 0..255"); return 1; }
+		if (bad) { b3m::set_error("symbol outside 0..255"); return 1; }
 		return 0;
 	} catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
 }

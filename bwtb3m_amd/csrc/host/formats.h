@@ -26,6 +26,8 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 // decodeRun() stream: calls sink(sym,len) per run; returns n
 uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx);
 uint64_t rl_length(const std::string &fn);
+// decode into out[0..cap) with the blocks in parallel; returns n
+uint64_t rl_decode_array(const std::string &fn, uint8_t *out, uint64_t cap, unsigned numthreads, bool *bad_symbol);
 struct RLIndexEntry { uint64_t pos, runs, syms; };
 std::vector<RLIndexEntry> rl_index(const std::string &fn);
 
