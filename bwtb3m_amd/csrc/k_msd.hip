@@ -14,16 +14,16 @@
 //   level 1 (k_msd_pass)      : records of every level-0 bucket partitioned by the next D1 <= 8
 //                               bits (chunks of 4096 records through LDS; wider fan-outs break
 //                               the 128-byte runs and halve the write bandwidth).
-//   finish  (k_finish_lds)    : one workgroup per final bucket: read ONCE into LDS, split by 5
-//                               more bits, each wave sorts sub-buckets (bin-scatter on the free key
-//                               bits + rank-in-bin), emits BWT byte (+ SA entry), marks key ties.
+//   finish  (k_finish_lds)    : one workgroup per final bucket: read ONCE into registers, counting
+//                               sort on 13 more key bits in LDS, rank inside the bin, BWT byte
+//                               (+ SA entry) dropped at the final place, key ties marked.
 //   ties    (k_tie_fix)       : runs of equal 29+D0 known bits ordered from the text.
 //
 // HBM traffic per suffix: 0.5 (text, twice) + 8 | 8 + 16 | 8 + 1 (+4) = ~41 B.
 // Buckets above the LDS capacity (skewed input) take k_bucket_finish: one more 8-bit partition
-// through HBM, then the same wave sort.  Sub-buckets above 512 records, and bins / tie groups
-// above 32 (repetitive input), are finished by the list-based key-extension rounds of
-// k_blocksort.hip, started at depth 0 inside their bucket.
+// through HBM, then one wave per sub-bucket.  Bins / tie groups above 32 records (repeats), sub-
+// buckets above 512 and buckets above 2^20 records go to the overflow list and are finished by the
+// list-based rounds of k_blocksort.hip (key extension, then prefix doubling), from depth 0.
 // pacterm: the terminator and everything behind it read as base 0 for bucketing; the exact tie
 // resolution (key_at with terminator tags) restores "terminator < A" where it matters.
 #include "b3m_internal.h"
@@ -806,8 +806,8 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // one thread per word of the tie bitmap: every run of set bits starting in the word is a tie group
 // (head = the position before the run).  The group's rotations agree on their first eq_syms
 // symbols; they are ordered by the next 31 bases (one gather each), by full comparison if that
-// does not decide.  Groups longer than LS_TIE_CAP are skipped: such a group fills one bin of
-// k_lds_sort beyond LS_TIE_CAP, so its whole bucket was flagged for the overflow path.
+// does not decide.  Groups are at most LS_TIE_CAP long (longer ones are on the overflow list and
+// set no bits); the length guard only keeps a corrupt bitmap from running away.
 __global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint32_t eq_syms, uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
 {
 	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -823,7 +823,7 @@ __global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uin
 		uint64_t pos = q - 1;
 		uint32_t g = 2;
 		for (uint64_t z = q + 1; z < len && g <= (uint32_t)LS_TIE_CAP && ((tiebits[z >> 5] >> (z & 31)) & 1u); ++z) ++g;
-		if (g > (uint32_t)LS_TIE_CAP) continue;   // lies in one bin of > LS_TIE_CAP records: that bucket went to the overflow path
+		if (g > (uint32_t)LS_TIE_CAP) continue;   // cannot happen (see above)
 		for (uint32_t a = 1; a < g; ++a) {
 			uint32_t x = sa[pos + a]; uint8_t bx = bwt[pos + a];
 			bool ex = (uint64_t)x + eq_syms + 32 <= T.nbases;
@@ -1014,9 +1014,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	out.msd_overflow_buckets = nov;
 	bool rerun_with_sa = false;
 	if (nov) {
-		// ---- fallback: oversized / deeply tied sub-buckets go through the key-extension rounds ----
+		// ---- fallback: the overflow list (hot bins, oversized sub-buckets, huge buckets) goes through the list-based rounds ----
 		Scope sc(tl, KF_TIES, 0);
-		B3M_REQUIRE(nov <= ovf_cap, "too many overflow sub-buckets for the workspace");
+		B3M_REQUIRE(nov <= ovf_cap, "too many overflow ranges for the workspace");
 		// order the (start, size) pairs by start and turn the sizes into list offsets, all on the device
 		// (a repeat-rich genome lists millions of bins); the record buffers are free by now
 		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
