@@ -572,3 +572,25 @@ def test_low_complexity_bucket_above_a_million_records(gpu, oracle):
     assert np.array_equal(out, oracle.bwt(s))
     assert res["tie_elements"] > (1 << 20) and res["tie_rounds"] <= 4 + 24
     plan.close()
+
+
+@pytest.mark.parametrize("nb", [24_000_000, 50_000_000, 100_000_000, 200_000_000])
+def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
+    # sizes whose level-1 digit is 1..5 bits wide (the oracle is too slow here): the on-device LF walk
+    # re-derives the text from the BWT (checkbwt, /root/reference/src/checkbwt.cpp:176-243)
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+    plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
+    out = plan.run(d_text)
+    torch.cuda.synchronize()
+    r = plan.result()
+    assert int(out[r["p0"]]) == 0
+    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    assert (m0, m1) == (0, 0)
+    # and a corrupted BWT is caught
+    bad = out.clone(); i = n // 3; bad[i] = (int(bad[i]) % 4) + 1 if int(bad[i]) != 0 else 1
+    if int(bad[i]) != int(out[i]):
+        m0, m1, _ = plan.lf_walk(bad, sarate=0)
+        assert m0 + m1 > 0
+    plan.close()
