@@ -42,10 +42,8 @@ constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
 // level 0
 constexpr int W0_THREADS = 1024;
-constexpr int W0_CHUNK = 32768;                        // positions counting-sorted in LDS at a time
-constexpr int W0_WORDS = W0_CHUNK / 16;                // 32-bit words of packed text per chunk
-constexpr int W0_TILE_CHUNKS = 8;
-constexpr int W0_TILE = W0_TILE_CHUNKS * W0_CHUNK;     // positions per workgroup (one row of the histogram matrix)
+constexpr int W0A_CHUNK = 65280, W0A_TCH = 4, W0A_BINS = 2048;    // <= 11 bits: 65,280 positions at a time (16-bit indices), 4 chunks per tile
+constexpr int W0B_CHUNK = 32768, W0B_TCH = 8, W0B_BINS = 4096;    // 12 bits
 constexpr int W0_MAXBITS = 12;
 constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
 // finish
@@ -167,14 +165,19 @@ __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t 
 	return true;
 }
 
-template <bool COUNT_ONLY>
+// CHUNK positions are counting-sorted at a time, TILE = TCH chunks share one row of the histogram matrix.
+// Two geometries: 65,280-position chunks for up to 2048 bins (32-record runs on average at 11 bits; the
+// index array alone is 128 KB of LDS, everything else is squeezed into the rest) and 32,768-position
+// chunks for 4096 bins.
+template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS>
 __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 {
-	__shared__ uint32_t cnt[W0_MAXBINS];
-	__shared__ uint32_t cur[COUNT_ONLY ? 1 : W0_MAXBINS];        // scatter cursor: exclusive start, then end of every digit run
-	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : W0_MAXBINS];
-	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : W0_CHUNK];         // chunk-local positions in digit order
-	__shared__ uint32_t stext[W0_WORDS + 4];                     // [0] = the word before the chunk
+	constexpr int WORDS = CHUNK / 16;
+	static_assert(CHUNK % 16 == 0 && CHUNK <= 65536, "chunk-local positions are 16-bit");
+	__shared__ uint32_t cur[MAXBINS];                            // count, then exclusive start, then end of every digit run
+	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MAXBINS];
+	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : CHUNK];            // chunk-local positions in digit order
+	__shared__ uint32_t stext[WORDS + 4];                        // [0] = the word before the chunk
 	__shared__ uint32_t wsum[W0_THREADS / 64];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
@@ -182,52 +185,53 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
-	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cnt[b] = 0; }
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
 	else { for (int b = tid; b < bins; b += W0_THREADS) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
 	__syncthreads();
-	for (int c = 0; c < W0_TILE_CHUNKS; ++c) {
-		const uint64_t cpos = A.P0 + (uint64_t)tile * W0_TILE + (uint64_t)c * W0_CHUNK;
+	for (int c = 0; c < TCH; ++c) {
+		const uint64_t cpos = A.P0 + (uint64_t)tile * (TCH * CHUNK) + (uint64_t)c * CHUNK;
 		if (cpos >= end) break;
-		if (cpos + W0_CHUNK <= A.start) continue;
+		if (cpos + CHUNK <= A.start) continue;
 		// the whole chunk inside the block, every window inside the text, a word in front of it
-		const bool fast = cpos >= A.start && cpos >= 16 && cpos + W0_CHUNK <= end && cpos + W0_CHUNK + 48 <= A.T.nbases;
+		const bool fast = cpos >= A.start && cpos >= 16 && cpos + CHUNK <= end && cpos + CHUNK + 48 <= A.T.nbases;
 		if (fast) {
 			const uint8_t *p = A.T.b + (((cpos >> 4) - 1) << 2);
-			for (int j = tid; j < W0_WORDS + 4; j += W0_THREADS) stext[j] = be32(p + 4 * j);
+			for (int j = tid; j < WORDS + 4; j += W0_THREADS) stext[j] = be32(p + 4 * j);
 		}
-		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cnt[b] = 0; }
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
 		__syncthreads();
 		// ---- count ----
 		if (fast) {
 			#pragma unroll
-			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
+			for (int j = 0; j < (WORDS + W0_THREADS - 1) / W0_THREADS; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
+				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
 				// the digit needs <= 12 bits of the window: 32-bit funnel shifts of two words do
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
 					uint32_t dgt = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
-					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cnt[dgt], 1u);
+					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cur[dgt], 1u);
 				}
 			}
 		} else {
 			#pragma nounroll
-			for (uint32_t li = tid; li < (uint32_t)W0_CHUNK; li += W0_THREADS) {
+			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					uint32_t dgt = (uint32_t)(x >> dsh);
-					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cnt[dgt], 1u);
+					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cur[dgt], 1u);
 				}
 			}
 		}
 		if (COUNT_ONLY) { __syncthreads(); continue; }
 		__syncthreads();
-		// ---- exclusive scan of cnt -> cur ----
+		// ---- exclusive scan of the counts, in place ----
 		{
-			constexpr int per = W0_MAXBINS / W0_THREADS;        // consecutive bins per thread
+			constexpr int per = MAXBINS / W0_THREADS;           // consecutive bins per thread
 			uint32_t loc[per]; uint32_t sum = 0;
 			#pragma unroll
-			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cnt[b] : 0; sum += loc[k]; }
+			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cur[b] : 0; sum += loc[k]; }
 			uint32_t inc = wave_incl_sum(sum);
 			uint32_t w = tid >> 6, l = tid & 63;
 			if (l == 63) wsum[w] = inc;
@@ -242,8 +246,9 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		// ---- place the chunk-local positions in digit order (order inside a digit is irrelevant) ----
 		if (fast) {
 			#pragma unroll
-			for (int j = 0; j < W0_WORDS / W0_THREADS; ++j) {
+			for (int j = 0; j < (WORDS + W0_THREADS - 1) / W0_THREADS; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
+				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			}
 		} else {
 			#pragma nounroll
-			for (uint32_t li = tid; li < (uint32_t)W0_CHUNK; li += W0_THREADS) {
+			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					uint32_t dgt = (uint32_t)(x >> dsh);
@@ -285,12 +290,12 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			A.rec_out[(uint64_t)gbase[dgt] + (q - rs)] = r;
 		}
 		__syncthreads();
-		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cnt[b];
+		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cur[b] - (b ? cur[b - 1] : 0u);
 		__syncthreads();
 	}
 	if (COUNT_ONLY) {
 		__syncthreads();
-		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tile + (uint64_t)b * ntiles] = cnt[b];
+		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tile + (uint64_t)b * ntiles] = cur[b];
 	}
 }
 
@@ -879,7 +884,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// ---- level 0: text -> records (keyA), partitioned by the first D0 bits ----
 	const uint64_t P0 = start & ~15ull;
 	const uint64_t span = start + len_in - P0;
-	const uint32_t ntA = (uint32_t)((span + W0_TILE - 1) / W0_TILE);
+	const bool geoA = dg.D0 <= 11;
+	const uint64_t tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
+	const uint32_t ntA = (uint32_t)((span + tile0 - 1) / tile0);
 	const uint32_t bins0 = 1u << dg.D0;
 	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
 	L0Args A{};
@@ -887,7 +894,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	A.keep_lo = 0; A.keep_hi = bins0;
 	{
 		Scope sc(tl, KF_MSD_HIST, span / 4);
-		hipLaunchKernelGGL((k_l0_pass<true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
 	out.slice_offset = 0;
 	if (nshards > 1) {
@@ -923,7 +931,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	{
 		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
-		hipLaunchKernelGGL((k_l0_pass<false>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		if (geoA) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		else hipLaunchKernelGGL((k_l0_pass<false, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
 	{
 		uint32_t tab0[3] = {0, 0, ntA};               // the one bucket entering level 0: {start, hist_off, ntiles}
