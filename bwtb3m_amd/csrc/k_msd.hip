@@ -37,7 +37,8 @@ constexpr int MSD_THREADS = 256;
 constexpr int MSD_ITEMS = 16;
 constexpr int MSD_CHUNK = MSD_THREADS * MSD_ITEMS;     // 4096 records staged through LDS at a time
 constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per workgroup
-constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass: full 128-byte runs per chunk
+constexpr int MSD_L1_THREADS = 1024;                   // level-1 scatter: 16 records per thread
+constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass (9 bits measured: level 1 +2.3 ms, level 0 at 10 bits -1.6 ms)
 constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
 // level 0
@@ -311,30 +312,31 @@ struct MsdArgs {
 	int shift;                   // digit = (rec >> shift) & (2^D - 1)
 };
 
-template <bool COUNT_ONLY>
-__global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
+template <bool COUNT_ONLY, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_msd_pass(MsdArgs A)
 {
+	constexpr int CHUNK = THREADS * MSD_ITEMS;               // records staged through LDS at a time
 	__shared__ uint32_t cnt[MSD_MAXBINS];
 	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
 	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
-	__shared__ uint64_t srec[COUNT_ONLY ? 1 : MSD_CHUNK];
-	__shared__ uint32_t wsum[8];
+	__shared__ uint64_t srec[COUNT_ONLY ? 1 : CHUNK];
+	__shared__ uint32_t wsum[THREADS / 64];
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
 	const MsdTile tile = A.tiles[blockIdx.x];
-	if (COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; }
-	else { for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; }
+	else { for (int b = tid; b < bins; b += THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
 	__syncthreads();
-	const uint32_t nchunks = (tile.count + MSD_CHUNK - 1) / MSD_CHUNK;
+	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;
 	for (uint32_t c = 0; c < nchunks; ++c) {
-		const uint32_t cbase = c * MSD_CHUNK;
-		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += MSD_THREADS) cnt[b] = 0; __syncthreads(); }
+		const uint32_t cbase = c * CHUNK;
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; __syncthreads(); }
 		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS]; uint32_t vmask = 0;
 		// all 16 loads go out back to back (clamped index, no branch around a load: a load
 		// inside its own if-block gets its own s_waitcnt and the chunk takes 16 round trips)
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) {
-			uint32_t e = cbase + s * MSD_THREADS + tid;
+			uint32_t e = cbase + s * THREADS + tid;
 			uint32_t ec = e < tile.count ? e : tile.count - 1;
 			rec[s] = A.rec_in[(uint64_t)tile.in_off + ec];
 			if (e < tile.count) vmask |= 1u << s;
@@ -345,21 +347,17 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
 		if (COUNT_ONLY) continue;
 		__syncthreads();
-		// exclusive scan of cnt over the bins -> start of every digit run inside the chunk
+		// exclusive scan of cnt over the bins -> start of every digit run inside the chunk (thread = one bin)
 		{
-			const int per = MSD_MAXBINS / MSD_THREADS;        // consecutive bins per thread
-			uint32_t loc[per]; uint32_t sum = 0;
-			#pragma unroll
-			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cnt[b] : 0; sum += loc[k]; }
-			uint32_t inc = wave_incl_sum(sum);
+			static_assert(COUNT_ONLY || THREADS >= MSD_MAXBINS, "one bin per thread");
+			const uint32_t v = (int)tid < bins ? cnt[tid] : 0u;
+			uint32_t inc = wave_incl_sum(v);
 			uint32_t w = tid >> 6, l = tid & 63;
 			if (l == 63) wsum[w] = inc;
 			__syncthreads();
 			uint32_t pre = 0;
 			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
-			uint32_t run = pre + inc - sum;
-			#pragma unroll
-			for (int k = 0; k < per; ++k) { int b = tid * per + k; if (b < bins) binstart[b] = run; run += loc[k]; }
+			if ((int)tid < bins) binstart[tid] = pre + inc - v;
 		}
 		__syncthreads();
 		#pragma unroll
@@ -367,18 +365,18 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pass(MsdArgs A)
 		__syncthreads();
 		// copy out run by run
 		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
-		for (uint32_t p = tid; p < nvalid; p += MSD_THREADS) {
+		for (uint32_t p = tid; p < nvalid; p += THREADS) {
 			uint64_t q = srec[p];
 			const uint32_t d = (uint32_t)(q >> A.shift) & (uint32_t)(bins - 1);
 			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = q;
 		}
 		__syncthreads();
-		for (int b = tid; b < bins; b += MSD_THREADS) gbase[b] += cnt[b];
+		for (int b = tid; b < bins; b += THREADS) gbase[b] += cnt[b];
 		__syncthreads();
 	}
 	if (COUNT_ONLY) {
 		__syncthreads();
-		for (int b = tid; b < bins; b += MSD_THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
+		for (int b = tid; b < bins; b += THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
 	}
 }
 
@@ -975,7 +973,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		const uint32_t ntB = (uint32_t)tiles.size();
 		{
 			Scope sc(tl, KF_MSD_HIST, 8 * len);
-			hipLaunchKernelGGL((k_msd_pass<true>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+			hipLaunchKernelGGL((k_msd_pass<true, MSD_THREADS>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
 		}
 		{
 			Scope sc(tl, KF_SCAN, 8ull * hoff);
@@ -983,7 +981,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		}
 		{
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-			hipLaunchKernelGGL((k_msd_pass<false>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
+			// 1024 threads = chunks of 16 Ki records (128 KB of LDS, one workgroup per CU): 64-record runs.
+			// Measured at C3: 256 threads (16-record runs) 17.3 ms, 512 threads 14.9 ms, 1024 threads 13.2 ms
+			hipLaunchKernelGGL((k_msd_pass<false, MSD_L1_THREADS>), dim3(ntB), dim3(MSD_L1_THREADS), 0, s, Bq);
 		}
 		nbF = bins0 << dg.D1;
 		B3M_REQUIRE((uint64_t)nbF + 1 <= MSD_TAB_MAX, "MSD level table too small");
