@@ -108,7 +108,6 @@ void inclusive_max_u32(uint32_t *d, uint64_t n, uint32_t *ws, hipStream_t s) { s
 // radix sort
 // ================================================================================================
 constexpr int RX_THREADS = 256;
-constexpr int RX_WAVES = RX_THREADS / 64;
 constexpr int RX_ITEMS = 16;                       // keys per thread
 constexpr int RX_TILE = RX_THREADS * RX_ITEMS;     // 4096 keys per workgroup
 constexpr int RX_BITS = 8;
@@ -150,41 +149,43 @@ __global__ __launch_bounds__(RX_THREADS) void k_global_hist(const KeyT *keys, ui
 	}
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(RX_THREADS) void k_tile_hist(const KeyT *keys, uint64_t n, int shift, uint32_t *tile_hist, uint32_t num_tiles)
+// THREADS x 16 keys per workgroup.  The length of a digit's run leaving the workgroup is what
+// bounds the scatter (k_msd.hip, NOTES_r01.md), so the tile is as large as the LDS allows.
+template <typename KeyT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile_hist(const KeyT *keys, uint64_t n, int shift, uint32_t *tile_hist, uint32_t num_tiles)
 {
 	__shared__ uint32_t h[RX_BINS];
-	h[threadIdx.x] = 0;
+	if (threadIdx.x < RX_BINS) h[threadIdx.x] = 0;
 	__syncthreads();
-	uint64_t base = (uint64_t)blockIdx.x * RX_TILE;
+	uint64_t base = (uint64_t)blockIdx.x * (THREADS * RX_ITEMS);
 	#pragma unroll
 	for (int t = 0; t < RX_ITEMS; ++t) {
-		uint64_t i = base + (uint64_t)t * RX_THREADS + threadIdx.x;
+		uint64_t i = base + (uint64_t)t * THREADS + threadIdx.x;
 		if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (RX_BINS - 1)], 1u);
 	}
 	__syncthreads();
-	tile_hist[(uint64_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+	if (threadIdx.x < RX_BINS) tile_hist[(uint64_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
-template <typename KeyT, bool HAS_VAL>
-__global__ __launch_bounds__(RX_THREADS) void k_scatter(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout,
-                                                          uint64_t n, int shift, const uint32_t *tile_off, uint32_t num_tiles)
+template <typename KeyT, bool HAS_VAL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_scatter(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout,
+                                                       uint64_t n, int shift, const uint32_t *tile_off, uint32_t num_tiles)
 {
+	constexpr int WAVES = THREADS / 64, TILE = THREADS * RX_ITEMS;
 	// per-wave running digit counts, later turned into LDS positions of each (wave,digit) run
-	__shared__ uint32_t whist[RX_WAVES][RX_BINS];
-	__shared__ uint32_t dig_start[RX_BINS];      // start of each digit's run inside the tile (exclusive scan)
-	__shared__ uint32_t gbase[RX_BINS];          // global position of each digit's run minus dig_start
-	__shared__ KeyT skey[RX_TILE];
-	__shared__ uint32_t sval[HAS_VAL ? RX_TILE : 1];
+	__shared__ uint32_t whist[WAVES][RX_BINS];
+	__shared__ uint32_t gbase[RX_BINS];          // global position of each digit's run minus its start inside the tile
+	__shared__ KeyT skey[TILE];
+	__shared__ uint32_t sval[HAS_VAL ? TILE : 1];
 	__shared__ uint32_t scan_lds[8];
 
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	for (int i = tid; i < RX_WAVES * RX_BINS; i += RX_THREADS) ((uint32_t *)whist)[i] = 0;
+	for (int i = tid; i < WAVES * RX_BINS; i += THREADS) ((uint32_t *)whist)[i] = 0;
 	__syncthreads();
 
-	const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
+	const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
 	const uint64_t wbase = tile_base + (uint64_t)wave * (64 * RX_ITEMS);
-	const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RX_TILE ? (n - tile_base) : (uint64_t)RX_TILE);
+	const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)TILE ? (n - tile_base) : (uint64_t)TILE);
 
 	KeyT key[RX_ITEMS];
 	uint32_t val[RX_ITEMS];
@@ -213,14 +214,21 @@ __global__ __launch_bounds__(RX_THREADS) void k_scatter(const KeyT *kin, const u
 		rnk[t] = old + below;
 	}
 	__syncthreads();
-	// digit totals over the 4 waves -> exclusive scan over digits -> LDS run starts
+	// digit totals over the waves -> exclusive scan over the 256 digits (threads 0..255) -> LDS run starts
 	{
-		uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
-		uint32_t tot = c0 + c1 + c2 + c3, all;
-		uint32_t ex = block_excl<OpSum>(tot, &all, scan_lds);
-		dig_start[tid] = ex;
-		gbase[tid] = tile_off[(uint64_t)tid * num_tiles + blockIdx.x] - ex;
-		whist[0][tid] = ex; whist[1][tid] = ex + c0; whist[2][tid] = ex + c0 + c1; whist[3][tid] = ex + c0 + c1 + c2;
+		uint32_t tot = 0;
+		if (tid < RX_BINS) { for (int w = 0; w < WAVES; ++w) tot += whist[w][tid]; }
+		uint32_t inc = wave_incl<OpSum>(tot);
+		if (tid < RX_BINS && lane == 63) scan_lds[wave] = inc;
+		__syncthreads();
+		if (tid < RX_BINS) {
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < wave; ++i) pre += scan_lds[i];
+			uint32_t ex = pre + inc - tot;
+			gbase[tid] = tile_off[(uint64_t)tid * num_tiles + blockIdx.x] - ex;
+			uint32_t run = ex;
+			for (int w = 0; w < WAVES; ++w) { uint32_t c = whist[w][tid]; whist[w][tid] = run; run += c; }
+		}
 	}
 	__syncthreads();
 	#pragma unroll
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_scatter(const KeyT *kin, const u
 	// coalesced-by-run write: consecutive threads write consecutive slots of the reordered tile
 	#pragma unroll
 	for (int t = 0; t < RX_ITEMS; ++t) {
-		uint32_t p = (uint32_t)t * RX_THREADS + tid;
+		uint32_t p = (uint32_t)t * THREADS + tid;
 		if (p < tile_n) {
 			KeyT k = skey[p];
 			uint32_t d = (uint32_t)(k >> shift) & (RX_BINS - 1);
@@ -257,7 +265,9 @@ static void radix_sort_impl(KeyT *kA, uint32_t *vA, KeyT *kB, uint32_t *vB, uint
 	B3M_REQUIRE(n <= ws.cap_elems, "radix workspace too small");
 	B3M_REQUIRE(n < (1ull << 32), "radix sort: n >= 2^32 not supported");
 	int npasses = (nbits + RX_BITS - 1) / RX_BITS;
-	uint32_t tiles = (uint32_t)radix_tiles(n);
+	// 8 Ki keys per workgroup: 32-key runs (4-byte keys at 16 Ki per workgroup measured slower: one workgroup per CU)
+	constexpr int TH = 512;
+	uint32_t tiles = (uint32_t)((n + (uint64_t)TH * RX_ITEMS - 1) / ((uint64_t)TH * RX_ITEMS));
 	// which digits are constant over all keys?  (one read of the keys, one small D2H)
 	uint32_t hg[8 * RX_BINS];
 	{
@@ -277,7 +287,7 @@ static void radix_sort_impl(KeyT *kA, uint32_t *vA, KeyT *kB, uint32_t *vB, uint
 		int shift = p * RX_BITS;
 		{
 			Scope sc(tl, KF_RADIX_HIST, n * sizeof(KeyT));
-			hipLaunchKernelGGL((k_tile_hist<KeyT>), dim3(tiles), dim3(RX_THREADS), 0, s, kin, n, shift, ws.tile_hist, tiles);
+			hipLaunchKernelGGL((k_tile_hist<KeyT, TH>), dim3(tiles), dim3(TH), 0, s, kin, n, shift, ws.tile_hist, tiles);
 		}
 		{
 			Scope sc(tl, KF_SCAN, (uint64_t)RX_BINS * tiles * 8);
@@ -286,8 +296,8 @@ static void radix_sort_impl(KeyT *kA, uint32_t *vA, KeyT *kB, uint32_t *vB, uint
 		{
 			uint64_t rec = sizeof(KeyT) + (vA ? 4 : 0);
 			Scope sc(tl, KF_RADIX_SCATTER, 2 * n * rec);
-			if (vA) hipLaunchKernelGGL((k_scatter<KeyT, true>), dim3(tiles), dim3(RX_THREADS), 0, s, kin, vin, kout, vout, n, shift, ws.tile_hist, tiles);
-			else hipLaunchKernelGGL((k_scatter<KeyT, false>), dim3(tiles), dim3(RX_THREADS), 0, s, kin, (const uint32_t *)nullptr, kout, (uint32_t *)nullptr, n, shift, ws.tile_hist, tiles);
+			if (vA) hipLaunchKernelGGL((k_scatter<KeyT, true, TH>), dim3(tiles), dim3(TH), 0, s, kin, vin, kout, vout, n, shift, ws.tile_hist, tiles);
+			else hipLaunchKernelGGL((k_scatter<KeyT, false, TH>), dim3(tiles), dim3(TH), 0, s, kin, (const uint32_t *)nullptr, kout, (uint32_t *)nullptr, n, shift, ws.tile_hist, tiles);
 		}
 		KeyT *tk = kin; kin = kout; kout = tk;
 		uint32_t *tv = vin; vin = vout; vout = tv;
