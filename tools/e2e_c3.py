@@ -1,0 +1,40 @@
+"""End-to-end run of the CLI at the headline size on the GPU box (not a pytest: minutes of host work).
+python tools/e2e_c3.py [nbases]"""
+import hashlib, os, subprocess, sys, time
+import numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from bwtb3m_amd import engine, synth, _lib
+import ctypes
+nb = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
+tmp = "/tmp/b3m_e2e"; os.makedirs(tmp, exist_ok=True)
+itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+buf = d_text.cpu().numpy()
+pac = os.path.join(tmp, "c3.pac"); buf.tofile(pac)
+print("pac file", os.path.getsize(pac), "bytes, n =", n, flush=True)
+plan = engine.Plan(n, itype)
+ref = plan.run(d_text); torch.cuda.synchronize()
+href = hashlib.sha256(ref.cpu().numpy().tobytes()).hexdigest()
+p0 = plan.result()["p0"]
+plan.close(); del ref, d_text; torch.cuda.empty_cache()
+for bwtonly in (1, 0):
+    out = os.path.join(tmp, "c3_%d.bwt" % bwtonly)
+    t0 = time.time()
+    r = subprocess.run(["/root/repo/bin/bwtb3m", "inputtype=pacterm", "bwtonly=%d" % bwtonly, "numthreads=16", "verbose=1", "outputfilename=" + out, pac],
+                       capture_output=True, text=True)
+    dt = time.time() - t0
+    print("bwtb3m bwtonly=%d: rc %d, %.1f s wall" % (bwtonly, r.returncode, dt), flush=True)
+    print("\n".join(r.stderr.strip().splitlines()[-12:]), flush=True)
+    assert r.returncode == 0
+    print({f: os.path.getsize(os.path.join(tmp, f)) for f in sorted(os.listdir(tmp)) if f.startswith("c3_%d" % bwtonly)}, flush=True)
+    t0 = time.time()
+    L = _lib.lib()
+    sym = np.empty(n, dtype=np.uint8); nout = ctypes.c_uint64(0)
+    rc = L.b3m_rl_read(out.encode(), sym.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), ctypes.byref(nout))
+    assert rc == 0 and nout.value == n
+    h = hashlib.sha256(sym.tobytes()).hexdigest()
+    print("decode %.1f s; decoded BWT == device BWT: %s" % (time.time() - t0, h == href), flush=True)
+    assert h == href
+t0 = time.time()
+r = subprocess.run(["/root/repo/bin/bwtb3mtobwa", os.path.join(tmp, "c3_0.bwt"), os.path.join(tmp, "bwa.bwt"), os.path.join(tmp, "bwa.sa")], capture_output=True, text=True)
+print("bwtb3mtobwa rc %d, %.1f s; %s" % (r.returncode, time.time() - t0, r.stderr.strip()[-300:]), flush=True)
+print({f: os.path.getsize(os.path.join(tmp, f)) for f in ("bwa.bwt", "bwa.sa") if os.path.exists(os.path.join(tmp, f))})
