@@ -551,6 +551,7 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
 	static_assert(F_CAP <= (1 << 13), "index field of an entry");
+	static_assert(F_PER % 6 == 0, "rank phase works on six records at a time");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t b = blockIdx.x;
 	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
@@ -576,17 +577,21 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	#pragma unroll
 	for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) cw[k * F_THREADS + tid] = 0;
 	__syncthreads();
-	// ---- count: slot of every record inside its bin ----
-	uint32_t bs[F_PER];                                       // slot inside the bin, later slot | start of the bin << 16
-	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) {
-		uint32_t e = k * F_THREADS + tid;
-		bs[k] = 0;
-		if (e < m) {
-			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
-			uint32_t old = atomicAdd(&cw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
-			bs[k] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+	// ---- count: slot of every record inside its bin.  No branch around an LDS access (a returning
+	// atomic or a load inside its own if-block is waited for on the spot: 12 serial round trips per
+	// phase): slots past the bucket's end add 0 to the spare word behind the table ----
+	uint32_t bs[F_PER];                                       // bin (F_BINS = none), then slot | start of the bin << 16
+	{
+		uint32_t old[F_PER];
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) {
+			const uint32_t e = k * F_THREADS + tid;
+			const uint32_t bin = e < m ? (((uint32_t)(r[k] >> 32) >> bsh) & bmask) : (uint32_t)F_BINS;
+			bs[k] = bin;
+			old[k] = atomicAdd(&cw[bin >> 1], e < m ? ((bin & 1u) ? 0x10000u : 1u) : 0u);
 		}
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) bs[k] = bs[k] | (((bs[k] & 1u) ? old[k] >> 16 : old[k] & 0xFFFFu) << 16);   // bin | slot << 16
 	}
 	__syncthreads();
 	// ---- exclusive scan over the bins, in place: thread = 16 consecutive bins = 8 words ----
@@ -623,15 +628,13 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 			if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c);
 		}
 	}
+	uint32_t stv[F_PER], env[F_PER];                          // start and end of the record's bin (spare bin: m, 0)
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) { const uint32_t bin = bs[k] & 0xFFFFu; stv[k] = cs[bin]; env[k] = cs[bin + 1]; }
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
-		uint32_t e = k * F_THREADS + tid;
-		if (e < m) {
-			uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask;
-			uint32_t st = cs[bin];
-			ent[st + bs[k]] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;
-			bs[k] |= st << 16;
-		}
+		const uint32_t e = k * F_THREADS + tid;
+		if (e < m) ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;      // a store: nothing waits for it
 	}
 	__syncthreads();
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
@@ -640,32 +643,34 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	// dest: place | hot bin << 29 | tied << 30 | has an equal predecessor << 31
 	uint32_t dest[F_PER];
 	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) {
-		uint32_t e = k * F_THREADS + tid;
-		dest[k] = 0;
-		if (e < m) {
-			const uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & bmask, st = bs[k] >> 16, slot = bs[k] & 0xFFFFu;
-			const uint32_t c = (uint32_t)cs[bin + 1] - st;
-			uint32_t lt = 0, ltk = 0, lek = 1;
-			if (c > 1) {
-				const uint32_t xk = (((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13, x = xk | e, xn = xk + 8192u;
-				lek = 0;
-				if (c <= 4) {
-					#pragma unroll
-					for (uint32_t j = 0; j < 4; ++j) {
-						uint32_t y = ent[st + j];                 // beyond the bin: the next bin's entries (ent is padded), masked out
-						y = j < c ? y : 0xFFFFFFFFu;
-						lt += y < x ? 1u : 0u; ltk += y < xk ? 1u : 0u; lek += y < xn ? 1u : 0u;
-					}
-				} else if (c <= (uint32_t)LS_TIE_CAP) {
-					for (uint32_t j = 0; j < c; ++j) {
-						uint32_t y = ent[st + j];
-						lt += y < x ? 1u : 0u; ltk += y < xk ? 1u : 0u; lek += y < xn ? 1u : 0u;
-					}
+	for (int h = 0; h < F_PER; h += 6) {                       // six records at a time: their 24 entry loads fly together
+		uint32_t y[6][4];
+		#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const uint32_t st = (h + k) * F_THREADS + tid < m ? stv[h + k] : 0u;     // beyond the bin: the next entries (ent is padded), masked out below
+			#pragma unroll
+			for (int j = 0; j < 4; ++j) y[k][j] = ent[st + j];
+		}
+		#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const int kk = h + k;
+			const uint32_t e = kk * F_THREADS + tid;
+			const uint32_t st = stv[kk], c = env[kk] - st, slot = bs[kk] >> 16;
+			const uint32_t xk = (((uint32_t)(r[kk] >> 32) >> 3) & lmask) << 13, x = xk | e, xn = xk + 8192u;
+			uint32_t lt = 0, ltk = 0, lek = 0;
+			#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				const uint32_t v = j < c ? y[k][j] : 0xFFFFFFFFu;
+				lt += v < x ? 1u : 0u; ltk += v < xk ? 1u : 0u; lek += v < xn ? 1u : 0u;
+			}
+			if (e < m && c > 4 && c <= (uint32_t)LS_TIE_CAP) {     // rare: longer bins with a loop
+				for (uint32_t j = 4; j < c; ++j) {
+					const uint32_t v = ent[st + j];
+					lt += v < x ? 1u : 0u; ltk += v < xk ? 1u : 0u; lek += v < xn ? 1u : 0u;
 				}
 			}
-			dest[k] = c > (uint32_t)LS_TIE_CAP ? (st + slot) | (1u << 29)        // hot bin: arrival order, positions into sa
-			                                   : (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
+			dest[kk] = c > (uint32_t)LS_TIE_CAP ? (st + slot) | (1u << 29)       // hot bin: arrival order, positions into sa
+			                                    : (st + lt) | (lek - ltk > 1 ? 1u << 30 : 0u) | (lt > ltk ? 1u << 31 : 0u);
 		}
 	}
 	// ---- drop BWT byte (and SA entry) at the final place; key-field ties are marked for k_tie_fix ----
