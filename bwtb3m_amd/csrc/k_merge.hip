@@ -124,18 +124,24 @@ __global__ __launch_bounds__(256) void k_gap_walk(GapWalkArgs A)
 	const uint32_t p0 = *A.rd.p0ptr;
 	const uint32_t last_code = base_at(T, A.a + A.m - 1);   // T[a+m-1], never the terminator
 	const bool term = T.type == B3M_INPUT_PACTERM;
-	uint32_t gtw = 0; uint64_t gtw_idx = ~0ull;          // cached word of gt_cur
+	// The only load a step must wait for is its rank line: the text (16 bases per big-endian word) and the
+	// gt bits (32 per word) are read a word AHEAD of the walk, which moves towards lower positions.
+	const uint32_t *tw = reinterpret_cast<const uint32_t *>(T.b);
+	uint64_t wi = (hi - 1) >> 4;
+	uint32_t word = hi > lo ? __builtin_bswap32(tw[wi]) : 0u, wnext = (hi > lo && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
+	uint64_t gtw_idx = hi >> 5;
+	uint32_t gtw = A.gt_cur[gtw_idx], gtnext = gtw_idx > 0 ? A.gt_cur[gtw_idx - 1] : 0u;
 	uint32_t outw = 0; uint64_t outw_idx = ~0ull;        // gt_next word being assembled
 	// the end bit of the parent: gt_P[Rend] is stored per node by the host from the anchor
 	uint64_t t = 0;
 	for (uint64_t j = hi; j-- > lo; ++t) {
 		// symbol T[j]
-		uint32_t code; bool is_term = false;
-		if (term && j == T.n - 1) { is_term = true; code = 0; }
-		else code = base_at(T, j % T.n);
+		if ((j >> 4) != wi) { wi = j >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
+		const bool is_term = term && j == T.n - 1;
+		const uint32_t code = is_term ? 0u : (word >> (2u * (15u - (uint32_t)(j & 15)))) & 3u;
 		// gt_R[j+1] relative to S_{Rbeg}; for j+1 == Rend it is the node's end bit kept at bit Rend
 		uint64_t g = j + 1;
-		if ((g >> 5) != gtw_idx) { gtw_idx = g >> 5; gtw = A.gt_cur[gtw_idx]; }
+		if ((g >> 5) != gtw_idx) { gtw_idx = g >> 5; gtw = gtnext; gtnext = gtw_idx > 0 ? A.gt_cur[gtw_idx - 1] : 0u; }
 		uint32_t gtbit = (gtw >> (g & 31)) & 1u;
 		uint32_t nrho;
 		if (is_term) nrho = 0;                              // S_{n-1} = "$..." is the smallest rotation
@@ -189,9 +195,16 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	uint64_t p = kn ? A.anchors[2 * kn + 1] : T.n;     // the last chain starts at position n == 0
 	const uint64_t pend = A.anchors[2 * k + 1];
 	uint32_t bad = 0;
+	// the text is read 16 bases (one big-endian word) at a time, one word ahead of the walk
+	const uint32_t *tw = reinterpret_cast<const uint32_t *>(T.b);
+	uint64_t wi = p > pend ? (p - 1) >> 4 : 0;
+	uint32_t word = p > pend ? __builtin_bswap32(tw[wi]) : 0u, wnext = (p > pend && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
 	while (p > pend) {
 		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (uint32_t)(p == T.n ? 0 : p);
-		uint32_t st = sym_at(T, p - 1);                 // symbol preceding the rotation at p
+		const uint64_t q = p - 1;
+		if ((q >> 4) != wi) { wi = q >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
+		const uint32_t base = (word >> (2u * (15u - (uint32_t)(q & 15)))) & 3u;
+		const uint32_t st = term ? (q == T.n - 1 ? 0u : base + 1u) : base;     // symbol preceding the rotation at p
 		uint32_t nr;
 		if (term && r == p0) {                          // the BWT holds the terminator here
 			bad += st != 0;
