@@ -96,8 +96,14 @@ void radix_ws_carve(RadixWs &ws, void *base, uint64_t n);
 // is one of the two buffer pairs.  Stable.  v may be null for keys only.
 void radix_sort_u64(uint64_t *kA, uint32_t *vA, uint64_t *kB, uint32_t *vB, uint64_t n, int nbits,
                     RadixWs &ws, hipStream_t s, Timeline *tl, uint64_t **k_res, uint32_t **v_res);
+// MSD sort of 32-bit keys (k_msd.hip): false = not applicable (few keys / skewed), kA then holds a permutation of the input
+uint64_t sort_u32_msd_scratch(uint64_t n);
+bool sort_u32_msd(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, uint32_t *scratch, uint64_t scratch_elems, uint32_t *scan_ws,
+                  hipStream_t s, Timeline *tl, uint32_t **k_res);
+// rank_list = true: the keys are ranks < 2^nbits plus 0xFFFFFFFF padding that may come back as 2^nbits - 1 (large lists
+// then take the MSD path); false: stable sort on the low nbits that keeps every key's high bits
 void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &ws, hipStream_t s,
-                    Timeline *tl, uint32_t **k_res);
+                    Timeline *tl, uint32_t **k_res, bool rank_list = false);
 
 // ---- block sort (row a7) ---------------------------------------------------------------------
 struct MsdTile { uint32_t in_off, count, hist_base, stride; };

@@ -462,7 +462,7 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 			uint32_t *sr = nullptr;
 			{
 				int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
-				radix_sort_u32(p->d_ranks[0], p->d_ranks[1], M.slots, nbits, p->merge_radix, s, tl, &sr);
+				radix_sort_u32(p->d_ranks[0], p->d_ranks[1], M.slots, nbits, p->merge_radix, s, tl, &sr, true);
 			}
 			{
 				Scope sc(tl, KF_INTERLEAVE, 4 * mr + 2 * (m + mr));
@@ -678,7 +678,7 @@ int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t 
 	gap_walk(G, s);
 	uint32_t *sr = nullptr;
 	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
-	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr);
+	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr, true);
 	if (d_sorted_ranks) B3M_HIP(hipMemcpyAsync(d_sorted_ranks, sr, 4 * mr, hipMemcpyDeviceToDevice, s));
 	if (d_G_dense) dense_gap_from_sorted(sr, mr, d_G_dense, m, s);
 	if (d_gtP) {
@@ -767,7 +767,7 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
 	gap_walk(G, s);
 	uint32_t *sr = nullptr;
 	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
-	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr);
+	radix_sort_u32(r0.as<uint32_t>(), r1.as<uint32_t>(), slots, nbits, rw, s, nullptr, &sr, true);
 	// positions covered by this chain range
 	uint64_t hi = mr - chain_first * chain_len;
 	uint64_t last = chain_first + num_chains;

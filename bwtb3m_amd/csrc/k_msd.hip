@@ -1072,4 +1072,235 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	out.d_sa = need_sa ? sa : nullptr;      // without need_sa only the entries of tied / overflow records were written
 }
 
+
+// ================================================================================================
+// Sort of 32-bit keys (the rank lists of the merges: SURVEY.md 8a row a9) by the same means as the
+// block sort: two unstable 8-bit partitions through LDS (64-key runs), then every final bucket's
+// remaining <= 15 bits are counted in an LDS histogram and the keys are written back in order (keys
+// only, so the sorted bucket IS its histogram).  32 B of traffic per key instead of the 48 B of a
+// four-pass LSD radix sort, on scatter passes that are not bound by stable ranking.
+// ================================================================================================
+constexpr int U32_LOWBITS = 15;
+constexpr int U32_BINS = 1 << U32_LOWBITS;
+constexpr int U32_THREADS = 1024;
+constexpr uint64_t U32_MIN_N = 1ull << 23;             // below this the LSD passes are as fast
+constexpr uint32_t U32_MAX_BUCKET = 65535;             // 16-bit counters: a larger final bucket (skewed ranks) -> LSD fallback
+
+struct U32Args {
+	const uint32_t *in; uint32_t *out;
+	const MsdTile *tiles;
+	uint32_t *hist;
+	int D, shift;
+};
+
+template <bool COUNT_ONLY, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_u32_pass(U32Args A)
+{
+	constexpr int CHUNK = THREADS * MSD_ITEMS;
+	__shared__ uint32_t cnt[MSD_MAXBINS];
+	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
+	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
+	__shared__ uint32_t skey[COUNT_ONLY ? 1 : CHUNK];
+	__shared__ uint32_t wsum[THREADS / 64];
+	const uint32_t tid = threadIdx.x;
+	const int bins = 1 << A.D;
+	const MsdTile tile = A.tiles[blockIdx.x];
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; }
+	else { for (int b = tid; b < bins; b += THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
+	__syncthreads();
+	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const uint32_t cbase = c * CHUNK;
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; __syncthreads(); }
+		uint32_t key[MSD_ITEMS], dg[MSD_ITEMS], slot[MSD_ITEMS]; uint32_t vmask = 0;
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) {                  // loads first, uses later
+			uint32_t e = cbase + s * THREADS + tid;
+			key[s] = A.in[(uint64_t)tile.in_off + (e < tile.count ? e : tile.count - 1)];
+			if (e < tile.count) vmask |= 1u << s;
+		}
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (key[s] >> A.shift) & (uint32_t)(bins - 1);
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
+		if (COUNT_ONLY) continue;
+		__syncthreads();
+		{
+			static_assert(COUNT_ONLY || THREADS >= MSD_MAXBINS, "one bin per thread");
+			const uint32_t v = (int)tid < bins ? cnt[tid] : 0u;
+			uint32_t inc = wave_incl_sum(v);
+			uint32_t w = tid >> 6, l = tid & 63;
+			if (l == 63) wsum[w] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
+			if ((int)tid < bins) binstart[tid] = pre + inc - v;
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) skey[binstart[dg[s]] + slot[s]] = key[s];
+		__syncthreads();
+		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
+		for (uint32_t p = tid; p < nvalid; p += THREADS) {
+			uint32_t q = skey[p];
+			const uint32_t dd = (q >> A.shift) & (uint32_t)(bins - 1);
+			A.out[(uint64_t)gbase[dd] + (p - binstart[dd])] = q;
+		}
+		__syncthreads();
+		for (int b = tid; b < bins; b += THREADS) gbase[b] += cnt[b];
+		__syncthreads();
+	}
+	if (COUNT_ONLY) {
+		__syncthreads();
+		for (int b = tid; b < bins; b += THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
+	}
+}
+
+// one workgroup per final bucket (< 2^16 keys): histogram of the low bits in 16-bit LDS counters (64 KB: two
+// workgroups per CU), exclusive scan in place, and every output slot finds its bin by binary search in
+// the scanned histogram (15 LDS reads): coalesced loads and stores
+__global__ __launch_bounds__(U32_THREADS) void k_u32_finish(const uint32_t *in, uint32_t *out, const uint32_t *bstart, int lowbits)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t hw[U32_BINS / 2 + 4];     // two 16-bit counters per word, then exclusive starts
+	__shared__ uint32_t wsum[U32_THREADS / 64];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t b = blockIdx.x;
+	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
+	if (m == 0) return;
+	const uint32_t bins = 1u << lowbits, mask = bins - 1;
+	const uint32_t prefix = b << lowbits;
+	for (uint32_t i = tid; i < U32_BINS / 2 + 4; i += U32_THREADS) hw[i] = 0;
+	__syncthreads();
+	for (uint32_t e0 = 0; e0 < m; e0 += 8 * U32_THREADS) {       // eight loads in flight per thread, then their atomics
+		uint32_t v[8];
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { uint32_t e = e0 + k * U32_THREADS + tid; v[k] = in[(uint64_t)s0 + (e < m ? e : m - 1)]; }
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			uint32_t e = e0 + k * U32_THREADS + tid, bin = v[k] & mask;
+			if (e < m) atomicAdd(&hw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
+		}
+	}
+	__syncthreads();
+	{
+		constexpr int WPT = (U32_BINS / 2) / U32_THREADS;       // 16 words = 32 bins per thread
+		uint32_t w[WPT]; uint32_t sum = 0;
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { w[k] = hw[tid * WPT + k]; sum += (w[k] & 0xFFFFu) + (w[k] >> 16); }
+		uint32_t inc = wave_incl_sum(sum);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t run = inc - sum;
+		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) {
+			uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+			hw[tid * WPT + k] = run | ((run + lo) << 16);       // starts < 2^16 because m < 2^16
+			run += lo + hi;
+		}
+	}
+	__syncthreads();
+	const uint16_t *hs = reinterpret_cast<const uint16_t *>(hw);  // hs[bin] = first slot of the bin
+	for (uint32_t s = tid; s < m; s += U32_THREADS) {
+		uint32_t lo = 0, hi = bins;                          // largest bin with hs[bin] <= s
+		while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (hs[mid] <= s) lo = mid; else hi = mid; }
+		out[(uint64_t)s0 + s] = prefix | lo;
+	}
+}
+
+// workspace: `scratch` (u32) of at least sort_u32_msd_scratch(n) entries, `scan_ws` for exclusive_sum_u32
+uint64_t sort_u32_msd_scratch(uint64_t n)
+{
+	uint64_t tiles = n / MSD_SUPER + 260;
+	return 2 * 256 * tiles + 4 * tiles + 65540 + 3 * 260 + 64;
+}
+// returns false (nothing sorted) when the keys are too few or too skewed for this path
+bool sort_u32_msd(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, uint32_t *scratch, uint64_t scratch_elems, uint32_t *scan_ws,
+                  hipStream_t s, Timeline *tl, uint32_t **k_res)
+{
+	if (n < U32_MIN_N || n >= (1ull << 32) || nbits <= U32_LOWBITS + 8 || nbits > 32 || scratch_elems < sort_u32_msd_scratch(n)) return false;
+	const int U = nbits - U32_LOWBITS;                       // upper bits: two levels of <= 8
+	const int D1 = std::min(8, U), D2 = U - D1;
+	if (D2 > 8 || D2 < 1) return false;
+	const uint64_t tiles_max = n / MSD_SUPER + 260;
+	uint32_t *histA = scratch, *histB = histA + 256 * tiles_max;
+	MsdTile *d_tiles = reinterpret_cast<MsdTile *>(histB + 256 * tiles_max);
+	uint32_t *starts = reinterpret_cast<uint32_t *>(d_tiles + tiles_max), *tab = starts + 65540;
+	// ---- level A: regular tiles ----
+	const uint32_t ntA = (uint32_t)((n + MSD_SUPER - 1) / MSD_SUPER);
+	std::vector<MsdTile> tiles(ntA);
+	for (uint32_t i = 0; i < ntA; ++i) { tiles[i].in_off = i * (uint32_t)MSD_SUPER; tiles[i].count = (uint32_t)std::min<uint64_t>(MSD_SUPER, n - (uint64_t)i * MSD_SUPER); tiles[i].hist_base = i; tiles[i].stride = ntA; }
+	B3M_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(MsdTile) * ntA, hipMemcpyHostToDevice, s));
+	uint32_t tab0[3] = {0, 0, ntA};
+	B3M_HIP(hipMemcpyAsync(tab, tab0, 12, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	U32Args A{kA, kB, d_tiles, histA, D1, nbits - D1};
+	{
+		Scope sc(tl, KF_RADIX_HIST, 4 * n);
+		hipLaunchKernelGGL((k_u32_pass<true, 256>), dim3(ntA), dim3(256), 0, s, A);
+	}
+	{
+		Scope sc(tl, KF_SCAN, 8ull * 256 * ntA);
+		exclusive_sum_u32(histA, (uint64_t)(1u << D1) * ntA, scan_ws, s);
+	}
+	{
+		Scope sc(tl, KF_RADIX_SCATTER, 8 * n);
+		hipLaunchKernelGGL((k_u32_pass<false, U32_THREADS>), dim3(ntA), dim3(U32_THREADS), 0, s, A);
+	}
+	const uint32_t nbA = 1u << D1;
+	hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nbA + 1)), dim3(256), 0, s, histA, tab, 1u, D1, (uint32_t)n, starts);
+	std::vector<uint32_t> st(nbA + 1);
+	B3M_HIP(hipMemcpyAsync(st.data(), starts, 4ull * (nbA + 1), hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	// ---- level B: tiles inside every level-A bucket ----
+	tiles.clear();
+	std::vector<uint32_t> tb(3ull * nbA);
+	uint64_t hoff = 0;
+	for (uint32_t b = 0; b < nbA; ++b) {
+		uint32_t sz = st[b + 1] - st[b];
+		uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
+		tb[b] = st[b]; tb[nbA + b] = (uint32_t)hoff; tb[2ull * nbA + b] = nt;
+		for (uint32_t j = 0; j < nt; ++j) {
+			MsdTile t; t.in_off = st[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
+			t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
+			tiles.push_back(t);
+		}
+		hoff += ((uint64_t)1 << D2) * nt;
+	}
+	B3M_REQUIRE(tiles.size() <= tiles_max && hoff <= 256 * tiles_max, "rank sort workspace too small");
+	B3M_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(tab, tb.data(), 4 * tb.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	const uint32_t ntB = (uint32_t)tiles.size();
+	U32Args Bq{kB, kA, d_tiles, histB, D2, nbits - D1 - D2};
+	{
+		Scope sc(tl, KF_RADIX_HIST, 4 * n);
+		hipLaunchKernelGGL((k_u32_pass<true, 256>), dim3(ntB), dim3(256), 0, s, Bq);
+	}
+	{
+		Scope sc(tl, KF_SCAN, 8ull * hoff);
+		exclusive_sum_u32(histB, hoff, scan_ws, s);
+	}
+	{
+		Scope sc(tl, KF_RADIX_SCATTER, 8 * n);
+		hipLaunchKernelGGL((k_u32_pass<false, U32_THREADS>), dim3(ntB), dim3(U32_THREADS), 0, s, Bq);
+	}
+	const uint32_t nbF = nbA << D2;
+	hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nbF + 1)), dim3(256), 0, s, histB, tab, nbA, D2, (uint32_t)n, starts);
+	// skew check: a final bucket handled by one workgroup must stay small
+	std::vector<uint32_t> fs(nbF + 1);
+	B3M_HIP(hipMemcpyAsync(fs.data(), starts, 4ull * (nbF + 1), hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	uint32_t mx = 0;
+	for (uint32_t b = 0; b < nbF; ++b) mx = std::max(mx, fs[b + 1] - fs[b]);
+	if (mx > U32_MAX_BUCKET) return false;                   // kA holds a permutation of the input: the caller sorts it the slow way
+	{
+		Scope sc(tl, KF_RADIX_SCATTER, 8 * n);
+		hipLaunchKernelGGL(k_u32_finish, dim3(nbF), dim3(U32_THREADS), 0, s, kA, kB, starts, U32_LOWBITS);
+	}
+	B3M_HIP(hipGetLastError());
+	*k_res = kB;
+	return true;
+}
+
 }  // namespace b3m

@@ -311,8 +311,13 @@ void radix_sort_u64(uint64_t *kA, uint32_t *vA, uint64_t *kB, uint32_t *vB, uint
 {
 	radix_sort_impl<uint64_t>(kA, vA, kB, vB, n, nbits, ws, s, tl, k_res, v_res);
 }
-void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &ws, hipStream_t s, Timeline *tl, uint32_t **k_res)
+void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &ws, hipStream_t s, Timeline *tl, uint32_t **k_res, bool rank_list)
 {
+	// large rank lists: unstable MSD partitions + LDS histograms (k_msd.hip); its scratch is carved from the tile histogram area
+	if (rank_list && n <= ws.cap_elems) {
+		const uint64_t have = (uint64_t)RX_BINS * (radix_tiles(ws.cap_elems) + 1);
+		if (sort_u32_msd(kA, kB, n, nbits, ws.tile_hist, have, ws.scan_ws, s, tl, k_res)) return;
+	}
 	radix_sort_impl<uint32_t>(kA, nullptr, kB, nullptr, n, nbits, ws, s, tl, k_res, nullptr);
 }
 
