@@ -594,3 +594,33 @@ def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
         m0, m1, _ = plan.lf_walk(bad, sarate=0)
         assert m0 + m1 > 0
     plan.close()
+
+
+def test_merge_with_skewed_rank_list_40mbase(gpu):
+    # two blocks of 20 Mbase: the right one is low-complexity, so the ranks of its suffixes among the left
+    # block's pile up in a few places -- the MSD rank sort must notice (a final bucket above 2^16 keys)
+    # and fall back to the stable LSD passes; the merged BWT must equal the single-block one
+    torch = gpu
+    from bwtb3m_amd import engine
+    from oracle import oracle as O
+    nb = 40_000_000
+    rng = np.random.default_rng(11)
+    b = rng.integers(0, 4, nb, dtype=np.uint8)
+    b[nb // 2:] = np.resize(np.array([0, 0, 0, 1, 0, 0, 2, 0], dtype=np.uint8), nb // 2)
+    b[nb // 2 + 1000: nb // 2 + 5_000_000] = 0
+    idx = rng.integers(nb // 2, nb, 20000); b[idx] = rng.integers(0, 4, 20000, dtype=np.uint8)
+    buf = O.pac_encode(b)
+    n = nb + 1
+    d_text = torch.from_numpy(np.asarray(buf)).cuda()
+    plan = engine.Plan(n, "pacterm", isasamplingrate=1 << 16)
+    one = plan.run(d_text).clone()
+    torch.cuda.synchronize()
+    assert plan.lf_walk(one, sarate=0)[:2] == (0, 0)
+    p0 = plan.result()["p0"]
+    plan.close()
+    plan = engine.Plan(n, "pacterm", blocksize=(n + 1) // 2)
+    assert plan.num_blocks == 2
+    two = plan.run(d_text)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two) and plan.result()["p0"] == p0
+    plan.close()
