@@ -793,7 +793,7 @@ int b3m_sort_u32(const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_
 	RadixWs rw; radix_ws_carve(rw, rws.p, count);
 	B3M_HIP(hipMemcpyAsync(a.p, d_keys, 4 * count, hipMemcpyDeviceToDevice, s));
 	uint32_t *res = nullptr;
-	radix_sort_u32(a.as<uint32_t>(), b.as<uint32_t>(), count, nbits, rw, s, nullptr, &res);
+	radix_sort_u32(a.as<uint32_t>(), b.as<uint32_t>(), count, nbits, rw, s, nullptr, &res, true);
 	B3M_HIP(hipMemcpyAsync(d_out, res, 4 * count, hipMemcpyDeviceToDevice, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	return 0;

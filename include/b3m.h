@@ -190,8 +190,9 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
                    const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
                    uint32_t *d_sorted_ranks, uint64_t *count_out, uint32_t *d_gt_abs_out, void *stream);
 
-/* row a9 helper: ascending LSD radix sort of u32 keys on bits [0,nbits) (the sparse gap array is a
- * sorted rank list; the multi-GPU driver re-sorts the rank buckets it receives). */
+/* row a9 helper: ascending sort of u32 keys that are all < 2^nbits (the sparse gap array is a sorted
+ * rank list; the multi-GPU driver re-sorts the rank buckets it receives).  Large lists take the MSD
+ * partition + LDS histogram path of the merges, small ones LSD radix passes. */
 int b3m_sort_u32(const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream);
 /* abs bit (start+k) |= rel bit k, k in [1,count]: block-relative gt bits of b3m_block_sort ->
  * the absolute-position bit array b3m_gap_chains works on. */

@@ -210,3 +210,22 @@ def test_readme_bwa_index_pipeline(gpu, oracle, tmp_path):
     assert np.array_equal(sym, np.delete(bw, primary) - 1)
     fsa = np.fromfile(str(tmp_path / "ref.fa.sa"), dtype=np.uint64)
     assert fsa[5] == 32 and fsa[6] == len(s) - 1 and np.array_equal(fsa[7:].astype(np.int64), sa[32::32])
+
+
+@pytest.mark.parametrize("count,nbits,kind", [(1000, 20, "uniform"), (20_000_000, 31, "uniform"), (20_000_000, 29, "uniform"),
+                                               (20_000_000, 31, "skewed"), (9_000_000, 24, "uniform")])
+def test_sort_u32_stage_entry(gpu, count, nbits, kind):
+    # b3m_sort_u32 (row a9 helper): large lists take the MSD partition + LDS histogram path, skewed ones
+    # (a final bucket of >= 2^16 keys) and small ones the LSD passes; either way the result is the sorted list
+    torch = gpu
+    import ctypes
+    from bwtb3m_amd import engine as eng
+    g = torch.Generator(device="cuda"); g.manual_seed(count + nbits)
+    keys = torch.randint(0, 1 << nbits, (count,), device="cuda", generator=g, dtype=torch.int64)
+    if kind == "skewed":
+        keys = torch.where(torch.rand(count, device="cuda", generator=g) < 0.5, torch.full_like(keys, 12345), keys)
+    k32 = keys.to(torch.int32)            # values < 2^31: same bits as u32
+    out = torch.empty_like(k32)
+    eng.check(eng.lib().b3m_sort_u32(eng._ptr(k32), ctypes.c_uint64(count), nbits, eng._ptr(out), eng._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.sort(k32).values)
