@@ -193,6 +193,8 @@ void gap_walk(const GapWalkArgs &A, hipStream_t s);
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
 void lf_walk(const TextView &T, const RankDict &rd, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out,
              unsigned long long *d_mismatch, hipStream_t s);
+void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
 void interleave(const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr,
                 uint8_t *d_out, uint32_t *d_tile_q /* scratch: tiles+1 */, hipStream_t s);
 uint64_t interleave_tiles(uint64_t total);

@@ -862,7 +862,6 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 {
 	B3M_TRY
 	B3M_REQUIRE(p && d_bwt && mismatches_out, "b3m_plan_lf_walk: null argument");
-	B3M_REQUIRE(p->type == B3M_INPUT_PAC || p->type == B3M_INPUT_PACTERM, "the LF walk needs a 2-bit alphabet (pac/pacterm)");
 	B3M_REQUIRE(p->nshards == 1, "the LF walk needs the whole BWT (unsharded plan)");
 	B3M_REQUIRE(p->isarate && !p->h_samples.empty(), "the plan has no (rank,pos) samples: create it with isasamplingrate > 0 and run it");
 	hipStream_t s = (hipStream_t)stream;
@@ -872,6 +871,26 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	uint64_t K = p->h_samples.size() / 2;
 	const std::vector<uint64_t> &anc = p->h_samples;
 	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
+	if (p->type == B3M_INPUT_BYTESTREAM) {
+		// byte alphabet: the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
+		const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
+		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);
+		RadixWs rw; radix_ws_carve(rw, rws.p, n);
+		B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
+		B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 4 * (nsa + 1), s));
+		lf_walk_bytes(T, d_bwt, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), lf.as<uint32_t>(), rw,
+		              danc.as<uint64_t>(), K, sarate, dsa.as<uint32_t>(), dmis.as<unsigned long long>(), s);
+		unsigned long long mm[2] = {0, 0};
+		B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
+		std::vector<uint32_t> hsa(nsa);
+		if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(hsa.data(), dsa.p, 4 * nsa, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		B3M_HIP(hipGetLastError());
+		mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+		if (nsa && sa_out) for (uint64_t i = 0; i < nsa; ++i) sa_out[i] = hsa[i];
+		return 0;
+	}
 	uint64_t nb = rank_blocks(n);
 	uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);

@@ -36,7 +36,6 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 	try {
 		if (!o || !o->input_fn || !*o->input_fn) throw std::runtime_error("no input file given");
 		Log log{o->verbose ? log_fd : -1};
-		Log logalways{log_fd};
 		const char *tname = (o->inputtype && *o->inputtype) ? o->inputtype : "bytestream";
 		int type = b3m_parse_input_type(tname);
 		if (type < 0) throw std::runtime_error(b3m_last_error());
@@ -58,8 +57,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		uint64_t sarate = o->sasamplingrate ? o->sasamplingrate : 32;
 		// bwtonly=1 lowers the default ISA sampling rate to 64 (/root/reference/ChangeLog:281);
 		// the caller passes the effective value, 0 means "default for the mode"
-		const bool two_bit = type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM;
-		const bool want_sa = !o->bwtonly && two_bit;          // sampled SA/ISA stage
+		const bool want_sa = !o->bwtonly;                     // sampled SA/ISA stage (byte alphabets walk the LF array)
 		// anchors of the LF walks: a divisor of the output rate, dense enough to fill the GPU
 		uint64_t anchor_rate = isarate;
 		if (want_sa && isarate > 1024 && isarate % 1024 == 0) anchor_rate = 1024;
@@ -100,8 +98,6 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			log("[V] sampled SA (rate %llu) and ISA (rate %llu) by LF walks, BWT verified against the text\n", (unsigned long long)sarate, (unsigned long long)isarate);
 		} else {
 			b3m::write_preisa(prefix + ".preisa", pairs.data(), res.num_samples);
-			if (!o->bwtonly)
-				logalways("[W] bwtonly=0: the sampled SA/ISA stage needs a 2-bit input type in this engine; %s.preisa was written, run bwtcomputessa on it\n", prefix.c_str());
 		}
 		double t3 = now();
 		log("[V] wrote %s (+.hist .meta .preisa) in %.3f s; total %.3f s\n", outfn.c_str(), t3 - t2, t3 - t0);

@@ -229,6 +229,54 @@ void lf_walk(const TextView &T, const RankDict &rd, const uint64_t *d_anchors, u
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
 }
 
+// Byte alphabets (byte LF walk): no rank dictionary -- the whole LF array is built by ONE
+// stable counting sort of the BWT by symbol (lf[i] = slot of i in that order, /root/reference/src/bwtdecodeblock.cpp:280-284)
+// and the chains walk it directly.
+__global__ void k_bwt_keys(const uint8_t *bwt, uint64_t n, uint64_t *keys, uint32_t *vals)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { keys[i] = bwt[i]; vals[i] = (uint32_t)i; }
+}
+__global__ void k_lf_from_sorted(const uint32_t *sorted_idx, uint64_t n, uint32_t *lf)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) lf[sorted_idx[j]] = (uint32_t)j;
+}
+struct LfWalkBytesArgs {
+	TextView T; const uint8_t *bwt; const uint32_t *lf;
+	const uint64_t *anchors; uint64_t nanchors; uint64_t sarate; uint32_t *sa_out; unsigned long long *mismatch;
+};
+__global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
+{
+	uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= A.nanchors) return;
+	const TextView &T = A.T;
+	uint64_t kn = k + 1 == A.nanchors ? 0 : k + 1;
+	uint32_t r = (uint32_t)A.anchors[2 * kn];
+	uint64_t p = kn ? A.anchors[2 * kn + 1] : T.n;     // the last chain starts at position n == 0
+	const uint64_t pend = A.anchors[2 * k + 1];
+	uint32_t bad = 0;
+	while (p > pend) {
+		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (uint32_t)(p == T.n ? 0 : p);
+		bad += A.bwt[r] != T.b[p - 1];                  // the symbol preceding the rotation at p
+		r = A.lf[r]; --p;
+	}
+	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
+	if (r != (uint32_t)A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
+}
+// d_keys/d_keys2 (n u64 each), d_vals/d_vals2 (n u32 each): sort buffers; d_lf: n u32
+void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
+{
+	const uint64_t n = T.n;
+	hipLaunchKernelGGL(k_bwt_keys, dim3(nblk(n)), dim3(256), 0, s, d_bwt, n, d_keys, d_vals);
+	uint64_t *rk; uint32_t *rv;
+	radix_sort_u64(d_keys, d_vals, d_keys2, d_vals2, n, 8, rw, s, nullptr, &rk, &rv);
+	hipLaunchKernelGGL(k_lf_from_sorted, dim3(nblk(n)), dim3(256), 0, s, rv, n, d_lf);
+	LfWalkBytesArgs A{T, d_bwt, d_lf, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	if (nanchors) hipLaunchKernelGGL(k_lf_walk_bytes, dim3(nblk(nanchors)), dim3(256), 0, s, A);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K9 interleave
 // ------------------------------------------------------------------------------------------------

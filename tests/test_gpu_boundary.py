@@ -229,3 +229,40 @@ def test_sort_u32_stage_entry(gpu, count, nbits, kind):
     eng.check(eng.lib().b3m_sort_u32(eng._ptr(k32), ctypes.c_uint64(count), nbits, eng._ptr(out), eng._stream()))
     torch.cuda.synchronize()
     assert torch.equal(out, torch.sort(k32).values)
+
+
+def test_cli_bwtonly0_bytestream_writes_sa_isa(gpu, oracle, tmp_path):
+    # byte alphabets have no 2-bit rank dictionary: the sampled SA/ISA stage walks the LF array
+    # (one stable sort of the BWT by symbol) and verifies every symbol against the text on the way
+    t = oracle.synth_bytes(200_000, 93).copy()
+    t[50_000:90_000] = t[10_000:50_000]          # a long repeat
+    inp = tmp_path / "t.bin"
+    inp.write_bytes(t.tobytes())
+    out = str(tmp_path / "t.bin.bwt")
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=bytestream", "outputfilename=" + out, "isasamplingrate=2048", "sasamplingrate=16", str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    sa = oracle.sa_circular(t)
+    isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
+    prefix = out[:-4]
+    assert not os.path.exists(prefix + ".preisa")
+    fsa = np.fromfile(prefix + ".sa", dtype=np.uint64)
+    assert fsa[0] == 16 and fsa[1] == len(fsa) - 2 and np.array_equal(fsa[2:].astype(np.int64), sa[::16])
+    fisa = np.fromfile(prefix + ".isa", dtype=np.uint64)
+    assert fisa[0] == 2048 and fisa[1] == len(fisa) - 2 and np.array_equal(fisa[2:].astype(np.int64), isa[::2048])
+
+
+def test_lf_walk_bytestream_catches_corruption(gpu, oracle):
+    from bwtb3m_amd import engine
+    t = oracle.synth_bytes(300_000, 94)
+    out, res, plan = engine.bwt_device(t, "bytestream", isasamplingrate=4096)
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(out)).cuda()
+    m0, m1, sa = plan.lf_walk(d, sarate=64)
+    assert (m0, m1) == (0, 0)
+    ref = oracle.sa_circular(t)
+    assert np.array_equal(np.asarray(sa, dtype=np.int64), ref[::64])
+    d[12345] = (int(d[12345]) + 1) % 256
+    m0, m1, _ = plan.lf_walk(d, sarate=0)
+    assert m0 + m1 > 0
+    plan.close()
