@@ -61,7 +61,11 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// anchors of the LF walks: a divisor of the output rate, dense enough to fill the GPU
 		uint64_t anchor_rate = isarate;
 		if (want_sa && isarate > 1024 && isarate % 1024 == 0) anchor_rate = 1024;
-		plan = b3m_plan_create(n, type, o->blocksize, o->mem, anchor_rate);
+		// byte alphabets are sorted as ONE block (no byte-alphabet merge): a memory target that would force several
+		// blocks (the reference's scripts pass mem= for host RAM) is not applied to them
+		uint64_t mem = o->mem;
+		if (type == B3M_INPUT_BYTESTREAM && mem) { log("[V] mem= is not applied to bytestream input (sorted as one block in HBM)\n"); mem = 0; }
+		plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
 		if (!plan) throw std::runtime_error(b3m_last_error());
 		log("[V] blocks %llu workspace %.2f GB\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9);
 		uint64_t tb = b3m_plan_text_bytes(plan);
