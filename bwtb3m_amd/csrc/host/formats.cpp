@@ -191,49 +191,74 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 	fwrite(head.data(), 1, head.size(), f);
 	uint64_t filepos = 8;
 	std::vector<RLIndexEntry> index;
-	// stream: the calling thread collects the runs of batch k+1 while the workers encode batch k
-	const uint64_t batch_runs = runs_per_block * numthreads * 8;
-	std::vector<RLRun> runsA, runsB;
-	runsA.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1); runsB.reserve((size_t)std::min<uint64_t>(batch_runs, n) + 1);
-	uint64_t i = 0;
-	auto collect = [&](std::vector<RLRun> &runs) {
-		runs.clear();
-		while (i < n && runs.size() < batch_runs) {
-			const uint8_t s = symbols[i]; uint64_t j = i + 1;
-			while (j < n && symbols[j] == s) ++j;
-			runs.push_back({(int64_t)s, j - i});
-			i = j;
-		}
+	// Blocks hold exactly runs_per_block runs, so a block's first symbol depends on every run before it.
+	// Pass 1 (parallel): run starts per 64 KiB segment -> prefix sums.  Pass 2 (parallel, in batches
+	// written in order): every worker finds its block's first run by a search in the prefix sums plus a
+	// scan inside one segment, collects the block's runs itself and encodes them.
+	const uint64_t SEG = 64 * 1024;
+	const uint64_t nseg = (n + SEG - 1) / SEG;
+	std::vector<uint64_t> segruns(nseg + 1, 0);             // segruns[s] = runs starting before segment s
+	{
+		std::atomic<uint64_t> next(0);
+		auto count = [&]() {
+			for (;;) {
+				uint64_t s = next.fetch_add(64);
+				if (s >= nseg) return;
+				for (uint64_t q = s; q < std::min(nseg, s + 64); ++q) {
+					uint64_t lo = q * SEG, hi = std::min(n, lo + SEG), c = 0;
+					for (uint64_t i = lo; i < hi; ++i) c += (i == 0 || symbols[i] != symbols[i - 1]);
+					segruns[q + 1] = c;
+				}
+			}
+		};
+		std::vector<std::thread> th;
+		for (unsigned t = 1; t < numthreads; ++t) th.emplace_back(count);
+		count();
+		for (auto &x : th) x.join();
+		for (uint64_t s = 0; s < nseg; ++s) segruns[s + 1] += segruns[s];
+	}
+	const uint64_t total_runs = segruns[nseg];
+	const uint64_t nblocks = (total_runs + runs_per_block - 1) / runs_per_block;
+	// position of the first symbol of run r (r < total_runs)
+	auto run_start = [&](uint64_t r) -> uint64_t {
+		uint64_t s = (uint64_t)(std::upper_bound(segruns.begin(), segruns.end(), r) - segruns.begin()) - 1;   // segruns[s] <= r < segruns[s+1]
+		uint64_t k = segruns[s];
+		for (uint64_t i = s * SEG;; ++i) if (i == 0 || symbols[i] != symbols[i - 1]) { if (k == r) return i; ++k; }
 	};
-	std::vector<RLRun> *cur = &runsA, *nxt = &runsB;
-	collect(*cur);
-	while (!cur->empty()) {
-		const std::vector<RLRun> &runs = *cur;
-		uint64_t nb = (runs.size() + runs_per_block - 1) / runs_per_block;
+	const uint64_t batch = (uint64_t)numthreads * 16;
+	for (uint64_t b0 = 0; b0 < nblocks; b0 += batch) {
+		const uint64_t nb = std::min(batch, nblocks - b0);
 		std::vector<std::vector<uint8_t>> bufs(nb);
+		std::vector<uint64_t> bsyms(nb, 0), bruns(nb, 0);
 		std::atomic<uint64_t> next_block(0);
 		auto work = [&]() {
+			std::vector<RLRun> runs; runs.reserve((size_t)runs_per_block);
 			for (;;) {
 				uint64_t b = next_block.fetch_add(1);
 				if (b >= nb) return;
-				uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block);
-				encode_block(runs.data() + r0, r1 - r0, bufs[b]);
+				const uint64_t r0 = (b0 + b) * runs_per_block, r1 = std::min(total_runs, r0 + runs_per_block);
+				runs.clear();
+				uint64_t i = run_start(r0), syms = 0;
+				while (runs.size() < r1 - r0) {
+					const uint8_t s = symbols[i]; uint64_t j = i + 1;
+					while (j < n && symbols[j] == s) ++j;
+					runs.push_back({(int64_t)s, j - i}); syms += j - i;
+					i = j;
+				}
+				bsyms[b] = syms; bruns[b] = runs.size();
+				encode_block(runs.data(), runs.size(), bufs[b]);
 			}
 		};
 		std::vector<std::thread> th;
 		unsigned T = (unsigned)std::min<uint64_t>(numthreads, nb);
 		for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
-		collect(*nxt);                                   // overlaps with the encoders
 		work();
 		for (auto &x : th) x.join();
 		for (uint64_t b = 0; b < nb; ++b) {
-			uint64_t r0 = b * runs_per_block, r1 = std::min<uint64_t>(runs.size(), r0 + runs_per_block), syms = 0;
-			for (uint64_t r = r0; r < r1; ++r) syms += runs[r].len;
-			index.push_back({filepos, r1 - r0, syms});
+			index.push_back({filepos, bruns[b], bsyms[b]});
 			fwrite(bufs[b].data(), 1, bufs[b].size(), f);
 			filepos += bufs[b].size();
 		}
-		std::swap(cur, nxt);
 	}
 	std::vector<uint8_t> tail;
 	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
