@@ -48,10 +48,7 @@ constexpr int W0B_CHUNK = 32768, W0B_TCH = 8, W0B_BINS = 4096;    // 12 bits
 constexpr int W0_MAXBITS = 12;
 constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
 // finish
-constexpr int F_THREADS = 512;
-constexpr int F_WAVES = F_THREADS / 64;
 constexpr int F_CAP = 6144;                            // records of a final bucket sorted in LDS
-constexpr int F_PER = F_CAP / F_THREADS;               // 12 records per thread
 constexpr uint32_t F_HUGE = 1u << 20;                      // buckets above this go to the list-based rounds directly
 constexpr int F_AVG = 5760;                            // target average bucket size
 constexpr int F_BINBITS = 13;
@@ -98,7 +95,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -113,6 +110,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 4));
 	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
 	ws.hugelist = (uint32_t *)p; ws.huge_cap = cap / F_HUGE + 16; p += al(4 * (ws.huge_cap + 2));
+	ws.midlist = (uint32_t *)p; p += al(4 * (ws.big_cap + 2));
 	ws.scan_ws = (uint32_t *)p;
 }
 
@@ -541,24 +539,31 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 // neighbour, and drops the BWT byte (and the SA entry) there; the bucket leaves as coalesced rows.
 // Buckets above F_CAP are listed for k_bucket_finish; a bucket with a bin above LS_TIE_CAP (a 16-mer
 // repeated inside the bucket) goes to the overflow list.
-template <bool WRITE_SA>
-__global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits,
-                                                               uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
+// THREADS = 512: every final bucket, 6144 records at most (two workgroups per CU).  THREADS = 1024: the buckets
+// between 6144 and 12288 records that the first launch listed (`midlist`; skewed base composition makes many),
+// one workgroup per CU.
+template <bool WRITE_SA, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits, const uint32_t *todo,
+                                                             uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t ent[F_CAP + 4];         // (low key bits << 13) | index, in bin order
+	constexpr int F_THREADS = THREADS, F_CAP = THREADS * 12, F_PER = 12, F_WAVES = THREADS / 64;
+	constexpr int IDXB = F_CAP <= 8192 ? 13 : 14;             // index field of an entry
+	__shared__ __attribute__((aligned(16))) uint32_t ent[F_CAP + 4];         // (low key bits << IDXB) | index, in bin order
 	__shared__ __attribute__((aligned(16))) uint32_t cw[F_BINS / 2 + 4];     // 16-bit counters, then exclusive starts, two per word
 	__shared__ __attribute__((aligned(16))) uint8_t obwt[F_CAP + 8];
 	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
-	static_assert(F_CAP <= (1 << 13), "index field of an entry");
+	static_assert(F_CAP <= (1 << IDXB), "index field of an entry");
 	static_assert(F_PER % 6 == 0, "rank phase works on six records at a time");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t b = blockIdx.x;
+	if (todo && blockIdx.x >= todo[0]) return;
+	const uint32_t b = todo ? todo[1 + blockIdx.x] : blockIdx.x;
 	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP) {
 		if (tid == 0) {
-			if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
+			if (midlist && m <= 2u * F_CAP) { uint32_t k = atomicAdd(&midlist[0], 1u); if (k < mid_cap) midlist[1 + k] = b; }
+			else if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
 				uint32_t k = atomicAdd(&hugelist[0], 1u); if (k < huge_cap) hugelist[1 + k] = b;
 				ovf_push(O, s0, m);
 			} else { uint32_t k = atomicAdd(&biglist[0], 1u); if (k < big_cap) biglist[1 + k] = b; }
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		const uint32_t e = k * F_THREADS + tid;
-		if (e < m) ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << 13) | e;      // a store: nothing waits for it
+		if (e < m) ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << IDXB) | e;      // a store: nothing waits for it
 	}
 	__syncthreads();
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(F_THREADS, 4) void k_finish_lds(const uint64_t *rec
 			const int kk = h + k;
 			const uint32_t e = kk * F_THREADS + tid;
 			const uint32_t st = stv[kk], c = env[kk] - st, slot = bs[kk] >> 16;
-			const uint32_t xk = (((uint32_t)(r[kk] >> 32) >> 3) & lmask) << 13, x = xk | e, xn = xk + 8192u;
+			const uint32_t xk = (((uint32_t)(r[kk] >> 32) >> 3) & lmask) << IDXB, x = xk | e, xn = xk + (1u << IDXB);
 			uint32_t lt = 0, ltk = 0, lek = 0;
 			#pragma unroll
 			for (uint32_t j = 0; j < 4; ++j) {
@@ -1005,10 +1010,15 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(M.biglist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(M.hugelist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
-		if (need_sa)
-			hipLaunchKernelGGL(k_finish_lds<true>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
-		else
-			hipLaunchKernelGGL(k_finish_lds<false>, dim3(nbF), dim3(F_THREADS), 0, s, cur, M.lvl_start, fbits, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
+		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
+		if (need_sa) {
+			hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(nbF), dim3(512), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)nullptr, M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+			hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+		} else {
+			hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(nbF), dim3(512), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)nullptr, M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+			hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+		}
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// The grid covers every bucket that could be that large; blocks beyond the list leave at once.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
