@@ -543,8 +543,8 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 // between 6144 and 12288 records that the first launch listed (`midlist`; skewed base composition makes many),
 // one workgroup per CU.
 template <bool WRITE_SA, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits, const uint32_t *todo,
-                                                             uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
+__device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *rec, const uint32_t *bstart, int fbits,
+                                              uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, const SortOut &O)
 {
 	constexpr int F_THREADS = THREADS, F_CAP = THREADS * 12, F_PER = 12, F_WAVES = THREADS / 64;
 	constexpr int IDXB = F_CAP <= 8192 ? 13 : 14;             // index field of an entry
@@ -556,8 +556,6 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, 
 	static_assert(F_CAP <= (1 << IDXB), "index field of an entry");
 	static_assert(F_PER % 6 == 0, "rank phase works on six records at a time");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	if (todo && blockIdx.x >= todo[0]) return;
-	const uint32_t b = todo ? todo[1 + blockIdx.x] : blockIdx.x;
 	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP) {
@@ -709,6 +707,19 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, 
 	}
 }
 
+template <bool WRITE_SA, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits, const uint32_t *todo,
+                                                             uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
+{
+	if (!todo) { finish_bucket<WRITE_SA, THREADS>(blockIdx.x, rec, bstart, fbits, midlist, mid_cap, biglist, big_cap, hugelist, huge_cap, O); return; }
+	// listed buckets: a fixed grid strides over the list (an empty list costs nothing)
+	const uint32_t cnt = todo[0];
+	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
+		finish_bucket<WRITE_SA, THREADS>(todo[1 + it], rec, bstart, fbits, midlist, mid_cap, biglist, big_cap, hugelist, huge_cap, O);
+		__syncthreads();
+	}
+}
+
 // HUGE BUCKETS (low-complexity input): every workgroup copies its share of the positions into the suffix array;
 // the bucket is already on the overflow list
 __global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *hugelist, uint32_t huge_cap, uint32_t *sa)
@@ -724,8 +735,8 @@ __global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const u
 // 8 bits, scatters it into its own range of the other record buffer (chunks of 4096 through LDS,
 // as k_msd_pass), and its four waves then sort the 256 sub-buckets one after the other.
 template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist,
-                                                                 int D, int shift, int sortbits, SortOut O)
+__device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart,
+                                           int D, int shift, int sortbits, const SortOut &O)
 {
 	constexpr int CH = MSD_THREADS * MSD_ITEMS;                 // 4096
 	__shared__ uint32_t cnt[MSD_MAXBINS];
@@ -735,8 +746,6 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 	__shared__ uint32_t wsum[8];
 	__shared__ __attribute__((aligned(16))) uint64_t big[CH];     // scatter staging, later the waves' sort buffers (32 KB)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	if (blockIdx.x >= biglist[0]) return;
-	const uint32_t b = biglist[1 + blockIdx.x];
 	const uint32_t s0 = bstart[b], s1 = bstart[b + 1], m = s1 - s0;
 	const uint32_t bins = 1u << D, dmask = bins - 1;
 	// ---- pass 1: histogram of the next digit over the bucket ----
@@ -813,6 +822,17 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 		for (int t = 0; t < LS_CAP / 64; ++t) { uint32_t e = t * 64 + lane; r[t] = rec_tmp[(uint64_t)s0 + lo + (e < mm ? e : mm - 1)]; }
 		wave_sort_bucket<WRITE_SA>(s0 + lo, mm, sortbits, outb, cb, O, r);
 		wave_sync();
+	}
+}
+
+template <bool WRITE_SA>
+__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist,
+                                                                 int D, int shift, int sortbits, SortOut O)
+{
+	const uint32_t cnt = biglist[0];
+	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {        // a fixed grid strides over the list
+		big_bucket<WRITE_SA>(biglist[1 + it], rec_in, rec_tmp, bstart, D, shift, sortbits, O);
+		__syncthreads();
 	}
 }
 
@@ -1011,7 +1031,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(M.hugelist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
-		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
+		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
 		if (need_sa) {
 			hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(nbF), dim3(512), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)nullptr, M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
 			hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
@@ -1020,9 +1040,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
 		}
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
-		// The grid covers every bucket that could be that large; blocks beyond the list leave at once.
+		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
-		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, M.big_cap);
+		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 2048);
 		if (need_sa)
 			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
 		else
