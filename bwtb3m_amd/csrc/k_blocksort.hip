@@ -469,10 +469,25 @@ __global__ __launch_bounds__(256) void k_histogram_packed(TextView T, uint64_t s
 	if (wl < w0) wl = w0;
 	uint32_t c1 = 0, c2 = 0, c3 = 0; uint64_t nb = 0;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < wl; w += stride) {
-		uint32_t x = *reinterpret_cast<const uint32_t *>(T.b + (w << 2));   // byte order is irrelevant for counting
+	auto count = [&](uint32_t x) {                                  // byte order is irrelevant for counting
 		uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
 		c1 += __popc(lo & ~hi); c2 += __popc(hi & ~lo); c3 += __popc(lo & hi); nb += 16;
+	};
+	// bulk: 16-byte loads (64 bases), two in flight per thread; the words before / after the 16-byte aligned part singly
+	const uint64_t q0 = (w0 + 3) >> 2, q1 = wl >> 2;               // whole groups of 4 words
+	if (q1 > q0) {
+		const uint4 *t4 = reinterpret_cast<const uint4 *>(T.b);
+		const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		for (uint64_t q = q0 + gid; q < q1; q += 2 * stride) {
+			uint4 a = t4[q];
+			uint4 b = q + stride < q1 ? t4[q + stride] : make_uint4(0, 0, 0, 0);
+			count(a.x); count(a.y); count(a.z); count(a.w);
+			if (q + stride < q1) { count(b.x); count(b.y); count(b.z); count(b.w); }
+		}
+		if (gid < (q0 << 2) - w0) count(*reinterpret_cast<const uint32_t *>(T.b + ((w0 + gid) << 2)));
+		if (gid < wl - (q1 << 2)) count(*reinterpret_cast<const uint32_t *>(T.b + (((q1 << 2) + gid) << 2)));
+	} else {
+		for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < wl; w += stride) count(*reinterpret_cast<const uint32_t *>(T.b + (w << 2)));
 	}
 	uint64_t c0 = nb - c1 - c2 - c3;
 	uint64_t d1 = c1, d2 = c2, d3 = c3;
