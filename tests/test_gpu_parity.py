@@ -624,3 +624,22 @@ def test_merge_with_skewed_rank_list_40mbase(gpu):
     torch.cuda.synchronize()
     assert torch.equal(one, two) and plan.result()["p0"] == p0
     plan.close()
+
+
+def test_bytestream_64mb_verified_by_the_lf_walk(gpu):
+    # a byte alphabet at a size the oracle cannot do in test time: key/index radix sort + byte LF walk on the device
+    torch = gpu
+    from bwtb3m_amd import engine
+    n = 64 * 1024 * 1024
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    t = torch.randint(0, 256, (n,), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+    t[10_000_000:14_000_000] = t[1_000_000:5_000_000]        # a 4 MB repeat: prefix doubling
+    plan = engine.Plan(n, "bytestream", isasamplingrate=1 << 14)
+    out = plan.run(t)
+    torch.cuda.synchronize()
+    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    assert (m0, m1) == (0, 0)
+    h = plan.histogram()
+    assert np.array_equal(h.astype(np.int64), torch.bincount(t.to(torch.int64), minlength=256).cpu().numpy())
+    assert torch.equal(torch.bincount(out.to(torch.int64), minlength=256), torch.bincount(t.to(torch.int64), minlength=256))
+    plan.close()
