@@ -266,3 +266,23 @@ def test_lf_walk_bytestream_catches_corruption(gpu, oracle):
     m0, m1, _ = plan.lf_walk(d, sarate=0)
     assert m0 + m1 > 0
     plan.close()
+
+
+def test_bench_line_contract(gpu):
+    # bench.py prints ONE JSON line with the metric of BASELINE.json plus the `roofline` and `cpu_baseline` objects
+    import json, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "2e7", "--steps", "2", "--warmup", "1", "--cpu-sample", "2e6"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert j["metric"] == base["metric"] and j["unit"] == "Gbase/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic" and j["value"] > 0
+    assert abs(j["value"] - 2e7 * 1e-9 / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
