@@ -35,7 +35,7 @@ def parse():
                     help="multi-GPU: suffix-range shards (no exchange) or block merging with RCCL all-to-all")
     ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",
                     help="N>1: skip the extra pass of the block-merge mode after the headline line")
-    ap.add_argument("--blocks-timeout", type=int, default=150)
+    ap.add_argument("--blocks-timeout", type=int, default=90)
     ap.add_argument("--check", action="store_true",
                     help="verify the result on the device at any size: LF walks over the BWT against the text (checkbwt)")
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
