@@ -130,6 +130,7 @@ struct BlockSortWs {
 	RadixWs radix;
 	MsdWs msd;
 	uint32_t *d_scalars = nullptr;    // small device scalars
+	uint64_t *d_symhist_out = nullptr; // optional: the MSD path adds the block's symbol histogram here (it falls out of the level-0 digit counts)
 };
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
 uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0);
@@ -139,6 +140,7 @@ struct BlockSortOut {
 	uint64_t tie_rounds = 0, tie_elements = 0;
 	uint64_t msd_overflow_buckets = 0;
 	bool used_msd = false;
+	bool symhist_done = false;        // ws.d_symhist_out was filled
 	uint64_t kept_len = 0;            // suffixes sorted here (= len unless this is a suffix-range shard)
 	uint64_t slice_offset = 0;        // global rank of the first of them
 };

@@ -390,14 +390,16 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
 		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
 		// one block: its BWT is the result and goes straight to the caller's buffer
+		p->bs.d_symhist_out = p->d_hist + 256 * k;
 		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out : p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
+		p->bs.d_symhist_out = nullptr;
 		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;
 		{
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
-			histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
+			if (!so.symhist_done) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
 			if (p->isarate) {
 				if (p->nshards > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
 				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,

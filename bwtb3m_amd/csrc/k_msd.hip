@@ -390,6 +390,25 @@ __global__ __launch_bounds__(256) void k_row_totals(const uint32_t *hist, uint32
 	if (threadIdx.x == 0) totals[blockIdx.x] = part[0];
 }
 
+// symbol histogram of the block from the level-0 digit totals: the leading base of a rotation is the top two bits of
+// its digit.  pacterm: symbol = base + 1; the terminator position was counted as base 0 (its window reads as zeros).
+__global__ __launch_bounds__(256) void k_symhist_from_totals(const unsigned long long *totals, uint32_t bins, int D, int pacterm, int has_term, unsigned long long *hist256)
+{
+	__shared__ unsigned long long part[4][256];
+	unsigned long long s[4] = {0, 0, 0, 0};
+	for (uint32_t d = threadIdx.x; d < bins; d += 256) s[d >> (D - 2)] += totals[d];
+	for (int c = 0; c < 4; ++c) part[c][threadIdx.x] = s[c];
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		unsigned long long t = 0;
+		for (int i = 0; i < 256; ++i) t += part[threadIdx.x][i];
+		if (pacterm) {
+			if (threadIdx.x == 0 && has_term) { t -= 1; atomicAdd(&hist256[0], 1ull); }
+			atomicAdd(&hist256[threadIdx.x + 1], t);
+		} else atomicAdd(&hist256[threadIdx.x], t);
+	}
+}
+
 // starts of the buckets leaving a level: bucket_tab = {start[nb], hist_off[nb], ntiles[nb]} of the
 // buckets entering it; out[(b << D) | d] = start of digit d inside bucket b; out[nb << D] = len
 __global__ void k_next_starts(const uint32_t *scanned, const uint32_t *bucket_tab, uint32_t nb, int D, uint32_t len, uint32_t *out)
@@ -925,13 +944,19 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
+	unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
+	if (ws.d_symhist_out && dg.D0 >= 2) {
+		hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		hipLaunchKernelGGL(k_symhist_from_totals, dim3(1), dim3(256), 0, s, d_tot, bins0, dg.D0, T.type == B3M_INPUT_PACTERM ? 1 : 0,
+		                   (T.type == B3M_INPUT_PACTERM && start + len_in == T.n) ? 1 : 0, reinterpret_cast<unsigned long long *>(ws.d_symhist_out));
+		out.symhist_done = true;
+	}
 	out.slice_offset = 0;
 	if (nshards > 1) {
 		// suffix-range shard: this rank keeps the level-0 digits [lo, hi) holding the ranks
 		// [shard*n/N, (shard+1)*n/N) as evenly as whole digits allow.  The totals come from the
 		// text alone, so every rank derives the same boundaries without talking to anyone.
-		unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
-		hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		if (!out.symhist_done) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
 		std::vector<unsigned long long> tot(bins0);
 		B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
@@ -1097,7 +1122,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
 		leave_fallback:;
 	}
-	if (rerun_with_sa) { block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }
+	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }   // the histogram was added by this pass already
 	B3M_HIP(hipGetLastError());
 	out.d_sa = need_sa ? sa : nullptr;      // without need_sa only the entries of tied / overflow records were written
 }

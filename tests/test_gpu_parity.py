@@ -371,6 +371,8 @@ def test_deep_repeats_use_prefix_doubling(gpu, oracle, itype, isarate):
     out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate)
     assert np.array_equal(out, oracle.bwt(s))
     assert 4 < res["tie_rounds"] <= 4 + 24, res["tie_rounds"]
+    # the symbol histogram is taken once even when the sort starts over with the suffix array kept
+    assert np.array_equal(plan.histogram().astype(np.int64), np.bincount(np.asarray(s, dtype=np.int64), minlength=256))
     if isarate:
         sa = oracle.sa_circular(s)
         smp = plan.samples()
