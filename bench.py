@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",
                     help="N>1: skip the extra pass of the block-merge mode after the headline line")
     ap.add_argument("--blocks-timeout", type=int, default=90)
-    ap.add_argument("--check", action="store_true",
-                    help="verify the result on the device at any size: LF walks over the BWT against the text (checkbwt)")
+    ap.add_argument("--no-check", dest="check", action="store_false",
+                    help="skip the verification after the timed loop (default: the timed isasamplingrate=0 result is compared with an "
+                         "isasamplingrate>0 run that is LF-walk-verified against the text, checkbwt semantics)")
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
     return ap.parse_args()
 
@@ -72,6 +73,39 @@ def cpu_baseline(buf, itype, sample, blocks):
                       % (len(sym), B, cores, dt, st[0], st[1], st[2])}
 
 
+def verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize):
+    """After the timed loop: prove that what was timed (the isasamplingrate=0 plan) is the BWT.  A second plan
+    with (rank,pos) samples constructs it again, that result is LF-walked against the text on the device
+    (every symbol, every chain closure: /root/reference/src/checkbwt.cpp:176-243), and the timed output must
+    equal it byte for byte; out[p0] is the terminator and the symbol histogram equals the text's."""
+    t0 = time.perf_counter()
+    res0 = plan.result()
+    from bwtb3m_amd import benchutil
+    hist_text = benchutil.text_histogram(d_text, n, itype)          # torch only, independent of the engine
+    assert plan.histogram().astype("int64").tolist() == hist_text, "bench check: the engine's symbol histogram (.hist) differs from the text's"
+    plan.close()
+    rate = 1 << 16 if n > (1 << 24) else 64
+    vplan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=rate)
+    d_ref = torch.empty(n, dtype=torch.uint8, device=d_out.device)
+    vplan.run(d_text, d_ref)
+    torch.cuda.synchronize()
+    m0, m1, _ = vplan.lf_walk(d_ref, sarate=0)
+    assert (m0, m1) == (0, 0), "bench check: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
+    assert torch.equal(d_out, d_ref), "bench check: the timed isasamplingrate=0 result differs from the LF-walk-verified one"
+    r1 = vplan.result()
+    assert r1["p0"] == res0["p0"], "bench check: p0 differs between the two variants"
+    if itype == "pacterm":
+        assert int(d_out[res0["p0"]]) == 0, "bench check: BWT[p0] is not the terminator"
+    hb = torch.zeros(256, dtype=torch.int64, device=d_out.device)
+    for o in range(0, n, 1 << 28):      # in slices: an int64 copy of 3 G symbols at once would be 24 GB
+        hb += torch.bincount(d_out[o:o + (1 << 28)].to(torch.int64), minlength=256)
+    assert hb.cpu().numpy().tolist() == hist_text, "bench check: symbol histogram of the BWT differs from the text's"
+    vplan.close()
+    return ("timed isasamplingrate=0 output == isasamplingrate=%d output, which the on-device LF walk verified against the text over all "
+            "%d symbols (0 symbol / 0 chain mismatches); BWT[p0]=terminator; histogram(BWT)==histogram(text); %.0f ms"
+            % (rate, n, (time.perf_counter() - t0) * 1e3))
+
+
 def main():
     a = parse()
     import numpy as np
@@ -102,7 +136,7 @@ def main():
     blocksize = int(a.blocksize)
     if a.blocks > 0:
         blocksize = (n + a.blocks - 1) // a.blocks
-    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=1024 if a.check else 0)
+    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=0)        # the timed variant: BWT only, no (rank,pos) samples
     d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
     for _ in range(a.warmup):
         plan.run(d_text, d_out)
@@ -136,11 +170,7 @@ def main():
         assert np.array_equal(d_out.cpu().numpy(), O.bwt(sym)), "bench --verify: BWT differs from the oracle"
         out["config"]["verified"] = True
     if a.check:
-        t0 = time.perf_counter()
-        m0, m1, _ = plan.lf_walk(d_out, sarate=0)
-        torch.cuda.synchronize()
-        assert (m0, m1) == (0, 0), "bench --check: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
-        out["config"]["checked"] = "LF walk over all %d symbols against the text: 0 mismatches (%.0f ms)" % (n, (time.perf_counter() - t0) * 1e3)
+        out["config"]["checked"] = verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize)
     if not a.no_cpu_baseline:
         sample = int(min(a.cpu_sample, n))
         # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)

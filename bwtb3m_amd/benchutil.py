@@ -41,3 +41,38 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
         "job_alg_bytes": alg_job, "job_frac": round(alg_job / (dt / steps) / 1e9 / (HBM_PEAK_GBS * peak_gpus), 5),
         "families_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in fam.items() if v["ms"] > 0},
     }
+
+
+def text_histogram(d_text, n, itype):
+    """symbol histogram of a packed input tensor, computed with torch alone (independent of the engine):
+    256-entry int64 list in the output alphabet (pacterm: base + 1, one terminator 0)"""
+    import torch
+    if itype == "bytestream":
+        h = torch.zeros(256, dtype=torch.int64, device=d_text.device)
+        for o in range(0, n, 1 << 28):
+            h += torch.bincount(d_text[o:min(n, o + (1 << 28))].to(torch.int64), minlength=256)
+        return h.cpu().tolist()
+    nb = n - 1 if itype == "pacterm" else n
+    full = nb // 4
+    hb = torch.zeros(256, dtype=torch.int64, device=d_text.device)
+    for o in range(0, full, 1 << 28):
+        hb += torch.bincount(d_text[o:min(full, o + (1 << 28))].to(torch.int64), minlength=256)
+    hb = hb.cpu().tolist()
+    base = [0, 0, 0, 0]
+    for byte, c in enumerate(hb):
+        if c:
+            for k in range(4):
+                base[(byte >> (2 * k)) & 3] += c
+    if nb % 4:
+        last = int(d_text[full])
+        for k in range(nb % 4):
+            base[(last >> (6 - 2 * k)) & 3] += 1
+    out = [0] * 256
+    if itype == "pacterm":
+        out[0] = 1
+        for c in range(4):
+            out[c + 1] = base[c]
+    else:
+        for c in range(4):
+            out[c] = base[c]
+    return out

@@ -598,6 +598,39 @@ def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
     plan.close()
 
 
+def test_config_c3_full_size_3gbase_pacterm(gpu):
+    """BASELINE configs[2] at FULL size (n = 3,000,000,001: level 0 at 11 bits, level 1 at 8 bits, positions above 2^31).
+    The timed variant (isasamplingrate=0, BWT only) must equal the isasamplingrate>0 variant, and that one is verified
+    on the device by LF walks over every symbol against the text (checkbwt, /root/reference/src/checkbwt.cpp:176-243)."""
+    torch = gpu
+    from bwtb3m_amd import benchutil, engine, synth
+    itype, d_text, n = synth.config_input_device("c3", device="cuda")
+    assert n == 3_000_000_001 and itype == "pacterm"
+    plan = engine.Plan(n, itype, isasamplingrate=0)
+    assert plan.num_blocks == 1
+    timed = torch.empty(n, dtype=torch.uint8, device="cuda")
+    plan.run(d_text, timed)
+    torch.cuda.synchronize()
+    r0 = plan.result()
+    h0 = plan.histogram().astype(np.int64).tolist()
+    plan.close()
+    plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
+    ref = plan.run(d_text)
+    torch.cuda.synchronize()
+    r1 = plan.result()
+    m0, m1, _ = plan.lf_walk(ref, sarate=0)
+    assert (m0, m1) == (0, 0)
+    assert torch.equal(timed, ref)
+    assert r0["p0"] == r1["p0"] and int(timed[r0["p0"]]) == 0
+    ht = benchutil.text_histogram(d_text, n, itype)
+    assert h0 == ht
+    hb = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for o in range(0, n, 1 << 28):
+        hb += torch.bincount(timed[o:o + (1 << 28)].to(torch.int64), minlength=256)
+    assert hb.cpu().tolist() == ht
+    plan.close()
+
+
 def test_merge_with_skewed_rank_list_40mbase(gpu):
     # two blocks of 20 Mbase: the right one is low-complexity, so the ranks of its suffixes among the left
     # block's pile up in a few places -- the MSD rank sort must notice (a final bucket above 2^16 keys)
