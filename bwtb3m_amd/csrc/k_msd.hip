@@ -37,7 +37,9 @@ constexpr int MSD_THREADS = 256;
 constexpr int MSD_ITEMS = 16;
 constexpr int MSD_CHUNK = MSD_THREADS * MSD_ITEMS;     // 4096 records staged through LDS at a time
 constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per workgroup
-constexpr int MSD_L1_THREADS = 1024;                   // level-1 scatter: 16 records per thread
+constexpr int L1_THREADS = 1024;                      // level 1: 16 records per thread, chunks of 16 Ki records sorted in LDS (128 KB)
+constexpr int L1_CHUNK = L1_THREADS * MSD_ITEMS;
+constexpr int L1_TCH = 4;                              // chunks per workgroup (its columns of the run table leave as 16-byte pieces)
 constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass (9 bits measured: level 1 +2.3 ms, level 0 at 10 bits -1.6 ms)
 constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
@@ -89,13 +91,14 @@ static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap,
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
 static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 33 + 4096; }                   // (start, size) pairs: every listed bin holds > 32 records
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
+static uint64_t msd_runtab_cap(uint64_t cap) { return (cap / L1_CHUNK + MSD_L0_MAX) * (uint64_t)MSD_MAXBINS; }   // one column per chunk, 2^D1 rows per level-0 bucket
 
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 {
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * msd_runtab_cap(cap)) + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -111,6 +114,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
 	ws.hugelist = (uint32_t *)p; ws.huge_cap = cap / F_HUGE + 16; p += al(4 * (ws.huge_cap + 2));
 	ws.midlist = (uint32_t *)p; p += al(4 * (ws.big_cap + 2));
+	ws.runtab = (uint32_t *)p; ws.runtab_cap = msd_runtab_cap(cap); p += al(4 * ws.runtab_cap);
 	ws.scan_ws = (uint32_t *)p;
 }
 
@@ -299,55 +303,56 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// level 1: records -> records
+// level 1: records -> records, CHUNK-LOCAL.  A chunk of THREADS*16 consecutive records of ONE level-0
+// bucket is sorted by its next D1 bits inside LDS and goes back to the SAME index range of the other
+// record buffer, whole lines only (a stream copy: what bounded the old level 1 was the partial lines of
+// its scattered 64-record runs, and it needed a counting pass over all records first to know where the
+// runs go).  Where digit d of chunk c sits is one entry of the run table, row (bucket, d), column c:
+//        start inside the chunk | length << 16
+// The final bucket (bucket, d) is the union of row (bucket, d)'s runs; the finish kernel gathers it.
+// No histogram pass, no scan over [digit][tile] matrices, no global offsets at this level.
 // ------------------------------------------------------------------------------------------------
-struct MsdArgs {
+struct L1Args {
 	const uint64_t *rec_in;
 	uint64_t *rec_out;
-	const MsdTile *tiles;
-	uint32_t *hist;              // COUNT_ONLY: counts out ; else scanned offsets in
+	const MsdTile *tiles;        // in_off, count, hist_base = table index of (digit 0, first chunk of the tile), stride = chunks of the bucket
+	uint32_t *runtab;
 	int D;                       // digit bits of this pass
 	int shift;                   // digit = (rec >> shift) & (2^D - 1)
 };
 
-template <bool COUNT_ONLY, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_msd_pass(MsdArgs A)
+template <int THREADS, int TCH>
+__global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 {
-	constexpr int CHUNK = THREADS * MSD_ITEMS;               // records staged through LDS at a time
+	constexpr int CHUNK = THREADS * MSD_ITEMS;               // records sorted in LDS at a time
 	__shared__ uint32_t cnt[MSD_MAXBINS];
-	__shared__ uint32_t binstart[COUNT_ONLY ? 1 : MSD_MAXBINS];
-	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MSD_MAXBINS];
-	__shared__ uint64_t srec[COUNT_ONLY ? 1 : CHUNK];
+	__shared__ uint32_t binstart[MSD_MAXBINS];
+	__shared__ uint32_t tabst[TCH][MSD_MAXBINS];
+	__shared__ __attribute__((aligned(16))) uint64_t srec[CHUNK];
 	__shared__ uint32_t wsum[THREADS / 64];
+	static_assert(THREADS >= MSD_MAXBINS, "one bin per thread");
 	const uint32_t tid = threadIdx.x;
 	const int bins = 1 << A.D;
 	const MsdTile tile = A.tiles[blockIdx.x];
-	if (COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; }
-	else { for (int b = tid; b < bins; b += THREADS) gbase[b] = A.hist[tile.hist_base + (uint64_t)b * tile.stride]; }
-	__syncthreads();
-	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;
+	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;       // <= TCH
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const uint32_t cbase = c * CHUNK;
-		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += THREADS) cnt[b] = 0; __syncthreads(); }
-		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS]; uint32_t vmask = 0;
-		// all 16 loads go out back to back (clamped index, no branch around a load: a load
-		// inside its own if-block gets its own s_waitcnt and the chunk takes 16 round trips)
+		const uint32_t nvalid = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
+		for (int b = tid; b < bins; b += THREADS) cnt[b] = 0;
+		__syncthreads();
+		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS];
+		// all 16 loads go out back to back (clamped index, no branch around a load)
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) {
-			uint32_t e = cbase + s * THREADS + tid;
-			uint32_t ec = e < tile.count ? e : tile.count - 1;
-			rec[s] = A.rec_in[(uint64_t)tile.in_off + ec];
-			if (e < tile.count) vmask |= 1u << s;
+			uint32_t e = s * THREADS + tid;
+			rec[s] = A.rec_in[(uint64_t)tile.in_off + cbase + (e < nvalid ? e : nvalid - 1)];
 		}
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
-		if (COUNT_ONLY) continue;
+		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
 		__syncthreads();
-		// exclusive scan of cnt over the bins -> start of every digit run inside the chunk (thread = one bin)
 		{
-			static_assert(COUNT_ONLY || THREADS >= MSD_MAXBINS, "one bin per thread");
 			const uint32_t v = (int)tid < bins ? cnt[tid] : 0u;
 			uint32_t inc = wave_incl_sum(v);
 			uint32_t w = tid >> 6, l = tid & 63;
@@ -355,27 +360,49 @@ __global__ __launch_bounds__(THREADS) void k_msd_pass(MsdArgs A)
 			__syncthreads();
 			uint32_t pre = 0;
 			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
-			if ((int)tid < bins) binstart[tid] = pre + inc - v;
+			if ((int)tid < bins) { binstart[tid] = pre + inc - v; tabst[c][tid] = (pre + inc - v) | (v << 16); }
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if (vmask & (1u << s)) srec[binstart[dg[s]] + slot[s]] = rec[s];
+		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) srec[binstart[dg[s]] + slot[s]] = rec[s];
 		__syncthreads();
-		// copy out run by run
-		const uint32_t nvalid = binstart[bins - 1] + cnt[bins - 1];
-		for (uint32_t p = tid; p < nvalid; p += THREADS) {
-			uint64_t q = srec[p];
-			const uint32_t d = (uint32_t)(q >> A.shift) & (uint32_t)(bins - 1);
-			A.rec_out[(uint64_t)gbase[d] + (p - binstart[d])] = q;
-		}
-		__syncthreads();
-		for (int b = tid; b < bins; b += THREADS) gbase[b] += cnt[b];
-		__syncthreads();
+		uint64_t *out = A.rec_out + (uint64_t)tile.in_off + cbase;
+		for (uint32_t p = tid; p < nvalid; p += THREADS) out[p] = srec[p];
 	}
-	if (COUNT_ONLY) {
-		__syncthreads();
-		for (int b = tid; b < bins; b += THREADS) A.hist[tile.hist_base + (uint64_t)b * tile.stride] = cnt[b];
+	__syncthreads();
+	// the tile's columns of the run table: digit d -> nchunks consecutive entries of row d
+	for (int d = tid; d < bins; d += THREADS) {
+		uint32_t *row = A.runtab + (uint64_t)tile.hist_base + (uint64_t)d * tile.stride;
+		for (uint32_t c = 0; c < nchunks; ++c) row[c] = tabst[c][d];
 	}
+}
+
+// sizes and starts of the final buckets from the run table: one workgroup per level-0 bucket; wave w sums the
+// rows d = w, w+4, ... (coalesced), then the 2^D sizes are scanned.  btab = {start[nb], tab_off[nb], nch[nb]}.
+__global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, const uint32_t *btab, uint32_t nb, int D, uint32_t len, uint32_t *lvl_start)
+{
+	__shared__ uint32_t sz[MSD_MAXBINS];
+	__shared__ uint32_t wsum[4];
+	const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t bins = 1u << D;
+	const uint32_t nch = btab[2 * nb + b];
+	const uint32_t *tab = runtab + btab[nb + b];
+	for (uint32_t d = wave; d < bins; d += 4) {
+		uint32_t sum = 0;
+		for (uint32_t c = lane; c < nch; c += 64) sum += tab[(uint64_t)d * nch + c] >> 16;
+		#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+		if (lane == 0) sz[d] = sum;
+	}
+	__syncthreads();
+	const uint32_t v = tid < bins ? sz[tid] : 0u;
+	uint32_t inc = wave_incl_sum(v);
+	if (lane == 63) wsum[wave] = inc;
+	__syncthreads();
+	uint32_t pre = 0;
+	for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+	if (tid < bins) lvl_start[((uint64_t)b << D) + tid] = btab[b] + pre + inc - v;
+	if (b == nb - 1 && tid == 0) lvl_start[(uint64_t)nb << D] = len;
 }
 
 // totals[d] = number of records with level-0 digit d (sum of row d of the [digit][tile] counts)
@@ -561,35 +588,97 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 // THREADS = 512: every final bucket, 6144 records at most (two workgroups per CU).  THREADS = 1024: the buckets
 // between 6144 and 12288 records that the first launch listed (`midlist`; skewed base composition makes many),
 // one workgroup per CU.
-template <bool WRITE_SA, int THREADS>
-__device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *rec, const uint32_t *bstart, int fbits,
-                                              uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, const SortOut &O)
+// debug build (-DB3M_CHECK_LDS, `make debug`): every LDS index of the finish is checked against its array and traps
+#ifdef B3M_CHECK_LDS
+#define LDS_CHK(idx, cap) do { if ((uint32_t)(idx) >= (uint32_t)(cap)) __builtin_trap(); } while (0)
+#else
+#define LDS_CHK(idx, cap) do { } while (0)
+#endif
+
+constexpr int G_NCH = 512;               // runs (chunks of the level-0 bucket) a gathering finish maps in LDS
+
+// where the records of a final bucket are: GATHER = false: rec[bstart[b] ...) contiguous (no level 1, or a bucket the
+// compaction kernel has copied together); GATHER = true: row (b >> D1, b & (2^D1 - 1)) of the level-1 run table
+struct FinishSrc {
+	const uint64_t *rec;
+	const uint32_t *bstart;      // starts of the final buckets in the OUTPUT (rank) order, nbF + 1 entries
+	const uint32_t *runtab;      // GATHER: run table of level 1
+	const uint32_t *btab;        // GATHER: {start[nb0], tab_off[nb0], nch[nb0]} of the level-0 buckets
+	uint32_t nb0; int D1; uint32_t chunk;
+};
+struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; };
+
+template <bool WRITE_SA, int THREADS, bool GATHER>
+__device__ __forceinline__ void finish_bucket(const uint32_t b, const FinishSrc &S, int fbits, const FinishLists &L, const SortOut &O)
 {
 	constexpr int F_THREADS = THREADS, F_CAP = THREADS * 12, F_PER = 12, F_WAVES = THREADS / 64;
 	constexpr int IDXB = F_CAP <= 8192 ? 13 : 14;             // index field of an entry
-	__shared__ __attribute__((aligned(16))) uint32_t ent[F_CAP + 4];         // (low key bits << IDXB) | index, in bin order
-	__shared__ __attribute__((aligned(16))) uint32_t cw[F_BINS / 2 + 4];     // 16-bit counters, then exclusive starts, two per word
-	__shared__ __attribute__((aligned(16))) uint8_t obwt[F_CAP + 8];
+	constexpr int ENT_N = F_CAP + 4, CW_N = F_BINS / 2 + 4, OBWT_N = F_CAP + 8, GF_N = F_CAP / 64 + 2;
+	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];          // (low key bits << IDXB) | index, in bin order
+	__shared__ __attribute__((aligned(16))) uint32_t cw[CW_N];            // 16-bit counters, then exclusive starts, two per word
+	__shared__ __attribute__((aligned(16))) uint8_t obwt[OBWT_N];
 	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
+	__shared__ uint32_t rpre[GATHER ? G_NCH + 1 : 1];         // GATHER: exclusive prefix of the run lengths
+	__shared__ uint32_t radr[GATHER ? G_NCH : 1];             // GATHER: record index of every run's first record
+	__shared__ uint16_t gfirst[GATHER ? GF_N : 1];            // GATHER: run holding slot 64 g
 	static_assert(F_CAP <= (1 << IDXB), "index field of an entry");
 	static_assert(F_PER % 6 == 0, "rank phase works on six records at a time");
+	static_assert(!GATHER || THREADS >= G_NCH, "one run per thread");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t s0 = bstart[b], m = bstart[b + 1] - s0;
+	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
 	if (m == 0) return;
-	if (m > (uint32_t)F_CAP) {
+	uint32_t nch = 0, b0 = 0;
+	if (GATHER) { b0 = b >> S.D1; nch = S.btab[2 * S.nb0 + b0]; }
+	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
 		if (tid == 0) {
-			if (midlist && m <= 2u * F_CAP) { uint32_t k = atomicAdd(&midlist[0], 1u); if (k < mid_cap) midlist[1 + k] = b; }
+			if (L.midlist && m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
 			else if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
-				uint32_t k = atomicAdd(&hugelist[0], 1u); if (k < huge_cap) hugelist[1 + k] = b;
+				uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b;
 				ovf_push(O, s0, m);
-			} else { uint32_t k = atomicAdd(&biglist[0], 1u); if (k < big_cap) biglist[1 + k] = b; }
+			} else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
 		}
 		return;
 	}
 	uint64_t r[F_PER];
-	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
+	if (GATHER) {
+		// ---- map the bucket's slots onto the runs of its row of the run table ----
+		const uint32_t *row = S.runtab + S.btab[S.nb0 + b0] + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
+		const uint32_t rent = tid < nch ? row[tid] : 0u;
+		const uint32_t rc = rent >> 16;
+		const uint32_t inc = wave_incl_sum(rc);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t ex = inc - rc;
+		for (uint32_t i = 0; i < wave; ++i) ex += wsum[i];
+		if (tid < nch) { rpre[tid] = ex; radr[tid] = S.btab[b0] + tid * S.chunk + (rent & 0xFFFFu); }
+		if (tid == nch - 1) rpre[nch] = ex + rc;               // = m
+		__syncthreads();
+		const uint32_t glast = (m - 1) >> 6;
+		if (tid <= glast + 1) {                                // largest run j with rpre[j] <= 64 tid (empty runs are skipped over)
+			const uint32_t target = tid << 6;
+			uint32_t lo = 0, hi = nch;
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; LDS_CHK(mid, G_NCH + 1); if (rpre[mid] <= target) lo = mid; else hi = mid; }
+			LDS_CHK(tid, GF_N);
+			gfirst[tid] = (uint16_t)lo;
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) {
+			const uint32_t eu = k * F_THREADS + tid;
+			const uint32_t e = eu < m ? eu : m - 1;
+			uint32_t g = (uint32_t)(k * F_WAVES) + wave; g = g < glast ? g : glast;       // wave-uniform
+			LDS_CHK(g + 1, GF_N);
+			const uint32_t j0 = __builtin_amdgcn_readfirstlane((uint32_t)gfirst[g]), j1 = __builtin_amdgcn_readfirstlane((uint32_t)gfirst[g + 1]);
+			uint32_t j = j0;
+			for (uint32_t i = j0 + 1; i <= j1; ++i) { LDS_CHK(i, G_NCH + 1); j += rpre[i] <= e ? 1u : 0u; }
+			LDS_CHK(j, G_NCH);
+			r[k] = S.rec[(uint64_t)radr[j] + (e - rpre[j])];
+		}
+	} else {
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = S.rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
+	}
 	// the key field sits in the high dword (bits 3..31), the predecessor symbol in its low 3 bits
 	const int binbits = fbits < F_BINBITS ? fbits : F_BINBITS;
 	const int lowbits = fbits - binbits;                      // <= 16
@@ -610,6 +699,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 			const uint32_t e = k * F_THREADS + tid;
 			const uint32_t bin = e < m ? (((uint32_t)(r[k] >> 32) >> bsh) & bmask) : (uint32_t)F_BINS;
 			bs[k] = bin;
+			LDS_CHK(bin >> 1, CW_N);
 			old[k] = atomicAdd(&cw[bin >> 1], e < m ? ((bin & 1u) ? 0x10000u : 1u) : 0u);
 		}
 		#pragma unroll
@@ -652,11 +742,11 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 	}
 	uint32_t stv[F_PER], env[F_PER];                          // start and end of the record's bin (spare bin: m, 0)
 	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) { const uint32_t bin = bs[k] & 0xFFFFu; stv[k] = cs[bin]; env[k] = cs[bin + 1]; }
+	for (int k = 0; k < F_PER; ++k) { const uint32_t bin = bs[k] & 0xFFFFu; LDS_CHK(bin + 1, 2 * CW_N); stv[k] = cs[bin]; env[k] = cs[bin + 1]; }
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		const uint32_t e = k * F_THREADS + tid;
-		if (e < m) ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << IDXB) | e;      // a store: nothing waits for it
+		if (e < m) { LDS_CHK(stv[k] + (bs[k] >> 16), ENT_N); ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << IDXB) | e; }      // a store: nothing waits for it
 	}
 	__syncthreads();
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
@@ -670,6 +760,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 		#pragma unroll
 		for (int k = 0; k < 6; ++k) {
 			const uint32_t st = (h + k) * F_THREADS + tid < m ? stv[h + k] : 0u;     // beyond the bin: the next entries (ent is padded), masked out below
+			LDS_CHK(st + 3, ENT_N);
 			#pragma unroll
 			for (int j = 0; j < 4; ++j) y[k][j] = ent[st + j];
 		}
@@ -687,6 +778,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 			}
 			if (e < m && c > 4 && c <= (uint32_t)LS_TIE_CAP) {     // rare: longer bins with a loop
 				for (uint32_t j = 4; j < c; ++j) {
+					LDS_CHK(st + j, ENT_N);
 					const uint32_t v = ent[st + j];
 					lt += v < x ? 1u : 0u; ltk += v < xk ? 1u : 0u; lek += v < xn ? 1u : 0u;
 				}
@@ -702,6 +794,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 		if (e < m) {
 			const uint32_t dp = dest[k] & 0xFFFFu, g = s0 + dp;
 			const uint32_t i = (uint32_t)r[k];
+			LDS_CHK(apad + dp, OBWT_N); LDS_CHK(dp, m);
 			obwt[apad + dp] = (uint8_t)((uint32_t)(r[k] >> 32) & 7u);     // hot bins: overwritten by the fallback's emit
 			if (WRITE_SA) osa[dp] = i;
 			else if (dest[k] & (3u << 29)) O.sa[g] = i;       // without consumers only k_tie_fix / the fallback read positions
@@ -716,6 +809,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 		const uint32_t lo = apad, hi = apad + m;               // valid bytes of obwt
 		const uint32_t ndw = (hi + 3) >> 2;
 		for (uint32_t j = tid; j < ndw; j += F_THREADS) {
+			LDS_CHK(4 * j + 3, OBWT_N);
 			if (4 * j >= lo && 4 * j + 4 <= hi) reinterpret_cast<uint32_t *>(gb)[j] = reinterpret_cast<const uint32_t *>(obwt)[j];
 			else { for (uint32_t q = 4 * j; q < 4 * j + 4; ++q) if (q >= lo && q < hi) gb[q] = obwt[q]; }
 		}
@@ -726,17 +820,70 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint64_t *
 	}
 }
 
-template <bool WRITE_SA, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(const uint64_t *rec, const uint32_t *bstart, int fbits, const uint32_t *todo,
-                                                             uint32_t *midlist, uint32_t mid_cap, uint32_t *biglist, uint32_t big_cap, uint32_t *hugelist, uint32_t huge_cap, SortOut O)
+template <bool WRITE_SA, int THREADS, bool GATHER>
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, const uint32_t *todo, FinishLists L, SortOut O)
 {
-	if (!todo) { finish_bucket<WRITE_SA, THREADS>(blockIdx.x, rec, bstart, fbits, midlist, mid_cap, biglist, big_cap, hugelist, huge_cap, O); return; }
+	if (!todo) { finish_bucket<WRITE_SA, THREADS, GATHER>(blockIdx.x, S, fbits, L, O); return; }
 	// listed buckets: a fixed grid strides over the list (an empty list costs nothing)
 	const uint32_t cnt = todo[0];
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
-		finish_bucket<WRITE_SA, THREADS>(todo[1 + it], rec, bstart, fbits, midlist, mid_cap, biglist, big_cap, hugelist, huge_cap, O);
+		finish_bucket<WRITE_SA, THREADS, GATHER>(todo[1 + it], S, fbits, L, O);
 		__syncthreads();
 	}
+}
+
+// Buckets the gathering finish has listed (above its LDS capacity, or spread over more runs than it maps): their runs are
+// copied together into [bstart[b], bstart[b+1]) of `out` (the record buffer level 1 has read and no longer needs), where
+// the mid / big / huge paths find them contiguous.  mid and big buckets (<= 2^20 records): one workgroup each; huge ones:
+// every workgroup takes segments of 256 runs.
+__device__ __forceinline__ void compact_segments(const uint32_t b, const FinishSrc &S, uint64_t *out, uint32_t seg_first, uint32_t seg_step)
+{
+	__shared__ uint32_t s_off[257];
+	__shared__ uint32_t s_src[256];
+	__shared__ uint32_t red[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t b0 = b >> S.D1, nch = S.btab[2 * S.nb0 + b0];
+	const uint32_t *row = S.runtab + S.btab[S.nb0 + b0] + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
+	const uint32_t dst0 = S.bstart[b], cbase = S.btab[b0];
+	for (uint32_t seg = seg_first; (uint64_t)seg * 256 < nch; seg += seg_step) {
+		// records of the runs before this segment
+		uint32_t part = 0;
+		for (uint32_t t = tid; t < seg * 256; t += 256) part += row[t] >> 16;
+		#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+		__syncthreads();
+		if (lane == 0) red[wave] = part;
+		__syncthreads();
+		const uint32_t base = red[0] + red[1] + red[2] + red[3];
+		const uint32_t c = seg * 256 + tid;
+		const uint32_t rent = c < nch ? row[c] : 0u, rc = rent >> 16;
+		const uint32_t inc = wave_incl_sum(rc);
+		__syncthreads();
+		if (lane == 63) red[wave] = inc;
+		__syncthreads();
+		uint32_t ex = inc - rc;
+		for (uint32_t i = 0; i < wave; ++i) ex += red[i];
+		s_off[tid] = ex; s_src[tid] = cbase + c * S.chunk + (rent & 0xFFFFu);
+		if (tid == 255) s_off[256] = ex + rc;
+		__syncthreads();
+		const uint32_t total = s_off[256];
+		for (uint32_t x = tid; x < total; x += 256) {
+			uint32_t lo = 0, hi = 256;                          // largest run with s_off <= x
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= x) lo = mid; else hi = mid; }
+			out[(uint64_t)dst0 + base + x] = S.rec[(uint64_t)s_src[lo] + (x - s_off[lo])];
+		}
+		__syncthreads();
+	}
+}
+__global__ __launch_bounds__(256) void k_compact_listed(FinishSrc S, uint64_t *out, const uint32_t *midlist, const uint32_t *biglist, uint32_t list_cap,
+                                                         const uint32_t *hugelist, uint32_t huge_cap)
+{
+	uint32_t nm = midlist[0]; if (nm > list_cap) nm = list_cap;
+	uint32_t nbg = biglist[0]; if (nbg > list_cap) nbg = list_cap;
+	for (uint32_t it = blockIdx.x; it < nm + nbg; it += gridDim.x)
+		compact_segments(it < nm ? midlist[1 + it] : biglist[1 + it - nm], S, out, 0, 1);
+	uint32_t nh = hugelist[0]; if (nh > huge_cap) nh = huge_cap;
+	for (uint32_t h = 0; h < nh; ++h) compact_segments(hugelist[1 + h], S, out, blockIdx.x, gridDim.x);
 }
 
 // HUGE BUCKETS (low-complexity input): every workgroup copies its share of the positions into the suffix array;
@@ -997,56 +1144,56 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const uint64_t *cur = ws.keyA; uint64_t *other = ws.keyB;
 	uint32_t nbF = bins0;               // final buckets
 	const int consumed = dg.D1;         // key-field bits used by level 1
+	FinishSrc FS{};                     // where the finish finds the records of a final bucket
+	FS.bstart = M.lvl_start;
+	bool gather = false;
 	if (dg.D1 == 0) {
 		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.lvl_start);
+		FS.rec = ws.keyA;
 	} else {
-		// ---- level 1: tiles of <= 64 Ki records inside every level-0 bucket, built on the host ----
+		// ---- level 1: every chunk of L1_CHUNK records of a level-0 bucket sorted in LDS, in place; tiles of <= L1_TCH chunks built on the host ----
 		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.sub_start);
 		std::vector<uint32_t> st(bins0 + 1);
 		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		std::vector<MsdTile> tiles;
 		std::vector<uint32_t> tab(3ull * bins0);
-		uint64_t hoff = 0;
+		uint64_t toff = 0;
+		const uint32_t TILE = (uint32_t)L1_CHUNK * L1_TCH;
 		for (uint32_t b = 0; b < bins0; ++b) {
-			uint32_t sz = st[b + 1] - st[b];
-			uint32_t nt = (sz + MSD_SUPER - 1) / MSD_SUPER;
-			tab[b] = st[b]; tab[bins0 + b] = (uint32_t)hoff; tab[2ull * bins0 + b] = nt;
-			for (uint32_t j = 0; j < nt; ++j) {
-				MsdTile t; t.in_off = st[b] + j * (uint32_t)MSD_SUPER; t.count = std::min<uint32_t>((uint32_t)MSD_SUPER, sz - j * (uint32_t)MSD_SUPER);
-				t.hist_base = (uint32_t)(hoff + j); t.stride = nt;
+			const uint32_t sz = st[b + 1] - st[b];
+			const uint32_t nch = (sz + L1_CHUNK - 1) / L1_CHUNK;
+			tab[b] = st[b]; tab[bins0 + b] = (uint32_t)toff; tab[2ull * bins0 + b] = nch;
+			for (uint32_t j = 0; j * TILE < sz; ++j) {
+				MsdTile t; t.in_off = st[b] + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
+				t.hist_base = (uint32_t)(toff + (uint64_t)j * L1_TCH); t.stride = nch;
 				tiles.push_back(t);
 			}
-			hoff += ((uint64_t)1 << dg.D1) * nt;
+			toff += ((uint64_t)1 << dg.D1) * nch;
 		}
-		B3M_REQUIRE(hoff <= M.hist_cap && tiles.size() <= M.tiles_cap && hoff < (1ull << 32), "MSD workspace too small");
+		B3M_REQUIRE(toff <= M.runtab_cap && tiles.size() <= M.tiles_cap && toff < (1ull << 32), "MSD workspace too small");
 		B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
-		MsdArgs Bq{};
-		Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.hist = M.hist; Bq.D = dg.D1; Bq.shift = 64 - dg.D1;
+		L1Args Bq{};
+		Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = dg.D1; Bq.shift = 64 - dg.D1;
 		const uint32_t ntB = (uint32_t)tiles.size();
 		{
-			Scope sc(tl, KF_MSD_HIST, 8 * len);
-			hipLaunchKernelGGL((k_msd_pass<true, MSD_THREADS>), dim3(ntB), dim3(MSD_THREADS), 0, s, Bq);
-		}
-		{
-			Scope sc(tl, KF_SCAN, 8ull * hoff);
-			exclusive_sum_u32(M.hist, hoff, M.scan_ws, s);
-		}
-		{
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-			// 1024 threads = chunks of 16 Ki records (128 KB of LDS, one workgroup per CU): 64-record runs.
-			// Measured at C3: 256 threads (16-record runs) 17.3 ms, 512 threads 14.9 ms, 1024 threads 13.2 ms
-			hipLaunchKernelGGL((k_msd_pass<false, MSD_L1_THREADS>), dim3(ntB), dim3(MSD_L1_THREADS), 0, s, Bq);
+			hipLaunchKernelGGL((k_l1_local<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Bq);
 		}
 		nbF = bins0 << dg.D1;
 		B3M_REQUIRE((uint64_t)nbF + 1 <= MSD_TAB_MAX, "MSD level table too small");
-		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)nbF + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
-		cur = ws.keyB; other = ws.keyA;
+		{
+			Scope sc(tl, KF_SCAN, 4ull * toff);
+			hipLaunchKernelGGL(k_run_totals, dim3(bins0), dim3(256), 0, s, M.runtab, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
+		}
+		FS.rec = ws.keyB; FS.runtab = M.runtab; FS.btab = M.bucket_tab; FS.nb0 = bins0; FS.D1 = dg.D1; FS.chunk = (uint32_t)L1_CHUNK;
+		gather = true;
 	}
 	// ---- finish: every final bucket sorted inside LDS; compulsory traffic = records in, BWT byte (+ SA entry) out ----
 	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
+	B3M_REQUIRE(fbits >= 1 && fbits <= REC_KEY_BITS && fbits - std::min(fbits, F_BINBITS) <= 16, "internal: free key bits of the finish");
 	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
 	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits};
 	{
@@ -1057,13 +1204,21 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
 		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
-		if (need_sa) {
-			hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(nbF), dim3(512), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)nullptr, M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
-			hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+		const FinishLists L1st{M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap};
+		const FinishLists L2nd{nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap};
+		if (gather) {
+			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512, true>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
+			else hipLaunchKernelGGL((k_finish_lds<false, 512, true>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
+			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
+			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
+			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
+			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
 		} else {
-			hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(nbF), dim3(512), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)nullptr, M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
-			hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, cur, M.lvl_start, fbits, (const uint32_t *)M.midlist, (uint32_t *)nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, O);
+			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512, false>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
+			else hipLaunchKernelGGL((k_finish_lds<false, 512, false>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
 		}
+		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024, false>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, L2nd, O);
+		else hipLaunchKernelGGL((k_finish_lds<false, 1024, false>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, L2nd, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
