@@ -29,6 +29,7 @@
 #include "b3m_internal.h"
 #include "b3m_text.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace b3m {
@@ -98,7 +99,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * msd_runtab_cap(cap)) + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -115,6 +116,8 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.hugelist = (uint32_t *)p; ws.huge_cap = cap / F_HUGE + 16; p += al(4 * (ws.huge_cap + 2));
 	ws.midlist = (uint32_t *)p; p += al(4 * (ws.big_cap + 2));
 	ws.runtab = (uint32_t *)p; ws.runtab_cap = msd_runtab_cap(cap); p += al(4 * ws.runtab_cap);
+	ws.runpre = (uint32_t *)p; p += al(4 * ws.runtab_cap);
+	ws.lists = p; p += 256;
 	ws.scan_ws = (uint32_t *)p;
 }
 
@@ -377,9 +380,12 @@ __global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 	}
 }
 
-// sizes and starts of the final buckets from the run table: one workgroup per level-0 bucket; wave w sums the
-// rows d = w, w+4, ... (coalesced), then the 2^D sizes are scanned.  btab = {start[nb], tab_off[nb], nch[nb]}.
-__global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, const uint32_t *btab, uint32_t nb, int D, uint32_t len, uint32_t *lvl_start)
+// sizes and starts of the final buckets from the run table: one workgroup per level-0 bucket; wave w walks the
+// rows d = w, w+4, ... (coalesced) and writes, for the gathering finish, the same row as start | prefix << 14
+// (prefix = records of the row's earlier runs, clamped: rows of buckets above the finish's capacity are never read
+// in that form).  Then the 2^D sizes are scanned.  btab = {start[nb], tab_off[nb], nch[nb]}.
+constexpr uint32_t RUN_PRE_MAX = (1u << 18) - 1;
+__global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, uint32_t *runpre, const uint32_t *btab, uint32_t nb, int D, uint32_t len, uint32_t *lvl_start)
 {
 	__shared__ uint32_t sz[MSD_MAXBINS];
 	__shared__ uint32_t wsum[4];
@@ -387,21 +393,28 @@ __global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, cons
 	const uint32_t bins = 1u << D;
 	const uint32_t nch = btab[2 * nb + b];
 	const uint32_t *tab = runtab + btab[nb + b];
+	uint32_t *pre = runpre + btab[nb + b];
 	for (uint32_t d = wave; d < bins; d += 4) {
-		uint32_t sum = 0;
-		for (uint32_t c = lane; c < nch; c += 64) sum += tab[(uint64_t)d * nch + c] >> 16;
-		#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-		if (lane == 0) sz[d] = sum;
+		uint32_t run = 0;
+		for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
+			const uint32_t c = c0 + lane;
+			const uint32_t e = c < nch ? tab[(uint64_t)d * nch + c] : 0u;
+			const uint32_t cnt = e >> 16;
+			const uint32_t inc = wave_incl_sum(cnt);
+			const uint32_t ex = run + inc - cnt;
+			if (c < nch) pre[(uint64_t)d * nch + c] = (e & 0x3FFFu) | ((ex < RUN_PRE_MAX ? ex : RUN_PRE_MAX) << 14);
+			run += __shfl(inc, 63, 64);
+		}
+		if (lane == 0) sz[d] = run;
 	}
 	__syncthreads();
 	const uint32_t v = tid < bins ? sz[tid] : 0u;
 	uint32_t inc = wave_incl_sum(v);
 	if (lane == 63) wsum[wave] = inc;
 	__syncthreads();
-	uint32_t pre = 0;
-	for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
-	if (tid < bins) lvl_start[((uint64_t)b << D) + tid] = btab[b] + pre + inc - v;
+	uint32_t pre0 = 0;
+	for (uint32_t i = 0; i < wave; ++i) pre0 += wsum[i];
+	if (tid < bins) lvl_start[((uint64_t)b << D) + tid] = btab[b] + pre0 + inc - v;
 	if (b == nb - 1 && tid == 0) lvl_start[(uint64_t)nb << D] = len;
 }
 
@@ -602,14 +615,21 @@ constexpr int G_NCH = 512;               // runs (chunks of the level-0 bucket) 
 struct FinishSrc {
 	const uint64_t *rec;
 	const uint32_t *bstart;      // starts of the final buckets in the OUTPUT (rank) order, nbF + 1 entries
-	const uint32_t *runtab;      // GATHER: run table of level 1
+	const uint32_t *runtab;      // GATHER: run table of level 1 (start | length << 16), read by the compaction kernel
+	const uint32_t *runpre;      // GATHER: the same rows as start | records before the run << 14 (k_run_totals)
 	const uint32_t *btab;        // GATHER: {start[nb0], tab_off[nb0], nch[nb0]} of the level-0 buckets
 	uint32_t nb0; int D1; uint32_t chunk;
 };
 struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; };
 
+// what a gathering finish needs to know of a bucket before it starts: fetched one bucket AHEAD by k_finish_rows, so that
+// the only global-memory round trip a bucket waits for is that of its records
+struct RowAhead { uint32_t s1; uint32_t v, vn; };          // end of the bucket in rank order; this thread's word of the row and the next one
+struct RowBucket { uint32_t nch, tab_off, start; };        // level-0 bucket: its chunks, its rows in the run table, its first record
+
 template <bool WRITE_SA, int THREADS, bool GATHER>
-__device__ __forceinline__ void finish_bucket(const uint32_t b, const FinishSrc &S, int fbits, const FinishLists &L, const SortOut &O)
+__device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s0, const uint32_t m, const RowBucket &RB, const RowAhead &RA,
+                                              const FinishSrc &S, int fbits, const FinishLists *Lp, const SortOut &O)
 {
 	constexpr int F_THREADS = THREADS, F_CAP = THREADS * 12, F_PER = 12, F_WAVES = THREADS / 64;
 	constexpr int IDXB = F_CAP <= 8192 ? 13 : 14;             // index field of an entry
@@ -619,19 +639,20 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const FinishSrc 
 	__shared__ __attribute__((aligned(16))) uint8_t obwt[OBWT_N];
 	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
-	__shared__ uint32_t rpre[GATHER ? G_NCH + 1 : 1];         // GATHER: exclusive prefix of the run lengths
-	__shared__ uint32_t radr[GATHER ? G_NCH : 1];             // GATHER: record index of every run's first record
+	__shared__ __attribute__((aligned(8))) uint2 rr[GATHER ? G_NCH + 1 : 1];   // GATHER: per run {records of the bucket before it, index of its first record}
 	__shared__ uint16_t gfirst[GATHER ? GF_N : 1];            // GATHER: run holding slot 64 g
+	__shared__ __attribute__((aligned(16))) uint4 gdesc[GATHER ? GF_N : 1];    // GATHER: where the 64 slots of group g are (see below)
+	__shared__ uint32_t gdesc2[GATHER ? GF_N : 1];
+	__shared__ uint32_t s_more;
 	static_assert(F_CAP <= (1 << IDXB), "index field of an entry");
 	static_assert(F_PER % 6 == 0, "rank phase works on six records at a time");
 	static_assert(!GATHER || THREADS >= G_NCH, "one run per thread");
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
 	if (m == 0) return;
-	uint32_t nch = 0, b0 = 0;
-	if (GATHER) { b0 = b >> S.D1; nch = S.btab[2 * S.nb0 + b0]; }
+	const uint32_t nch = GATHER ? RB.nch : 0u;
 	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
 		if (tid == 0) {
+			const FinishLists L = *Lp;                          // cold: the lists live in device memory, not in the kernel's registers
 			if (L.midlist && m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
 			else if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
 				uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b;
@@ -642,39 +663,62 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const FinishSrc 
 	}
 	uint64_t r[F_PER];
 	if (GATHER) {
-		// ---- map the bucket's slots onto the runs of its row of the run table ----
-		const uint32_t *row = S.runtab + S.btab[S.nb0 + b0] + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
-		const uint32_t rent = tid < nch ? row[tid] : 0u;
-		const uint32_t rc = rent >> 16;
-		const uint32_t inc = wave_incl_sum(rc);
-		if (lane == 63) wsum[wave] = inc;
-		__syncthreads();
-		uint32_t ex = inc - rc;
-		for (uint32_t i = 0; i < wave; ++i) ex += wsum[i];
-		if (tid < nch) { rpre[tid] = ex; radr[tid] = S.btab[b0] + tid * S.chunk + (rent & 0xFFFFu); }
-		if (tid == nch - 1) rpre[nch] = ex + rc;               // = m
-		__syncthreads();
+		// ---- map the bucket's slots onto the runs of its row (start | records before the run << 14, k_run_totals) ----
 		const uint32_t glast = (m - 1) >> 6;
-		if (tid <= glast + 1) {                                // largest run j with rpre[j] <= 64 tid (empty runs are skipped over)
-			const uint32_t target = tid << 6;
-			uint32_t lo = 0, hi = nch;
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; LDS_CHK(mid, G_NCH + 1); if (rpre[mid] <= target) lo = mid; else hi = mid; }
-			LDS_CHK(tid, GF_N);
-			gfirst[tid] = (uint16_t)lo;
+		{
+			const uint32_t v = RA.v, vn = tid + 1 < nch ? RA.vn : (m << 14);
+			const uint32_t pre = v >> 14, end = vn >> 14;
+			if (tid < nch) {
+				LDS_CHK(tid, G_NCH);
+				rr[tid] = make_uint2(pre, RB.start + tid * S.chunk + (v & 0x3FFFu));
+				for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) { LDS_CHK(g, GF_N); gfirst[g] = (uint16_t)tid; }     // the run holding slot 64 g (empty runs write nothing)
+			}
+			if (tid == 0) { rr[nch] = make_uint2(m, 0u); LDS_CHK(glast + 1, GF_N); gfirst[glast + 1] = (uint16_t)(nch - 1); s_more = 0u; }
 		}
 		__syncthreads();
+		// one descriptor per group of 64 slots: the group starts inside run j0 and up to three more runs begin inside it
+		// (runs are ~64 records): {o1 | o2 << 8 | o3 << 16, A, B - o1, C - o2} and D - o3: slot x of the group is record
+		// A + x below o1, (B - o1) + x below o2, ...  A bucket with a group that meets more than four runs (many short
+		// runs: skewed composition) is listed and takes the copy-together path instead.
+		if (tid <= glast) {
+			const uint32_t sl = tid << 6;
+			LDS_CHK(tid + 1, GF_N);
+			const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
+			const uint2 q0 = rr[j0];
+			uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
+			for (uint32_t i = j0 + 1; i <= j1 && i < nch; ++i) {
+				LDS_CHK(i + 1, G_NCH + 1);
+				const uint2 qi = rr[i];
+				if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;         // empty, or begins beyond the group
+				const uint32_t oo = qi.x - sl, bb = qi.y - oo;
+				if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
+				++found;
+			}
+			if (found > 3) s_more = 1u;
+			LDS_CHK(tid, GF_N);
+			gdesc[tid] = make_uint4(o1 | (o2 << 8) | (o3 << 16), q0.y + (sl - q0.x), b1, b2);
+			gdesc2[tid] = b3;
+		}
+		__syncthreads();
+		if (s_more) {
+			if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+			return;
+		}
+		uint32_t adr[F_PER];
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) {
 			const uint32_t eu = k * F_THREADS + tid;
 			const uint32_t e = eu < m ? eu : m - 1;
 			uint32_t g = (uint32_t)(k * F_WAVES) + wave; g = g < glast ? g : glast;       // wave-uniform
-			LDS_CHK(g + 1, GF_N);
-			const uint32_t j0 = __builtin_amdgcn_readfirstlane((uint32_t)gfirst[g]), j1 = __builtin_amdgcn_readfirstlane((uint32_t)gfirst[g + 1]);
-			uint32_t j = j0;
-			for (uint32_t i = j0 + 1; i <= j1; ++i) { LDS_CHK(i, G_NCH + 1); j += rpre[i] <= e ? 1u : 0u; }
-			LDS_CHK(j, G_NCH);
-			r[k] = S.rec[(uint64_t)radr[j] + (e - rpre[j])];
+			LDS_CHK(g, GF_N);
+			const uint4 d = gdesc[g];
+			const uint32_t d3 = gdesc2[g];
+			const uint32_t x = e - (g << 6);
+			const uint32_t o1 = d.x & 0xFFu, o2 = (d.x >> 8) & 0xFFu, o3 = d.x >> 16;
+			adr[k] = (x >= o3 ? d3 : x >= o2 ? d.w : x >= o1 ? d.z : d.y) + x;
 		}
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) r[k] = S.rec[adr[k]];
 	} else {
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = S.rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
@@ -820,16 +864,39 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const FinishSrc 
 	}
 }
 
-template <bool WRITE_SA, int THREADS, bool GATHER>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, const uint32_t *todo, FinishLists L, SortOut O)
+template <bool WRITE_SA, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, const uint32_t *todo, const FinishLists *L, SortOut O)
 {
-	if (!todo) { finish_bucket<WRITE_SA, THREADS, GATHER>(blockIdx.x, S, fbits, L, O); return; }
+	const RowBucket RB{0u, 0u, 0u}; const RowAhead RA{0u, 0u, 0u};
+	if (!todo) {
+		const uint32_t s0 = S.bstart[blockIdx.x], m = S.bstart[blockIdx.x + 1] - s0;
+		finish_bucket<WRITE_SA, THREADS, false>(blockIdx.x, s0, m, RB, RA, S, fbits, L, O); return;
+	}
 	// listed buckets: a fixed grid strides over the list (an empty list costs nothing)
 	const uint32_t cnt = todo[0];
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
-		finish_bucket<WRITE_SA, THREADS, GATHER>(todo[1 + it], S, fbits, L, O);
+		const uint32_t b = todo[1 + it];
+		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O);
 		__syncthreads();
 	}
+}
+
+// The gathering finish: one workgroup per final bucket, consecutive workgroups = consecutive digits of one level-0 bucket
+// (they read neighbouring runs of the same chunks at about the same time).  Bounds, level-0 bucket entry and the thread's
+// words of the run-table row are all requested before anything waits.
+template <bool WRITE_SA, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbits, const FinishLists *L, SortOut O)
+{
+	const uint32_t tid = threadIdx.x, b = blockIdx.x;
+	const uint32_t b0 = b >> S.D1;
+	const RowBucket RB{S.btab[2 * S.nb0 + b0], S.btab[S.nb0 + b0], S.btab[b0]};
+	const uint32_t s0 = S.bstart[b], s1 = S.bstart[b + 1];
+	if (s1 == s0) return;                                      // empty (a suffix-range shard keeps a digit range; nch may be 0)
+	const uint32_t tc = tid < RB.nch ? tid : RB.nch - 1, tn = tc + 1 < RB.nch ? tc + 1 : tc;
+	const uint32_t *row = S.runpre + RB.tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * RB.nch;
+	const RowAhead RA{s1, row[tc], row[tn]};
+	finish_bucket<WRITE_SA, THREADS, true>(b, s0, s1 - s0, RB, RA, S, fbits, L, O);
 }
 
 // Buckets the gathering finish has listed (above its LDS capacity, or spread over more runs than it maps): their runs are
@@ -1186,9 +1253,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_REQUIRE((uint64_t)nbF + 1 <= MSD_TAB_MAX, "MSD level table too small");
 		{
 			Scope sc(tl, KF_SCAN, 4ull * toff);
-			hipLaunchKernelGGL(k_run_totals, dim3(bins0), dim3(256), 0, s, M.runtab, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
+			hipLaunchKernelGGL(k_run_totals, dim3(bins0), dim3(256), 0, s, M.runtab, M.runpre, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
 		}
-		FS.rec = ws.keyB; FS.runtab = M.runtab; FS.btab = M.bucket_tab; FS.nb0 = bins0; FS.D1 = dg.D1; FS.chunk = (uint32_t)L1_CHUNK;
+		FS.rec = ws.keyB; FS.runtab = M.runtab; FS.runpre = M.runpre; FS.btab = M.bucket_tab; FS.nb0 = bins0; FS.D1 = dg.D1; FS.chunk = (uint32_t)L1_CHUNK;
 		gather = true;
 	}
 	// ---- finish: every final bucket sorted inside LDS; compulsory traffic = records in, BWT byte (+ SA entry) out ----
@@ -1204,21 +1271,24 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
 		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
-		const FinishLists L1st{M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap};
-		const FinishLists L2nd{nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap};
+		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap},
+		                           {nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap}};
+		FinishLists *dl = reinterpret_cast<FinishLists *>(M.lists);       // [0]: first launch (lists mid / big / huge), [1]: the mid launch
+		B3M_HIP(hipMemcpyAsync(dl, hl, sizeof hl, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipStreamSynchronize(s));                                 // hl lives on this stack frame
 		if (gather) {
-			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512, true>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
-			else hipLaunchKernelGGL((k_finish_lds<false, 512, true>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
+			if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, dl, O);
+			else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, dl, O);
 			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
 			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
 			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
 		} else {
-			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512, false>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
-			else hipLaunchKernelGGL((k_finish_lds<false, 512, false>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, L1st, O);
+			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, dl, O);
+			else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, dl, O);
 		}
-		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024, false>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, L2nd, O);
-		else hipLaunchKernelGGL((k_finish_lds<false, 1024, false>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, L2nd, O);
+		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, dl + 1, O);
+		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, dl + 1, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
