@@ -40,6 +40,7 @@ def parse():
                     help="skip the verification after the timed loop (default: the timed isasamplingrate=0 result is compared with an "
                          "isasamplingrate>0 run that is LF-walk-verified against the text, checkbwt semantics)")
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
+    ap.add_argument("--e2e-steps", type=int, default=3, help="host-memory runs (pinned input -> pinned BWT bytes) reported as `e2e`; 0 = skip")
     return ap.parse_args()
 
 
@@ -106,6 +107,30 @@ def verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize)
             % (rate, n, (time.perf_counter() - t0) * 1e3))
 
 
+def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps):
+    """input in host memory (page cache) -> BWT symbols in host memory, through PCIe both ways.
+    Pinned host buffers; the BWT leaves the device in slices while later buckets are still being sorted."""
+    h_text = d_text.cpu().pin_memory()
+    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    plan.run_host(h_text, h_out)                       # warm-up (first touch of the pinned pages)
+    acc = {"h2d_ms": 0.0, "construct_ms": 0.0, "d2h_tail_ms": 0.0, "total_ms": 0.0}
+    streamed = 0
+    for _ in range(steps):
+        t = plan.run_host(h_text, h_out)
+        for k in acc:
+            acc[k] += t[k]
+        streamed = t["streamed_bytes"]
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(h_out, d_out.cpu()))
+    assert ok, "bench e2e: the BWT that arrived in host memory differs from the device-resident result"
+    res = {k: round(v / steps, 3) for k, v in acc.items()}
+    res.update({"value_e2e": round(nbases / (acc["total_ms"] / steps) / 1e6, 4), "unit": "Gbase/s", "steps": steps,
+                "bytes_in": int(h_text.numel()), "bytes_out": int(n), "streamed_bytes": int(streamed), "equals_device_result": ok,
+                "what": "pinned host text -> HBM (PCIe) -> construction -> BWT bytes in pinned host memory (PCIe), wall clock of "
+                        "b3m_plan_run_host; RL file writing is separate (DESIGN.md 4)"})
+    return res
+
+
 def main():
     a = parse()
     import numpy as np
@@ -164,6 +189,9 @@ def main():
                    "parallelism": "1 GPU", "input_gen_s": round(gen_s, 2)},
         "roofline": roof,
     }
+    out["config"]["value_is"] = "device-resident: packed text in HBM -> BWT bytes in HBM (SURVEY 8d end-to-end figure: `e2e`)"
+    if a.e2e_steps > 0:
+        out["e2e"] = measure_e2e(torch, plan, d_text, d_out, n, nbases, a.e2e_steps)
     if a.verify:
         from oracle import oracle as O
         sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)

@@ -38,6 +38,11 @@ class Result(ctypes.Structure):
     ]
 
 
+class E2ETimes(ctypes.Structure):
+    _fields_ = [("h2d_ms", ctypes.c_double), ("construct_ms", ctypes.c_double), ("d2h_tail_ms", ctypes.c_double),
+                ("total_ms", ctypes.c_double), ("streamed_bytes", ctypes.c_uint64)]
+
+
 class KernelTime(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("ms", ctypes.c_double), ("launches", ctypes.c_uint64),
                 ("alg_bytes", ctypes.c_uint64)]
@@ -60,6 +65,9 @@ SYMBOLS = [
     ("b3m_plan_workspace_bytes", _u64, [_p]),
     ("b3m_plan_text_bytes", _u64, [_p]),
     ("b3m_plan_run", _i, [_p, _p, _p, _p]),
+    ("b3m_plan_run_host", _i, [_p, _p, _p, ctypes.POINTER(E2ETimes), _p]),
+    ("b3m_host_alloc", _p, [_u64]),
+    ("b3m_host_free", None, [_p]),
     ("b3m_plan_result", _i, [_p, ctypes.POINTER(Result)]),
     ("b3m_plan_samples", _i, [_p, _p, _u64]),
     ("b3m_plan_histogram", _i, [_p, _p]),

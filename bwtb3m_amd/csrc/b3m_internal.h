@@ -124,6 +124,9 @@ struct MsdWs {
 };
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span);
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);
+// a caller that streams the BWT away while it is being made: the MSD finish runs in `nslices` slices of whole level-0
+// buckets and calls fn(ctx, first, last) on the host once the kernels that make bwt[first, last) final are enqueued
+struct SliceHook { int nslices; void (*fn)(void *ctx, uint64_t first, uint64_t last); void *ctx; };
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
@@ -133,6 +136,7 @@ struct BlockSortWs {
 	RadixWs radix;
 	MsdWs msd;
 	uint32_t *d_scalars = nullptr;    // small device scalars
+	const SliceHook *slice_hook = nullptr;
 	uint64_t *d_symhist_out = nullptr; // optional: the MSD path adds the block's symbol histogram here (it falls out of the level-0 digit counts)
 };
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
@@ -143,6 +147,7 @@ struct BlockSortOut {
 	uint64_t tie_rounds = 0, tie_elements = 0;
 	uint64_t msd_overflow_buckets = 0;
 	bool used_msd = false;
+	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
 	uint64_t kept_len = 0;            // suffixes sorted here (= len unless this is a suffix-range shard)
 	uint64_t slice_offset = 0;        // global rank of the first of them

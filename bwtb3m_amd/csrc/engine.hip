@@ -3,6 +3,7 @@
 // libmaus2::suffixsort::bwtb3m::BwtMergeSortTemplate::computeBwt steps 3-9.
 #include "b3m_internal.h"
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <cstdio>
 
@@ -138,6 +139,8 @@ struct b3m_plan {
 	std::vector<uint64_t> h_hist;          // 256
 	Timeline tl;
 	double kms[KF_COUNT]{}; uint64_t klaunch[KF_COUNT]{}; uint64_t kbytes[KF_COUNT]{};
+	hipStream_t copy_stream = nullptr;     // host-memory runs: slices of the BWT leave on this stream while later buckets sort
+	b3m_e2e_times e2e{};
 };
 
 static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
@@ -354,6 +357,7 @@ uint64_t b3m_plan_slice_capacity(const b3m_plan *p) { return p ? (p->nshards > 1
 void b3m_plan_destroy(b3m_plan *p)
 {
 	if (!p) return;
+	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
 	if (p->arena) (void)hipFree(p->arena);
 	delete p;
 }
@@ -361,20 +365,55 @@ uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 
 uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 0; }
 uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
 
-int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *stream)
+namespace {
+struct HostSink {            // SliceHook context of a host-memory run
+	b3m_plan *p; hipStream_t s; uint8_t *d_bwt; uint8_t *h_bwt; std::vector<hipEvent_t> evs; uint64_t copied = 0;
+	static void slice(void *ctx, uint64_t first, uint64_t last)
+	{
+		HostSink *k = (HostSink *)ctx;
+		if (last <= first) return;
+		hipEvent_t e = k->p->tl.get();
+		B3M_HIP(hipEventRecord(e, k->s));
+		B3M_HIP(hipStreamWaitEvent(k->p->copy_stream, e, 0));
+		B3M_HIP(hipMemcpyAsync(k->h_bwt + first, k->d_bwt + first, last - first, hipMemcpyDeviceToHost, k->p->copy_stream));
+		k->evs.push_back(e); k->copied += last - first;
+	}
+};
+}
+
+static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_in, uint8_t *d_bwt_out, uint8_t *h_bwt_out, void *stream)
 {
 	B3M_TRY
-	B3M_REQUIRE(p && d_text_in && d_bwt_out, "b3m_plan_run: null argument");
+	const bool host = h_text_in != nullptr;
+	B3M_REQUIRE(p && (host ? (h_bwt_out != nullptr) : (d_text_in && d_bwt_out)), "b3m_plan_run: null argument");
 	hipStream_t s = (hipStream_t)stream;
+	hipEvent_t evh0 = nullptr, evh1 = nullptr, evh2 = nullptr, evh3 = nullptr;
+	HostSink sink{p, s, nullptr, h_bwt_out, {}, 0};
+	SliceHook hook{8, &HostSink::slice, &sink};
+	double wall0 = 0;
+	if (host) {
+		B3M_REQUIRE(p->nshards == 1, "host-memory runs need an unsharded plan");
+		if (!p->copy_stream) B3M_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+		d_bwt_out = p->d_bwt[0];                    // one block: the leaf sort writes here; several: the last level is copied here
+		sink.d_bwt = d_bwt_out;
+		p->e2e = b3m_e2e_times{};
+	}
 	const uint64_t n = p->n, B = p->leaves.size();
 	Timeline *tl = &p->tl;
 	tl->reset(); tl->stream = s; tl->enabled = true;
 	hipEvent_t ev0 = tl->get(), ev1 = tl->get();
+	if (host) {
+		evh0 = tl->get(); evh1 = tl->get(); evh2 = tl->get(); evh3 = tl->get();
+		B3M_HIP(hipStreamSynchronize(s));
+		wall0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		B3M_HIP(hipEventRecord(evh0, s));
+	}
 	B3M_HIP(hipEventRecord(ev0, s));
 	// resident, padded copy of the packed text
 	uint64_t tb = packed_text_bytes(n, p->type);
 	B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
-	B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+	if (host) { B3M_HIP(hipMemcpyAsync(p->d_text, h_text_in, tb, hipMemcpyHostToDevice, s)); B3M_HIP(hipEventRecord(evh1, s)); }
+	else B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
 	B3M_HIP(hipMemsetAsync(p->d_hist, 0, 8 * 256 * B, s));
 	B3M_HIP(hipMemsetAsync(p->d_anchors, 0, 4 * (p->total_anchors + 1), s));
@@ -391,8 +430,10 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
 		// one block: its BWT is the result and goes straight to the caller's buffer
 		p->bs.d_symhist_out = p->d_hist + 256 * k;
+		p->bs.slice_hook = (host && B == 1) ? &hook : nullptr;
 		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out : p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
-		p->bs.d_symhist_out = nullptr;
+		p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr;
+		if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
 		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 		p->res.tie_elements += so.tie_elements;
@@ -479,7 +520,18 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 		}
 		cur = nxt;
 	}
-	if (B > 1) B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], n, hipMemcpyDeviceToDevice, s));
+	if (B > 1 && !host) B3M_HIP(hipMemcpyAsync(d_bwt_out, p->d_bwt[cur], n, hipMemcpyDeviceToDevice, s));
+	if (host) {
+		B3M_HIP(hipEventRecord(evh2, s));                                   // construction done
+		if (sink.copied != n) {                                                 // nothing streamed (several blocks, small input) or rewritten slices: one copy of the whole result
+			B3M_HIP(hipStreamSynchronize(p->copy_stream));
+			B3M_HIP(hipMemcpyAsync(h_bwt_out, B > 1 ? p->d_bwt[cur] : d_bwt_out, n, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipEventRecord(evh3, s));
+		} else {
+			B3M_HIP(hipEventRecord(evh3, p->copy_stream));
+			B3M_HIP(hipStreamWaitEvent(s, evh3, 0));
+		}
+	}
 	uint64_t p0pair[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipEventRecord(ev1, s));
@@ -494,6 +546,16 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	}
 	float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
 	p->res.ms_total = ms;
+	if (host) {
+		B3M_HIP(hipStreamSynchronize(p->copy_stream));
+		const double wall1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		float a = 0, b = 0, c = 0;
+		(void)hipEventElapsedTime(&a, evh0, evh1); (void)hipEventElapsedTime(&b, evh1, evh2); (void)hipEventElapsedTime(&c, evh2, evh3);
+		p->e2e.h2d_ms = a; p->e2e.construct_ms = b; p->e2e.d2h_tail_ms = c > 0 ? c : 0; p->e2e.total_ms = wall1 - wall0;
+		p->e2e.streamed_bytes = sink.copied == n ? n : 0;
+		for (auto e : sink.evs) tl->pool.push_back(e);
+		tl->pool.push_back(evh0); tl->pool.push_back(evh1); tl->pool.push_back(evh2); tl->pool.push_back(evh3);
+	}
 	tl->collect(p->kms, p->klaunch, p->kbytes);
 	tl->pool.push_back(ev0); tl->pool.push_back(ev1);
 	p->res.ms_sort = p->kms[KF_KEYS] + p->kms[KF_RADIX_HIST] + p->kms[KF_SCAN] + p->kms[KF_RADIX_SCATTER] + p->kms[KF_TIES] + p->kms[KF_EMIT]
@@ -514,6 +576,26 @@ int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *s
 	return 0;
 	B3M_CATCH(1)
 }
+
+int b3m_plan_run(b3m_plan *p, const void *d_text_in, uint8_t *d_bwt_out, void *stream)
+{
+	if (!d_text_in) { set_error("b3m_plan_run: null argument"); return 1; }
+	return plan_run_impl(p, d_text_in, nullptr, d_bwt_out, nullptr, stream);
+}
+int b3m_plan_run_host(b3m_plan *p, const void *h_text, uint8_t *h_bwt_out, b3m_e2e_times *times, void *stream)
+{
+	if (!h_text) { set_error("b3m_plan_run_host: null argument"); return 1; }
+	int rc = plan_run_impl(p, nullptr, h_text, nullptr, h_bwt_out, stream);
+	if (rc == 0 && times) *times = p->e2e;
+	return rc;
+}
+void *b3m_host_alloc(uint64_t bytes)
+{
+	void *q = nullptr;
+	if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return nullptr; }
+	return q;
+}
+void b3m_host_free(void *q) { if (q) (void)hipHostFree(q); }
 
 int b3m_plan_result(const b3m_plan *p, b3m_result *out)
 {

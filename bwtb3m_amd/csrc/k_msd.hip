@@ -338,18 +338,20 @@ __global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 	const int bins = 1 << A.D;
 	const MsdTile tile = A.tiles[blockIdx.x];
 	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;       // <= TCH
+	uint64_t rec[MSD_ITEMS];
+	// all 16 loads of a chunk go out back to back (clamped index, no branch around a load); the loads of chunk c+1 are
+	// issued before chunk c is copied out, so that the read stream and the write stream overlap inside the one workgroup a CU holds
+	{
+		const uint32_t nv0 = tile.count < (uint32_t)CHUNK ? tile.count : (uint32_t)CHUNK;
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) { uint32_t e = s * THREADS + tid; rec[s] = A.rec_in[(uint64_t)tile.in_off + (e < nv0 ? e : nv0 - 1)]; }
+	}
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const uint32_t cbase = c * CHUNK;
 		const uint32_t nvalid = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
 		for (int b = tid; b < bins; b += THREADS) cnt[b] = 0;
 		__syncthreads();
-		uint64_t rec[MSD_ITEMS]; uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS];
-		// all 16 loads go out back to back (clamped index, no branch around a load)
-		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) {
-			uint32_t e = s * THREADS + tid;
-			rec[s] = A.rec_in[(uint64_t)tile.in_off + cbase + (e < nvalid ? e : nvalid - 1)];
-		}
+		uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS];
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
 		#pragma unroll
@@ -368,6 +370,11 @@ __global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 		__syncthreads();
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) srec[binstart[dg[s]] + slot[s]] = rec[s];
+		if (c + 1 < nchunks) {
+			const uint32_t nb1 = cbase + CHUNK, nv1 = tile.count - nb1 < (uint32_t)CHUNK ? tile.count - nb1 : (uint32_t)CHUNK;
+			#pragma unroll
+			for (int s = 0; s < MSD_ITEMS; ++s) { uint32_t e = s * THREADS + tid; rec[s] = A.rec_in[(uint64_t)tile.in_off + nb1 + (e < nv1 ? e : nv1 - 1)]; }
+		}
 		__syncthreads();
 		uint64_t *out = A.rec_out + (uint64_t)tile.in_off + cbase;
 		for (uint32_t p = tid; p < nvalid; p += THREADS) out[p] = srec[p];
@@ -865,12 +872,13 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 }
 
 template <bool WRITE_SA, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, const uint32_t *todo, const FinishLists *L, SortOut O)
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, uint32_t b_first, const uint32_t *todo, const FinishLists *L, SortOut O)
 {
 	const RowBucket RB{0u, 0u, 0u}; const RowAhead RA{0u, 0u, 0u};
 	if (!todo) {
-		const uint32_t s0 = S.bstart[blockIdx.x], m = S.bstart[blockIdx.x + 1] - s0;
-		finish_bucket<WRITE_SA, THREADS, false>(blockIdx.x, s0, m, RB, RA, S, fbits, L, O); return;
+		const uint32_t b = b_first + blockIdx.x;
+		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O); return;
 	}
 	// listed buckets: a fixed grid strides over the list (an empty list costs nothing)
 	const uint32_t cnt = todo[0];
@@ -886,9 +894,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbit
 // (they read neighbouring runs of the same chunks at about the same time).  Bounds, level-0 bucket entry and the thread's
 // words of the run-table row are all requested before anything waits.
 template <bool WRITE_SA, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbits, const FinishLists *L, SortOut O)
+__global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *L, SortOut O)
 {
-	const uint32_t tid = threadIdx.x, b = blockIdx.x;
+	const uint32_t tid = threadIdx.x, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
 	const RowBucket RB{S.btab[2 * S.nb0 + b0], S.btab[S.nb0 + b0], S.btab[b0]};
 	const uint32_t s0 = S.bstart[b], s1 = S.bstart[b + 1];
@@ -1074,15 +1082,17 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // symbols; they are ordered by the next 31 bases (one gather each), by full comparison if that
 // does not decide.  Groups are at most LS_TIE_CAP long (longer ones are on the overflow list and
 // set no bits); the length guard only keeps a corrupt bitmap from running away.
-__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint32_t eq_syms, uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+// The launch covers the records [lo, hi) (tie groups never cross a bucket, so slices of whole buckets are independent).
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
 {
-	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t nwords = (len + 31) >> 5;
-	if (w >= nwords) return;
+	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if ((w << 5) >= hi) return;
 	uint32_t bits = tiebits[w];
 	if (!bits) return;
 	uint32_t prevbit = w ? (tiebits[w - 1] >> 31) : 0u;
 	uint32_t starts = bits & ~((bits << 1) | prevbit);          // set bits whose predecessor bit is clear
+	if ((w << 5) < lo) starts &= ~((1u << (lo - (w << 5))) - 1u);             // runs of the neighbouring slices are theirs
+	if ((w << 5) + 32 > hi) starts &= (1u << (hi - (w << 5))) - 1u;
 	while (starts) {
 		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
 		uint64_t q = (w << 5) + k;                               // first tied record; head = q-1
@@ -1211,6 +1221,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const uint64_t *cur = ws.keyA; uint64_t *other = ws.keyB;
 	uint32_t nbF = bins0;               // final buckets
 	const int consumed = dg.D1;         // key-field bits used by level 1
+	bool sliced = false;
 	FinishSrc FS{};                     // where the finish finds the records of a final bucket
 	FS.bstart = M.lvl_start;
 	bool gather = false;
@@ -1276,19 +1287,43 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		FinishLists *dl = reinterpret_cast<FinishLists *>(M.lists);       // [0]: first launch (lists mid / big / huge), [1]: the mid launch
 		B3M_HIP(hipMemcpyAsync(dl, hl, sizeof hl, hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));                                 // hl lives on this stack frame
+		// The first launch goes out in slices of whole level-0 buckets (one slice unless the caller streams the result away:
+		// ws.slice_hook), each followed by the tie fix of its records: after that a slice of the BWT is final unless one
+		// of its buckets was listed (out.late_writes).
+		const uint32_t nsl = (ws.slice_hook && ws.slice_hook->nslices > 1 && dg.D1 > 0) ? (uint32_t)std::min<uint64_t>(ws.slice_hook->nslices, bins0) : 1u;
+		std::vector<uint32_t> lvl0;                                       // starts of the level-0 buckets (rank order) at the slice borders
+		if (nsl > 1) {
+			lvl0.resize(nsl + 1);
+			std::vector<uint32_t> hs(bins0 + 1);
+			B3M_HIP(hipMemcpyAsync(hs.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			for (uint32_t i = 0; i <= nsl; ++i) lvl0[i] = hs[(uint64_t)bins0 * i / nsl];
+		}
+		for (uint32_t sl = 0; sl < nsl; ++sl) {
+			const uint32_t l0a = (uint32_t)((uint64_t)bins0 * sl / nsl), l0b = (uint32_t)((uint64_t)bins0 * (sl + 1) / nsl);
+			const uint32_t bfa = nsl > 1 ? l0a << dg.D1 : 0u, bfb = nsl > 1 ? l0b << dg.D1 : nbF;
+			const uint64_t ra = nsl > 1 ? lvl0[sl] : 0, rb = nsl > 1 ? lvl0[sl + 1] : len;
+			if (bfb == bfa) continue;
+			if (gather) {
+				if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+			} else {
+				if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, dl, O);
+				else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, dl, O);
+			}
+			if (nsl > 1) {
+				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0);
+				ws.slice_hook->fn(ws.slice_hook->ctx, ra, rb);
+			}
+		}
 		if (gather) {
-			if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, dl, O);
-			else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, dl, O);
 			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
 			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
 			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
-		} else {
-			if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, dl, O);
-			else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(nbF), dim3(512), 0, s, FS, fbits, (const uint32_t *)nullptr, dl, O);
 		}
-		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, dl + 1, O);
-		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, (const uint32_t *)M.midlist, dl + 1, O);
+		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
+		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
@@ -1297,15 +1332,27 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
 		else
 			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+		sliced = nsl > 1;
 	}
-	{
+	if (sliced) {
+		// every slice has had its tie fix; only buckets that were listed (skewed input) still have open ties, and they were
+		// written after their slice was handed to the hook
+		uint32_t lc[3] = {0, 0, 0};
+		B3M_HIP(hipMemcpyAsync(&lc[0], M.midlist, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipMemcpyAsync(&lc[1], M.biglist, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipMemcpyAsync(&lc[2], M.hugelist, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		out.late_writes = (lc[0] | lc[1] | lc[2]) != 0;
+	}
+	if (!sliced || out.late_writes) {
 		Scope sc(tl, KF_TIES, len / 8);
-		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, eq_syms, sa, d_bwt, start, d_p0);
+		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
 	}
 	uint32_t nov = 0;
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	out.msd_overflow_buckets = nov;
+	if (nov) out.late_writes = true;
 	bool rerun_with_sa = false;
 	if (nov) {
 		// ---- fallback: the overflow list (hot bins, oversized sub-buckets, huge buckets) goes through the list-based rounds ----

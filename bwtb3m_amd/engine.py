@@ -91,6 +91,14 @@ class Plan:
             return d_out[: self.result()["slice_len"]]
         return d_out
 
+    def run_host(self, h_text, h_out):
+        """the same pass from host memory to host memory (b3m_plan_run_host): h_text / h_out are CPU uint8 tensors, pinned
+        for asynchronous copies.  Returns the HIP-event / wall-clock splits of the run."""
+        assert not h_text.is_cuda and not h_out.is_cuda and h_text.numel() >= self.text_bytes and h_out.numel() >= self.n
+        t = _lib.E2ETimes()
+        check(lib().b3m_plan_run_host(self._h, _ptr(h_text), _ptr(h_out), ctypes.byref(t), _stream()))
+        return {k: getattr(t, k) for k, _ in _lib.E2ETimes._fields_}
+
     def result(self):
         r = _lib.Result()
         check(lib().b3m_plan_result(self._h, ctypes.byref(r)))

@@ -107,6 +107,22 @@ uint64_t  b3m_plan_text_bytes(const b3m_plan *p);            /* packed input siz
  * d_bwt_out: n bytes, one symbol per byte, in rank order. */
 int b3m_plan_run(b3m_plan *p, const void *d_text, uint8_t *d_bwt_out, void *stream);
 
+/* The same pass from HOST memory to HOST memory: what SURVEY.md 8(d) calls end to end (input in the page cache -> BWT symbols in
+ * host memory; role of the file -> memory and memory -> encoder hand-offs around BwtMergeSort::computeBwt,
+ * /root/reference/src/bwtb3m.cpp:63).  h_text: b3m_plan_text_bytes() bytes, h_bwt_out: n bytes; pinned memory (b3m_host_alloc) makes
+ * both copies asynchronous.  One block: the BWT leaves the device in slices of whole buckets, in rank order, while later buckets are
+ * still being sorted.  times (may be NULL): HIP-event splits of this run. */
+typedef struct b3m_e2e_times {
+	double h2d_ms;         /* packed text, host -> HBM */
+	double construct_ms;   /* first kernel .. last kernel (slices of the BWT already leave during this) */
+	double d2h_tail_ms;    /* device -> host copies still running after the last kernel */
+	double total_ms;       /* host wall clock: call entry (stream idle) .. last byte in host memory */
+	uint64_t streamed_bytes; /* bytes of the BWT that left in slices during construction (0: one copy at the end) */
+} b3m_e2e_times;
+int   b3m_plan_run_host(b3m_plan *p, const void *h_text, uint8_t *h_bwt_out, b3m_e2e_times *times, void *stream);
+void *b3m_host_alloc(uint64_t bytes);     /* pinned host memory (hipHostMalloc) */
+void  b3m_host_free(void *p);
+
 typedef struct b3m_result {
 	uint64_t n, num_blocks, levels;
 	uint64_t p0;                 /* rank of the rotation starting at position 0 (pacterm: BWA "primary") */
