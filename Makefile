@@ -33,8 +33,16 @@ bin/%: $(CSRC)/host/cli_%.cpp $(LIB) $(HDRS)
 oracle:
 	$(MAKE) -C oracle -s
 
+# debug build: every LDS index of the finish kernel is checked against its array and traps (B3M_LIB=bwtb3m_amd/libb3m_dbg.so)
+DBG_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/dbg_%.o,$(HIP_SRCS))
+$(OBJDIR)/dbg_%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DB3M_CHECK_LDS -c $< -o $@
+debug: $(DBG_OBJS) $(HOST_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o bwtb3m_amd/libb3m_dbg.so $^ -pthread
+
 clean:
 	rm -rf $(OBJDIR) $(LIB) bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean debug

@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libb3m.so")
+# B3M_LIB: another build of the same library (the LDS-checking debug build, `make debug`); never a different backend
+_SO = os.environ.get("B3M_LIB") or os.path.join(_HERE, "libb3m.so")
 
 INPUT_TYPES = {"bytestream": 0, "compactstream": 1, "pac": 2, "pacterm": 3, "lz4": 4, "utf-8": 5}
 

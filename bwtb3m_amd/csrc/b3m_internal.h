@@ -131,6 +131,7 @@ struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
 	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
+	uint8_t *sa_hi = nullptr;                    // texts of 2^32 symbols and more: bits 32.. of the suffix array entries (MSD path)
 	uint32_t *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each); t[5] = ISA of the doubling rounds
 	uint32_t *scan_ws = nullptr;
 	RadixWs radix;
@@ -144,6 +145,7 @@ uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0);
 void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span = 0);
 struct BlockSortOut {
 	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions
+	uint8_t *d_sa_hi = nullptr;       // their bits 32.. (texts of 2^32 symbols and more), else null
 	uint64_t tie_rounds = 0, tie_elements = 0;
 	uint64_t msd_overflow_buckets = 0;
 	bool used_msd = false;
@@ -174,8 +176,8 @@ void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, ui
              hipStream_t s);
 // gt bits of the block's own positions (start, start+len) from the text alone (no SA needed)
 void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t *d_gt_abs, hipStream_t s);
-// sample of position k*rate -> pairs[k - first] = (rank, pos); slots of other shards stay untouched
-void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint64_t first, uint64_t cap,
+// sample of position k*rate -> pairs[k - first] = (rank + rank_off, pos); slots of other shards stay untouched
+void emit_samples(const uint32_t *d_sa, const uint8_t *d_sa_hi, uint64_t len, uint64_t rate, uint64_t rank_off, uint64_t *d_pairs, uint64_t first, uint64_t cap,
                   hipStream_t s);
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum /* += */, hipStream_t s);
@@ -202,10 +204,12 @@ struct GapWalkArgs {
 };
 void gap_walk(const GapWalkArgs &A, hipStream_t s);
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
-void lf_walk(const TextView &T, const RankDict &rd, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out,
-             unsigned long long *d_mismatch, hipStream_t s);
+// d_blocks: rank dictionary of the whole BWT (rank_build64), p0 = rank of the terminator entry (~0: none), C = symbol starts
+void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
+void lf_walk(const TextView &T, const uint32_t *d_blocks, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
+             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
-                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
 void interleave(const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr,
                 uint8_t *d_out, uint32_t *d_tile_q /* scratch: tiles+1 */, hipStream_t s);
 uint64_t interleave_tiles(uint64_t total);

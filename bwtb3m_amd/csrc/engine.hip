@@ -46,9 +46,11 @@ __global__ void k_set_endbit(const uint32_t *rank, const uint64_t *p0pair, uint3
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0 && (uint64_t)rank[0] > p0pair[0]) atomicOr(&gt[bit >> 5], 1u << (bit & 31));
 }
-__global__ void k_p0_to_pair(const uint32_t *p0, uint64_t *pair, uint64_t pos)
+// p0 (rank of the block's first suffix inside the sort just done, 0xFFFFFFFF if that suffix lies in another suffix-range
+// shard) -> (rank + off, pos); an absent p0 leaves the pair as it is (~0: set before the leaves)
+__global__ void k_p0_to_pair(const uint32_t *p0, uint64_t *pair, uint64_t pos, uint64_t off)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0) { pair[0] = p0[0]; pair[1] = pos; }
+	if (threadIdx.x == 0 && blockIdx.x == 0 && p0[0] != 0xFFFFFFFFu) { pair[0] = (uint64_t)p0[0] + off; pair[1] = pos; }
 }
 __global__ void k_emit_gt_ptr(const uint32_t *sa, uint64_t len, uint64_t start, const uint32_t *p0, uint32_t *gt)
 {
@@ -108,6 +110,7 @@ struct MergeT {
 struct b3m_plan {
 	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
 	int shard = 0, nshards = 1; uint64_t shard_cap = 0;   // suffix-range shard of a single-block plan
+	int seq_shards = 1;                                   // texts of 2^32 symbols and more on one GPU: the suffix-range shards of the one block, one after the other
 	std::vector<Leaf> leaves;
 	std::vector<MergeT> merges;
 	std::vector<std::vector<int>> level_merges;         // merge ids per level
@@ -241,7 +244,9 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	            std::string("input type ") + b3m_input_type_name(inputtype) + " is not supported by the GPU engine yet");
 	B3M_REQUIRE(n >= 1, "empty input");
 	B3M_REQUIRE(inputtype != B3M_INPUT_PACTERM || n >= 1, "pacterm needs n >= 1");
-	B3M_REQUIRE(n < (1ull << 32), "n >= 2^32 symbols is not supported yet (u32 positions)");
+	B3M_REQUIRE(n < (1ull << 36), "n >= 2^36 symbols is not supported");
+	B3M_REQUIRE(n < (1ull << 32) || ((inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM) && blocksize == 0),
+	            "texts of 2^32 symbols and more: pac/pacterm only, sorted as suffix-range shards of one block (no blocksize=)");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) throw Error("no HIP device available: libb3m has no CPU fallback");
 	size_t free_b = 0, total_b = 0;
@@ -256,6 +261,13 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		blocksize = n;                                         // one block = the whole text, every rank sorts a rank range of it
 		p->shard_cap = n / nshards + n / 64 + (1ull << 20);    // whole level-0 digits: ~n/256 of imbalance, generous slack
 		if (p->shard_cap > n) p->shard_cap = n;
+		B3M_REQUIRE(p->shard_cap < (1ull << 32), "a suffix-range shard must stay below 2^32 suffixes: use more shards");
+	} else if (n >= (1ull << 32)) {
+		// one GPU, more than 2^32 suffixes: the same shards, run one after the other inside b3m_plan_run (the packed text is
+		// resident once; every shard scans it again and keeps its range of level-0 digits)
+		p->seq_shards = (int)(n / (3ull << 30)) + 1;
+		blocksize = n;
+		p->shard_cap = n / p->seq_shards + n / 64 + (1ull << 20);
 	}
 	// per-suffix bytes of the leaf sort workspace ~ 2*(8+4) + 1 + 12 + radix scratch: see blocksort_ws_bytes
 	if (blocksize == 0) {
@@ -279,10 +291,11 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
 	uint64_t o_text = take(p->text_cap);
 	const uint64_t bwt_cap = (nshards > 1) ? p->shard_cap : n;
+	const bool sharded_sort = nshards > 1 || p->seq_shards > 1;
 	uint64_t o_bwt0 = take(bwt_cap + 16), o_bwt1 = take(B > 1 ? n + 16 : 16);
 	p->gt_words = (n + 1 + 31) / 32 + 2;
 	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
-	const uint64_t sort_cap = (nshards > 1) ? p->shard_cap : p->blocksize;
+	const uint64_t sort_cap = sharded_sort ? p->shard_cap : p->blocksize;
 	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, p->blocksize));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
@@ -419,6 +432,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	B3M_HIP(hipMemsetAsync(p->d_anchors, 0, 4 * (p->total_anchors + 1), s));
 	B3M_HIP(hipMemsetAsync(p->d_endrank, 0, 4 * B, s));
 	B3M_HIP(hipMemsetAsync(p->d_sample_cnt, 0, 4 * (B + 1), s));
+	B3M_HIP(hipMemsetAsync(p->d_p0pairs, 0xFF, 16 * B, s));                // "p0 not seen" until a sort finds the block's first suffix
 	if (B > 1) B3M_HIP(hipMemsetAsync(p->d_gt[0], 0, 4 * p->gt_words, s));
 	p->res = b3m_result{};
 	p->res.n = n; p->res.num_blocks = B; p->res.levels = p->levels;
@@ -426,26 +440,32 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	for (uint64_t k = 0; k < B; ++k) {
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
-		B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
 		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
-		// one block: its BWT is the result and goes straight to the caller's buffer
-		p->bs.d_symhist_out = p->d_hist + 256 * k;
-		p->bs.slice_hook = (host && B == 1) ? &hook : nullptr;
-		block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out : p->d_bwt[0] + lf.a, p->d_p0tmp + k, p->shard, p->nshards, need_sa);
-		p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr;
-		if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
-		p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len;
-		p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
-		p->res.tie_elements += so.tie_elements;
-		{
+		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
+		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
+		if (p->isarate && nsh > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
+		for (int sh = (p->seq_shards > 1 ? 0 : p->shard); sh < (p->seq_shards > 1 ? p->seq_shards : p->shard + 1); ++sh) {
+			B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
+			// one block: its BWT is the result and goes straight to the caller's buffer
+			p->bs.d_symhist_out = (sh == 0 || p->seq_shards == 1) ? p->d_hist + 256 * k : nullptr;      // the histogram of the whole block falls out of every shard's level-0 totals: taken once
+			p->bs.slice_hook = (host && B == 1 && nsh == 1) ? &hook : nullptr;
+			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a, p->d_p0tmp + k, sh, nsh, need_sa);
+			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr;
+			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
+			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
+			p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
+			p->res.tie_elements += so.tie_elements;
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
-			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a);
-			if (!so.symhist_done) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
-			if (p->isarate) {
-				if (p->nshards > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
-				emit_samples(so.d_sa, so.kept_len, p->isarate, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,
+			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a, so.slice_offset);
+			if (!so.symhist_done && (sh == 0 || p->seq_shards == 1)) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
+			if (p->isarate)
+				emit_samples(so.d_sa, so.d_sa_hi, so.kept_len, p->isarate, so.slice_offset, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,
 				             p->sample_off[k + 1] - p->sample_off[k], s);
-			}
+			acc += so.kept_len;
+		}
+		if (p->seq_shards > 1) { B3M_REQUIRE(acc == lf.m, "internal: suffix-range shards do not cover the block"); p->res.slice_offset = 0; p->res.slice_len = acc; }
+		else { p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len; }
+		{
 			if (B > 1) emit_gt_from_text(T, lf.a, lf.m, p->d_gt[0], s);
 		}
 		if (B > 1) {
@@ -537,13 +557,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	B3M_HIP(hipEventRecord(ev1, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
-	p->res.p0 = p0pair[0];
+	p->res.p0 = p0pair[0];                 // a global rank (k_p0_to_pair adds the shard's offset)
 	p->res.has_p0 = 1;
-	if (p->nshards > 1) {
-		// the shard that holds the rotation starting at 0 knows p0 (as a global rank)
-		if ((uint32_t)p0pair[0] == 0xFFFFFFFFu) { p->res.has_p0 = 0; p->res.p0 = ~0ull; }
-		else p->res.p0 = p0pair[0] + p->res.slice_offset;
-	}
+	if (p0pair[0] == ~0ull) { p->res.has_p0 = 0; B3M_REQUIRE(p->nshards > 1, "internal: the block's first suffix was not found"); }   // it lies in another GPU's shard
 	float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1);
 	p->res.ms_total = ms;
 	if (host) {
@@ -567,9 +583,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	if (p->isarate && p->total_samples) {
 		std::vector<uint64_t> raw(2 * p->total_samples);
 		B3M_HIP(hipMemcpy(raw.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
-		if (p->nshards > 1) {
+		if (p->nshards > 1) {            // a shard keeps the samples of its own suffixes (ranks are global already)
 			for (uint64_t i = 0; i < p->total_samples; ++i)
-				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i] + p->res.slice_offset); p->h_samples.push_back(raw[2 * i + 1]); }
+				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
 		} else p->h_samples.swap(raw);
 	}
 	p->res.num_samples = p->h_samples.size() / 2;
@@ -920,7 +936,7 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
 	DevBuf bwt_tmp(d_bwt_out ? 16 : len);
 	block_sort(pt.T, start, len, bs, s, nullptr, so, d_bwt_out ? d_bwt_out : bwt_tmp.as<uint8_t>(), d_p0);
 	if (d_gt_abs) {
-		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, d_p0, d_pair, start);
+		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, d_p0, d_pair, start, (uint64_t)0);
 		emit_gt_from_text(pt.T, start, len, d_gt_abs, s);
 		uint64_t endpos = start + len;
 		B3M_HIP(hipMemcpyAsync(d_ep, &endpos, 8, hipMemcpyHostToDevice, s));
@@ -955,48 +971,46 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	uint64_t K = p->h_samples.size() / 2;
 	const std::vector<uint64_t> &anc = p->h_samples;
 	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
+	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	if (p->type == B3M_INPUT_BYTESTREAM) {
 		// byte alphabet: the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
-		const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
-		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);
+		B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
+		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
 		RadixWs rw; radix_ws_carve(rw, rws.p, n);
 		B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
 		B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
-		B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 4 * (nsa + 1), s));
+		B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
 		lf_walk_bytes(T, d_bwt, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), lf.as<uint32_t>(), rw,
-		              danc.as<uint64_t>(), K, sarate, dsa.as<uint32_t>(), dmis.as<unsigned long long>(), s);
+		              danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
 		unsigned long long mm[2] = {0, 0};
 		B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
-		std::vector<uint32_t> hsa(nsa);
-		if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(hsa.data(), dsa.p, 4 * nsa, hipMemcpyDeviceToHost, s));
+		if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		B3M_HIP(hipGetLastError());
 		mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
-		if (nsa && sa_out) for (uint64_t i = 0; i < nsa; ++i) sa_out[i] = hsa[i];
 		return 0;
 	}
+	// 2-bit alphabets: rank dictionary of the whole BWT; ranks and positions are 64-bit, the cumulative counts in the line
+	// headers 32-bit (every symbol fewer than 2^32 times: texts up to ~16 G uniform bases)
+	for (int c = 0; c < 5; ++c) B3M_REQUIRE(p->h_hist[c] < (1ull << 32), "LF walk: a symbol occurs 2^32 times or more (rank dictionary headers are 32-bit)");
 	uint64_t nb = rank_blocks(n);
-	uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
-	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(4 * (nsa + 1)), dmis(16);
-	uint32_t p032 = (p->type == B3M_INPUT_PACTERM) ? (uint32_t)p->res.p0 : 0xFFFFFFFFu;   // pac: no terminator entry
-	B3M_HIP(hipMemcpyAsync(p0d.p, &p032, 4, hipMemcpyHostToDevice, s));
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
+	const uint64_t p064 = (p->type == B3M_INPUT_PACTERM) ? p->res.p0 : ~0ull;   // pac: no terminator entry
+	B3M_HIP(hipMemcpyAsync(p0d.p, &p064, 8, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
-	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 4 * (nsa + 1), s));
-	rank_build(d_bwt, n, p0d.as<uint32_t>(), p->type, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
-	RankDict rd{};
-	rd.blocks = blocks.as<uint32_t>(); rd.m = n; rd.p0ptr = p0d.as<uint32_t>();
-	if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = p->h_hist[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += p->h_hist[c + 1]; } }
-	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += p->h_hist[c]; } }
-	lf_walk(T, rd, danc.as<uint64_t>(), K, sarate, dsa.as<uint32_t>(), dmis.as<unsigned long long>(), s);
+	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
+	rank_build64(d_bwt, n, p0d.as<uint64_t>(), p->type, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
+	uint64_t C[4];
+	if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = p->h_hist[0]; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += p->h_hist[c + 1]; } }
+	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += p->h_hist[c]; } }
+	lf_walk(T, blocks.as<uint32_t>(), p064, C, danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
 	unsigned long long mm[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
-	std::vector<uint32_t> hsa(nsa);
-	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(hsa.data(), dsa.p, 4 * nsa, hipMemcpyDeviceToHost, s));
+	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
 	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
-	if (nsa && sa_out) for (uint64_t i = 0; i < nsa; ++i) sa_out[i] = hsa[i];
 	return 0;
 	B3M_CATCH(1)
 }

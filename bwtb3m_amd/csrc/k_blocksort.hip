@@ -230,18 +230,18 @@ void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t
 }
 
 // (rank,pos) samples: the sample of position x = k*rate has the fixed slot k - first: no counter
-__global__ void k_emit_samples(const uint32_t *sa, uint64_t len, uint64_t rate, uint64_t *pairs, uint64_t first, uint64_t cap)
+__global__ void k_emit_samples(const uint32_t *sa, const uint8_t *sa_hi, uint64_t len, uint64_t rate, uint64_t rank_off, uint64_t *pairs, uint64_t first, uint64_t cap)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= len) return;
-	uint32_t x = sa[r];
+	const uint64_t x = (uint64_t)sa[r] | (sa_hi ? (uint64_t)sa_hi[r] << 32 : 0ull);
 	const uint32_t r32 = (uint32_t)rate;
 	bool hit; uint64_t q;
 	if ((r32 & (r32 - 1)) == 0) { hit = (x & (r32 - 1)) == 0; q = x >> (31 - __clz(r32)); }     // power of two: no division
 	else { q = x / r32; hit = q * r32 == x; }
 	if (hit) {
 		uint64_t k = q - first;
-		if (k < cap) { pairs[2 * k] = r; pairs[2 * k + 1] = x; }
+		if (k < cap) { pairs[2 * k] = r + rank_off; pairs[2 * k + 1] = x; }
 	}
 }
 // rank of S_x among the sorted block: lower bound by rotation comparison; one thread per query
@@ -282,7 +282,9 @@ uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span)
 	if (span < cap) span = cap;
 	uint64_t b = 0;
 	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
-	b += 6 * al(4 * (cap + 1));                         // tie-list buffers + inverse suffix array of the doubling rounds
+	if (span >= (1ull << 32)) b += al(cap);           // bits 32.. of the suffix array entries
+	if (span >= (1ull << 32)) b += al(cap / 8 + 64);    // tie bitmap only: the list-based rounds (32-bit positions) do not run on such texts
+	else b += 6 * al(4 * (cap + 1));                    // tie-list buffers + inverse suffix array of the doubling rounds
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
 	b += al(msd_ws_bytes(cap, span));
@@ -298,7 +300,10 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span
 	ws.keyB = (uint64_t *)p; p += al(8 * cap);
 	ws.idxA = (uint32_t *)p; p += al(4 * cap);
 	ws.idxB = (uint32_t *)p; p += al(4 * cap);
-	for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
+	ws.sa_hi = nullptr;
+	if (span >= (1ull << 32)) { ws.sa_hi = p; p += al(cap); }
+	if (span >= (1ull << 32)) { for (int i = 0; i < 6; ++i) ws.t[i] = nullptr; ws.t[0] = (uint32_t *)p; p += al(cap / 8 + 64); }
+	else for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
 	msd_ws_carve(ws.msd, p, cap, span); p += al(msd_ws_bytes(cap, span));
@@ -424,7 +429,7 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 {
 	B3M_REQUIRE(nshards > 1 || len <= ws.cap, "block_sort: block larger than workspace");
 	B3M_REQUIRE(nshards <= 1 || msd_applicable(T, len), "suffix-range shards need a 2-bit input of at least 2^18 symbols");
-	B3M_REQUIRE(T.n < (1ull << 32), "n >= 2^32 is not supported yet (u32 positions)");
+	B3M_REQUIRE(T.n < (1ull << 32) || msd_applicable(T, len), "texts of 2^32 symbols and more need a pac/pacterm input (record sort with 36-bit positions)");
 	out = BlockSortOut();
 	if (len == 0) return;
 	if (msd_applicable(T, len)) {
@@ -450,9 +455,10 @@ void emit_gt(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t p0, ui
 {
 	if (len) hipLaunchKernelGGL(k_emit_gt, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, start, p0, d_gt_abs);
 }
-void emit_samples(const uint32_t *d_sa, uint64_t len, uint64_t rate, uint64_t *d_pairs, uint64_t first, uint64_t cap, hipStream_t s)
+void emit_samples(const uint32_t *d_sa, const uint8_t *d_sa_hi, uint64_t len, uint64_t rate, uint64_t rank_off, uint64_t *d_pairs, uint64_t first, uint64_t cap, hipStream_t s)
 {
-	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, rate, d_pairs, first, cap);
+	B3M_REQUIRE(rate < (1ull << 32), "sampling rate out of range");
+	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, d_sa_hi, len, rate, rank_off, d_pairs, first, cap);
 }
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum, hipStream_t s)

@@ -26,12 +26,13 @@ uint64_t rank_blocks(uint64_t m) { return m / RANK_BLK_SYMS + 1; }
 // pass 1: one thread per payload word = 16 consecutive symbols: pack the 2-bit codes, count them
 // with popcounts (the p0 entry is stored as code 0 and not counted).  wc[w] = the four counts of
 // the word, one byte each.
-__global__ __launch_bounds__(256) void k_rank_pack_words(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, int sub, uint32_t *blocks,
+template <typename P0T>
+__global__ __launch_bounds__(256) void k_rank_pack_words(const uint8_t *bwt, uint64_t m, const P0T *p0ptr, int sub, uint32_t *blocks,
                                                            uint32_t *wc, uint64_t nwords)
 {
 	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= nwords) return;
-	const uint32_t p0 = *p0ptr;
+	const uint64_t p0 = sizeof(P0T) == 4 && *p0ptr == (P0T)0xFFFFFFFFu ? ~0ull : (uint64_t)*p0ptr;
 	uint64_t base = w * 16;
 	uint32_t word = 0, valid = 0;           // valid: bit 2k set if symbol k counts
 	if (base + 16 <= m) {
@@ -72,25 +73,38 @@ __global__ void k_rank_headers(uint32_t *blocks, const uint32_t *cnt, uint64_t n
 }
 
 // d_scratch: 4*nb u32 (line counts) followed by 12*nb u32 (word counts)
-void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch,
-                uint32_t *scan_ws, hipStream_t s)
+template <typename P0T>
+static void rank_build_t(const uint8_t *d_bwtL, uint64_t m, const P0T *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch,
+                         uint32_t *scan_ws, hipStream_t s)
 {
 	B3M_REQUIRE(type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
 	uint64_t nb = rank_blocks(m);
 	int sub = (type == B3M_INPUT_PACTERM) ? 1 : 0;
 	uint32_t *cnt = d_scratch, *wc = d_scratch + 4 * nb;
-	hipLaunchKernelGGL(k_rank_pack_words, dim3(nblk(nb * 12)), dim3(256), 0, s, d_bwtL, m, d_p0, sub, d_blocks, wc, nb * 12);
+	hipLaunchKernelGGL(k_rank_pack_words<P0T>, dim3(nblk(nb * 12)), dim3(256), 0, s, d_bwtL, m, d_p0, sub, d_blocks, wc, nb * 12);
 	hipLaunchKernelGGL(k_rank_line_counts, dim3(nblk(nb)), dim3(256), 0, s, wc, nb, cnt);
 	for (int c = 0; c < 4; ++c) exclusive_sum_u32(cnt + c * nb, nb, scan_ws, s);
 	hipLaunchKernelGGL(k_rank_headers, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, cnt, nb);
 }
 
+void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s)
+{
+	rank_build_t<uint32_t>(d_bwtL, m, d_p0, type, d_blocks, d_scratch, scan_ws, s);
+}
+// the same over a BWT of 2^32 symbols and more: the rank of the terminator entry is a 64-bit device scalar (~0: none).  The counts in the
+// line headers stay 32-bit: every symbol must occur fewer than 2^32 times (checked by the caller)
+void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s)
+{
+	rank_build_t<uint64_t>(d_bwt, m, d_p0, type, d_blocks, d_scratch, scan_ws, s);
+}
+
 // rank_c(BWT_L, rho): occurrences of code c in BWT_L[0, rho), p0 entry never counted.
 // rank_c(B,r) counts B[0,r) -- convention of /root/reference/src/bwtdecodeblock.cpp:232-241.
-__device__ __forceinline__ uint32_t rank_query(const RankDict &rd, uint32_t p0, uint32_t code, uint32_t rho)
+template <typename RT>
+__device__ __forceinline__ uint32_t rank_query_t(const uint32_t *blocks, RT p0, uint32_t code, RT rho)
 {
-	uint32_t b = rho / RANK_BLK_SYMS, off = rho - b * RANK_BLK_SYMS;
-	const uint4 *line = reinterpret_cast<const uint4 *>(rd.blocks + (uint64_t)b * 16);
+	const RT b = rho / RANK_BLK_SYMS; const uint32_t off = (uint32_t)(rho - b * RANK_BLK_SYMS);
+	const uint4 *line = reinterpret_cast<const uint4 *>(blocks + (uint64_t)b * 16);
 	uint4 h = line[0], p0v = line[1], p1v = line[2], p2v = line[3];
 	uint32_t hd[4] = {h.x, h.y, h.z, h.w};
 	uint32_t w[12] = {p0v.x, p0v.y, p0v.z, p0v.w, p1v.x, p1v.y, p1v.z, p1v.w, p2v.x, p2v.y, p2v.z, p2v.w};
@@ -108,6 +122,7 @@ __device__ __forceinline__ uint32_t rank_query(const RankDict &rd, uint32_t p0, 
 	if (code == 0 && p0 >= b * RANK_BLK_SYMS && p0 < rho) cnt -= 1;
 	return cnt;
 }
+__device__ __forceinline__ uint32_t rank_query(const RankDict &rd, uint32_t p0, uint32_t code, uint32_t rho) { return rank_query_t<uint32_t>(rd.blocks, p0, code, rho); }
 
 // ------------------------------------------------------------------------------------------------
 // K7 LF walk
@@ -175,12 +190,13 @@ void gap_walk(const GapWalkArgs &A, hipStream_t s)
 // and SA[r] = p is stored when r is a multiple of the SA sampling rate.  The rank the chain
 // arrives with must be anchor k's (checked).
 // ------------------------------------------------------------------------------------------------
+struct RankDict64 { const uint32_t *blocks; uint64_t m; uint64_t p0; uint64_t C[4]; };     // p0 = ~0: no terminator entry
 struct LfWalkArgs {
-	TextView T; RankDict rd;
+	TextView T; RankDict64 rd;
 	const uint64_t *anchors;        // (rank, pos) pairs sorted by pos; pos of anchor 0 is 0
 	uint64_t nanchors;
 	uint64_t sarate;                // 0: no SA samples
-	uint32_t *sa_out;               // ceil(n / sarate) positions
+	uint64_t *sa_out;               // ceil(n / sarate) positions
 	unsigned long long *mismatch;   // [0] symbol mismatches, [1] chain closure mismatches
 };
 __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
@@ -189,9 +205,9 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	if (k >= A.nanchors) return;
 	const TextView &T = A.T;
 	const bool term = T.type == B3M_INPUT_PACTERM;
-	const uint32_t p0 = *A.rd.p0ptr;
+	const uint64_t p0 = A.rd.p0;
 	uint64_t kn = k + 1 == A.nanchors ? 0 : k + 1;
-	uint32_t r = (uint32_t)A.anchors[2 * kn];
+	uint64_t r = A.anchors[2 * kn];
 	uint64_t p = kn ? A.anchors[2 * kn + 1] : T.n;     // the last chain starts at position n == 0
 	const uint64_t pend = A.anchors[2 * k + 1];
 	uint32_t bad = 0;
@@ -200,32 +216,32 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	uint64_t wi = p > pend ? (p - 1) >> 4 : 0;
 	uint32_t word = p > pend ? __builtin_bswap32(tw[wi]) : 0u, wnext = (p > pend && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
 	while (p > pend) {
-		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (uint32_t)(p == T.n ? 0 : p);
+		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
 		const uint64_t q = p - 1;
 		if ((q >> 4) != wi) { wi = q >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
 		const uint32_t base = (word >> (2u * (15u - (uint32_t)(q & 15)))) & 3u;
 		const uint32_t st = term ? (q == T.n - 1 ? 0u : base + 1u) : base;     // symbol preceding the rotation at p
-		uint32_t nr;
+		uint64_t nr;
 		if (term && r == p0) {                          // the BWT holds the terminator here
 			bad += st != 0;
 			nr = 0;                                      // the rotation starting with the terminator is the smallest
 		} else {
-			uint32_t b = r / RANK_BLK_SYMS, off = r - b * RANK_BLK_SYMS;
-			uint32_t word = A.rd.blocks[(uint64_t)b * 16 + 4 + (off >> 4)];
+			const uint64_t b = r / RANK_BLK_SYMS; const uint32_t off = (uint32_t)(r - b * RANK_BLK_SYMS);
+			uint32_t word = A.rd.blocks[b * 16 + 4 + (off >> 4)];
 			uint32_t code = (word >> (2 * (off & 15))) & 3u;
 			uint32_t sb = term ? code + 1 : code;
 			bad += sb != st;
-			nr = A.rd.C[code] + rank_query(A.rd, p0, code, r);
+			nr = A.rd.C[code] + rank_query_t<uint64_t>(A.rd.blocks, p0, code, r);
 		}
 		r = nr; --p;
 	}
 	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
-	if (r != (uint32_t)A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
+	if (r != A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
 }
-void lf_walk(const TextView &T, const RankDict &rd, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out,
-             unsigned long long *d_mismatch, hipStream_t s)
+void lf_walk(const TextView &T, const uint32_t *d_blocks, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
+             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
 {
-	LfWalkArgs A{T, rd, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	LfWalkArgs A{T, RankDict64{d_blocks, T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
 }
 
@@ -244,7 +260,7 @@ __global__ void k_lf_from_sorted(const uint32_t *sorted_idx, uint64_t n, uint32_
 }
 struct LfWalkBytesArgs {
 	TextView T; const uint8_t *bwt; const uint32_t *lf;
-	const uint64_t *anchors; uint64_t nanchors; uint64_t sarate; uint32_t *sa_out; unsigned long long *mismatch;
+	const uint64_t *anchors; uint64_t nanchors; uint64_t sarate; uint64_t *sa_out; unsigned long long *mismatch;
 };
 __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 {
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 	const uint64_t pend = A.anchors[2 * k + 1];
 	uint32_t bad = 0;
 	while (p > pend) {
-		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (uint32_t)(p == T.n ? 0 : p);
+		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
 		bad += A.bwt[r] != T.b[p - 1];                  // the symbol preceding the rotation at p
 		r = A.lf[r]; --p;
 	}
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 }
 // d_keys/d_keys2 (n u64 each), d_vals/d_vals2 (n u32 each): sort buffers; d_lf: n u32
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
-                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint32_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
 {
 	const uint64_t n = T.n;
 	hipLaunchKernelGGL(k_bwt_keys, dim3(nblk(n)), dim3(256), 0, s, d_bwt, n, d_keys, d_vals);

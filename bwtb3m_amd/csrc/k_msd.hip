@@ -61,8 +61,15 @@ constexpr int LS_BINBITS = 8;
 constexpr int LS_BINS = 1 << LS_BINBITS;               // bin-scatter table of the wave sort
 constexpr int LS_TIE_CAP = 32;                         // bins / tie groups up to this size are finished in-kernel
 constexpr int LS_WAVES = MSD_THREADS / 64;
-constexpr int REC_KEY_SHIFT = 35;
-constexpr int REC_KEY_BITS = 29;
+// record = [key field | 3 bits predecessor symbol | pb bits position], pb = 32 for texts below 2^32 symbols, 36 above
+// (then the key field has 25 bits instead of 29: more key ties for k_tie_fix, nothing else changes)
+__host__ __device__ inline int rec_key_shift(int pb) { return pb + 3; }
+__host__ __device__ inline int rec_key_bits(int pb) { return 61 - pb; }
+constexpr int POSBITS_BIG = 36;
+// suffix array entries: low 32 bits, and for texts of 2^32 symbols and more a byte array with the bits above
+struct SaOut { uint32_t *lo; uint8_t *hi; };
+__device__ __forceinline__ void sa_set(const SaOut &A, uint64_t slot, uint64_t pos) { A.lo[slot] = (uint32_t)pos; if (A.hi) A.hi[slot] = (uint8_t)(pos >> 32); }
+__device__ __forceinline__ uint64_t sa_get(const SaOut &A, uint64_t slot) { return (uint64_t)A.lo[slot] | (A.hi ? (uint64_t)A.hi[slot] << 32 : 0ull); }
 
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
@@ -144,11 +151,12 @@ __device__ __forceinline__ uint32_t pred_sym(const TextView &T, uint64_t i)
 	if (T.type == B3M_INPUT_PACTERM) return i == 0 ? 0u : base_at(T, i - 1) + 1u;     // T[n-1] is the terminator
 	return base_at(T, i ? i - 1 : T.n - 1);
 }
-__device__ __forceinline__ uint64_t make_rec(uint64_t x, int D1, uint32_t pred, uint32_t idx, uint32_t *dig)
+__device__ __forceinline__ uint64_t make_rec(uint64_t x, int D1, uint32_t pred, uint64_t idx, uint32_t *dig, int pb)
 {
 	*dig = (uint32_t)(x >> (64 - D1));
-	uint64_t kf = (x >> (64 - D1 - REC_KEY_BITS)) & ((1ull << REC_KEY_BITS) - 1);
-	return (kf << REC_KEY_SHIFT) | ((uint64_t)pred << 32) | idx;
+	const int kb = rec_key_bits(pb);
+	uint64_t kf = (x >> (64 - D1 - kb)) & ((1ull << kb) - 1);
+	return (kf << rec_key_shift(pb)) | ((uint64_t)pred << pb) | idx;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -161,6 +169,7 @@ struct L0Args {
 	uint32_t *hist;              // COUNT_ONLY: counts out [digit][tile] ; else scanned offsets in
 	int D;                       // digit bits
 	uint32_t keep_lo, keep_hi;   // scatter: only records with keep_lo <= digit < keep_hi are kept (suffix-range shard)
+	int pb;                      // position bits of a record
 };
 
 // window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
@@ -285,12 +294,12 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				const uint32_t xh = __funnelshift_l(w1, w0, sh), xl = __funnelshift_l(w2, w1, sh);
 				const uint32_t pr = (__funnelshift_l(w0, wp, sh) & 3u) + padd;
 				dgt = xh >> dsh32;
-				const uint32_t kf = __funnelshift_l(xl, xh, (uint32_t)A.D) >> (32 - REC_KEY_BITS);
-				r = ((uint64_t)((kf << 3) | pr) << 32) | (uint32_t)(cpos + li);
+				const uint32_t kf = __funnelshift_l(xl, xh, (uint32_t)A.D) >> (32 - rec_key_bits(A.pb));
+				r = ((uint64_t)((kf << 3) | pr) << A.pb) | (cpos + li);
 			} else {
 				uint64_t x; uint32_t pr;
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
-				r = make_rec(x, A.D, pr, (uint32_t)(cpos + li), &dgt);
+				r = make_rec(x, A.D, pr, cpos + li, &dgt, A.pb);
 			}
 			const uint32_t rs = dgt ? cur[dgt - 1] : 0u;          // start of run dgt
 			A.rec_out[(uint64_t)gbase[dgt] + (q - rs)] = r;
@@ -483,7 +492,7 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct SortOut { uint32_t *sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; };
+struct SortOut { SaOut sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; int pb; };
 
 // a sub-bucket the in-kernel sort cannot finish: (start, size) goes to the overflow list (lane 0 only)
 __device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m)
@@ -500,7 +509,9 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t *cnt = cb, *bst = cb + LS_BINS;
-	uint32_t *sa = O.sa; uint8_t *bwt = O.bwt; const uint64_t start = O.start; uint32_t *p0 = O.p0;
+	const SaOut sa = O.sa; uint8_t *bwt = O.bwt; const uint64_t start = O.start; uint32_t *p0 = O.p0;
+	const int REC_KEY_SHIFT = rec_key_shift(O.pb);
+	const uint64_t posmask = (1ull << O.pb) - 1;
 	uint32_t *tiebits = O.tiebits;
 	if (m == 0) return;
 	const int binbits = sortbits < LS_BINBITS ? (sortbits > 0 ? sortbits : 0) : LS_BINBITS;
@@ -572,7 +583,7 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 		// a bin beyond LS_TIE_CAP: the key-extension rounds sort this sub-bucket from depth 0
 		if (lane == 0) ovf_push(O, b0, m);
 		#pragma unroll
-		for (int t = 0; t < PER; ++t) if (t * 64 + lane < m) sa[b0 + t * 64 + lane] = (uint32_t)r[t];
+		for (int t = 0; t < PER; ++t) if (t * 64 + lane < m) sa_set(sa, b0 + t * 64 + lane, r[t] & posmask);
 		return;
 	}
 	// tie groups (equal key field): bit p of the tie bitmap = "record p has the key field of
@@ -588,10 +599,10 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 				bool sp = e > 0 && (outb[e - 1] >> REC_KEY_SHIFT) == kf;
 				bool sn = e + 1 < m && (outb[e + 1] >> REC_KEY_SHIFT) == kf;
 				if (sp) { uint32_t g = b0 + e; atomicOr(&tiebits[g >> 5], 1u << (g & 31)); }
-				const uint32_t i = (uint32_t)q;
-				if (WRITE_SA || sp || sn) sa[b0 + e] = i;       // without consumers only k_tie_fix reads positions
-				bwt[b0 + e] = (uint8_t)((q >> 32) & 7u);
-				if (i == (uint32_t)start) *p0 = b0 + e;
+				const uint64_t i = q & posmask;
+				if (WRITE_SA || sp || sn) sa_set(sa, b0 + e, i);       // without consumers only k_tie_fix reads positions
+				bwt[b0 + e] = (uint8_t)((q >> O.pb) & 7u);
+				if (i == start) *p0 = b0 + e;
 			}
 		}
 	}
@@ -730,10 +741,11 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; r[k] = S.rec[(uint64_t)s0 + (e < m ? e : m - 1)]; }
 	}
-	// the key field sits in the high dword (bits 3..31), the predecessor symbol in its low 3 bits
+	// the key field sits in the high dword (from bit hks up), the predecessor symbol in the 3 bits below it
 	const int binbits = fbits < F_BINBITS ? fbits : F_BINBITS;
 	const int lowbits = fbits - binbits;                      // <= 16
-	const int bsh = REC_KEY_SHIFT - 32 + lowbits;
+	const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;      // key field and predecessor symbol inside the high dword
+	const int bsh = hks + lowbits;
 	const uint32_t bmask = (1u << binbits) - 1, lmask = (1u << lowbits) - 1;
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);   // obwt keeps the byte phase of the global address
 	#pragma unroll
@@ -797,7 +809,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		const uint32_t e = k * F_THREADS + tid;
-		if (e < m) { LDS_CHK(stv[k] + (bs[k] >> 16), ENT_N); ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> 3) & lmask) << IDXB) | e; }      // a store: nothing waits for it
+		if (e < m) { LDS_CHK(stv[k] + (bs[k] >> 16), ENT_N); ent[stv[k] + (bs[k] >> 16)] = ((((uint32_t)(r[k] >> 32) >> hks) & lmask) << IDXB) | e; }      // a store: nothing waits for it
 	}
 	__syncthreads();
 	// ---- the owner of a record scans its bin: final place, ties.  Three counts over the bin's
@@ -820,7 +832,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 			const int kk = h + k;
 			const uint32_t e = kk * F_THREADS + tid;
 			const uint32_t st = stv[kk], c = env[kk] - st, slot = bs[kk] >> 16;
-			const uint32_t xk = (((uint32_t)(r[kk] >> 32) >> 3) & lmask) << IDXB, x = xk | e, xn = xk + (1u << IDXB);
+			const uint32_t xk = (((uint32_t)(r[kk] >> 32) >> hks) & lmask) << IDXB, x = xk | e, xn = xk + (1u << IDXB);
 			uint32_t lt = 0, ltk = 0, lek = 0;
 			#pragma unroll
 			for (uint32_t j = 0; j < 4; ++j) {
@@ -844,13 +856,13 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 		uint32_t e = k * F_THREADS + tid;
 		if (e < m) {
 			const uint32_t dp = dest[k] & 0xFFFFu, g = s0 + dp;
-			const uint32_t i = (uint32_t)r[k];
+			const uint64_t i = r[k] & ((1ull << O.pb) - 1);
 			LDS_CHK(apad + dp, OBWT_N); LDS_CHK(dp, m);
-			obwt[apad + dp] = (uint8_t)((uint32_t)(r[k] >> 32) & 7u);     // hot bins: overwritten by the fallback's emit
-			if (WRITE_SA) osa[dp] = i;
-			else if (dest[k] & (3u << 29)) O.sa[g] = i;       // without consumers only k_tie_fix / the fallback read positions
+			obwt[apad + dp] = (uint8_t)(((uint32_t)(r[k] >> 32) >> hps) & 7u);     // hot bins: overwritten by the fallback's emit
+			if (WRITE_SA) { osa[dp] = (uint32_t)i; if (O.sa.hi) O.sa.hi[g] = (uint8_t)(i >> 32); }
+			else if (dest[k] & (3u << 29)) sa_set(O.sa, g, i);       // without consumers only k_tie_fix / the fallback read positions
 			if (dest[k] & (1u << 31)) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
-			if (i == (uint32_t)O.start) *O.p0 = g;
+			if (i == O.start) *O.p0 = g;
 		}
 	}
 	__syncthreads();
@@ -867,7 +879,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 	}
 	if (WRITE_SA) {
 		#pragma unroll
-		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa[s0 + e] = osa[e]; }
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa.lo[s0 + e] = osa[e]; }
 	}
 }
 
@@ -963,12 +975,12 @@ __global__ __launch_bounds__(256) void k_compact_listed(FinishSrc S, uint64_t *o
 
 // HUGE BUCKETS (low-complexity input): every workgroup copies its share of the positions into the suffix array;
 // the bucket is already on the overflow list
-__global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *hugelist, uint32_t huge_cap, uint32_t *sa)
+__global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *hugelist, uint32_t huge_cap, SaOut sa, int pb)
 {
 	uint32_t nh = hugelist[0]; if (nh > huge_cap) nh = huge_cap;
 	for (uint32_t h = 0; h < nh; ++h) {
 		const uint32_t b = hugelist[1 + h], s0 = bstart[b], m = bstart[b + 1] - s0;
-		for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) sa[s0 + e] = (uint32_t)rec[s0 + e];
+		for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) sa_set(sa, (uint64_t)s0 + e, rec[s0 + e] & ((1ull << pb) - 1));
 	}
 }
 
@@ -1055,7 +1067,7 @@ __device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec
 		if (mm == 0) continue;
 		if (mm > (uint32_t)LS_CAP) {
 			if (lane == 0) ovf_push(O, s0 + lo, mm);
-			for (uint32_t e = lane; e < mm; e += 64) O.sa[s0 + lo + e] = (uint32_t)rec_tmp[(uint64_t)s0 + lo + e];
+			for (uint32_t e = lane; e < mm; e += 64) sa_set(O.sa, (uint64_t)s0 + lo + e, rec_tmp[(uint64_t)s0 + lo + e] & ((1ull << O.pb) - 1));
 			continue;
 		}
 		uint64_t r[LS_CAP / 64];
@@ -1083,7 +1095,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // does not decide.  Groups are at most LS_TIE_CAP long (longer ones are on the overflow list and
 // set no bits); the length guard only keeps a corrupt bitmap from running away.
 // The launch covers the records [lo, hi) (tie groups never cross a bucket, so slices of whole buckets are independent).
-__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, uint32_t *sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
 {
 	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if ((w << 5) >= hi) return;
@@ -1101,23 +1113,23 @@ __global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uin
 		for (uint64_t z = q + 1; z < len && g <= (uint32_t)LS_TIE_CAP && ((tiebits[z >> 5] >> (z & 31)) & 1u); ++z) ++g;
 		if (g > (uint32_t)LS_TIE_CAP) continue;   // cannot happen (see above)
 		for (uint32_t a = 1; a < g; ++a) {
-			uint32_t x = sa[pos + a]; uint8_t bx = bwt[pos + a];
+			uint64_t x = sa_get(sa, pos + a); uint8_t bx = bwt[pos + a];
 			bool ex = (uint64_t)x + eq_syms + 32 <= T.nbases;
 			uint64_t dx = ex ? window32(T, (uint64_t)x + eq_syms) >> 2 : 0;
 			uint32_t j = a;
 			while (j > 0) {
-				uint32_t y = sa[pos + j - 1];
+				uint64_t y = sa_get(sa, pos + j - 1);
 				bool ey = (uint64_t)y + eq_syms + 32 <= T.nbases;
 				uint64_t dy = ey ? window32(T, (uint64_t)y + eq_syms) >> 2 : 0;
 				bool y_le_x;
 				if (ex && ey && dx != dy) y_le_x = dy < dx;
 				else y_le_x = compare_rotations(T, y, x) <= 0;
 				if (y_le_x) break;
-				sa[pos + j] = y; bwt[pos + j] = bwt[pos + j - 1]; --j;
+				sa_set(sa, pos + j, y); bwt[pos + j] = bwt[pos + j - 1]; --j;
 			}
-			sa[pos + j] = x; bwt[pos + j] = bx;
+			sa_set(sa, pos + j, x); bwt[pos + j] = bx;
 		}
-		for (uint32_t a = 0; a < g; ++a) if (sa[pos + a] == (uint32_t)start) *p0 = (uint32_t)(pos + a);
+		for (uint32_t a = 0; a < g; ++a) if (sa_get(sa, pos + a) == start) *p0 = (uint32_t)(pos + a);
 	}
 }
 
@@ -1150,7 +1162,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
 	const MsdDigits dg = msd_digits(len_in);
 	B3M_REQUIRE(dg.D0 >= 1 && dg.D0 <= W0_MAXBITS && dg.D1 >= 0 && dg.D1 <= MSD_MAXBITS, "internal: MSD digit split");
-	uint32_t *sa = ws.idxA;
+	const bool big = T.n >= (1ull << 32);                    // positions need more than 32 bits: 36-bit record positions, suffix array in two arrays
+	B3M_REQUIRE(!big || ws.sa_hi != nullptr, "internal: workspace has no room for positions above 2^32");
+	B3M_REQUIRE(T.n < (1ull << POSBITS_BIG), "texts of 2^36 symbols and more are not supported");
+	const int pb = big ? POSBITS_BIG : 32;
+	const int REC_KEY_BITS = rec_key_bits(pb);
+	const SaOut sa{ws.idxA, big ? ws.sa_hi : nullptr};
 	out.used_msd = true;
 	// ---- level 0: text -> records (keyA), partitioned by the first D0 bits ----
 	const uint64_t P0 = start & ~15ull;
@@ -1162,7 +1179,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
 	L0Args A{};
 	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_out = ws.keyA; A.hist = M.hist; A.D = dg.D0;
-	A.keep_lo = 0; A.keep_hi = bins0;
+	A.keep_lo = 0; A.keep_hi = bins0; A.pb = pb;
 	{
 		Scope sc(tl, KF_MSD_HIST, span / 4);
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
@@ -1196,12 +1213,13 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		A.keep_lo = lo; A.keep_hi = hi;
 		out.slice_offset = cum[lo];
 		len = cum[hi] - cum[lo];
-		B3M_REQUIRE(len <= ws.cap, "suffix-range shard larger than the workspace (skewed input): use block mode or fewer shards");
+		B3M_REQUIRE(len <= ws.cap && len < (1ull << 32), "suffix-range shard larger than the workspace (skewed input): use block mode or fewer shards");
 		if (lo) B3M_HIP(hipMemsetAsync(M.hist, 0, 4ull * lo * ntA, s));
 		if (hi < bins0) B3M_HIP(hipMemsetAsync(M.hist + (uint64_t)hi * ntA, 0, 4ull * (bins0 - hi) * ntA, s));
 	}
 	out.kept_len = len;
-	if (len == 0) { out.d_sa = sa; return; }          // empty shard (one huge digit took the neighbours' share)
+	B3M_REQUIRE(len < (1ull << 32), "more than 2^32 suffixes in one sort: use suffix-range shards");
+	if (len == 0) { out.d_sa = sa.lo; out.d_sa_hi = sa.hi; return; }          // empty shard (one huge digit took the neighbours' share)
 	{
 		Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
 		exclusive_sum_u32(M.hist, (uint64_t)bins0 * ntA, M.scan_ws, s);
@@ -1273,7 +1291,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
 	B3M_REQUIRE(fbits >= 1 && fbits <= REC_KEY_BITS && fbits - std::min(fbits, F_BINBITS) <= 16, "internal: free key bits of the finish");
 	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
-	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits};
+	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits, pb};
 	{
 		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
@@ -1326,7 +1344,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
-		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa);
+		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa, pb);
 		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 2048);
 		if (need_sa)
 			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
@@ -1358,6 +1376,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// ---- fallback: the overflow list (hot bins, oversized sub-buckets, huge buckets) goes through the list-based rounds ----
 		Scope sc(tl, KF_TIES, 0);
 		B3M_REQUIRE(nov <= ovf_cap, "too many overflow ranges for the workspace");
+		B3M_REQUIRE(!big, "repeat-rich input of 2^32 symbols and more: the list-based rounds (32-bit positions) cannot finish its overflow list yet");
 		// order the (start, size) pairs by start and turn the sizes into list offsets, all on the device
 		// (a repeat-rich genome lists millions of bins); the record buffers are free by now
 		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
@@ -1382,21 +1401,22 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// suffix array: a run that was asked for the BWT only starts over with the array kept.
 		const bool whole = start == 0 && len_in == T.n && nshards <= 1;
 		const uint64_t R0 = 4;
-		out.tie_rounds = tie_rounds(T, sa, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
 		if (left && whole && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
-			isa_from_sa(sa, len, ws.t[5], s);
-			out.tie_rounds += tie_rounds(T, sa, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
+			isa_from_sa(sa.lo, len, ws.t[5], s);
+			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
 		}
 		// BWT symbols (and p0) of the slots finished here
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, ws.t[0], (uint32_t *)nullptr);
-		emit_bwt_list(T, ws.t[0], total, sa, start, d_bwt, d_p0, s);
+		emit_bwt_list(T, ws.t[0], total, sa.lo, start, d_bwt, d_p0, s);
 		leave_fallback:;
 	}
 	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }   // the histogram was added by this pass already
 	B3M_HIP(hipGetLastError());
-	out.d_sa = need_sa ? sa : nullptr;      // without need_sa only the entries of tied / overflow records were written
+	out.d_sa = need_sa ? sa.lo : nullptr;      // without need_sa only the entries of tied / overflow records were written
+	out.d_sa_hi = need_sa ? sa.hi : nullptr;
 }
 
 

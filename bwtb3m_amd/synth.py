@@ -10,6 +10,7 @@ CONFIGS = {
     "c1": ("bytestream", 1 << 20, 0),
     "c2": ("pacterm", 5_000_000, 1),
     "c3": ("pacterm", 3_000_000_000, 2),
+    "c5": ("pacterm", 30_000_000_000, 4),      # BASELINE configs[4]: n = 30,000,000,001 > 2^32 (36-bit record positions, suffix-range shards)
 }
 
 

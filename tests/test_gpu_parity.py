@@ -631,6 +631,99 @@ def test_config_c3_full_size_3gbase_pacterm(gpu):
     plan.close()
 
 
+def _sample_checks(torch, d_text, n, samples, out_slice, slice_offset):
+    """(rank, pos) samples of a BWT (slice): (i) the BWT symbol at every sampled rank is the text symbol before pos, (ii) the sampled
+    suffixes, taken in rank order, are in ascending order (first 32 bases compared; ties skipped: uniform DNA has next to none)."""
+    nb = n - 1
+    s = torch.from_numpy(samples.astype(np.int64)).cuda()
+    s = s[torch.argsort(s[:, 0])]
+    rank, pos = s[:, 0], s[:, 1]
+    def base(i):            # base at position i (i < nb), int64 tensor
+        byte = d_text[i >> 2].to(torch.int64)
+        return (byte >> (((~i) & 3) << 1)) & 3
+    prev = torch.where(pos > 0, base(torch.clamp(pos - 1, min=0)) + 1, torch.zeros_like(pos))      # T[n-1] = terminator 0 precedes position 0
+    got = out_slice[rank - slice_offset].to(torch.int64)
+    assert bool((got == prev).all()), "BWT symbol at a sampled rank differs from the text"
+    key = torch.zeros_like(pos)
+    for t in range(31):     # 62 bits: first 31 bases, positions past the end read as -1 < A (terminator smallest)
+        p = pos + t
+        b = torch.where(p < nb, base(torch.clamp(p, max=nb - 1)), torch.full_like(p, 0))
+        key = key * 4 + b
+    ok = key[1:] >= key[:-1]
+    assert bool(ok.all()), "sampled suffixes are not in rank order"
+    assert int((key[1:] == key[:-1]).sum()) < max(8, len(key) // 1000)
+
+
+def test_beyond_2_32_symbols_one_gpu(gpu):
+    """n = 2^32 + 12345 > 2^32 (reference contract: /root/reference/README.md:42,46, BASELINE configs[4]): 36-bit record positions, the block
+    sorted as suffix-range shards one after the other, ranks and positions 64-bit in the LF walk that verifies every symbol
+    (checkbwt, /root/reference/src/checkbwt.cpp:176-243)."""
+    torch = gpu
+    from bwtb3m_amd import benchutil, engine, synth
+    nb = (1 << 32) + 12344
+    itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+    assert n == (1 << 32) + 12345
+    plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
+    assert plan.num_blocks == 1
+    out = plan.run(d_text)
+    torch.cuda.synchronize()
+    r = plan.result()
+    assert r["p0"] < n and int(out[r["p0"]]) == 0
+    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    assert (m0, m1) == (0, 0)
+    ht = benchutil.text_histogram(d_text, n, itype)
+    assert plan.histogram().astype(np.int64).tolist() == ht
+    hb = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for o in range(0, n, 1 << 28):
+        hb += torch.bincount(out[o:o + (1 << 28)].to(torch.int64), minlength=256)
+    assert hb.cpu().tolist() == ht
+    _sample_checks(torch, d_text, n, plan.samples()[::64], out, 0)
+    # a corrupted symbol above rank 2^32 is caught
+    bad_i = n - 777
+    keep = int(out[bad_i]); out[bad_i] = (keep % 4) + 1 if keep != 0 else 1
+    if int(out[bad_i]) != keep:
+        m0, m1, _ = plan.lf_walk(out, sarate=0)
+        assert m0 + m1 > 0
+    out[bad_i] = keep
+    plan.close()
+    # the BWT-only variant (no suffix array kept) gives the same bytes
+    plan = engine.Plan(n, itype, isasamplingrate=0)
+    out2 = plan.run(d_text)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and plan.result()["p0"] == r["p0"]
+    plan.close()
+
+
+def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
+    """BASELINE configs[4] geometry: n = 30,000,000,001, the suffix-range shards of an 8-GPU run rehearsed one after the other on ONE GPU
+    (each GPU of the node would hold the same 7.5 GB text and sort 3.75 G suffixes).  The slices must tile the rank space, every sampled
+    rank must carry the right symbol and the sampled suffixes must be in order; the symbol histogram of all slices is the text's."""
+    torch = gpu
+    from bwtb3m_amd import benchutil, engine, synth
+    itype, d_text, n = synth.config_input_device("c5", device="cuda")
+    assert n == 30_000_000_001
+    ht = benchutil.text_histogram(d_text, n, itype)
+    hb = torch.zeros(256, dtype=torch.int64, device="cuda")
+    nsh, off, p0s = 8, 0, []
+    for k in range(nsh):
+        plan = engine.Plan(n, itype, isasamplingrate=1 << 20, shard=k, nshards=nsh)
+        sl = plan.run(d_text)
+        torch.cuda.synchronize()
+        r = plan.result()
+        assert r["slice_offset"] == off and r["slice_len"] == sl.numel() and abs(sl.numel() - n / nsh) < n / 64
+        if r["has_p0"]:
+            p0s.append(r["p0"]); assert int(sl[r["p0"] - off]) == 0
+        for o in range(0, sl.numel(), 1 << 28):
+            hb += torch.bincount(sl[o:o + (1 << 28)].to(torch.int64), minlength=256)
+        sm = plan.samples()
+        assert len(sm) > 1000 and int(sm[:, 0].min()) >= off and int(sm[:, 0].max()) < off + sl.numel()
+        _sample_checks(torch, d_text, n, sm, sl, off)
+        off += sl.numel()
+        plan.close(); del sl
+    assert off == n and len(p0s) == 1
+    assert hb.cpu().tolist() == ht
+
+
 def test_merge_with_skewed_rank_list_40mbase(gpu):
     # two blocks of 20 Mbase: the right one is low-complexity, so the ranks of its suffixes among the left
     # block's pile up in a few places -- the MSD rank sort must notice (a final bucket above 2^16 keys)
