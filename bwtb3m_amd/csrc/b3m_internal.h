@@ -192,6 +192,13 @@ struct RankDict { const uint32_t *blocks; uint64_t m; const uint32_t *p0ptr; uin
 // builds the 2-bit rank dictionary of BWT(L); scratch: 4 * rank_blocks(m) u32 + scan ws
 void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int type, uint32_t *d_blocks,
                 uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
+// multi-GPU merges: 2-bit transport form of a block BWT and the dictionary built from such slices
+constexpr int DICT_MAX_PARTS = 8;
+void pack2(const uint8_t *d_bwt, uint64_t m, int type, uint8_t *d_packed, hipStream_t s);
+void rank_build_from_parts(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0, uint32_t *d_blocks,
+                           uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
+void dict_bytes(const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int type, uint8_t *d_out, hipStream_t s);
+void rank_cuts(const uint32_t *d_sr, uint64_t cnt, const uint64_t *d_bounds, int nb, uint64_t *d_cuts, hipStream_t s);
 struct GapWalkArgs {
 	TextView T; RankDict rd;
 	uint64_t a, m, mr;

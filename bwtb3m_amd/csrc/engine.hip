@@ -236,6 +236,7 @@ const char *b3m_input_type_name(int t) { return (t >= 0 && t < 6) ? type_names[t
 	catch (...) { b3m::set_error("unknown error"); return ret; }
 
 void b3m_plan_destroy(b3m_plan *p);
+void b3m_dist_destroy(struct b3m_dist_plan *p);
 static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize, uint64_t mem, uint64_t isasamplingrate, int shard, int nshards)
 {
 	b3m_plan *p = nullptr;
@@ -1011,6 +1012,255 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
 	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+	return 0;
+	B3M_CATCH(1)
+}
+
+
+// ================================================================================================
+// b3m_dist_plan: this rank's part of the multi-GPU block merge (north-star exchange path).
+// One process per GPU; the collectives (RCCL all-to-all of gap buckets, broadcasts of packed BWT(L) slices and gt words) are
+// issued by the host side between these calls (bwtb3m_amd/distributed.py, torch.distributed).  Everything here works in ONE
+// workspace allocated at creation: padded text, leaf sort, rank dictionary, walk / sort buffers.  No hipMalloc per call.
+// ================================================================================================
+struct b3m_dist_plan {
+	uint64_t n = 0; int type = 0;
+	uint64_t max_leaf = 0, max_L = 0, max_R = 0;
+	uint8_t *arena = nullptr; uint64_t ws_bytes = 0;
+	uint8_t *d_text = nullptr; uint64_t text_cap = 0;
+	BlockSortWs bs;
+	uint32_t *d_sa_last = nullptr; uint64_t sa_len = 0;            // suffix array of the last leaf sort (inside bs)
+	uint32_t *d_blocks = nullptr, *d_scratch = nullptr, *d_scan_ws = nullptr;   // rank dictionary of BWT(L)
+	uint64_t dict_m = 0, dict_p0 = 0;
+	uint32_t *d_r0 = nullptr, *d_r1 = nullptr; RadixWs radix;       // rank lists (walk output, received buckets)
+	uint32_t *d_tile_q = nullptr;
+	uint32_t *d_anchors = nullptr; uint64_t anchors_cap = 0;
+	uint64_t *d_small = nullptr;                                   // [0..1] p0 pair, [2] end rank (u32), [3] end position, [8..8+64) bounds, [72..72+64) cuts, [136..] query positions / ranks
+	uint32_t *d_p0u = nullptr;
+};
+static const uint64_t DIST_SMALL = 136 + 2 * 4096;
+
+b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uint64_t max_L, uint64_t max_R)
+{
+	b3m_dist_plan *p = nullptr;
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "the multi-GPU block merge needs a 2-bit alphabet (pac/pacterm)");
+	B3M_REQUIRE(n >= 1 && n < (1ull << 32), "n out of range for the block-merge mode (use suffix-range shards above 2^32)");
+	B3M_REQUIRE(max_leaf >= 1 && max_leaf <= n && max_L <= n && max_R <= n, "dist plan: sizes out of range");
+	p = new b3m_dist_plan();
+	p->n = n; p->type = inputtype; p->max_leaf = max_leaf; p->max_L = max_L; p->max_R = max_R;
+	uint64_t off = 0;
+	auto take = [&](uint64_t bytes) { uint64_t o = off; off += al256(bytes); return o; };
+	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
+	const uint64_t nbk = rank_blocks(max_L ? max_L : 1);
+	const uint64_t chains_max = max_R / 32 + 2;
+	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(max_leaf)), o_rb = take(64 * nbk), o_rs = take(64 * nbk + 64),
+	         o_sw = take(4 * scan_ws_elems(nbk) + 64), o_r0 = take(4 * (max_R + 64)), o_r1 = take(4 * (max_R + 64)), o_rx = take(radix_ws_bytes(max_R + 64)),
+	         o_tq = take(4 * (interleave_tiles(max_L + max_R + 1) + 2)), o_an = take(4 * chains_max), o_sm = take(8 * DIST_SMALL), o_p0 = take(64);
+	p->ws_bytes = off;
+	size_t free_b = 0, total_b = 0;
+	B3M_HIP(hipMemGetInfo(&free_b, &total_b));
+	if (off > free_b) throw Error("dist plan: workspace does not fit the free HBM");
+	B3M_HIP(hipMalloc((void **)&p->arena, off));
+	uint8_t *A = p->arena;
+	p->d_text = A + o_text;
+	blocksort_ws_carve(p->bs, A + o_bs, max_leaf);
+	p->d_blocks = (uint32_t *)(A + o_rb); p->d_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
+	p->d_r0 = (uint32_t *)(A + o_r0); p->d_r1 = (uint32_t *)(A + o_r1);
+	radix_ws_carve(p->radix, A + o_rx, max_R + 64);
+	p->d_tile_q = (uint32_t *)(A + o_tq);
+	p->d_anchors = (uint32_t *)(A + o_an); p->anchors_cap = chains_max;
+	p->d_small = (uint64_t *)(A + o_sm); p->d_p0u = (uint32_t *)(A + o_p0);
+	return p;
+	B3M_CATCH((b3m_dist_destroy(p), (b3m_dist_plan *)nullptr))
+}
+void b3m_dist_destroy(b3m_dist_plan *p)
+{
+	if (!p) return;
+	if (p->arena) (void)hipFree(p->arena);
+	delete p;
+}
+uint64_t b3m_dist_workspace_bytes(const b3m_dist_plan *p) { return p ? p->ws_bytes : 0; }
+
+static TextView dist_text(const b3m_dist_plan *p) { return TextView{p->d_text, p->n, num_bases(p->n, p->type), p->type}; }
+
+int b3m_dist_set_text(b3m_dist_plan *p, const void *d_text, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_text, "b3m_dist_set_text: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t tb = packed_text_bytes(p->n, p->type);
+	B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
+	B3M_HIP(hipMemcpyAsync(p->d_text, d_text, tb, hipMemcpyDeviceToDevice, s));
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* leaf [a, a+m): BWT bytes, gt bits OR-ed into the absolute-position bit array d_gt_abs ((n+1+31)/32+2 words), rank of S_a;
+ * hist5_out (host, may be NULL): symbol counts 0..4 of the leaf's text.  The suffix array stays in the workspace for b3m_dist_rank_of. */
+int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, uint64_t *hist5_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_bwt_out && d_gt_abs, "b3m_dist_leaf: null argument");
+	B3M_REQUIRE(a + m <= p->n && m >= 1 && m <= p->max_leaf, "leaf out of range");
+	hipStream_t s = (hipStream_t)stream;
+	const TextView T = dist_text(p);
+	BlockSortOut so;
+	uint64_t *d_pair = p->d_small, *d_ep = p->d_small + 3; uint32_t *d_er = (uint32_t *)(p->d_small + 2);
+	uint64_t *d_hist = p->d_small + 136;                    // 256 u64, free until the first rank query
+	B3M_HIP(hipMemsetAsync(p->d_small, 0xFF, 16, s));
+	B3M_HIP(hipMemsetAsync(p->d_small + 2, 0, 8, s));
+	B3M_HIP(hipMemsetAsync(p->d_p0u, 0xFF, 4, s));
+	B3M_HIP(hipMemsetAsync(d_hist, 0, 8 * 256, s));
+	p->bs.d_symhist_out = d_hist;
+	block_sort(T, a, m, p->bs, s, nullptr, so, d_bwt_out, p->d_p0u);
+	p->bs.d_symhist_out = nullptr;
+	if (!so.symhist_done) histogram_symbols(T, a, m, d_hist, s);
+	p->d_sa_last = so.d_sa; p->sa_len = m;
+	hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0u, d_pair, a, (uint64_t)0);
+	emit_gt_from_text(T, a, m, d_gt_abs, s);
+	const uint64_t endpos = a + m;
+	B3M_HIP(hipMemcpyAsync(d_ep, &endpos, 8, hipMemcpyHostToDevice, s));
+	rank_of_positions(T, so.d_sa, m, d_ep, 1, d_er, s);
+	hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, d_er, d_pair, d_gt_abs, a + m);
+	uint64_t pr[2] = {0, 0}, hh[256];
+	B3M_HIP(hipMemcpyAsync(pr, d_pair, 16, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(hh, d_hist, 8 * 256, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	if (p0_out) *p0_out = pr[0];
+	if (hist5_out) for (int c = 0; c < 5; ++c) hist5_out[c] = hh[c];
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* ranks of the rotations starting at positions[] (host) among the suffixes of the last leaf sorted here: the chain anchors (z-ranks) */
+int b3m_dist_rank_of(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, uint64_t *ranks_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && p->d_sa_last, "b3m_dist_rank_of: no leaf sorted yet");
+	hipStream_t s = (hipStream_t)stream;
+	const TextView T = dist_text(p);
+	std::vector<uint32_t> h;
+	for (uint64_t o = 0; o < count; o += 4096) {
+		const uint64_t c = std::min<uint64_t>(4096, count - o);
+		uint64_t *d_pos = p->d_small + 136; uint32_t *d_rk = (uint32_t *)(p->d_small + 136 + 4096);
+		B3M_HIP(hipMemcpyAsync(d_pos, positions + o, 8 * c, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemsetAsync(d_rk, 0, 4 * c, s));
+		rank_of_positions(T, p->d_sa_last, p->sa_len, d_pos, c, d_rk, s);
+		h.resize(c);
+		B3M_HIP(hipMemcpyAsync(h.data(), d_rk, 4 * c, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		for (uint64_t i = 0; i < c; ++i) ranks_out[o + i] = h[i];
+	}
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_dist_pack2(b3m_dist_plan *p, const uint8_t *d_bwt, uint64_t m, uint8_t *d_packed, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && (m == 0 || (d_bwt && d_packed)), "b3m_dist_pack2: null argument");
+	pack2(d_bwt, m, p->type, d_packed, (hipStream_t)stream);
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* rank dictionary of BWT(L) (|L| = m, p0L = rank of L's first suffix) from the packed slices of L's owners, in rank order */
+int b3m_dist_build_dict(b3m_dist_plan *p, const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0L, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_parts && part_syms && m >= 1 && m <= p->max_L, "b3m_dist_build_dict: bad argument");
+	rank_build_from_parts(d_parts, part_syms, nparts, m, p0L, p->d_blocks, p->d_scratch, p->d_scan_ws, (hipStream_t)stream);
+	p->dict_m = m; p->dict_p0 = p0L;
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* this rank's chains of the merge (L = [a, a+m), R = [a+m, a+m+mr)) walked through the dictionary: ascending ranks of the walked suffixes of R in
+ * d_sorted_out (capacity num_chains*chain_len), their number in *count_out, and cuts_out[j] = #{ranks < bounds[j]} (host; bounds = borders of the
+ * rank slices of the group: the gap buckets of the all-to-all).  symstart[4]: C array of L (symbols smaller than code c in L's text).
+ * gt arrays as b3m_gap_chains.  One host synchronisation (the bucket sizes are split sizes of the collective). */
+int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const uint64_t *symstart, const uint32_t *d_gt_abs_in, uint32_t *d_gt_abs_out,
+                  const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                  const uint64_t *bounds, int nbounds, uint32_t *d_sorted_out, uint64_t *cuts_out, uint64_t *count_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && symstart && d_gt_abs_in && d_gt_abs_out && count_out, "b3m_dist_walk: null argument");
+	B3M_REQUIRE(p->dict_m == m, "b3m_dist_walk: the dictionary in the workspace is not this merge's");
+	B3M_REQUIRE(a + m + mr <= p->n && mr >= 1 && chain_len >= 1 && nbounds >= 0 && nbounds <= 64, "b3m_dist_walk: range out of bounds");
+	const uint64_t total_chains = (mr + chain_len - 1) / chain_len;
+	B3M_REQUIRE(chain_first + num_chains <= total_chains, "chain range out of bounds");
+	hipStream_t s = (hipStream_t)stream;
+	*count_out = 0;
+	if (num_chains == 0) { for (int j = 0; j < nbounds; ++j) cuts_out[j] = 0; return 0; }
+	const uint64_t slots = num_chains * chain_len;
+	B3M_REQUIRE(slots <= p->max_R + 64 && num_chains <= p->anchors_cap, "b3m_dist_walk: chain range larger than the workspace");
+	const TextView T = dist_text(p);
+	std::vector<uint32_t> a32(num_chains);
+	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
+	B3M_HIP(hipMemcpyAsync(p->d_anchors, a32.data(), 4 * num_chains, hipMemcpyHostToDevice, s));
+	const uint32_t p032 = (uint32_t)p->dict_p0;
+	B3M_HIP(hipMemcpyAsync(p->d_p0u, &p032, 4, hipMemcpyHostToDevice, s));
+	if (nbounds) B3M_HIP(hipMemcpyAsync(p->d_small + 8, bounds, 8 * nbounds, hipMemcpyHostToDevice, s));
+	RankDict rd{};
+	rd.blocks = p->d_blocks; rd.m = m; rd.p0ptr = p->d_p0u;
+	for (int c = 0; c < 4; ++c) rd.C[c] = (uint32_t)symstart[c];
+	GapWalkArgs G{};
+	G.T = T; G.rd = rd; G.a = a; G.m = m; G.mr = mr; G.gt_cur = d_gt_abs_in; G.gt_next = d_gt_abs_out;
+	G.anchors = p->d_anchors; G.num_chains = num_chains; G.chain_len = chain_len; G.chain_first = chain_first; G.ranks_out = p->d_r0;
+	gap_walk(G, s);
+	uint32_t *sr = nullptr;
+	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
+	radix_sort_u32(p->d_r0, p->d_r1, slots, nbits, p->radix, s, nullptr, &sr, true);
+	const uint64_t hi = mr - chain_first * chain_len, last = chain_first + num_chains;
+	const uint64_t lo = (last * chain_len >= mr) ? 0 : mr - last * chain_len;
+	const uint64_t cnt = hi - lo;
+	if (d_sorted_out) B3M_HIP(hipMemcpyAsync(d_sorted_out, sr, 4 * cnt, hipMemcpyDeviceToDevice, s));
+	if (nbounds) {
+		rank_cuts(sr, cnt, p->d_small + 8, nbounds, p->d_small + 72, s);
+		B3M_HIP(hipMemcpyAsync(cuts_out, p->d_small + 72, 8 * nbounds, hipMemcpyDeviceToHost, s));
+	}
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	*count_out = cnt;
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* bytes of BWT(L)[l0, l1) from the dictionary in the workspace (p0_byte: the true symbol of L's p0 entry) */
+int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t l0, uint64_t l1, int p0_byte, uint8_t *d_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && l0 <= l1 && l1 <= p->dict_m && (l1 == l0 || d_out), "b3m_dist_l_bytes: bad argument");
+	dict_bytes(p->d_blocks, l0, l1, p->dict_p0, p0_byte, p->type, d_out, (hipStream_t)stream);
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* ascending sort of the rank buckets this rank received (all keys < 2^nbits), in the workspace */
+int b3m_dist_sort_u32(b3m_dist_plan *p, const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream)
+{
+	B3M_TRY
+	hipStream_t s = (hipStream_t)stream;
+	if (count == 0) return 0;
+	B3M_REQUIRE(p && d_keys && d_out && nbits >= 1 && nbits <= 32, "b3m_dist_sort_u32: bad argument");
+	B3M_REQUIRE(count <= p->max_R + 64, "b3m_dist_sort_u32: more keys than the workspace holds");
+	B3M_HIP(hipMemcpyAsync(p->d_r0, d_keys, 4 * count, hipMemcpyDeviceToDevice, s));
+	uint32_t *res = nullptr;
+	radix_sort_u32(p->d_r0, p->d_r1, count, nbits, p->radix, s, nullptr, &res, true);
+	B3M_HIP(hipMemcpyAsync(d_out, res, 4 * count, hipMemcpyDeviceToDevice, s));
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* interleave of this rank's slice: d_sr = its (slice-relative) sorted ranks, m symbols of BWT(L), mr of BWT(R) */
+int b3m_dist_interleave(b3m_dist_plan *p, const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && m + mr <= p->max_L + p->max_R + 1, "b3m_dist_interleave: slice larger than the workspace");
+	interleave(d_sr, d_bwtL, m, d_bwtR, mr, d_out, p->d_tile_q, (hipStream_t)stream);
 	return 0;
 	B3M_CATCH(1)
 }

@@ -72,6 +72,78 @@ __global__ void k_rank_headers(uint32_t *blocks, const uint32_t *cnt, uint64_t n
 	out[0] = cnt[0 * nb + b]; out[1] = cnt[1 * nb + b]; out[2] = cnt[2 * nb + b]; out[3] = cnt[3 * nb + b];
 }
 
+// ---- 2-bit transport form of a block BWT (multi-GPU merges: BWT(L) travels packed, 4 symbols per byte) ----------------
+// code = symbol - sub (pacterm: base + 1 -> base); symbol k of the slice in byte k>>2 at bits 2*(k&3).  The slice's p0 entry
+// (and the pacterm terminator, which is the p0 entry of every node that holds block 0) packs as garbage: its true byte
+// travels beside the slice and the dictionary never counts it.
+__global__ __launch_bounds__(256) void k_pack2(const uint8_t *bwt, uint64_t m, int sub, uint8_t *packed)
+{
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q * 4 >= m) return;
+	uint32_t v = 0;
+	for (int k = 0; k < 4; ++k) if (q * 4 + k < m) v |= (((uint32_t)bwt[q * 4 + k] - (uint32_t)sub) & 3u) << (2 * k);
+	packed[q] = (uint8_t)v;
+}
+void pack2(const uint8_t *d_bwt, uint64_t m, int type, uint8_t *d_packed, hipStream_t s)
+{
+	if (m) hipLaunchKernelGGL(k_pack2, dim3(nblk((m + 3) / 4)), dim3(256), 0, s, d_bwt, m, type == B3M_INPUT_PACTERM ? 1 : 0, d_packed);
+}
+// rank dictionary payload + word counts from up to DICT_MAX_PARTS packed slices laid end to end (symbol g of L lies in the part
+// whose [off, off + syms) holds g)
+struct PackedParts { const uint8_t *p[DICT_MAX_PARTS]; uint64_t off[DICT_MAX_PARTS + 1]; int n; };
+__global__ __launch_bounds__(256) void k_rank_words_from_parts(PackedParts P, uint64_t m, uint64_t p0, uint32_t *blocks, uint32_t *wc, uint64_t nwords)
+{
+	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords) return;
+	const uint64_t base = w * 16;
+	uint32_t word = 0, valid = 0;
+	int j = 0;
+	while (j + 1 < P.n && P.off[j + 1] <= base) ++j;
+	for (int k = 0; k < 16; ++k) {
+		const uint64_t g = base + k;
+		if (g >= m) break;
+		while (j + 1 < P.n && P.off[j + 1] <= g) ++j;
+		const uint64_t l = g - P.off[j];
+		word |= (((uint32_t)P.p[j][l >> 2] >> (2 * (l & 3))) & 3u) << (2 * k);
+		valid |= 1u << (2 * k);
+	}
+	if (p0 >= base && p0 < base + 16) { uint32_t k = (uint32_t)(p0 - base); word &= ~(3u << (2 * k)); valid &= ~(1u << (2 * k)); }
+	uint32_t lo = word & 0x55555555u, hi = (word >> 1) & 0x55555555u;
+	uint32_t c1 = __popc(lo & ~hi & valid), c2 = __popc(hi & ~lo & valid), c3 = __popc(lo & hi & valid);
+	uint32_t c0 = __popc(valid) - c1 - c2 - c3;
+	uint64_t b = w / 12, jj = w - b * 12;
+	blocks[b * 16 + 4 + jj] = word;
+	wc[w] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+}
+// bytes of BWT(L)[l0, l1) back from the dictionary payload (the p0 entry gets its true byte)
+__global__ __launch_bounds__(256) void k_dict_bytes(const uint32_t *blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int add, uint8_t *out)
+{
+	uint64_t g = l0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= l1) return;
+	const uint64_t b = g / RANK_BLK_SYMS; const uint32_t off = (uint32_t)(g - b * RANK_BLK_SYMS);
+	const uint32_t word = blocks[b * 16 + 4 + (off >> 4)];
+	uint32_t v = ((word >> (2 * (off & 15))) & 3u) + (uint32_t)add;
+	if (g == p0) v = (uint32_t)p0_byte;
+	out[g - l0] = (uint8_t)v;
+}
+void dict_bytes(const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int type, uint8_t *d_out, hipStream_t s)
+{
+	if (l1 > l0) hipLaunchKernelGGL(k_dict_bytes, dim3(nblk(l1 - l0)), dim3(256), 0, s, d_blocks, l0, l1, p0, p0_byte, type == B3M_INPUT_PACTERM ? 1 : 0, d_out);
+}
+// cuts[j] = #{q : sr[q] < bounds[j]} over an ascending rank list
+__global__ void k_cuts(const uint32_t *sr, uint64_t cnt, const uint64_t *bounds, int nb, uint64_t *cuts)
+{
+	int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nb) return;
+	uint64_t lo = 0, hi = cnt;
+	while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if ((uint64_t)sr[mid] < bounds[j]) lo = mid + 1; else hi = mid; }
+	cuts[j] = lo;
+}
+void rank_cuts(const uint32_t *d_sr, uint64_t cnt, const uint64_t *d_bounds, int nb, uint64_t *d_cuts, hipStream_t s)
+{
+	if (nb) hipLaunchKernelGGL(k_cuts, dim3(nblk(nb, 64)), dim3(64), 0, s, d_sr, cnt, d_bounds, nb, d_cuts);
+}
+
 // d_scratch: 4*nb u32 (line counts) followed by 12*nb u32 (word counts)
 template <typename P0T>
 static void rank_build_t(const uint8_t *d_bwtL, uint64_t m, const P0T *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch,
@@ -96,6 +168,22 @@ void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int typ
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s)
 {
 	rank_build_t<uint64_t>(d_bwt, m, d_p0, type, d_blocks, d_scratch, scan_ws, s);
+}
+
+// the dictionary of BWT(L) from its packed slices (see k_pack2); d_scratch / scan_ws as rank_build
+void rank_build_from_parts(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0, uint32_t *d_blocks,
+                           uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s)
+{
+	B3M_REQUIRE(nparts >= 1 && nparts <= DICT_MAX_PARTS, "too many packed slices for one dictionary");
+	PackedParts P{}; P.n = nparts; P.off[0] = 0;
+	for (int i = 0; i < nparts; ++i) { P.p[i] = d_parts[i]; P.off[i + 1] = P.off[i] + part_syms[i]; }
+	B3M_REQUIRE(P.off[nparts] == m, "packed slices do not add up to |L|");
+	uint64_t nb = rank_blocks(m);
+	uint32_t *cnt = d_scratch, *wc = d_scratch + 4 * nb;
+	hipLaunchKernelGGL(k_rank_words_from_parts, dim3(nblk(nb * 12)), dim3(256), 0, s, P, m, p0, d_blocks, wc, nb * 12);
+	hipLaunchKernelGGL(k_rank_line_counts, dim3(nblk(nb)), dim3(256), 0, s, wc, nb, cnt);
+	for (int c = 0; c < 4; ++c) exclusive_sum_u32(cnt + c * nb, nb, scan_ws, s);
+	hipLaunchKernelGGL(k_rank_headers, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, cnt, nb);
 }
 
 // rank_c(BWT_L, rho): occurrences of code c in BWT_L[0, rho), p0 entry never counted.

@@ -99,53 +99,106 @@ def split_even(total, parts):
 
 
 # ---------------------------------------------------------------------------------------------------
-# the product backend: HIP kernels through the C ABI
+# the product backend: this rank's b3m_dist_plan (HIP kernels, one persistent workspace) through the C ABI
 # ---------------------------------------------------------------------------------------------------
 class HipBackend:
+    """include/b3m.h, "multi-GPU block merge": every compute step of a rank.  The workspace (padded text, leaf sort, rank dictionary,
+    walk / sort buffers) is allocated once in setup(); the tensors that travel (slices, packed slices, rank buckets) are torch's."""
+
     def __init__(self, device):
         from . import engine  # noqa: F401  (fails loudly if libb3m.so is missing)
         self.engine = engine
         self.device = device
+        self._h = None
+
+    def setup(self, n, itype, max_leaf, max_L, max_R):
+        eng = self.engine
+        self.close()
+        self.n, self.type = n, eng._type_id(itype)
+        self._h = eng.lib().b3m_dist_create(n, self.type, max_leaf, max_L, max_R)
+        if not self._h:
+            raise eng._lib.B3MError(eng.lib().b3m_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.engine.lib().b3m_dist_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
     def gt_words(self, n):
         return (n + 1 + 31) // 32 + 2
 
-    def block_sort(self, d_text, n, itype, a, m):
-        """-> (sa, bwt, gt_abs words with this leaf's bits, p0)"""
+    def set_text(self, d_text):
         eng = self.engine
-        sa = torch.empty(m, dtype=torch.int32, device=self.device)
+        eng.check(eng.lib().b3m_dist_set_text(self._h, eng._ptr(d_text), eng._stream()))
+
+    def leaf(self, a, m):
+        """-> (bwt, gt_abs words with this leaf's bits, p0, symbol counts 0..4 of the leaf's text)"""
+        eng = self.engine
         bw = torch.empty(m, dtype=torch.uint8, device=self.device)
-        gt_abs = torch.zeros(self.gt_words(n), dtype=torch.int32, device=self.device)
+        gt_abs = torch.zeros(self.gt_words(self.n), dtype=torch.int32, device=self.device)
         p0 = ctypes.c_uint64(0)
-        eng.check(eng.lib().b3m_block_sort_abs(eng._ptr(d_text), n, eng._type_id(itype), a, m, eng._ptr(sa), eng._ptr(bw),
-                                               eng._ptr(gt_abs), ctypes.byref(p0), eng._stream()))
-        return sa, bw, gt_abs, int(p0.value)
+        h5 = (ctypes.c_uint64 * 5)()
+        eng.check(eng.lib().b3m_dist_leaf(self._h, a, m, eng._ptr(bw), eng._ptr(gt_abs), ctypes.byref(p0), h5, eng._stream()))
+        return bw, gt_abs, int(p0.value), [int(x) for x in h5]
 
-    def rank_of(self, d_text, n, itype, sa, positions):
-        return self.engine.rank_of(d_text, n, itype, sa, positions).astype(np.int64)
+    def rank_of(self, positions):
+        eng = self.engine
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        out = np.zeros(len(pos), dtype=np.uint64)
+        if len(pos):
+            eng.check(eng.lib().b3m_dist_rank_of(self._h, pos.ctypes.data, len(pos), out.ctypes.data, eng._stream()))
+        return out.astype(np.int64)
 
-    def gap_chains(self, d_text, n, itype, a, m, mr, bwtL, p0L, gt_abs, anchors, chain_first, num_chains, chain_len):
-        """-> (ascending ranks of the walked suffixes of R (int32 tensor), gt_abs_out words)"""
+    def pack2(self, bwt):
+        eng = self.engine
+        m = bwt.numel()
+        pk = torch.empty((m + 3) // 4, dtype=torch.uint8, device=self.device)
+        eng.check(eng.lib().b3m_dist_pack2(self._h, eng._ptr(bwt), m, eng._ptr(pk), eng._stream()))
+        return pk
+
+    def build_dict(self, parts, m, p0L):
+        eng = self.engine
+        k = len(parts)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t, _ in parts])
+        syms = (ctypes.c_uint64 * k)(*[int(c) for _, c in parts])
+        eng.check(eng.lib().b3m_dist_build_dict(self._h, ptrs, syms, k, m, p0L, eng._stream()))
+
+    def walk(self, a, m, mr, symstart, gt_abs, anchors, chain_first, num_chains, chain_len, bounds):
+        """-> (ascending ranks of the walked suffixes of R (int32 tensor), cuts[j] = #ranks < bounds[j] (numpy), gt_abs_out words)"""
         eng = self.engine
         cap = max(1, num_chains * chain_len)
         sr = torch.empty(cap, dtype=torch.int32, device=self.device)
-        gt_out = torch.zeros(self.gt_words(n), dtype=torch.int32, device=self.device)
+        gt_out = torch.zeros(self.gt_words(self.n), dtype=torch.int32, device=self.device)
         cnt = ctypes.c_uint64(0)
         anc = np.ascontiguousarray(anchors, dtype=np.uint64)
-        eng.check(eng.lib().b3m_gap_chains(eng._ptr(d_text), n, eng._type_id(itype), a, m, mr, eng._ptr(bwtL), p0L, eng._ptr(gt_abs),
-                                           anc.ctypes.data, chain_first, num_chains, chain_len, eng._ptr(sr), ctypes.byref(cnt),
-                                           eng._ptr(gt_out), eng._stream()))
-        return sr[: cnt.value], gt_out
+        bd = np.ascontiguousarray(bounds, dtype=np.uint64)
+        cuts = np.zeros(len(bd), dtype=np.uint64)
+        ss = (ctypes.c_uint64 * 4)(*[int(x) for x in symstart])
+        eng.check(eng.lib().b3m_dist_walk(self._h, a, m, mr, ss, eng._ptr(gt_abs), eng._ptr(gt_out), anc.ctypes.data, chain_first, num_chains, chain_len,
+                                          bd.ctypes.data, len(bd), eng._ptr(sr), cuts.ctypes.data, ctypes.byref(cnt), eng._stream()))
+        return sr[: cnt.value], cuts.astype(np.int64), gt_out
+
+    def l_bytes(self, l0, l1, p0_byte):
+        eng = self.engine
+        out = torch.empty(l1 - l0, dtype=torch.uint8, device=self.device)
+        eng.check(eng.lib().b3m_dist_l_bytes(self._h, l0, l1, int(p0_byte), eng._ptr(out), eng._stream()))
+        return out
 
     def sort_u32(self, keys, nbits):
         eng = self.engine
         out = torch.empty_like(keys)
         if keys.numel():
-            eng.check(eng.lib().b3m_sort_u32(eng._ptr(keys), keys.numel(), nbits, eng._ptr(out), eng._stream()))
+            eng.check(eng.lib().b3m_dist_sort_u32(self._h, eng._ptr(keys), keys.numel(), nbits, eng._ptr(out), eng._stream()))
         return out
 
     def interleave(self, sr_local, bwtL, bwtR):
-        out, _ = self.engine.interleave(sr_local, bwtL, bwtR, 0)
+        eng = self.engine
+        m, mr = bwtL.numel(), bwtR.numel()
+        out = torch.empty(m + mr, dtype=torch.uint8, device=self.device)
+        if m + mr:
+            eng.check(eng.lib().b3m_dist_interleave(self._h, eng._ptr(sr_local), eng._ptr(bwtL), m, eng._ptr(bwtR), mr, eng._ptr(out), eng._stream()))
         return out
 
 
@@ -229,10 +282,10 @@ def _replace_bits_seg(dst, seg, seg_w0, b, e):
 # the distributed hot path
 # ---------------------------------------------------------------------------------------------------
 class DistributedBwt:
-    """construct the BWT of a replicated packed text on dist.get_world_size() GPUs.
+    """construct the BWT of a replicated packed text on dist.get_world_size() GPUs by balanced block merging.
 
-    run() returns this rank's contiguous slice of the BWT, its offset, and p0 (rank of the
-    rotation starting at 0).  Groups are created once (new_group is collective over ALL ranks)."""
+    run() returns this rank's contiguous slice of the BWT, its offset, and p0 (rank of the rotation starting at 0).  Groups are
+    created once (new_group is collective over ALL ranks); the backend's workspace is allocated once, in __init__."""
 
     def __init__(self, n, itype, backend, device):
         self.n, self.itype, self.be, self.device = n, itype, backend, device
@@ -242,28 +295,37 @@ class DistributedBwt:
         self.groups = {}
         for mg in self.plan.merges:          # same order on every rank
             self.groups[mg.idx] = dist.new_group(ranks=mg.group)
+        mine = [mg for mg in self.plan.merges if self.rank in mg.group]
+        self.be.setup(n, itype, self.plan.leaves[self.rank].m, max([mg.L.m for mg in mine] + [1]), max([mg.R.m for mg in mine] + [1]))
         self.timing = {}
 
+    def _symstart(self, ranks):
+        """C array of a node's text: symbols smaller than code c (pacterm: code c = symbol c + 1, the terminator is smaller than every base)"""
+        h = self.leaf_hist[ranks].sum(axis=0)
+        if self.itype == "pacterm":
+            return [int(h[0] + h[1:1 + c].sum()) for c in range(4)]
+        return [int(h[:c].sum()) for c in range(4)]
+
     def run(self, d_text):
-        n, itype, be, plan, me = self.n, self.itype, self.be, self.plan, self.rank
+        n, be, plan, me = self.n, self.be, self.plan, self.rank
         dev = self.device
         tm = self.timing = {"leaf": 0.0, "anchors": 0.0, "walk": 0.0, "exchange": 0.0, "interleave": 0.0}
         t0 = time.perf_counter()
         leaf = plan.leaves[me]
-        sa, my_bwt, gt_cur, p0 = be.block_sort(d_text, n, itype, leaf.a, leaf.m)
+        be.set_text(d_text)
+        my_bwt, gt_cur, p0, h5 = be.leaf(leaf.a, leaf.m)
         node_p0 = {me: p0}
-        # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks -----------
+        # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks; leaf histograms for the C arrays -----
         t1 = time.perf_counter()
         tm["leaf"] += t1 - t0
         anchors = torch.zeros(max(1, plan.total_anchors), dtype=torch.int64, device=dev)
         for mg in plan.merges_with_leaf_on_left(me):
-            pos = plan.anchor_positions(mg)
-            r = be.rank_of(d_text, n, itype, sa, pos)
+            r = be.rank_of(plan.anchor_positions(mg))
             anchors[mg.anchor_off:mg.anchor_off + mg.num_chains] = torch.from_numpy(r).to(dev)
-        del sa
         if self.world > 1:
             _all_reduce_sum(anchors)
         h_anchors = anchors.cpu().numpy()
+        self.leaf_hist = _all_gather_i64(h5, None, dev) if self.world > 1 else np.array([h5], dtype=np.int64)
         tm["anchors"] += time.perf_counter() - t1
         # ---- merge levels ----------------------------------------------------------------------------------
         my_off = 0                  # offset of my slice inside my current node's BWT
@@ -273,13 +335,13 @@ class DistributedBwt:
             if not mine:
                 continue
             mg = mine[0]
-            my_bwt, my_off, gt_cur, p0P = self._merge(mg, d_text, my_bwt, gt_cur, node_p0[my_node.ranks[0]], h_anchors, tm)
+            my_bwt, my_off, gt_cur, p0P = self._merge(mg, my_bwt, my_off, gt_cur, node_p0[my_node.ranks[0]], h_anchors, tm)
             my_node = Node(mg.L.a, mg.L.m + mg.R.m, mg.group)
             node_p0[my_node.ranks[0]] = p0P
         return my_bwt, my_off, node_p0[my_node.ranks[0]]
 
-    def _merge(self, mg, d_text, my_bwt, gt_cur, my_node_p0, h_anchors, tm):
-        n, itype, be, me, dev = self.n, self.itype, self.be, self.rank, self.device
+    def _merge(self, mg, my_bwt, my_off, gt_cur, my_node_p0, h_anchors, tm):
+        n, be, me, dev = self.n, self.be, self.rank, self.device
         grp = self.groups[mg.idx]
         members = mg.group
         gs = len(members)
@@ -288,20 +350,22 @@ class DistributedBwt:
         a, m, mr = mg.L.a, mg.L.m, mg.R.m
         rbeg, rend = a + m, a + m + mr
         t0 = time.perf_counter()
-        # 1. slice sizes and node p0 of both sides
-        info = _all_gather_i64([my_bwt.numel(), my_node_p0], grp, dev)
+        # 1. slice sizes, node p0 of both sides, and the true symbol of my node's p0 entry (the packed form cannot carry it)
+        sz = my_bwt.numel()
+        p0_byte = int(my_bwt[my_node_p0 - my_off]) if my_off <= my_node_p0 < my_off + sz else -1
+        info = _all_gather_i64([sz, my_node_p0, p0_byte], grp, dev)
         sizes = info[:, 0]
         p0L = int(info[0, 1])
+        p0L_byte = int(info[:nL, 2].max())
         assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
-        offL = np.concatenate([[0], np.cumsum(sizes[:nL])])
         offR = np.concatenate([[0], np.cumsum(sizes[nL:])])
-        # 2. BWT(L) to every member (rank dictionary input)
-        bwtL = torch.empty(m, dtype=torch.uint8, device=dev)
+        # 2. BWT(L) to every member as packed slices, 2 bits per symbol (the rank dictionary is built from them where it is used)
+        parts = []
         for j in range(nL):
-            part = bwtL[int(offL[j]):int(offL[j + 1])]
-            if gi == j:
-                part.copy_(my_bwt)
+            cj = int(sizes[j])
+            part = be.pack2(my_bwt) if gi == j else torch.empty((cj + 3) // 4, dtype=torch.uint8, device=dev)
             _broadcast(part, members[j], grp)
+            parts.append((part, cj))
         # 3. gt bits: L's positions (a, rbeg) are valid on L's members, R's (rbeg, rend] on R's.
         #    Everybody gets both word ranges; partial edge words are merged bit-exactly.
         lw0, lw1 = a >> 5, (rbeg >> 5) + 1
@@ -314,11 +378,14 @@ class DistributedBwt:
         _replace_bits_seg(gt_cur, rseg, w0, rbeg + 1, rend + 1)
         t1 = time.perf_counter()
         tm["exchange"] += t1 - t0
-        # 4. walk my chain range
+        # 4. dictionary, then my chain range; the ranks come back sorted and already cut at the borders of the group's rank slices
+        be.build_dict(parts, m, p0L)
         cb = split_even(mg.num_chains, gs)
         c0, c1 = cb[gi], cb[gi + 1]
         anc = h_anchors[mg.anchor_off + c0: mg.anchor_off + c1]
-        sr_mine, gt_out = be.gap_chains(d_text, n, itype, a, m, mr, bwtL, p0L, gt_cur, anc, c0, c1 - c0, mg.chain_len)
+        lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
+        sr_mine, cut, gt_out = be.walk(a, m, mr, self._symstart(mg.L.ranks), gt_cur, anc, c0, c1 - c0, mg.chain_len, lam)
+        del parts
         t2 = time.perf_counter()
         tm["walk"] += t2 - t1
         # new gt bits of R's positions relative to S_a: union over walkers (disjoint positions)
@@ -329,9 +396,6 @@ class DistributedBwt:
         _replace_bits_seg(gt_new, oseg, w0, rbeg, rend)
         _set_bit(gt_new, rend, 1 if int(h_anchors[mg.anchor_off]) > p0L else 0)
         # 5. all-to-all of gap buckets by owning slice of the rank space [0, m]
-        lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
-        bounds = torch.tensor(lam, dtype=torch.int64, device=dev)
-        cut = torch.searchsorted(sr_mine, bounds.to(torch.int32)).cpu().numpy()
         send_counts = np.diff(cut)
         rc = _all_gather_i64(list(send_counts), grp, dev)          # rc[i][j] = i sends to j
         recv_counts = rc[:, gi]
@@ -356,11 +420,11 @@ class DistributedBwt:
         assert bwtR_part.numel() == int(cj[gi])
         t3 = time.perf_counter()
         tm["exchange"] += t3 - t2
-        # 7. interleave my slice
+        # 7. interleave my slice; its range of BWT(L) comes out of the dictionary
         l0, l1 = lam[gi], (lam[gi + 1] if gi + 1 < gs else m)
         l1 = min(l1, m)
         sr_local = (sr_slice - l0) if l0 else sr_slice
-        out = be.interleave(sr_local, bwtL[l0:l1].contiguous(), bwtR_part)
+        out = be.interleave(sr_local, be.l_bytes(l0, l1, p0L_byte), bwtR_part)
         # new rank of L's p0 entry: p0L + #{q : sr[q] <= p0L}
         cand = -1
         if l0 <= p0L < l1:
@@ -433,10 +497,9 @@ def _run_mode(job, d_text, steps, warmup, dev, fam_of=None):
 
 
 def bench_main(a, rank, local_rank, world):
-    """N>1 leg of bench.py: one process per GPU (torchrun), RCCL process group.  Headline = the mode
-    asked for (default: suffix-range shards).  With --also-blocks (default) one pass of the
-    block-merging / all-to-all mode follows AFTER the JSON line, reported on stderr, under a
-    watchdog so that it can never cost the headline."""
+    """N>1 leg of bench.py: one process per GPU (torchrun), RCCL process group.  Headline = the mode asked for (default:
+    suffix-range shards); the other mode runs too (one step) and both are in the ONE JSON line (`config.modes`).  Any failure
+    or a hung collective ends the process with a non-zero status -- no line is printed for a run that did not finish."""
     import sys
     import threading
     from . import benchutil, synth
@@ -457,68 +520,74 @@ def bench_main(a, rank, local_rank, world):
     itype, d_text, n = synth.config_input_device(a.config, size=want, device=dev)
     nbases = n - 1 if itype == "pacterm" else n
     mode = getattr(a, "mode", "prefix")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def _bail():
+        sys.stderr.write("[bench] rank %d: watchdog fired after %d s (a collective never completed): exit 3\n" % (rank, a.blocks_timeout))
+        sys.stderr.flush()
+        os._exit(3)
 
     def make(m):
         return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev)
 
-    job = make(mode)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    dt, out, off, p0, fam = _run_mode(job, d_text, a.steps, a.warmup, dev,
-                                      fam_of=(lambda j: j.plan.kernel_times()) if mode != "blocks" else None)
-    if a.verify:
-        full = gather_result(out)
-        if rank == 0:
-            from oracle import oracle as O
-            sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)
-            assert np.array_equal(full.cpu().numpy(), O.bwt(sym)), "distributed BWT differs from the oracle"
-    if rank == 0:
-        levels = len(job.plan.levels) if mode == "blocks" else 0
-        alg_job = nbases * (9.5 + 41.0 * levels)
-        if fam:
-            # dominant kernel of rank 0's shard (every rank runs the same kernels on its own suffix range)
-            roof = benchutil.dominant_roofline(fam, a.steps, dt, nbases, levels, 0, root, peak_gpus=world)
-            roof["rank"] = 0
-        else:
-            roof = {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / a.steps) / 1e9, 1),
-                    "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / a.steps) / 1e9 / (8000.0 * world), 5), "traffic": None}
-        res = {
-            "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
-            "value": round(nbases * a.steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
-                       "merge_levels": levels, "mode": mode,
-                       "parallelism": ("%d GPUs: 1 leaf block per GPU, RCCL all-to-all gap merge" % world) if mode == "blocks"
-                       else ("%d GPUs: suffix-range shards of the replicated text, no exchange step" % world),
-                       "rank0_phase_s": {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}},
-            "roofline": roof,
-        }
-        print(json.dumps(res), flush=True)
-    if getattr(a, "also_blocks", True) and mode != "blocks":
-        # secondary measurement: must never endanger the line above
-        def _bail():
-            sys.stderr.write("[bench] block-merge mode watchdog fired after %d s: skipped\n" % a.blocks_timeout)
-            sys.stderr.flush()
-            os._exit(0)
+    def measure(m, steps, warmup):
         wd = threading.Timer(a.blocks_timeout, _bail)
         wd.daemon = True
         wd.start()
         try:
-            del job, out
+            job = make(m)
+            dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times()) if m != "blocks" else None)
+            del out
+            phases = {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}
+            levels = len(job.plan.levels) if m == "blocks" else 0
+            return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job}
+        finally:
+            wd.cancel()
+
+    try:
+        if a.verify:
+            raise SystemExit("bench.py --verify with --gpus > 1: use tests/ (the oracle is test infrastructure, not part of the package)")
+        res_main = measure(mode, a.steps, a.warmup)
+        other = "blocks" if mode != "blocks" else "prefix"
+        res_other = None
+        if getattr(a, "also_blocks", True) and n < (1 << 32):
+            res_main.pop("job", None)
             torch.cuda.empty_cache()
-            job2 = make("blocks")
-            dt2, out2, off2, p02, _ = _run_mode(job2, d_text, 1, 1, dev)
-            if rank == 0:
-                sys.stderr.write("[bench] block-merge mode (1 leaf block per GPU, %d merge levels, RCCL all-to-all of gap buckets): "
-                                 "%.1f ms/step = %.3f Gbase/s; rank0 phases %s\n"
-                                 % (len(job2.plan.levels), dt2 * 1e3, nbases / dt2 / 1e9, {k: round(v, 4) for k, v in job2.timing.items()}))
-                sys.stderr.flush()
-        except BaseException as ex:   # noqa: BLE001
-            # the peers are (or will be) stuck in a collective this rank has left: no barrier, no
-            # process-group teardown -- leave at once with status 0; their watchdogs do the same
-            sys.stderr.write("[bench] block-merge mode failed on rank %d: %r\n" % (rank, ex))
-            sys.stderr.flush()
-            os._exit(0)
-        # the watchdog stays armed across the final barrier
+            res_other = measure(other, 1, 1)
+            res_other.pop("job", None)
+    except BaseException as ex:   # noqa: BLE001
+        # peers may be stuck in a collective this rank has left: no barrier, no teardown -- fail at once
+        sys.stderr.write("[bench] rank %d failed: %r\n" % (rank, ex))
+        sys.stderr.flush()
+        os._exit(2)
+    if rank == 0:
+        def summary(r):
+            return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
+                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"]}
+        dt, steps, fam, levels = res_main["dt"], res_main["steps"], res_main["fam"], res_main["levels"]
+        alg_job = nbases * (9.5 + 41.0 * levels)
+        if fam:
+            # dominant kernel of rank 0's shard (every rank runs the same kernels on its own suffix range)
+            roof = benchutil.dominant_roofline(fam, steps, dt, nbases, levels, 0, root, peak_gpus=world)
+            roof["rank"] = 0
+        else:
+            roof = {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / steps) / 1e9, 1),
+                    "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / steps) / 1e9 / (8000.0 * world), 5), "traffic": None}
+        names = {"blocks": "%d GPUs: 1 leaf block per GPU, balanced merges, RCCL all-to-all of gap buckets" % world,
+                 "prefix": "%d GPUs: suffix-range shards of the replicated text, no exchange step" % world}
+        modes = {mode: summary(res_main)}
+        if res_other is not None:
+            modes[other] = summary(res_other)
+        res = {
+            "metric": "Gbase/s BWT construction (3 Gbase pacterm) at 1/2/4/8 MI355X; % HBM roofline",
+            "value": round(nbases * steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
+                       "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes,
+                       "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices in HBM"},
+            "roofline": roof,
+        }
+        print(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()

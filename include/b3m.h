@@ -220,6 +220,27 @@ int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64
                    const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out,
                    uint64_t p0L, uint64_t *p0P_out, void *stream);
 
+/* ---- multi-GPU block merge: this rank's part, one persistent workspace -------------- */
+/* One process per GPU.  The collectives between these calls -- broadcast of the packed BWT(L) slices, RCCL all-to-all(v) of the gap buckets
+ * (rank lists cut at the borders of the group's rank slices) and of the BWT(R) ranges -- are issued by the host side
+ * (bwtb3m_amd/distributed.py over torch.distributed); the reference has no counterpart (single process, OpenMP: SURVEY.md 5).
+ * max_leaf / max_L / max_R: largest leaf this rank sorts, largest left / right side of a merge it takes part in. */
+typedef struct b3m_dist_plan b3m_dist_plan;
+b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uint64_t max_L, uint64_t max_R);
+void     b3m_dist_destroy(b3m_dist_plan *p);
+uint64_t b3m_dist_workspace_bytes(const b3m_dist_plan *p);
+int b3m_dist_set_text(b3m_dist_plan *p, const void *d_text, void *stream);
+int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, uint64_t *hist5_out, void *stream);
+int b3m_dist_rank_of(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, uint64_t *ranks_out, void *stream);
+int b3m_dist_pack2(b3m_dist_plan *p, const uint8_t *d_bwt, uint64_t m, uint8_t *d_packed, void *stream);   /* 4 symbols per byte */
+int b3m_dist_build_dict(b3m_dist_plan *p, const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0L, void *stream);
+int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const uint64_t *symstart, const uint32_t *d_gt_abs_in, uint32_t *d_gt_abs_out,
+                  const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                  const uint64_t *bounds, int nbounds, uint32_t *d_sorted_out, uint64_t *cuts_out, uint64_t *count_out, void *stream);
+int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t l0, uint64_t l1, int p0_byte, uint8_t *d_out, void *stream);
+int b3m_dist_sort_u32(b3m_dist_plan *p, const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream);
+int b3m_dist_interleave(b3m_dist_plan *p, const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out, void *stream);
+
 /* ---- output formats (host): rows a11/a12 ------------------------------------------------------ */
 
 /* RL-encoded .bwt container (role of libmaus2::huffman::RLEncoderStd, usage

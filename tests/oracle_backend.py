@@ -24,24 +24,65 @@ def _words_to_bits(words, count):
 
 
 class OracleBackend:
+    """same interface as bwtb3m_amd.distributed.HipBackend (this rank's b3m_dist_plan), computed by the oracle on CPU tensors"""
+
     def __init__(self, sym, itype):
         self.sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        self.itype = itype
         self.sigma = {"pacterm": 5, "pac": 4}.get(itype, 256)
+        self.sub = 1 if itype == "pacterm" else 0
+
+    def setup(self, n, itype, max_leaf, max_L, max_R):
+        self.n = n
+        self.limits = (max_leaf, max_L, max_R)
 
     def gt_words(self, n):
         return (n + 1 + 31) // 32 + 2
 
-    def block_sort(self, d_text, n, itype, a, m):
+    def set_text(self, d_text):
+        pass
+
+    def leaf(self, a, m):
+        assert m <= self.limits[0]
+        n = self.n
         sa = O.leaf_sort(self.sym, a, m)
         bw, p0, gt = O.leaf_products(self.sym, a, m, sa)
+        self.sa = sa
         absb = np.zeros(self.gt_words(n) * 32, dtype=np.uint8)
         absb[a + 1: a + m + 1] = gt[1:]
-        return torch.from_numpy(sa), torch.from_numpy(bw), torch.from_numpy(_bits_to_words(absb)), p0
+        h5 = np.bincount(self.sym[a:a + m], minlength=5)[:5]
+        return torch.from_numpy(bw), torch.from_numpy(_bits_to_words(absb)), p0, [int(x) for x in h5]
 
-    def rank_of(self, d_text, n, itype, sa, positions):
-        return np.array([O.rank_of(self.sym, sa.numpy(), int(x)) for x in positions], dtype=np.int64)
+    def rank_of(self, positions):
+        return np.array([O.rank_of(self.sym, self.sa, int(x)) for x in positions], dtype=np.int64)
 
-    def gap_chains(self, d_text, n, itype, a, m, mr, bwtL, p0L, gt_abs, anchors, chain_first, num_chains, chain_len):
+    def pack2(self, bwt):
+        b = bwt.numpy().astype(np.int64)
+        codes = (b - self.sub) & 3
+        pad = np.zeros((len(codes) + 3) // 4 * 4, dtype=np.int64)
+        pad[: len(codes)] = codes
+        q = pad.reshape(-1, 4)
+        return torch.from_numpy((q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8))
+
+    def build_dict(self, parts, m, p0L):
+        assert m <= self.limits[1]
+        out = []
+        for t, cnt in parts:
+            v = t.numpy().astype(np.int64)
+            codes = np.stack([(v >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[:cnt]
+            out.append((codes + self.sub).astype(np.uint8))
+        self.bwtL = np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+        assert len(self.bwtL) == m
+        self.p0L = p0L
+
+    def walk(self, a, m, mr, symstart, gt_abs, anchors, chain_first, num_chains, chain_len, bounds):
+        n = self.n
+        # the C array handed in must be the one of L's text
+        hist = np.bincount(self.sym[a:a + m], minlength=5)
+        if self.itype == "pacterm":
+            assert list(symstart) == [int(hist[0] + hist[1:1 + c].sum()) for c in range(4)]
+        else:
+            assert list(symstart) == [int(hist[:c].sum()) for c in range(4)]
         nb = self.gt_words(n) * 32
         gtb = _words_to_bits(gt_abs, nb)
         gtR = gtb[a + m: a + m + mr + 1].copy()
@@ -51,11 +92,19 @@ class OracleBackend:
             c = chain_first + i
             k_hi = mr - c * chain_len
             k_lo = max(0, k_hi - chain_len)
-            rk, gtP = O.gap_range(self.sym, a, m, mr, bwtL.numpy(), p0L, gtR, self.sigma, k_hi, k_lo, int(anchors[i]))
+            rk, gtP = O.gap_range(self.sym, a, m, mr, self.bwtL, self.p0L, gtR, self.sigma, k_hi, k_lo, int(anchors[i]))
             ranks.append(rk)
             out_bits[a + m + k_lo: a + m + k_hi] = gtP[m + k_lo: m + k_hi]
         r = np.sort(np.concatenate(ranks)) if ranks else np.zeros(0, dtype=np.int64)
-        return torch.from_numpy(r.astype(np.int32)), torch.from_numpy(_bits_to_words(out_bits))
+        cuts = np.searchsorted(r, np.asarray(bounds, dtype=np.int64), side="left").astype(np.int64)
+        return torch.from_numpy(r.astype(np.int32)), cuts, torch.from_numpy(_bits_to_words(out_bits))
+
+    def l_bytes(self, l0, l1, p0_byte):
+        out = self.bwtL[l0:l1].copy()
+        if l0 <= self.p0L < l1:
+            assert p0_byte >= 0
+            out[self.p0L - l0] = p0_byte
+        return torch.from_numpy(out)
 
     def sort_u32(self, keys, nbits):
         return torch.sort(keys)[0]

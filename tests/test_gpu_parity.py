@@ -771,3 +771,24 @@ def test_bytestream_64mb_verified_by_the_lf_walk(gpu):
     assert np.array_equal(h.astype(np.int64), torch.bincount(t.to(torch.int64), minlength=256).cpu().numpy())
     assert torch.equal(torch.bincount(out.to(torch.int64), minlength=256), torch.bincount(t.to(torch.int64), minlength=256))
     plan.close()
+
+
+def test_bench_two_ranks_on_one_gpu_reports_both_modes_and_fails_loudly(gpu, tmp_path):
+    """the N>1 leg of bench.py rehearsed with two ranks on this one GPU (gloo transport, HIP compute): ONE JSON line that carries both
+    modes (suffix-range shards and the block merge with its all-to-all of gap buckets); a rank that fails must end the run non-zero."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, B3M_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "c2", "--size", "3000000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and set(j["config"]["modes"]) == {"prefix", "blocks"}
+    assert j["config"]["modes"]["blocks"]["merge_levels"] == 1 and j["config"]["modes"]["blocks"]["ms_per_step"] > 0
+    assert set(j["config"]["modes"]["blocks"]["rank0_phase_s"]) >= {"leaf", "walk", "exchange", "interleave"}
+    # block mode on a byte alphabet is refused by the library: the run must fail, not report
+    cmd_bad = cmd[:-4] + ["--config", "c1", "--mode", "blocks"]
+    r = subprocess.run(cmd_bad, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
