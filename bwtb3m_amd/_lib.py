@@ -69,6 +69,8 @@ SYMBOLS = [
     ("b3m_plan_run_host", _i, [_p, _p, _p, ctypes.POINTER(E2ETimes), _p]),
     ("b3m_host_alloc", _p, [_u64]),
     ("b3m_host_free", None, [_p]),
+    ("b3m_compact_info", _i, [_p, _u64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    ("b3m_compact_decode", _i, [_p, _u64, ctypes.c_uint32, _p, _p]),
     ("b3m_plan_result", _i, [_p, ctypes.POINTER(Result)]),
     ("b3m_plan_samples", _i, [_p, _p, _u64]),
     ("b3m_plan_histogram", _i, [_p, _p]),

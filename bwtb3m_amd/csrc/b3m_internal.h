@@ -181,6 +181,7 @@ void emit_samples(const uint32_t *d_sa, const uint8_t *d_sa_hi, uint64_t len, ui
                   hipStream_t s);
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum /* += */, hipStream_t s);
+void compact_decode(const uint8_t *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, hipStream_t s);
 void histogram_symbols(const TextView &T, uint64_t start, uint64_t len, uint64_t *d_hist256, hipStream_t s);
 
 // ---- merge (rows a8-a10) ------------------------------------------------------------------------
@@ -207,9 +208,10 @@ struct GapWalkArgs {
 	const uint32_t *anchors;   // num_chains ranks
 	uint64_t num_chains, chain_len;
 	uint64_t chain_first;     // global index of this launch's first chain (multi-GPU: each rank walks a chain range)
-	uint32_t *ranks_out;       // [chain_len][num_chains] layout, invalid slots = 0xFFFFFFFF
+	uint32_t *ranks_out;       // gap_walk_slots() entries in any order, unused slots = 0xFFFFFFFF
 };
 void gap_walk(const GapWalkArgs &A, hipStream_t s);
+uint64_t gap_walk_slots(uint64_t num_chains, uint64_t chain_len);   // entries of ranks_out the walk fills (chains padded to whole quads of steps)
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
 // d_blocks: rank dictionary of the whole BWT (rank_build64), p0 = rank of the terminator entry (~0: none), C = symbol starts
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);

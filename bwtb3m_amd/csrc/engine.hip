@@ -153,6 +153,7 @@ static void chains_for(uint64_t mr, uint64_t &chain_len, uint64_t &num_chains)
 	const uint64_t target = 512ull * 1024;      // lanes to fill: 256 CUs x 32 waves x 64
 	const uint64_t min_len = 32;
 	chain_len = std::max<uint64_t>(min_len, (mr + target - 1) / target);
+	chain_len = (chain_len + 3) & ~3ull;         // whole quads of steps: the walk pads a chain's slots to a multiple of 4, and padding keys pile up in the rank sort
 	num_chains = (mr + chain_len - 1) / chain_len;
 	if (num_chains == 0) { num_chains = 1; }
 }
@@ -174,7 +175,7 @@ static void build_tree(b3m_plan *p)
 		for (size_t i = 0; i + 1 < cur.size(); i += 2) {
 			MergeT M; M.L = cur[i]; M.R = cur[i + 1]; M.level = level;
 			chains_for(M.R.m, M.chain_len, M.num_chains);
-			M.slots = M.chain_len * M.num_chains;
+			M.slots = gap_walk_slots(M.num_chains, M.chain_len);
 			M.anchor_off = aoff; aoff += M.num_chains;
 			ids.push_back((int)p->merges.size());
 			p->merges.push_back(M);
@@ -224,8 +225,9 @@ static const char *type_names[6] = {"bytestream", "compactstream", "pac", "pacte
 int b3m_parse_input_type(const char *name)
 {
 	if (name) for (int i = 0; i < 6; ++i) if (!strcmp(name, type_names[i])) return i;
-	// message of the reference's switch: /root/reference/src/checkbwt.cpp:274
-	set_error(std::string("Unknown input type ") + (name ? name : "(null)"));
+	// the message of the reference's input-type switch, verbatim (/root/reference/src/checkbwt.cpp:274: the text thrown by
+	// BwtMergeSort::computeBwt, which that program repeats)
+	set_error("libmaus2::suffixsort::bwtb3m::BwtMergeSort::computeBwt: unknown/unsupported input type");
 	return -1;
 }
 const char *b3m_input_type_name(int t) { return (t >= 0 && t < 6) ? type_names[t] : "unknown"; }
@@ -614,6 +616,33 @@ void *b3m_host_alloc(uint64_t bytes)
 }
 void b3m_host_free(void *q) { if (q) (void)hipHostFree(q); }
 
+/* compactstream input (libmaus2 CompactArray file, layout [UPSTREAM-RECALL], see include/b3m.h) */
+int b3m_compact_info(const uint8_t *file_head32, uint64_t file_size, uint32_t *bits_out, uint64_t *n_out, uint64_t *data_off_out)
+{
+	B3M_TRY
+	B3M_REQUIRE(file_head32 && file_size >= 32, "not a compact array file (shorter than its header)");
+	auto be64 = [&](int k) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | file_head32[8 * k + i]; return v; };
+	const uint64_t bits = be64(0), n = be64(1), nw = be64(2), nw2 = be64(3);
+	B3M_REQUIRE(bits >= 1 && bits <= 8, "compactstream: 1..8 bits per symbol are supported");
+	B3M_REQUIRE(nw == nw2 && nw <= (file_size - 32) / 8 && (n == 0 || (n * bits + 63) / 64 <= nw), "not a compact array file (word count does not fit)");
+	if (bits_out) *bits_out = (uint32_t)bits;
+	if (n_out) *n_out = n;
+	if (data_off_out) *data_off_out = 32;
+	return 0;
+	B3M_CATCH(1)
+}
+/* d_words: the word stream (file image from data_off on) readable up to ceil(n*bits/8)+1 bytes; d_out: n bytes */
+int b3m_compact_decode(const void *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(d_words && d_out && bits >= 1 && bits <= 8, "b3m_compact_decode: bad argument");
+	compact_decode((const uint8_t *)d_words, n, bits, d_out, (hipStream_t)stream);
+	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
 int b3m_plan_result(const b3m_plan *p, b3m_result *out)
 {
 	if (!p || !out) { set_error("null argument"); return 1; }
@@ -770,7 +799,7 @@ int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t 
 	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
 	DevBuf an(4 * num_chains);
 	B3M_HIP(hipMemcpy(an.p, a32.data(), 4 * num_chains, hipMemcpyHostToDevice));
-	uint64_t slots = num_chains * chain_len;
+	uint64_t slots = gap_walk_slots(num_chains, chain_len);
 	DevBuf r0(4 * slots), r1(4 * slots), rws(radix_ws_bytes(slots));
 	RadixWs rw; radix_ws_carve(rw, rws.p, slots);
 	GapWalkArgs G{};
@@ -858,7 +887,7 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
 	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
 	DevBuf an(4 * num_chains);
 	B3M_HIP(hipMemcpy(an.p, a32.data(), 4 * num_chains, hipMemcpyHostToDevice));
-	uint64_t slots = num_chains * chain_len;
+	uint64_t slots = gap_walk_slots(num_chains, chain_len);
 	DevBuf r0(4 * slots), r1(4 * slots), rws(radix_ws_bytes(slots));
 	RadixWs rw; radix_ws_carve(rw, rws.p, slots);
 	GapWalkArgs G{};
@@ -1056,7 +1085,7 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	const uint64_t nbk = rank_blocks(max_L ? max_L : 1);
 	const uint64_t chains_max = max_R / 32 + 2;
 	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(max_leaf)), o_rb = take(64 * nbk), o_rs = take(64 * nbk + 64),
-	         o_sw = take(4 * scan_ws_elems(nbk) + 64), o_r0 = take(4 * (max_R + 64)), o_r1 = take(4 * (max_R + 64)), o_rx = take(radix_ws_bytes(max_R + 64)),
+	         o_sw = take(4 * scan_ws_elems(nbk) + 64), o_r0 = take(4 * (max_R + max_R / 8 + 256)), o_r1 = take(4 * (max_R + max_R / 8 + 256)), o_rx = take(radix_ws_bytes(max_R + max_R / 8 + 256)),
 	         o_tq = take(4 * (interleave_tiles(max_L + max_R + 1) + 2)), o_an = take(4 * chains_max), o_sm = take(8 * DIST_SMALL), o_p0 = take(64);
 	p->ws_bytes = off;
 	size_t free_b = 0, total_b = 0;
@@ -1068,7 +1097,7 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	blocksort_ws_carve(p->bs, A + o_bs, max_leaf);
 	p->d_blocks = (uint32_t *)(A + o_rb); p->d_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 	p->d_r0 = (uint32_t *)(A + o_r0); p->d_r1 = (uint32_t *)(A + o_r1);
-	radix_ws_carve(p->radix, A + o_rx, max_R + 64);
+	radix_ws_carve(p->radix, A + o_rx, max_R + max_R / 8 + 256);
 	p->d_tile_q = (uint32_t *)(A + o_tq);
 	p->d_anchors = (uint32_t *)(A + o_an); p->anchors_cap = chains_max;
 	p->d_small = (uint64_t *)(A + o_sm); p->d_p0u = (uint32_t *)(A + o_p0);
@@ -1195,8 +1224,8 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
 	hipStream_t s = (hipStream_t)stream;
 	*count_out = 0;
 	if (num_chains == 0) { for (int j = 0; j < nbounds; ++j) cuts_out[j] = 0; return 0; }
-	const uint64_t slots = num_chains * chain_len;
-	B3M_REQUIRE(slots <= p->max_R + 64 && num_chains <= p->anchors_cap, "b3m_dist_walk: chain range larger than the workspace");
+	const uint64_t slots = gap_walk_slots(num_chains, chain_len);
+	B3M_REQUIRE(slots <= p->max_R + p->max_R / 8 + 256 && num_chains <= p->anchors_cap, "b3m_dist_walk: chain range larger than the workspace");
 	const TextView T = dist_text(p);
 	std::vector<uint32_t> a32(num_chains);
 	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
@@ -1246,7 +1275,7 @@ int b3m_dist_sort_u32(b3m_dist_plan *p, const uint32_t *d_keys, uint64_t count, 
 	hipStream_t s = (hipStream_t)stream;
 	if (count == 0) return 0;
 	B3M_REQUIRE(p && d_keys && d_out && nbits >= 1 && nbits <= 32, "b3m_dist_sort_u32: bad argument");
-	B3M_REQUIRE(count <= p->max_R + 64, "b3m_dist_sort_u32: more keys than the workspace holds");
+	B3M_REQUIRE(count <= p->max_R + p->max_R / 8 + 256, "b3m_dist_sort_u32: more keys than the workspace holds");
 	B3M_HIP(hipMemcpyAsync(p->d_r0, d_keys, 4 * count, hipMemcpyDeviceToDevice, s));
 	uint32_t *res = nullptr;
 	radix_sort_u32(p->d_r0, p->d_r1, count, nbits, p->radix, s, nullptr, &res, true);

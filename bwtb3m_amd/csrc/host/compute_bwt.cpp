@@ -39,14 +39,21 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		const char *tname = (o->inputtype && *o->inputtype) ? o->inputtype : "bytestream";
 		int type = b3m_parse_input_type(tname);
 		if (type < 0) throw std::runtime_error(b3m_last_error());
-		if (type != B3M_INPUT_BYTESTREAM && type != B3M_INPUT_PAC && type != B3M_INPUT_PACTERM)
-			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, pac, pacterm)");
+		if (type != B3M_INPUT_BYTESTREAM && type != B3M_INPUT_PAC && type != B3M_INPUT_PACTERM && type != B3M_INPUT_COMPACTSTREAM)
+			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, compactstream, pac, pacterm)");
 		std::string outfn = (o->output_fn && *o->output_fn) ? o->output_fn : (std::string((o->tmpprefix && *o->tmpprefix) ? o->tmpprefix : "bwtb3m_out") + ".bwt");
 		std::string prefix = b3m::clip_off(outfn, ".bwt");
 		double t0 = now();
 		std::vector<uint8_t> file = b3m::read_file(o->input_fn);
 		uint64_t n;
-		if (type == B3M_INPUT_BYTESTREAM) n = file.size();
+		// compactstream (row f4): 2-bit files are a .pac payload behind a 32-byte header; other widths are decoded to bytes on the device
+		uint32_t cbits = 0; uint64_t coff = 0; const int filetype = type;
+		if (type == B3M_INPUT_COMPACTSTREAM) {
+			if (b3m_compact_info(file.data(), file.size(), &cbits, &n, &coff)) throw std::runtime_error(b3m_last_error());
+			file.erase(file.begin(), file.begin() + (long)coff);
+			file.resize(file.size() + 16, 0);
+			type = cbits == 2 ? B3M_INPUT_PAC : B3M_INPUT_BYTESTREAM;
+		} else if (type == B3M_INPUT_BYTESTREAM) n = file.size();
 		else {
 			if (file.size() < 2 || file.back() > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
 			n = (file.size() - 2) * 4 + file.back() + (type == B3M_INPUT_PACTERM ? 1 : 0);
@@ -69,10 +76,20 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (!plan) throw std::runtime_error(b3m_last_error());
 		log("[V] blocks %llu workspace %.2f GB\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9);
 		uint64_t tb = b3m_plan_text_bytes(plan);
-		if (tb > file.size()) throw std::runtime_error("internal: packed size mismatch");
-		HIPCHK(hipMalloc(&d_text, tb + 16));
 		HIPCHK(hipMalloc((void **)&d_bwt, n));
-		HIPCHK(hipMemcpy(d_text, file.data(), tb, hipMemcpyHostToDevice));
+		if (filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2) {
+			void *d_words = nullptr;
+			HIPCHK(hipMalloc(&d_words, file.size()));
+			HIPCHK(hipMemcpy(d_words, file.data(), file.size(), hipMemcpyHostToDevice));
+			HIPCHK(hipMalloc(&d_text, n + 16));
+			if (b3m_compact_decode(d_words, n, cbits, (uint8_t *)d_text, nullptr)) { (void)hipFree(d_words); throw std::runtime_error(b3m_last_error()); }
+			HIPCHK(hipDeviceSynchronize());
+			(void)hipFree(d_words);
+		} else {
+			if (tb > file.size()) throw std::runtime_error("internal: packed size mismatch");
+			HIPCHK(hipMalloc(&d_text, tb + 16));
+			HIPCHK(hipMemcpy(d_text, file.data(), tb, hipMemcpyHostToDevice));
+		}
 		double t1 = now();
 		if (b3m_plan_run(plan, d_text, d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
 		double t2 = now();

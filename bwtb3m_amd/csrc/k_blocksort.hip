@@ -277,6 +277,21 @@ __global__ __launch_bounds__(256) void k_histogram(TextView T, uint64_t start, u
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
 
+// compactstream (row a3/f4, role of CompactInputTypes::linear_wrapper): symbol i = `bits` bits at bit offset i*bits of the
+// big-endian word stream, most significant bit first -> one byte per symbol (alphabets above 4 symbols take the byte paths)
+__global__ void k_compact_decode(const uint8_t *words, uint64_t n, uint32_t bits, uint8_t *out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t bo = i * bits, by = bo >> 3; const uint32_t sh = (uint32_t)(bo & 7);
+	const uint32_t two = ((uint32_t)words[by] << 8) | (uint32_t)words[by + 1];     // the file is padded to whole 64-bit words (+ 8 bytes here)
+	out[i] = (uint8_t)((two >> (16 - sh - bits)) & ((1u << bits) - 1u));
+}
+void compact_decode(const uint8_t *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(k_compact_decode, dim3(nblk(n)), dim3(256), 0, s, d_words, n, bits, d_out);
+}
+
 uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span)
 {
 	if (span < cap) span = cap;

@@ -13,6 +13,7 @@
 // Integer/bit work bound by HBM latency and bandwidth; no MFMA.
 #include "b3m_internal.h"
 #include "b3m_text.h"
+#include <cstdlib>
 
 namespace b3m {
 
@@ -264,9 +265,97 @@ __global__ __launch_bounds__(256) void k_gap_walk(GapWalkArgs A)
 	for (; t < A.chain_len; ++t) A.ranks_out[t * A.num_chains + c] = 0xFFFFFFFFu;
 }
 
+// FOUR LANES PER CHAIN.  The one-lane walk asks the vector memory pipe for 4 x 16 bytes of a different line in every lane: 256
+// line look-ups per wave and step.  Here the four lanes of a quad share a chain and a step is ONE 16-byte load per lane (lane 0
+// of the quad: the counts, lanes 1..3: four payload words each): 16 lines per wave-instruction, all 64 bytes of each used.  The
+// partial counts meet by two quad shuffles; every lane then knows the new rank.  Ranks leave as whole lines: lane k of a quad
+// keeps the rank of step 4i + k and the quads of a wave store 16 x 16 contiguous bytes every fourth step (layout
+// [step / 4][chain][4]; the rank list is sorted afterwards, its order is free).
+__global__ __launch_bounds__(256) void k_gap_walk4(GapWalkArgs A)
+{
+	const uint64_t c = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+	const uint32_t sub = threadIdx.x & 3u;
+	if (c >= A.num_chains) return;                            // whole quads leave together
+	const TextView &T = A.T;
+	const uint64_t Rbeg = A.a + A.m, Rend = Rbeg + A.mr;
+	uint64_t hi = Rend - (A.chain_first + c) * A.chain_len;   // chain covers positions [lo, hi)
+	uint64_t lo = (hi - Rbeg > A.chain_len) ? hi - A.chain_len : Rbeg;
+	uint32_t rho = A.anchors[c];                              // rank_L(S_hi)
+	const uint32_t p0 = *A.rd.p0ptr;
+	const uint32_t last_code = base_at(T, A.a + A.m - 1);
+	const bool term = T.type == B3M_INPUT_PACTERM;
+	const uint32_t *tw = reinterpret_cast<const uint32_t *>(T.b);
+	uint64_t wi = (hi - 1) >> 4;
+	uint32_t word = hi > lo ? __builtin_bswap32(tw[wi]) : 0u, wnext = (hi > lo && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
+	uint64_t gtw_idx = hi >> 5;
+	uint32_t gtw = A.gt_cur[gtw_idx], gtnext = gtw_idx > 0 ? A.gt_cur[gtw_idx - 1] : 0u;
+	uint32_t outw = 0; uint64_t outw_idx = ~0ull;
+	const uint32_t C0 = A.rd.C[0], C1 = A.rd.C[1], C2 = A.rd.C[2], C3 = A.rd.C[3];
+	uint32_t keep = 0xFFFFFFFFu;
+	uint64_t t = 0;
+	const uint64_t steps4 = (A.chain_len + 3) & ~3ull;       // slots of a chain, padded to whole quads of steps
+	uint32_t *outp = A.ranks_out + c * 4 + sub;               // + (t / 4) * 4 * num_chains
+	for (uint64_t j = hi; j-- > lo; ++t) {
+		if ((j >> 4) != wi) { wi = j >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
+		const bool is_term = term && j == T.n - 1;
+		const uint32_t code = is_term ? 0u : (word >> (2u * (15u - (uint32_t)(j & 15)))) & 3u;
+		uint64_t g = j + 1;
+		if ((g >> 5) != gtw_idx) { gtw_idx = g >> 5; gtw = gtnext; gtnext = gtw_idx > 0 ? A.gt_cur[gtw_idx - 1] : 0u; }
+		const uint32_t gtbit = (gtw >> (g & 31)) & 1u;
+		// one rank line, 16 bytes per lane
+		const uint32_t b = rho / RANK_BLK_SYMS, off = rho - b * RANK_BLK_SYMS;
+		const uint4 q = reinterpret_cast<const uint4 *>(A.rd.blocks + (uint64_t)b * 16)[sub];
+		uint32_t part;
+		if (sub == 0) part = code == 0 ? q.x : code == 1 ? q.y : code == 2 ? q.z : q.w;
+		else {
+			const uint32_t pat = code * 0x55555555u;
+			const int base = 64 * ((int)sub - 1);             // symbols before this lane's four words
+			const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+			part = 0;
+			#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int nsym = (int)off - base - 16 * i;
+				const uint32_t mask = nsym >= 16 ? 0x55555555u : (nsym <= 0 ? 0u : (0x55555555u & ((1u << (2 * nsym)) - 1u)));
+				const uint32_t y = w4[i] ^ pat;
+				part += __popc(~(y | (y >> 1)) & mask);
+			}
+		}
+		part += __shfl_xor(part, 1, 64);
+		part += __shfl_xor(part, 2, 64);
+		uint32_t cnt = part;
+		if (code == 0 && p0 >= b * RANK_BLK_SYMS && p0 < rho) cnt -= 1;          // the p0 entry is stored as code 0 but never counted
+		const uint32_t Cc = code == 0 ? C0 : code == 1 ? C1 : code == 2 ? C2 : C3;
+		rho = is_term ? 0u : Cc + cnt + ((last_code == code && gtbit) ? 1u : 0u);
+		if ((t & 3) == sub) keep = rho;
+		if ((t & 3) == 3) { outp[(t >> 2) * 4 * A.num_chains] = keep; keep = 0xFFFFFFFFu; }
+		if (sub == 0) {
+			const uint32_t ob = rho > p0 ? 1u : 0u;
+			if ((j >> 5) != outw_idx) {
+				if (outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+				outw_idx = j >> 5; outw = 0;
+			}
+			outw |= ob << (j & 31);
+		}
+	}
+	if (sub == 0 && outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+	// the open quad of steps, then the unused slots of a short chain
+	if (t & 3) { outp[(t >> 2) * 4 * A.num_chains] = keep; t = (t + 3) & ~3ull; }
+	for (; t < steps4; t += 4) outp[(t >> 2) * 4 * A.num_chains] = 0xFFFFFFFFu;
+}
+
+// slots the walk writes for a merge's chain table: the caller sizes and sorts this many entries (unused ones hold 0xFFFFFFFF)
+uint64_t gap_walk_slots(uint64_t num_chains, uint64_t chain_len) { return num_chains * ((chain_len + 3) & ~3ull); }
+
 void gap_walk(const GapWalkArgs &A, hipStream_t s)
 {
-	if (A.num_chains) hipLaunchKernelGGL(k_gap_walk, dim3(nblk(A.num_chains, 256)), dim3(256), 0, s, A);
+	if (!A.num_chains) return;
+	static const int one_lane = getenv("B3M_WALK_ONE_LANE") ? atoi(getenv("B3M_WALK_ONE_LANE")) : 0;   // measurement switch
+	if (one_lane) {
+		// the one-lane kernel fills [chain_len][num_chains]; the rest of the padded table must read as unused
+		const uint64_t used = A.num_chains * A.chain_len, all = gap_walk_slots(A.num_chains, A.chain_len);
+		if (all > used) fill_u32(A.ranks_out + used, 0xFFFFFFFFu, all - used, s);
+		hipLaunchKernelGGL(k_gap_walk, dim3(nblk(A.num_chains, 256)), dim3(256), 0, s, A);
+	} else hipLaunchKernelGGL(k_gap_walk4, dim3(nblk(A.num_chains * 4, 256)), dim3(256), 0, s, A);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ import torch.distributed as dist
 def chains_for(mr, world_hint=1):
     """chain table of a merge: same rule as the single-GPU engine (engine.hip: chains_for)"""
     target = 256 * 1024 * max(1, world_hint)
-    chain_len = max(32, (mr + target - 1) // target)
+    chain_len = (max(32, (mr + target - 1) // target) + 3) & ~3      # whole quads of steps (gap_walk_slots)
     return chain_len, (mr + chain_len - 1) // chain_len
 
 

@@ -39,6 +39,8 @@ def num_symbols(file_bytes, inputtype):
             raise _lib.B3MError("not a .pac file")
         l = (nb - 2) * 4 + int(file_bytes[-1])
         return l + (1 if t == INPUT_TYPES["pacterm"] else 0)
+    if t == INPUT_TYPES["compactstream"]:
+        return compact_info(file_bytes)[1]
     raise _lib.B3MError("input type not supported by the GPU engine yet")
 
 
@@ -134,9 +136,41 @@ class Plan:
         return out
 
 
+def compact_info(file_bytes):
+    """(bits per symbol, number of symbols, offset of the word stream) of a compactstream file image (b3m_compact_info)"""
+    fb = np.ascontiguousarray(file_bytes[:32], dtype=np.uint8)
+    bits, n, off = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib().b3m_compact_info(fb.ctypes.data, len(file_bytes), ctypes.byref(bits), ctypes.byref(n), ctypes.byref(off)))
+    return int(bits.value), int(n.value), int(off.value)
+
+
+def compact_to_plan_input(file_bytes, device="cuda"):
+    """compactstream file image -> (inputtype to plan with, device tensor to run it on, n): 2-bit files are a .pac payload in all but the
+    header, other widths are decoded to one byte per symbol on the device (b3m_compact_decode)"""
+    bits, n, off = compact_info(file_bytes)
+    fb = np.ascontiguousarray(file_bytes, dtype=np.uint8)
+    words = torch.zeros(len(fb) - off + 16, dtype=torch.uint8, device=device)       # padded: the pac plan copies n/4 + 2 bytes
+    words[: len(fb) - off] = torch.from_numpy(fb[off:].copy()).to(device)
+    if bits == 2:
+        return "pac", words, n
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device=device)
+    check(lib().b3m_compact_decode(_ptr(words), n, bits, _ptr(out), _stream()))
+    return "bytestream", out[:n], n
+
+
 def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0):
     """convenience: host packed bytes -> (bwt numpy, result dict)"""
     fb = np.ascontiguousarray(file_bytes, dtype=np.uint8)
+    if _type_id(inputtype) == INPUT_TYPES["compactstream"]:
+        itype, d, n = compact_to_plan_input(fb)
+        plan = Plan(n, itype, blocksize=blocksize, isasamplingrate=isasamplingrate)
+        try:
+            out = plan.run(d)
+            torch.cuda.synchronize()
+            return out.cpu().numpy(), plan.result(), plan
+        except Exception:
+            plan.close()
+            raise
     n = num_symbols(fb, inputtype)
     plan = Plan(n, inputtype, blocksize=blocksize, isasamplingrate=isasamplingrate)
     try:

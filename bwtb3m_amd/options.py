@@ -102,7 +102,7 @@ class BwtMergeSortOptions:
     def parseInputType(name):
         if name not in INPUT_TYPES:
             # message of the reference's switch, /root/reference/src/checkbwt.cpp:274
-            raise B3MError("Unknown input type " + str(name))
+            raise B3MError("libmaus2::suffixsort::bwtb3m::BwtMergeSort::computeBwt: unknown/unsupported input type")   # /root/reference/src/checkbwt.cpp:274
         return INPUT_TYPES[name]
 
     def __init__(self, arginfo=None, **kw):

@@ -38,7 +38,7 @@ extern "C" {
 /* input types, /root/reference/src/bwtb3m.cpp:43, enum use at /root/reference/src/checkbwt.cpp:257-270 */
 enum {
 	B3M_INPUT_BYTESTREAM = 0,
-	B3M_INPUT_COMPACTSTREAM = 1, /* parsed, not yet constructed */
+	B3M_INPUT_COMPACTSTREAM = 1, /* b3m_compute_bwt / b3m_compact_*: 2-bit files as pac, other widths through the byte paths */
 	B3M_INPUT_PAC = 2,
 	B3M_INPUT_PACTERM = 3,
 	B3M_INPUT_LZ4 = 4,           /* parsed, not yet constructed */
@@ -122,6 +122,15 @@ typedef struct b3m_e2e_times {
 int   b3m_plan_run_host(b3m_plan *p, const void *h_text, uint8_t *h_bwt_out, b3m_e2e_times *times, void *stream);
 void *b3m_host_alloc(uint64_t bytes);     /* pinned host memory (hipHostMalloc) */
 void  b3m_host_free(void *p);
+
+/* row f4, inputtype=compactstream (producers /root/reference/src/fagzToCompact4.cpp:113 (2 bits), fagzToCompact.cpp:85 (3 bits)): a libmaus2
+ * CompactArray file.  Layout [UPSTREAM-RECALL, unpinned]: four big-endian u64 (bits per symbol, number of symbols, number of 64-bit words,
+ * the word count again), then the words, big-endian, symbols from the most significant bit down.  2-bit files are sorted like a .pac
+ * payload (same bit order); other widths are decoded to one byte per symbol on the device and take the byte paths.
+ * Circular, no terminator (as bytestream).  b3m_compute_bwt accepts the type; at plan level: b3m_compact_info + (bits == 2 ?
+ * plan of type pac on the word stream : b3m_compact_decode + plan of type bytestream). */
+int b3m_compact_info(const uint8_t *file_head32, uint64_t file_size, uint32_t *bits_out, uint64_t *n_out, uint64_t *data_off_out);
+int b3m_compact_decode(const void *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, void *stream);
 
 typedef struct b3m_result {
 	uint64_t n, num_blocks, levels;

@@ -211,10 +211,38 @@ def pac_decode(buf):
     return out[:l]
 
 
+def compact_encode(symbols, bits):
+    """libmaus2 CompactArray file image [UPSTREAM-RECALL, unpinned: no sample file or source in /root/reference; producers
+    /root/reference/src/fagzToCompact4.cpp:113 (2 bits) and fagzToCompact.cpp:85 (3 bits)]: four big-endian u64 -- bits per
+    symbol, number of symbols, number of 64-bit words, the word count again -- then the words, big-endian, symbols packed
+    from the most significant bit down."""
+    sym = np.asarray(symbols, dtype=np.uint64)
+    n = len(sym)
+    nbits = n * bits
+    nw = (nbits + 63) // 64
+    bitarr = np.zeros(nw * 64, dtype=np.uint8)
+    for k in range(bits):
+        bitarr[k:n * bits:bits] = ((sym >> np.uint64(bits - 1 - k)) & np.uint64(1)).astype(np.uint8)
+    data = np.packbits(bitarr)
+    hdr = np.array([bits, n, nw, nw], dtype=">u8").view(np.uint8)
+    return np.concatenate([hdr, data]).astype(np.uint8)
+
+
+def compact_decode(buf):
+    buf = np.asarray(buf, dtype=np.uint8)
+    bits, n, nw, nw2 = (int(x) for x in buf[:32].view(">u8"))
+    assert nw == nw2 and 1 <= bits <= 8 and len(buf) >= 32 + 8 * nw and nw * 64 >= n * bits, "not a compact array file"
+    bitarr = np.unpackbits(buf[32:32 + 8 * nw])[: n * bits].reshape(n, bits).astype(np.uint16)
+    w = (1 << np.arange(bits - 1, -1, -1)).astype(np.uint16)
+    return (bitarr * w).sum(axis=1).astype(np.uint8)
+
+
 def symbols_from_file_bytes(buf, inputtype):
     """Logical symbol sequence of an input file (row a3)."""
     if inputtype == "bytestream":
         return np.asarray(buf, dtype=np.uint8)
+    if inputtype == "compactstream":
+        return compact_decode(buf)
     if inputtype == "pac":
         return pac_decode(buf)
     if inputtype == "pacterm":

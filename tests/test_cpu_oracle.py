@@ -128,3 +128,18 @@ def test_pac_round_trip(oracle):
         assert len(buf) == l // 4 + 2            # file size is floor(l/4)+2
         assert np.array_equal(oracle.pac_decode(buf), b)
     assert len(oracle.pac_encode(np.zeros(5_000_000, dtype=np.uint8))) == 1_250_002
+
+
+def test_compactstream_codec_round_trip():
+    # row f4: the compact array image (recalled layout, see oracle.compact_encode) encodes and decodes every width
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for bits in (1, 2, 3, 4, 7, 8):
+        for n in (0, 1, 31, 32, 33, 1000):
+            sym = rng.integers(0, 1 << bits, n, dtype=np.uint8)
+            buf = O.compact_encode(sym, bits)
+            assert len(buf) == 32 + 8 * ((n * bits + 63) // 64)
+            assert np.array_equal(O.symbols_from_file_bytes(buf, "compactstream"), sym)
+    # 2-bit compact words are a .pac payload: same bit order
+    b = rng.integers(0, 4, 1001, dtype=np.uint8)
+    assert np.array_equal(O.compact_encode(b, 2)[32:32 + 250], O.pac_encode(b)[:250])

@@ -792,3 +792,31 @@ def test_bench_two_ranks_on_one_gpu_reports_both_modes_and_fails_loudly(gpu, tmp
     cmd_bad = cmd[:-4] + ["--config", "c1", "--mode", "blocks"]
     r = subprocess.run(cmd_bad, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+@pytest.mark.parametrize("bits,n", [(2, 1), (2, 1000), (2, 300000), (3, 777), (3, 100000), (1, 5000), (4, 65536), (8, 4097)])
+def test_compactstream_inputs(gpu, oracle, bits, n):
+    # row f4: inputtype=compactstream (2-bit files sorted as a .pac payload, other widths decoded to bytes on the device); circular BWT, no terminator
+    rng = np.random.default_rng(bits * 1000 + n)
+    sym = rng.integers(0, 1 << bits, n, dtype=np.uint8)
+    if n > 5000:
+        sym[n // 2: n // 2 + 700] = sym[100:800]          # a repeat
+    buf = oracle.compact_encode(sym, bits)
+    out, res, plan = _plan_bwt(gpu, buf, "compactstream")
+    assert np.array_equal(out, oracle.bwt(sym))
+    plan.close()
+
+
+def test_cli_compactstream(gpu, oracle, tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(3)
+    for bits, n in ((2, 20000), (3, 20000)):
+        sym = rng.integers(0, min(1 << bits, 6), n, dtype=np.uint8)
+        fn = tmp_path / ("in%d.compact" % bits)
+        oracle.compact_encode(sym, bits).tofile(fn)
+        outfn = tmp_path / ("out%d.bwt" % bits)
+        r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=compactstream", "bwtonly=1", "outputfilename=%s" % outfn, str(fn)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        d = subprocess.run([os.path.join(root, "bin", "bwtb3mdecoderl"), str(outfn)], capture_output=True)
+        assert d.returncode == 0 and np.array_equal(np.frombuffer(d.stdout, dtype=np.uint8), oracle.bwt(sym))
