@@ -212,6 +212,12 @@ struct GapWalkArgs {
 };
 void gap_walk(const GapWalkArgs &A, hipStream_t s);
 uint64_t gap_walk_slots(uint64_t num_chains, uint64_t chain_len);   // entries of ranks_out the walk fills (chains padded to whole quads of steps)
+// byte alphabets: count rows every 64 symbols of BWT(L) (bytes, 64-byte aligned, readable to the next multiple of 64) and the walk over them
+uint64_t byte_rank_rows(uint64_t m);
+uint64_t byte_rank_tiles(uint64_t m);
+void byte_rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, uint32_t *d_occ, uint32_t *d_th, hipStream_t s);
+void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_bwtL, const uint32_t *d_p0, const uint32_t *d_C, uint64_t a, uint64_t m, uint64_t mr,
+                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s);
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
 // d_blocks: rank dictionary of the whole BWT (rank_build64), p0 = rank of the terminator entry (~0: none), C = symbol starts
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);

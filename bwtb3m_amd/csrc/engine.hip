@@ -277,17 +277,16 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		// fixed part: text, 2 bwt arrays, gt; merge part needs ranks (8 B per R suffix) + rank blocks
 		uint64_t fixed = packed_text_bytes(n, inputtype) + 2 * n + n / 2 + (64ull << 20);
 		uint64_t b = n;
-		while (b > 1024 && fixed + blocksort_ws_bytes(b) + (b < n ? 9 * n / 2 : 0) > budget) b = (b + 1) / 2;
+		// byte alphabets: count rows of BWT(L), 16 B per symbol of the largest left side, instead of 0.33 B
+		const uint64_t merge_part = inputtype == B3M_INPUT_BYTESTREAM ? 9 * n / 2 + 9 * n : 9 * n / 2;
+		while (b > 1024 && fixed + blocksort_ws_bytes(b) + (b < n ? merge_part : 0) > budget) b = (b + 1) / 2;
 		blocksize = b;
-		if (inputtype == B3M_INPUT_BYTESTREAM && b < n)
-			throw Error("bytestream input does not fit a single block in the memory target; multi-block merging of byte alphabets is not implemented yet");
 	}
 	if (blocksize > n) blocksize = n;
 	p->blocksize = blocksize;
 	build_tree(p);
-	B3M_REQUIRE(p->leaves.size() == 1 || inputtype != B3M_INPUT_BYTESTREAM,
-	            "multi-block merging of byte alphabets is not implemented yet (use one block)");
 	const uint64_t B = p->leaves.size();
+	const bool bytes = inputtype == B3M_INPUT_BYTESTREAM;
 	// ---- carve the arena ----
 	uint64_t off = 0;
 	auto take = [&](uint64_t bytes) { uint64_t o = off; off += al256(bytes); return o; };
@@ -305,7 +304,9 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint64_t nbk = rank_blocks(maxL);
 	uint64_t o_rb = 0, o_rs = 0, o_sw = 0, o_r0 = 0, o_r1 = 0, o_tq = 0, o_mr = 0;
 	if (B > 1) {
-		o_rb = take(64 * nbk); o_rs = take(64 * nbk + 64); o_sw = take(4 * scan_ws_elems(nbk) + 64);
+		// byte alphabets: count rows (1 KB per 64 symbols of L), an aligned copy of BWT(L) + the 256 symbol starts + the build's tile counts
+		if (bytes) { o_rb = take(1024 * byte_rank_rows(maxL)); o_rs = take(maxL + 256 + 1024 * byte_rank_tiles(maxL) + 1024); o_sw = take(64); }
+		else { o_rb = take(64 * nbk); o_rs = take(64 * nbk + 64); o_sw = take(4 * scan_ws_elems(nbk) + 64); }
 		o_r0 = take(4 * p->max_slots + 64); o_r1 = take(4 * p->max_slots + 64);
 		o_tq = take(4 * (interleave_tiles(maxTot) + 2));
 		o_mr = take(radix_ws_bytes(p->max_slots));
@@ -469,7 +470,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		if (p->seq_shards > 1) { B3M_REQUIRE(acc == lf.m, "internal: suffix-range shards do not cover the block"); p->res.slice_offset = 0; p->res.slice_len = acc; }
 		else { p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len; }
 		{
-			if (B > 1) emit_gt_from_text(T, lf.a, lf.m, p->d_gt[0], s);
+			if (B > 1 && p->type == B3M_INPUT_BYTESTREAM) hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((lf.m + 255) / 256)), dim3(256), 0, s, so.d_sa, lf.m, lf.a, p->d_p0tmp + k, p->d_gt[0]);
+			else if (B > 1) emit_gt_from_text(T, lf.a, lf.m, p->d_gt[0], s);
 		}
 		if (B > 1) {
 			Scope sc(tl, KF_ANCHOR, 0);
@@ -509,21 +511,39 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 				clear_bits(p->d_gt[nxt], Rbeg, Rend + 1, s);
 				hipLaunchKernelGGL(k_merge_prologue, dim3(1), dim3(64), 0, s, p->d_p0pairs + 2 * M.L.lo, p->d_anchors + M.anchor_off,
 				                   p->d_gt[nxt], Rend, d_p0u);
-				rank_build(p->d_bwt[cur] + a, m, d_p0u, p->type, p->d_rank_blocks, p->d_rank_scratch, p->d_scan_ws, s);
-				rd.blocks = p->d_rank_blocks; rd.m = m; rd.p0ptr = d_p0u;
 				uint64_t hl[256] = {0};
 				for (int k = M.L.lo; k < M.L.hi; ++k) for (int c = 0; c < 256; ++c) hl[c] += hh[256 * k + c];
+				if (p->type == B3M_INPUT_BYTESTREAM) {
+					// byte alphabet: aligned copy of BWT(L) + count rows every 64 symbols + the 256 symbol starts of L's text
+					uint8_t *lcopy = reinterpret_cast<uint8_t *>(p->d_rank_scratch);
+					uint32_t *d_C = reinterpret_cast<uint32_t *>(lcopy + ((m + 255) & ~255ull)), *d_th = d_C + 256;
+					uint32_t hC[256]; { uint64_t acc = 0; for (int c = 0; c < 256; ++c) { hC[c] = (uint32_t)acc; acc += hl[c]; } }
+					B3M_HIP(hipMemcpyAsync(lcopy, p->d_bwt[cur] + a, m, hipMemcpyDeviceToDevice, s));
+					B3M_HIP(hipMemsetAsync(lcopy + m, 0, ((m + 255) & ~255ull) - m, s));
+					B3M_HIP(hipMemcpyAsync(d_C, hC, 1024, hipMemcpyHostToDevice, s));
+					B3M_HIP(hipStreamSynchronize(s));                  // hC is on this stack frame
+					byte_rank_build(lcopy, m, d_p0u, p->d_rank_blocks, d_th, s);
+				} else
+				rank_build(p->d_bwt[cur] + a, m, d_p0u, p->type, p->d_rank_blocks, p->d_rank_scratch, p->d_scan_ws, s);
+				rd.blocks = p->d_rank_blocks; rd.m = m; rd.p0ptr = d_p0u;
 				if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = hl[0]; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c + 1]; } }
 				else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { rd.C[c] = (uint32_t)acc; acc += hl[c]; } }
 			}
 			{
 				Scope sc(tl, KF_GAPWALK, mr * (64 + 4));
+				if (p->type == B3M_INPUT_BYTESTREAM) {
+					uint8_t *lcopy = reinterpret_cast<uint8_t *>(p->d_rank_scratch);
+					uint32_t *d_C = reinterpret_cast<uint32_t *>(lcopy + ((m + 255) & ~255ull));
+					gap_walk_bytes(T, p->d_rank_blocks, lcopy, d_p0u, d_C, a, m, mr, p->d_gt[cur], p->d_gt[nxt], p->d_anchors + M.anchor_off, M.num_chains, M.chain_len,
+					               p->d_ranks[0], s);
+				} else {
 				GapWalkArgs G{};
 				G.T = T; G.rd = rd; G.a = a; G.m = m; G.mr = mr;
 				G.gt_cur = p->d_gt[cur]; G.gt_next = p->d_gt[nxt];
 				G.anchors = p->d_anchors + M.anchor_off; G.num_chains = M.num_chains; G.chain_len = M.chain_len;
 				G.ranks_out = p->d_ranks[0];
 				gap_walk(G, s);
+				}
 			}
 			uint32_t *sr = nullptr;
 			{

@@ -359,6 +359,155 @@ void gap_walk(const GapWalkArgs &A, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// BYTE ALPHABETS (bytestream, compactstream above 2 bits): rank structure and LF walk of the gap merge (rows a8/a9 for
+// sigma <= 256).  BWT(L) stays as bytes; occ[b][c] = occurrences of c in BWT_L[0, 64 b) (the p0 entry never counted),
+// one 1-KB row per 64 symbols (16 B per symbol of L).  A rank query = one count (4 bytes of a random row) + the
+// <= 64 bytes of the block before the rank (one line), compared as bytes with SWAR arithmetic.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t BR_BLK = 64;                 // symbols per count row
+constexpr uint32_t BR_TILE = 256;               // rows per build tile (16 Ki symbols)
+uint64_t byte_rank_rows(uint64_t m) { return m / BR_BLK + 1; }
+uint64_t byte_rank_tiles(uint64_t m) { return (byte_rank_rows(m) + BR_TILE - 1) / BR_TILE; }
+// pass 1: histogram of every tile -> th[c][tile]
+__global__ __launch_bounds__(256) void k_br_tile_hist(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, uint32_t *th, uint64_t ntiles)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t t = blockIdx.x, lo = t * BR_TILE * BR_BLK, hi = lo + (uint64_t)BR_TILE * BR_BLK < m ? lo + (uint64_t)BR_TILE * BR_BLK : m;
+	const uint64_t p0 = *p0ptr;
+	for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) if (i != p0) atomicAdd(&h[bwt[i]], 1u);
+	__syncthreads();
+	th[(uint64_t)threadIdx.x * ntiles + t] = h[threadIdx.x];
+}
+// pass 2: exclusive scan of every symbol's row of tile counts (one workgroup per symbol)
+__global__ __launch_bounds__(256) void k_br_colscan(uint32_t *th, uint64_t ntiles)
+{
+	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t carry;
+	uint32_t *row = th + (uint64_t)blockIdx.x * ntiles;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	if (tid == 0) carry = 0;
+	__syncthreads();
+	for (uint64_t base = 0; base < ntiles; base += 256) {
+		const uint64_t i = base + tid;
+		const uint32_t v = i < ntiles ? row[i] : 0u;
+		const uint32_t inc = wave_incl_sum(v);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t pre = carry;
+		for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+		if (i < ntiles) row[i] = pre + inc - v;
+		__syncthreads();
+		if (tid == 255) carry = pre + inc;
+		__syncthreads();
+	}
+}
+// pass 3: the count rows of a tile, row by row (thread c keeps the running count of symbol c)
+__global__ __launch_bounds__(256) void k_br_rows(const uint8_t *bwt, uint64_t m, const uint32_t *p0ptr, const uint32_t *th, uint64_t ntiles, uint32_t *occ, uint64_t nrows)
+{
+	__shared__ uint32_t run[256];
+	const uint64_t t = blockIdx.x;
+	const uint32_t c = threadIdx.x;
+	run[c] = th[(uint64_t)c * ntiles + t];
+	const uint64_t p0 = *p0ptr;
+	__syncthreads();
+	for (uint32_t r = 0; r < BR_TILE; ++r) {
+		const uint64_t row = t * BR_TILE + r;
+		if (row >= nrows) break;
+		occ[row * 256 + c] = run[c];
+		__syncthreads();
+		const uint64_t i = row * BR_BLK + c;
+		if (c < BR_BLK && i < m && i != p0) atomicAdd(&run[bwt[i]], 1u);
+		__syncthreads();
+	}
+}
+// d_occ: 256 * byte_rank_rows(m) u32; d_th: 256 * byte_rank_tiles(m) u32 scratch
+void byte_rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, uint32_t *d_occ, uint32_t *d_th, hipStream_t s)
+{
+	const uint64_t nrows = byte_rank_rows(m), ntiles = byte_rank_tiles(m);
+	hipLaunchKernelGGL(k_br_tile_hist, dim3((uint32_t)ntiles), dim3(256), 0, s, d_bwtL, m, d_p0, d_th, ntiles);
+	hipLaunchKernelGGL(k_br_colscan, dim3(256), dim3(256), 0, s, d_th, ntiles);
+	hipLaunchKernelGGL(k_br_rows, dim3((uint32_t)ntiles), dim3(256), 0, s, d_bwtL, m, d_p0, d_th, ntiles, d_occ, nrows);
+}
+// bytes of w equal to c (SWAR): x = w ^ cccc; a byte of x is zero iff equal
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t c4)
+{
+	const uint32_t x = w ^ c4;
+	const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;      // high bit of every byte set iff the byte is non-zero
+	return __popc(~t & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t byte_rank_query(const uint32_t *occ, const uint8_t *bwt, uint32_t p0, uint32_t c, uint32_t rho)
+{
+	const uint32_t b = rho / BR_BLK, off = rho - b * BR_BLK;
+	uint32_t cnt = occ[(uint64_t)b * 256 + c];
+	const uint4 *line = reinterpret_cast<const uint4 *>(bwt + (uint64_t)b * BR_BLK);     // bwt is 64-byte aligned and padded
+	const uint32_t c4 = c * 0x01010101u;
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		if ((uint32_t)(16 * q) >= off) break;
+		const uint4 v = line[q];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int nb = (int)off - 16 * q - 4 * i;          // bytes of this word before the rank
+			if (nb <= 0) break;
+			uint32_t ww = w[i];
+			if (nb < 4) ww = (ww & ((1u << (8 * nb)) - 1u)) | (~c4 & ~((1u << (8 * nb)) - 1u));     // bytes at and behind the rank never match
+			cnt += eq_bytes(ww, c4);
+		}
+	}
+	if (p0 >= b * BR_BLK && p0 < rho && bwt[p0] == c) cnt -= 1;      // the p0 entry is never counted
+	return cnt;
+}
+struct ByteWalkArgs {
+	TextView T;
+	const uint32_t *occ; const uint8_t *bwtL; const uint32_t *p0ptr; const uint32_t *C;      // C: 256 symbol starts of L's text (device)
+	uint64_t a, m, mr;
+	const uint32_t *gt_cur; uint32_t *gt_next;
+	const uint32_t *anchors; uint64_t num_chains, chain_len, chain_first;
+	uint32_t *ranks_out;       // [chain_len][num_chains], unused slots 0xFFFFFFFF (then up to gap_walk_slots: filled by the caller)
+};
+__global__ __launch_bounds__(256) void k_gap_walk_bytes(ByteWalkArgs A)
+{
+	uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= A.num_chains) return;
+	const TextView &T = A.T;
+	const uint64_t Rbeg = A.a + A.m, Rend = Rbeg + A.mr;
+	uint64_t hi = Rend - (A.chain_first + c) * A.chain_len;
+	uint64_t lo = (hi - Rbeg > A.chain_len) ? hi - A.chain_len : Rbeg;
+	uint32_t rho = A.anchors[c];
+	const uint32_t p0 = *A.p0ptr;
+	const uint32_t last_sym = T.b[A.a + A.m - 1];
+	uint32_t outw = 0; uint64_t outw_idx = ~0ull;
+	uint64_t t = 0;
+	for (uint64_t j = hi; j-- > lo; ++t) {
+		const uint32_t sym = T.b[j];
+		const uint64_t g = j + 1;
+		const uint32_t gtbit = (A.gt_cur[g >> 5] >> (g & 31)) & 1u;
+		rho = A.C[sym] + byte_rank_query(A.occ, A.bwtL, p0, sym, rho) + ((last_sym == sym && gtbit) ? 1u : 0u);
+		A.ranks_out[t * A.num_chains + c] = rho;
+		const uint32_t ob = rho > p0 ? 1u : 0u;
+		if ((j >> 5) != outw_idx) {
+			if (outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+			outw_idx = j >> 5; outw = 0;
+		}
+		outw |= ob << (j & 31);
+	}
+	if (outw_idx != ~0ull && outw) atomicOr(&A.gt_next[outw_idx], outw);
+	for (; t < A.chain_len; ++t) A.ranks_out[t * A.num_chains + c] = 0xFFFFFFFFu;
+}
+void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_bwtL, const uint32_t *d_p0, const uint32_t *d_C, uint64_t a, uint64_t m, uint64_t mr,
+                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s)
+{
+	if (!num_chains) return;
+	ByteWalkArgs A{T, d_occ, d_bwtL, d_p0, d_C, a, m, mr, gt_cur, gt_next, d_anchors, num_chains, chain_len, 0, ranks_out};
+	const uint64_t used = num_chains * chain_len, all = gap_walk_slots(num_chains, chain_len);
+	if (all > used) fill_u32(ranks_out + used, 0xFFFFFFFFu, all - used, s);
+	hipLaunchKernelGGL(k_gap_walk_bytes, dim3(nblk(num_chains, 256)), dim3(256), 0, s, A);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LF walks over the FINAL BWT (the sampled SA stage of bwtcomputessa,
 // /root/reference/src/bwtcomputessa.cpp:39-51, and the verification walk of checkbwt,
 // /root/reference/src/checkbwt.cpp:176-241).  Chain k starts at anchor k+1 (rank r of the rotation

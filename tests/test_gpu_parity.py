@@ -257,7 +257,7 @@ def test_errors_are_loud(gpu):
     with pytest.raises(B3MError):
         engine.Plan(0, "bytestream")
     with pytest.raises(B3MError):
-        engine.Plan(100000, "bytestream", blocksize=1000)   # byte-alphabet merges not implemented
+        engine.Plan(100, "lz4")
 
 
 def test_library_is_the_hip_one(gpu):
@@ -820,3 +820,40 @@ def test_cli_compactstream(gpu, oracle, tmp_path):
         assert r.returncode == 0, r.stderr
         d = subprocess.run([os.path.join(root, "bin", "bwtb3mdecoderl"), str(outfn)], capture_output=True)
         assert d.returncode == 0 and np.array_equal(np.frombuffer(d.stdout, dtype=np.uint8), oracle.bwt(sym))
+
+
+@pytest.mark.parametrize("n,bs,kind", [(1000, 100, "random"), (1000, 333, "small"), (65536, 8192, "random"), (65537, 10000, "small"), (300000, 37501, "repeat"),
+                                        (4097, 1000, "periodic"), (200000, 100000, "text")])
+def test_bytestream_multi_block_merges(gpu, oracle, n, bs, kind):
+    """byte alphabets through the gap merge (rows a8-a10 for sigma <= 256): count rows every 64 symbols of BWT(L), byte LF walk.  The reference
+    merges every input type through the same path (/root/reference/src/bwtb3m.cpp:62-63 with mem=)."""
+    rng = np.random.default_rng(n + bs)
+    if kind == "random":
+        t = rng.integers(0, 256, n, dtype=np.uint8)
+    elif kind == "small":
+        t = rng.integers(0, 3, n, dtype=np.uint8) + 250          # the largest byte values
+    elif kind == "repeat":
+        t = rng.integers(0, 256, n, dtype=np.uint8); t[n // 2: n // 2 + 40000] = t[1000:41000]
+    elif kind == "periodic":
+        t = np.resize(np.frombuffer(b"abcab", dtype=np.uint8), n).copy(); t[-1] = 0
+    else:
+        words = [b"the ", b"quick ", b"brown ", b"fox ", b"jumps ", b"over ", b"lazy ", b"dog\n"]
+        t = np.frombuffer(b"".join(words[i] for i in rng.integers(0, len(words), n // 4))[:n].ljust(n, b"."), dtype=np.uint8).copy()
+    ref = oracle.bwt(t)
+    out, res, plan = _plan_bwt(gpu, t, "bytestream", blocksize=bs, isarate=64)
+    assert res["num_blocks"] == (n + bs - 1) // bs or res["num_blocks"] > 1
+    assert np.array_equal(out, ref)
+    # the (rank,pos) samples carried through the merges are those of the final order
+    sa = oracle.sa_circular(t)
+    isa = np.empty(n, dtype=np.int64); isa[sa] = np.arange(n)
+    sm = plan.samples()
+    assert len(sm) == (n + 63) // 64 and all(int(isa[int(p)]) == int(r) for r, p in sm[:: max(1, len(sm) // 200)])
+    plan.close()
+
+
+def test_compactstream_3bit_multi_block(gpu, oracle):
+    rng = np.random.default_rng(8)
+    sym = rng.integers(0, 6, 120000, dtype=np.uint8)
+    out, res, plan = _plan_bwt(gpu, oracle.compact_encode(sym, 3), "compactstream", blocksize=16000)
+    assert res["num_blocks"] == 8 and np.array_equal(out, oracle.bwt(sym))
+    plan.close()
