@@ -71,6 +71,11 @@ SYMBOLS = [
     ("b3m_host_free", None, [_p]),
     ("b3m_compact_info", _i, [_p, _u64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
     ("b3m_compact_decode", _i, [_p, _u64, ctypes.c_uint32, _p, _p]),
+    ("b3m_plan_set_keep_sa", _i, [_p, _i]),
+    ("b3m_plan_has_sa", _i, [_p]),
+    ("b3m_plan_tie_pending", _i, [_p, ctypes.POINTER(_u64)]),
+    ("b3m_plan_tie_export", _i, [_p, _p, _p, _p]),
+    ("b3m_plan_tie_finish", _i, [_p, _p, _p, _u64, _u64, _p, _p]),
     ("b3m_plan_result", _i, [_p, ctypes.POINTER(Result)]),
     ("b3m_plan_samples", _i, [_p, _p, _u64]),
     ("b3m_plan_histogram", _i, [_p, _p]),

@@ -149,6 +149,8 @@ struct BlockSortOut {
 	uint64_t tie_rounds = 0, tie_elements = 0;
 	uint64_t msd_overflow_buckets = 0;
 	bool used_msd = false;
+	uint64_t tie_left = 0;            // suffix-range shard: slots still tied after the local rounds (finished globally), their list and labels in ws
+	uint32_t *tie_U = nullptr, *tie_gid = nullptr;
 	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
 	uint64_t kept_len = 0;            // suffixes sorted here (= len unless this is a suffix-range shard)

@@ -110,6 +110,7 @@ struct MergeT {
 struct b3m_plan {
 	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
 	int shard = 0, nshards = 1; uint64_t shard_cap = 0;   // suffix-range shard of a single-block plan
+	int keep_sa = 0;                                      // b3m_plan_set_keep_sa: the next runs keep the whole suffix array of the sort (tie export needs it)
 	int seq_shards = 1;                                   // texts of 2^32 symbols and more on one GPU: the suffix-range shards of the one block, one after the other
 	std::vector<Leaf> leaves;
 	std::vector<MergeT> merges;
@@ -142,6 +143,8 @@ struct b3m_plan {
 	std::vector<uint64_t> h_hist;          // 256
 	Timeline tl;
 	double kms[KF_COUNT]{}; uint64_t klaunch[KF_COUNT]{}; uint64_t kbytes[KF_COUNT]{};
+	uint64_t tie_left = 0; uint32_t *tie_U = nullptr, *tie_gid = nullptr;   // suffix-range shard: what its local rounds left tied (b3m_plan_tie_*)
+	uint32_t *d_sa_slice = nullptr; uint64_t slice_off = 0, slice_len = 0;
 	hipStream_t copy_stream = nullptr;     // host-memory runs: slices of the BWT leave on this stream while later buckets sort
 	b3m_e2e_times e2e{};
 };
@@ -444,7 +447,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	for (uint64_t k = 0; k < B; ++k) {
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
-		const bool need_sa = B > 1 || p->isarate != 0;       // anchors / samples read the suffix array
+		const bool need_sa = B > 1 || p->isarate != 0 || p->keep_sa;       // anchors / samples / the tie export read the suffix array
 		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
 		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
 		if (p->isarate && nsh > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
@@ -457,6 +460,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr;
 			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
+			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
+			p->d_sa_slice = so.d_sa; p->slice_off = so.slice_offset; p->slice_len = so.kept_len;
+			B3M_REQUIRE(!(so.tie_left && p->seq_shards > 1), "internal: deferred ties in a sequential shard");
 			p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 			p->res.tie_elements += so.tie_elements;
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
@@ -659,6 +665,101 @@ int b3m_compact_decode(const void *d_words, uint64_t n, uint32_t bits, uint8_t *
 	B3M_REQUIRE(d_words && d_out && bits >= 1 && bits <= 8, "b3m_compact_decode: bad argument");
 	compact_decode((const uint8_t *)d_words, n, bits, d_out, (hipStream_t)stream);
 	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* ---- suffix-range shards and long repeats (row a6): a shard's local sort stops after a few key-extension rounds; what is still tied is
+ * finished by prefix doubling over the suffix arrays of ALL shards, in O(log longest repeat) rounds -- the bound the reference gets per block
+ * from lcpnext / largelcpthres (/root/reference/src/bwtb3m.cpp:55, ChangeLog:205-211).  Every rank runs the same rounds on the union list. ---- */
+__global__ void k_tie_pairs(const uint32_t *U, const uint32_t *gid, uint64_t u, uint32_t off, uint32_t *pairs)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) { pairs[2 * s] = U[s] + off; pairs[2 * s + 1] = gid[s] + off; }
+}
+__global__ void k_tie_unpairs(const uint32_t *pairs, uint64_t u, uint32_t *U, uint32_t *gid)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) { U[s] = pairs[2 * s]; gid[s] = pairs[2 * s + 1]; }
+}
+__global__ void k_sub_u32(const uint32_t *pairs, uint64_t u, uint32_t off, uint32_t *out)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) out[s] = pairs[2 * s] - off;
+}
+int b3m_plan_set_keep_sa(b3m_plan *p, int on) { if (!p) { set_error("null argument"); return 1; } p->keep_sa = on ? 1 : 0; return 0; }
+int b3m_plan_has_sa(const b3m_plan *p) { return p && p->d_sa_slice != nullptr; }
+int b3m_plan_tie_pending(const b3m_plan *p, uint64_t *count_out)
+{
+	if (!p || !count_out) { set_error("null argument"); return 1; }
+	*count_out = p->tie_left; return 0;
+}
+/* d_sa_slice_out: slice_len u32 (this shard's suffix array, rank order); d_pairs_out: 2 * pending u32 = (global slot, global group label) */
+int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_sa_slice_out, "b3m_plan_tie_export: null argument");
+	B3M_REQUIRE(p->nshards > 1 && p->n < (1ull << 32), "tie export: suffix-range shards of a text below 2^32 symbols only");
+	hipStream_t s = (hipStream_t)stream;
+	B3M_REQUIRE(p->d_sa_slice || p->slice_len == 0, "tie export: the shard kept no suffix array: b3m_plan_set_keep_sa(plan, 1) and run it again");
+	if (p->slice_len) B3M_HIP(hipMemcpyAsync(d_sa_slice_out, p->d_sa_slice, 4 * p->slice_len, hipMemcpyDeviceToDevice, s));
+	if (p->tie_left) {
+		B3M_REQUIRE(d_pairs_out, "b3m_plan_tie_export: null argument");
+		hipLaunchKernelGGL(k_tie_pairs, dim3((uint32_t)((p->tie_left + 255) / 256)), dim3(256), 0, s, p->tie_U, p->tie_gid, p->tie_left, (uint32_t)p->slice_off, d_pairs_out);
+	}
+	B3M_HIP(hipStreamSynchronize(s));
+	return 0;
+	B3M_CATCH(1)
+}
+/* d_sa_global: n u32, all shards' slices in rank order (changed in place); d_pairs_all: the exported pairs of all shards, concatenated in shard
+ * order (total of them); my_first: index of this shard's first pair.  Repairs this shard's slice of the BWT in d_bwt_slice (+ p0, samples). */
+int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pairs_all, uint64_t total, uint64_t my_first, uint8_t *d_bwt_slice, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_sa_global && d_pairs_all && d_bwt_slice, "b3m_plan_tie_finish: null argument");
+	B3M_REQUIRE(p->nshards > 1 && p->n < (1ull << 32), "tie finish: suffix-range shards of a text below 2^32 symbols only");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t n = p->n;
+	BlockSortWs &ws = p->bs;
+	B3M_REQUIRE(total <= ws.cap, "tie finish: more tied suffixes over all shards than one shard's workspace holds (low-complexity input)");
+	if (total == 0) return 0;
+	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
+	DevBuf isa(4 * n);
+	isa_from_sa(d_sa_global, n, isa.as<uint32_t>(), s);
+	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
+	hipLaunchKernelGGL(k_tie_unpairs, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, d_pairs_all, total, Bf[0], Bf[1]);
+	const uint64_t R0 = 4;
+	uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
+	uint64_t left = 0;
+	const uint64_t rounds = tie_rounds(T, d_sa_global, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, n, s, &left, 0, isa.as<uint32_t>(), h0);
+	p->res.tie_rounds += rounds;
+	// my slice back into the workspace, the BWT symbols of the slots that were open here, p0, samples
+	const uint64_t mine = p->tie_left;
+	if (p->slice_len) B3M_HIP(hipMemcpyAsync(p->d_sa_slice, d_sa_global + p->slice_off, 4 * p->slice_len, hipMemcpyDeviceToDevice, s));
+	if (mine) {
+		uint32_t *Ul = ws.t[0];
+		hipLaunchKernelGGL(k_sub_u32, dim3((uint32_t)((mine + 255) / 256)), dim3(256), 0, s, d_pairs_all + 2 * my_first, mine, (uint32_t)p->slice_off, Ul);
+		B3M_HIP(hipMemsetAsync(p->d_p0tmp, 0xFF, 4, s));
+		emit_bwt_list(T, Ul, mine, p->d_sa_slice, 0, d_bwt_slice, p->d_p0tmp, s);
+		hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp, p->d_p0pairs, (uint64_t)0, p->slice_off);
+		if (p->isarate && p->total_samples) {
+			B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
+			emit_samples(p->d_sa_slice, nullptr, p->slice_len, p->isarate, p->slice_off, p->d_samples, 0, p->total_samples, s);
+		}
+	}
+	uint64_t p0pair[2] = {~0ull, 0};
+	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	if (p0pair[0] != ~0ull) { p->res.p0 = p0pair[0]; p->res.has_p0 = 1; }
+	if (mine && p->isarate && p->total_samples) {
+		std::vector<uint64_t> raw(2 * p->total_samples);
+		B3M_HIP(hipMemcpy(raw.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		p->h_samples.clear();
+		for (uint64_t i = 0; i < p->total_samples; ++i) if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
+		p->res.num_samples = p->h_samples.size() / 2;
+	}
+	p->tie_left = 0;
 	return 0;
 	B3M_CATCH(1)
 }

@@ -1400,8 +1400,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// instead of (longest repeat)/21.  Doubling reads the rank of EVERY suffix, i.e. the complete
 		// suffix array: a run that was asked for the BWT only starts over with the array kept.
 		const bool whole = start == 0 && len_in == T.n && nshards <= 1;
+		// a suffix-range shard of the whole text cannot rank the suffixes of the other shards: after the same few key-extension
+		// rounds it hands what is left to the caller, who finishes it by prefix doubling over ALL shards' suffix arrays
+		// (b3m_plan_tie_export / b3m_plan_tie_finish): O(log longest repeat) rounds there too
+		const bool defer = nshards > 1 && start == 0 && len_in == T.n;
 		const uint64_t R0 = 4;
-		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer) ? R0 : 0);
+		if (left && defer && out.tie_rounds >= R0) {
+			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
+			out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1];
+		}
 		if (left && whole && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
@@ -1409,8 +1417,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
 		}
 		// BWT symbols (and p0) of the slots finished here
-		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, ws.t[0], (uint32_t *)nullptr);
-		emit_bwt_list(T, ws.t[0], total, sa.lo, start, d_bwt, d_p0, s);
+		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)
+		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[5], (uint32_t *)nullptr);
+		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s);
 		leave_fallback:;
 	}
 	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }   // the histogram was added by this pass already

@@ -454,9 +454,42 @@ class PrefixShardedBwt:
 
     def run(self, d_text):
         sl = self.plan.run(d_text, self.out)
+        if self.world > 1:
+            # long repeats (row a6): what the local rounds left tied on any shard is finished by prefix doubling over all shards' suffix arrays
+            pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
+            if int(pend[:, 0].sum()) > 0:
+                from . import engine
+                if not self.plan.has_sa():                       # a BWT-only run kept no suffix array: once more, with it
+                    engine.rerun_for_ties(self.plan, d_text, self.out)
+                    pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
+                else:
+                    pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
+                sizes, counts, me = pend[:, 1], pend[:, 0], self.rank
+
+                def gather_sa(sa):
+                    return _all_gather_v(sa, sizes)
+
+                def gather_pairs(pairs):
+                    allp = _all_gather_v(pairs.reshape(-1), 2 * counts).reshape(-1, 2)
+                    return allp, int(counts[:me].sum())
+
+                engine.finish_shard_ties(self.plan, sl, gather_sa, gather_pairs)
         r = self.plan.result()
         off = r["slice_offset"] if self.world > 1 else 0
         return sl, off, (r["p0"] if r["has_p0"] else None)
+
+
+def _all_gather_v(t, sizes):
+    """concatenation of every rank's 1-D tensor (sizes[i] entries from rank i), on every rank"""
+    mx = int(max(1, sizes.max()))
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    dev = pad.device
+    if _staged(pad):
+        pad = pad.cpu()
+    parts = [torch.empty_like(pad) for _ in range(len(sizes))]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: int(sz)] for p, sz in zip(parts, sizes)]).to(dev)
 
 
 def gather_result(slice_t, group=None):

@@ -101,6 +101,30 @@ class Plan:
         check(lib().b3m_plan_run_host(self._h, _ptr(h_text), _ptr(h_out), ctypes.byref(t), _stream()))
         return {k: getattr(t, k) for k, _ in _lib.E2ETimes._fields_}
 
+    # ---- suffix-range shards and long repeats (b3m_plan_tie_*): see finish_shard_ties() ----
+    def keep_sa(self, on=True):
+        check(lib().b3m_plan_set_keep_sa(self._h, 1 if on else 0))
+
+    def has_sa(self):
+        return bool(lib().b3m_plan_has_sa(self._h))
+
+    def tie_pending(self):
+        c = ctypes.c_uint64(0)
+        check(lib().b3m_plan_tie_pending(self._h, ctypes.byref(c)))
+        return int(c.value)
+
+    def tie_export(self, device):
+        """-> (this shard's suffix array slice (int32 tensor, rank order), its tied slots as (global slot, global label) pairs (int32 [k, 2]))"""
+        r = self.result()
+        k = self.tie_pending()
+        sa = torch.empty(max(1, r["slice_len"]), dtype=torch.int32, device=device)
+        pairs = torch.empty((max(1, k), 2), dtype=torch.int32, device=device)
+        check(lib().b3m_plan_tie_export(self._h, _ptr(sa), _ptr(pairs), _stream()))
+        return sa[: r["slice_len"]], pairs[:k]
+
+    def tie_finish(self, sa_global, pairs_all, my_first, d_bwt_slice):
+        check(lib().b3m_plan_tie_finish(self._h, _ptr(sa_global), _ptr(pairs_all), pairs_all.shape[0], int(my_first), _ptr(d_bwt_slice), _stream()))
+
     def result(self):
         r = _lib.Result()
         check(lib().b3m_plan_result(self._h, ctypes.byref(r)))
@@ -156,6 +180,26 @@ def compact_to_plan_input(file_bytes, device="cuda"):
     out = torch.empty(max(n, 1), dtype=torch.uint8, device=device)
     check(lib().b3m_compact_decode(_ptr(words), n, bits, _ptr(out), _stream()))
     return "bytestream", out[:n], n
+
+
+def rerun_for_ties(plan, d_text, out):
+    """a shard that ran BWT-only kept no suffix array: sort it once more with the array kept (only when some shard reports long repeats)"""
+    if not plan.has_sa():
+        plan.keep_sa(True)
+        plan.run(d_text, out)
+    return plan
+
+
+def finish_shard_ties(plan, out_slice, gather_sa, gather_pairs):
+    """Suffix-range shards of a repeat-rich text: finish what the shards' local rounds left tied (row a6).  gather_sa(slice) -> every shard's
+    suffix array slice concatenated in rank order (n entries); gather_pairs(pairs) -> (all shards' pairs concatenated in shard order, index of
+    this shard's first pair, total).  Called by EVERY shard (collectively) when any shard has plan.tie_pending() > 0; a shard whose BWT-only
+    run kept no suffix array must have been run again with plan.keep_sa() first (rerun_for_ties)."""
+    sa, pairs = plan.tie_export(out_slice.device)
+    sa_global = gather_sa(sa)
+    pairs_all, my_first = gather_pairs(pairs)
+    if pairs_all.shape[0]:
+        plan.tie_finish(sa_global.contiguous(), pairs_all.contiguous(), my_first, out_slice)
 
 
 def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0):

@@ -132,6 +132,17 @@ void  b3m_host_free(void *p);
 int b3m_compact_info(const uint8_t *file_head32, uint64_t file_size, uint32_t *bits_out, uint64_t *n_out, uint64_t *data_off_out);
 int b3m_compact_decode(const void *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, void *stream);
 
+/* Suffix-range shards and long repeats (the reference bounds the repeat cost of a block with lcpnext / largelcpthres,
+ * /root/reference/src/bwtb3m.cpp:55, ChangeLog:205-211).  A shard's b3m_plan_run stops its local sort after a few key-extension rounds; if
+ * b3m_plan_tie_pending reports suffixes still tied on ANY shard, the caller gathers every shard's suffix array slice (b3m_plan_tie_export; over
+ * RCCL all-gather between GPUs) and tied-slot list, and every shard calls b3m_plan_tie_finish on the same global arrays: prefix doubling,
+ * O(log longest repeat) rounds, after which the shard's slice of the BWT (and p0, samples) is final.  bwtb3m_amd.distributed does this. */
+int b3m_plan_set_keep_sa(b3m_plan *p, int on);   /* the next runs keep the shard's whole suffix array (a BWT-only run writes only what k_tie_fix reads) */
+int b3m_plan_has_sa(const b3m_plan *p);          /* did the last run keep it */
+int b3m_plan_tie_pending(const b3m_plan *p, uint64_t *count_out);
+int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs_out, void *stream);
+int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pairs_all, uint64_t total, uint64_t my_first, uint8_t *d_bwt_slice, void *stream);
+
 typedef struct b3m_result {
 	uint64_t n, num_blocks, levels;
 	uint64_t p0;                 /* rank of the rotation starting at position 0 (pacterm: BWA "primary") */

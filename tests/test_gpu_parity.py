@@ -400,6 +400,31 @@ def test_msd_leaves_then_merges(gpu, oracle, itype):
 # suffix-range shards (multi-GPU mode without an exchange step): the slices of all shards,
 # concatenated in shard order, are the BWT
 # ---------------------------------------------------------------------------------------------
+def _run_all_shards(torch, engine, d_text, n, itype, nshards, isarate):
+    """every suffix-range shard of a text on this one GPU, as the ranks of a multi-GPU run would: each plan runs, and if any shard's local rounds
+    left suffixes tied (long repeats) all of them finish collectively over the gathered suffix arrays (engine.finish_shard_ties)"""
+    plans, slices = [], []
+    for k in range(nshards):
+        plan = engine.Plan(n, itype, shard=k, nshards=nshards, isasamplingrate=isarate)
+        slices.append(plan.run(d_text).clone())
+        plans.append(plan)
+    pend = [p.tie_pending() for p in plans]
+    if sum(pend):
+        for k, p in enumerate(plans):          # BWT-only runs kept no suffix array
+            if not p.has_sa():
+                sl = torch.empty(p.slice_capacity, dtype=torch.uint8, device="cuda")
+                engine.rerun_for_ties(p, d_text, sl)
+                slices[k] = sl[: p.result()["slice_len"]].clone()
+        pend = [p.tie_pending() for p in plans]
+        exported = [p.tie_export("cuda") for p in plans]
+        sa_all = torch.cat([e[0] for e in exported])
+        pairs_all = torch.cat([e[1] for e in exported])
+        assert sa_all.numel() == n
+        for k, p in enumerate(plans):
+            engine.finish_shard_ties(p, slices[k], lambda sa: sa_all.clone(), lambda pr, k=k: (pairs_all, sum(pend[:k])))
+    return plans, slices
+
+
 @pytest.mark.parametrize("itype,kind,nshards", [("pacterm", "uniform", 2), ("pacterm", "uniform", 8), ("pac", "uniform", 3),
                                                  ("pacterm", "repeat", 4), ("pac", "twosym", 4)])
 def test_suffix_range_shards(gpu, oracle, itype, kind, nshards):
@@ -418,10 +443,9 @@ def test_suffix_range_shards(gpu, oracle, itype, kind, nshards):
     sa = oracle.sa_circular(s)
     isa = np.empty_like(sa); isa[sa] = np.arange(len(sa))
     d = torch.from_numpy(buf).cuda()
+    plans, slices = _run_all_shards(torch, engine, d, len(s), itype, nshards, 1024)
     parts, off, p0s, nsmp = [], 0, [], 0
-    for k in range(nshards):
-        plan = engine.Plan(len(s), itype, shard=k, nshards=nshards, isasamplingrate=1024)
-        sl = plan.run(d)
+    for plan, sl in zip(plans, slices):
         r = plan.result()
         assert r["slice_offset"] == off and r["slice_len"] == sl.numel()
         off += sl.numel()
@@ -453,7 +477,9 @@ def _prefix_worker(rank, world, port, nb, q):
         from bwtb3m_amd import distributed as D
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
-        b = O.synth_bases(nb, 123)
+        b = O.synth_bases(abs(nb), 123)
+        if nb < 0:              # long repeats: the shards' local rounds leave ties, the driver finishes them over both ranks' suffix arrays
+            b = b.copy(); b[400000:430000] = b[50000:80000]; b[200000:215000] = 3
         buf = O.pac_encode(b)
         sym = O.symbols_from_file_bytes(buf, "pacterm")
         job = D.PrefixShardedBwt(len(sym), "pacterm", dev)
@@ -468,13 +494,14 @@ def _prefix_worker(rank, world, port, nb, q):
         dist.destroy_process_group()
 
 
-def test_prefix_sharded_driver_two_ranks(gpu):
+@pytest.mark.parametrize("nb", [600001, -600001])
+def test_prefix_sharded_driver_two_ranks(gpu, nb):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_prefix_worker, args=(r, 2, port, 600001, q)) for r in range(2)]
+    procs = [ctx.Process(target=_prefix_worker, args=(r, 2, port, nb, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -857,3 +884,30 @@ def test_compactstream_3bit_multi_block(gpu, oracle):
     out, res, plan = _plan_bwt(gpu, oracle.compact_encode(sym, 3), "compactstream", blocksize=16000)
     assert res["num_blocks"] == 8 and np.array_equal(out, oracle.bwt(sym))
     plan.close()
+
+
+def test_long_repeats_in_suffix_range_shards(gpu, oracle):
+    """row a6 for the default multi-GPU mode: 8 suffix-range shards of a text with long repeats (a 40-kb near-copy, a 3-kb tandem array, a homopolymer
+    run).  The shards' local sorts stop after four key-extension rounds; the rest is prefix doubling over all shards' suffix arrays: a handful of
+    rounds, not (repeat length / 21).  Reference: the per-block bound of lcpnext / largelcpthres, /root/reference/src/bwtb3m.cpp:55, ChangeLog:205-211."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    nb = (1 << 20) + 77
+    rng = np.random.default_rng(61)
+    b = rng.integers(0, 4, nb, dtype=np.uint8)
+    b[600000:640000] = b[100000:140000]; b[610000] ^= 1; b[625000] ^= 2          # 40-kb copy, two substitutions
+    b[300000:330000] = np.resize(b[300000:303000], 30000)                          # tandem repeat of a 3-kb unit
+    b[800000:820000] = 0                                                           # 20 kb of A
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    ref = oracle.bwt(s)
+    d = torch.from_numpy(buf).cuda()
+    plans, slices = _run_all_shards(torch, engine, d, len(s), "pacterm", 8, 0)
+    got = torch.cat(slices).cpu().numpy()
+    assert np.array_equal(got, ref)
+    rounds = max(p.result()["tie_rounds"] for p in plans)
+    assert 4 < rounds <= 4 + 20, rounds          # 4 local rounds + log2(40000 / 64) doubling rounds, not 40000 / 21 = 1900
+    p0s = [p.result()["p0"] for p in plans if p.result()["has_p0"]]
+    assert len(p0s) == 1 and int(got[p0s[0]]) == 0
+    for p in plans:
+        p.close()
