@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	uint32_t word = p > pend ? __builtin_bswap32(tw[wi]) : 0u, wnext = (p > pend && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
 	while (p > pend) {
 		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
+		if (r >= T.n) { bad += 1; break; }                 // a corrupt BWT can send the walk anywhere: stop the chain (counted: symbol mismatch + closure)
 		const uint64_t q = p - 1;
 		if ((q >> 4) != wi) { wi = q >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
 		const uint32_t base = (word >> (2u * (15u - (uint32_t)(q & 15)))) & 3u;

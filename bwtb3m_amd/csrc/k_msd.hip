@@ -919,6 +919,220 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbi
 	finish_bucket<WRITE_SA, THREADS, true>(b, s0, s1 - s0, RB, RA, S, fbits, L, O);
 }
 
+// ------------------------------------------------------------------------------------------------
+// THE FAST FINISH (gathering, 512 threads, what C3 runs): the same counting sort as finish_bucket with the per-record
+// instruction count cut (the kernel is instruction-issue bound, not HBM bound):
+//   * one 32-bit table word per bin (count, then start | count << 16): one LDS atomic and one LDS read per record;
+//   * an entry is (free key bits << 13 | index) cut to 32 bits: above the low key bits it keeps the low TAGB = 19 - lowbits bits
+//     of its bin.  Relative to the first value of the record's own bin, modulo 2^32, the entries of that bin are below
+//     2^(13 + lowbits) and those of other bins are not -- unless a bin is an exact multiple of 2^TAGB bins further on, so the
+//     four entries a record reads from its bin's start need no "is this still my bin" mask.  Such a bin within three
+//     entries means at most two entries in 2^TAGB - 1 bins, hence an aligned block of 2^(TAGB-2) empty bins: every wave
+//     checks its bins for such blocks and a bucket that has one (tiny, or skewed) is listed for the copy-together path;
+//   * items whose 512 slots all lie inside the bucket run without per-lane guards;
+//   * the run-to-slot map is two 16-byte broadcast reads per 64 slots.
+// Requires TAGB >= 7, i.e. at most 12 low key bits (level 1 of 4 bits or more); other geometries keep finish_bucket.
+// ------------------------------------------------------------------------------------------------
+template <bool WRITE_SA>
+__global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
+{
+	constexpr int F_THREADS = 512, F_CAP = 6144, F_PER = 12, F_WAVES = 8, IDXB = 13;
+	constexpr int ENT_N = F_CAP + 8, TAB_N = F_BINS + 4, OBWT_N = F_CAP + 8, GF_N = F_CAP / 64 + 2;
+	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];
+	__shared__ __attribute__((aligned(16))) uint32_t tab[TAB_N];
+	__shared__ __attribute__((aligned(16))) uint8_t obwt[OBWT_N];
+	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
+	__shared__ uint32_t wsum[F_WAVES];
+	__shared__ __attribute__((aligned(8))) uint2 rr[G_NCH + 1];
+	__shared__ uint16_t gfirst[GF_N];
+	__shared__ __attribute__((aligned(16))) uint4 gda[GF_N], gdb[GF_N];      // {o1, o2, o3, A} and {B - o1, C - o2, D - o3, -}
+	__shared__ uint32_t s_slow;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
+	const uint32_t b0 = b >> S.D1;
+	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
+	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+	if (m == 0) return;
+	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
+		if (tid == 0) {
+			const FinishLists L = *Lp;
+			if (m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+			else if (m > F_HUGE) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
+			else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
+		}
+		return;
+	}
+	// ---- slots -> runs (see finish_bucket) ----
+	const uint32_t glast = (m - 1) >> 6;
+	{
+		const uint32_t *row = S.runpre + tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
+		const uint32_t tc = tid < nch ? tid : nch - 1, tn = tc + 1 < nch ? tc + 1 : tc;
+		const uint32_t v = row[tc], vn = tid + 1 < nch ? row[tn] : (m << 14);
+		const uint32_t pre = v >> 14, end = vn >> 14;
+		if (tid < nch) {
+			rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
+			for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
+		}
+		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; }
+		#pragma unroll
+		for (int k = 0; k < F_BINS / F_THREADS; ++k) tab[k * F_THREADS + tid] = 0;
+		if (tid < 8) ent[m + tid] = 0xFFFFFFFFu;                // what a record reads past the last entry compares greater
+	}
+	__syncthreads();
+	if (tid <= glast) {
+		const uint32_t sl = tid << 6;
+		const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
+		const uint2 q0 = rr[j0];
+		uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
+		for (uint32_t i = j0 + 1; i <= j1 && i < nch; ++i) {
+			const uint2 qi = rr[i];
+			if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
+			const uint32_t oo = qi.x - sl, bb = qi.y - oo;
+			if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
+			++found;
+		}
+		if (found > 3) s_slow = 1u;
+		gda[tid] = make_uint4(o1, o2, o3, q0.y + (sl - q0.x));
+		gdb[tid] = make_uint4(b1, b2, b3, 0u);
+	}
+	__syncthreads();
+	if (s_slow) {
+		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+		return;
+	}
+	const uint32_t kfull = m / F_THREADS;                        // items 0 .. kfull-1 have all their 512 slots inside the bucket
+	uint64_t r[F_PER];
+	{
+		uint32_t adr[F_PER];
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) {
+			const uint32_t eu = k * F_THREADS + tid;
+			const uint32_t e = eu < m ? eu : m - 1;
+			uint32_t g = (uint32_t)(k * F_WAVES) + wave; g = g < glast ? g : glast;
+			const uint4 da = gda[g], db = gdb[g];
+			const uint32_t x = e - (g << 6);
+			adr[k] = (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
+		}
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) r[k] = S.rec[adr[k]];
+	}
+	const int binbits = F_BINBITS, lowbits = fbits - binbits;
+	const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;
+	const int bsh = hks + lowbits;
+	const int tagb = 32 - IDXB - lowbits;                        // bin bits an entry keeps (7..11)
+	const uint32_t bsl = (uint32_t)(IDXB + lowbits);
+	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
+	// ---- count ----
+	uint32_t slot[F_PER];
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & (uint32_t)(F_BINS - 1);
+		if ((uint32_t)k < kfull) slot[k] = atomicAdd(&tab[bin], 1u);
+		else { slot[k] = 0; if (k * F_THREADS + tid < m) slot[k] = atomicAdd(&tab[bin], 1u); }
+	}
+	__syncthreads();
+	// ---- scan: thread = 16 consecutive bins; tab[bin] = start | count << 16 ----
+	{
+		constexpr int WPT = F_BINS / F_THREADS;                  // 16
+		uint32_t w[WPT]; uint32_t sum = 0, cmax = 0;
+		#pragma unroll
+		for (int q = 0; q < WPT / 4; ++q) {
+			const uint4 v = reinterpret_cast<const uint4 *>(tab)[tid * (WPT / 4) + q];
+			w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+		}
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { sum += w[k]; cmax = cmax > w[k] ? cmax : w[k]; }
+		{
+			// an aligned block of 2^(tagb-2) empty bins = G = 2^(tagb-6) lanes (16 bins each) with nothing: bin tags could alias (see the header)
+			unsigned long long g = __ballot(sum != 0);
+			const int G = 1 << ((tagb < 11 ? tagb : 11) - 6);      // (11 bin bits and more: a half wave's 512 bins; with all 13 kept nothing can alias)
+			for (int sft = 1; sft < G; sft <<= 1) g |= g >> sft;
+			const unsigned long long gm = G == 2 ? 0x5555555555555555ull : G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull
+			                            : G == 16 ? 0x0001000100010001ull : 0x0000000100000001ull;
+			if ((g & gm) != gm && lane == 0) s_slow = 1u;
+		}
+		uint32_t inc = wave_incl_sum(sum);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t run = inc - sum;
+		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
+		if (cmax > (uint32_t)LS_TIE_CAP) {                      // a 16-mer repeated inside the bucket: that bin goes to the overflow list on its own
+			uint32_t st = run;
+			#pragma unroll 1
+			for (int k = 0; k < WPT; ++k) { if (w[k] > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, w[k]); st += w[k]; }
+		}
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k]; w[k] = run | (c << 16); run += c; }
+		#pragma unroll
+		for (int q = 0; q < WPT / 4; ++q) reinterpret_cast<uint4 *>(tab)[tid * (WPT / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+	}
+	__syncthreads();
+	if (s_slow) {
+		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+		return;
+	}
+	// ---- entries into bin order: (low 11 bits of the bin | low key bits) << 13 | index ----
+	uint32_t tb[F_PER];                                           // start | count << 16 of the record's bin
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t hi = (uint32_t)(r[k] >> 32);
+		tb[k] = tab[(hi >> bsh) & (uint32_t)(F_BINS - 1)];
+	}
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t hi = (uint32_t)(r[k] >> 32), e = k * F_THREADS + tid;
+		const uint32_t x = ((hi >> hks) << IDXB) | e;             // cut to 32 bits: tagb bin bits | low key bits | index
+		if ((uint32_t)k < kfull || e < m) ent[(tb[k] & 0xFFFFu) + slot[k]] = x;
+	}
+	__syncthreads();
+	// ---- rank inside the bin from the four entries at its start; ties of the whole key field ----
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t hi = (uint32_t)(r[k] >> 32), e = k * F_THREADS + tid;
+		const bool valid = (uint32_t)k < kfull || e < m;
+		const uint32_t st = valid ? (tb[k] & 0xFFFFu) : 0u, c = tb[k] >> 16;
+		const uint32_t B = (hi >> bsh) << bsl;                    // first value of the record's bin
+		const uint32_t x = ((hi >> hks) << IDXB) | e, dx = x - B;
+		const uint32_t y0 = ent[st], y1 = ent[st + 1], y2 = ent[st + 2], y3 = ent[st + 3];
+		const bool l0 = y0 - B < dx, l1 = y1 - B < dx, l2 = y2 - B < dx, l3 = y3 - B < dx;         // modulo 2^32: other bins (and the 0xFFFFFFFF pad) are >= 2^bsl
+		uint32_t lt = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
+		const bool e0 = (y0 ^ x) < (1u << IDXB), e1 = (y1 ^ x) < (1u << IDXB), e2 = (y2 ^ x) < (1u << IDXB), e3 = (y3 ^ x) < (1u << IDXB);
+		uint32_t eq = (e0 ? 1u : 0u) + (e1 ? 1u : 0u) + (e2 ? 1u : 0u) + (e3 ? 1u : 0u);
+		bool prev = (e0 && l0) || (e1 && l1) || (e2 && l2) || (e3 && l3);
+		if (valid && c > 4 && c <= (uint32_t)LS_TIE_CAP) {       // rare: longer bins
+			for (uint32_t j = 4; j < c; ++j) {
+				const uint32_t y = ent[st + j];
+				const bool ej = (y ^ x) < (1u << IDXB), lj = y - B < dx;
+				lt += lj ? 1u : 0u; eq += ej ? 1u : 0u; prev = prev || (ej && lj);
+			}
+		}
+		const bool hot = c > (uint32_t)LS_TIE_CAP;
+		const uint32_t dp = hot ? st + slot[k] : st + lt;
+		if (valid) {
+			const uint32_t g = s0 + dp;
+			const uint32_t lo32 = (uint32_t)r[k];
+			obwt[apad + dp] = (uint8_t)((hi >> hps) & 7u);       // hot bins: overwritten by the fallback's emit
+			if (WRITE_SA) { osa[dp] = lo32; if (O.sa.hi) O.sa.hi[g] = (uint8_t)(hi & ((1u << hps) - 1u)); }
+			else if (hot || eq > 1) sa_set(O.sa, g, r[k] & ((1ull << O.pb) - 1));       // only k_tie_fix / the fallback read positions
+			if (prev && !hot) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
+			if (lo32 == (uint32_t)O.start && (r[k] & ((1ull << O.pb) - 1)) == O.start) *O.p0 = g;
+		}
+	}
+	__syncthreads();
+	{
+		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);
+		const uint32_t lo = apad, hi = apad + m;
+		const uint32_t ndw = (hi + 3) >> 2;
+		for (uint32_t j = tid; j < ndw; j += F_THREADS) {
+			if (4 * j >= lo && 4 * j + 4 <= hi) reinterpret_cast<uint32_t *>(gb)[j] = reinterpret_cast<const uint32_t *>(obwt)[j];
+			else { for (uint32_t q = 4 * j; q < 4 * j + 4; ++q) if (q >= lo && q < hi) gb[q] = obwt[q]; }
+		}
+	}
+	if (WRITE_SA) {
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa.lo[s0 + e] = osa[e]; }
+	}
+}
+
 // Buckets the gathering finish has listed (above its LDS capacity, or spread over more runs than it maps): their runs are
 // copied together into [bstart[b], bstart[b+1]) of `out` (the record buffer level 1 has read and no longer needs), where
 // the mid / big / huge paths find them contiguous.  mid and big buckets (<= 2^20 records): one workgroup each; huge ones:
@@ -1322,7 +1536,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			const uint32_t bfa = nsl > 1 ? l0a << dg.D1 : 0u, bfb = nsl > 1 ? l0b << dg.D1 : nbF;
 			const uint64_t ra = nsl > 1 ? lvl0[sl] : 0, rb = nsl > 1 ? lvl0[sl + 1] : len;
 			if (bfb == bfa) continue;
-			if (gather) {
+			static const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
+			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
+				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+			} else if (gather) {
 				if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else {
