@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	const int tagb = 32 - IDXB - lowbits;                        // bin bits an entry keeps (7..11)
 	const uint32_t bsl = (uint32_t)(IDXB + lowbits);
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
-	// ---- count ----
+	// ---- count.  Items below kfull run without per-lane guards (the branch on k < kfull is scalar) ----
 	uint32_t slot[F_PER];
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
@@ -1070,53 +1070,59 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
 		return;
 	}
-	// ---- entries into bin order: (low 11 bits of the bin | low key bits) << 13 | index ----
+	// ---- entries into bin order ----
 	uint32_t tb[F_PER];                                           // start | count << 16 of the record's bin
 	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) {
-		const uint32_t hi = (uint32_t)(r[k] >> 32);
-		tb[k] = tab[(hi >> bsh) & (uint32_t)(F_BINS - 1)];
-	}
+	for (int k = 0; k < F_PER; ++k) tb[k] = tab[((uint32_t)(r[k] >> 32) >> bsh) & (uint32_t)(F_BINS - 1)];
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
 		const uint32_t hi = (uint32_t)(r[k] >> 32), e = k * F_THREADS + tid;
 		const uint32_t x = ((hi >> hks) << IDXB) | e;             // cut to 32 bits: tagb bin bits | low key bits | index
-		if ((uint32_t)k < kfull || e < m) ent[(tb[k] & 0xFFFFu) + slot[k]] = x;
+		if ((uint32_t)k < kfull) ent[(tb[k] & 0xFFFFu) + slot[k]] = x;
+		else if (e < m) ent[(tb[k] & 0xFFFFu) + slot[k]] = x;
 	}
 	__syncthreads();
-	// ---- rank inside the bin from the four entries at its start; ties of the whole key field ----
-	#pragma unroll
-	for (int k = 0; k < F_PER; ++k) {
+	// ---- rank inside the bin from the four entries at its start; ties of the whole key field.  Relative to xk0 (the record's
+	// entry without its index) modulo 2^32: t < 8192 <=> same key, t < index <=> same key and an earlier record; relative to
+	// the bin's first value B: below the own offset <=> sorts before me.  Everything rare (bins above four entries, ties, the
+	// block's first suffix) sits behind ONE branch per record. ----
+	const uint32_t start_lo = (uint32_t)O.start;
+	auto rank_drop = [&](const int k, const bool guard) {
 		const uint32_t hi = (uint32_t)(r[k] >> 32), e = k * F_THREADS + tid;
-		const bool valid = (uint32_t)k < kfull || e < m;
+		const bool valid = !guard || e < m;
 		const uint32_t st = valid ? (tb[k] & 0xFFFFu) : 0u, c = tb[k] >> 16;
 		const uint32_t B = (hi >> bsh) << bsl;                    // first value of the record's bin
-		const uint32_t x = ((hi >> hks) << IDXB) | e, dx = x - B;
+		const uint32_t xk0 = (hi >> hks) << IDXB, dx = (xk0 | e) - B;
 		const uint32_t y0 = ent[st], y1 = ent[st + 1], y2 = ent[st + 2], y3 = ent[st + 3];
-		const bool l0 = y0 - B < dx, l1 = y1 - B < dx, l2 = y2 - B < dx, l3 = y3 - B < dx;         // modulo 2^32: other bins (and the 0xFFFFFFFF pad) are >= 2^bsl
-		uint32_t lt = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-		const bool e0 = (y0 ^ x) < (1u << IDXB), e1 = (y1 ^ x) < (1u << IDXB), e2 = (y2 ^ x) < (1u << IDXB), e3 = (y3 ^ x) < (1u << IDXB);
-		uint32_t eq = (e0 ? 1u : 0u) + (e1 ? 1u : 0u) + (e2 ? 1u : 0u) + (e3 ? 1u : 0u);
-		bool prev = (e0 && l0) || (e1 && l1) || (e2 && l2) || (e3 && l3);
-		if (valid && c > 4 && c <= (uint32_t)LS_TIE_CAP) {       // rare: longer bins
-			for (uint32_t j = 4; j < c; ++j) {
-				const uint32_t y = ent[st + j];
-				const bool ej = (y ^ x) < (1u << IDXB), lj = y - B < dx;
-				lt += lj ? 1u : 0u; eq += ej ? 1u : 0u; prev = prev || (ej && lj);
+		uint32_t lt = (y0 - B < dx ? 1u : 0u) + (y1 - B < dx ? 1u : 0u) + (y2 - B < dx ? 1u : 0u) + (y3 - B < dx ? 1u : 0u);
+		const uint32_t t0 = y0 - xk0, t1 = y1 - xk0, t2 = y2 - xk0, t3 = y3 - xk0;
+		uint32_t eq = (t0 < 8192u ? 1u : 0u) + (t1 < 8192u ? 1u : 0u) + (t2 < 8192u ? 1u : 0u) + (t3 < 8192u ? 1u : 0u);
+		const uint32_t lo32 = (uint32_t)r[k];
+		uint32_t dp = st + lt;
+		if (valid && (eq > 1 || c > 4 || lo32 == start_lo)) {    // rare
+			bool prev = t0 < e || t1 < e || t2 < e || t3 < e;
+			const bool hot = c > (uint32_t)LS_TIE_CAP;
+			if (c > 4 && !hot) {
+				#pragma unroll 1
+				for (uint32_t j = 4; j < c; ++j) {
+					const uint32_t y = ent[st + j], t = y - xk0;
+					lt += y - B < dx ? 1u : 0u; eq += t < 8192u ? 1u : 0u; prev = prev || t < e;
+				}
 			}
-		}
-		const bool hot = c > (uint32_t)LS_TIE_CAP;
-		const uint32_t dp = hot ? st + slot[k] : st + lt;
-		if (valid) {
+			dp = hot ? st + slot[k] : st + lt;
 			const uint32_t g = s0 + dp;
-			const uint32_t lo32 = (uint32_t)r[k];
-			obwt[apad + dp] = (uint8_t)((hi >> hps) & 7u);       // hot bins: overwritten by the fallback's emit
-			if (WRITE_SA) { osa[dp] = lo32; if (O.sa.hi) O.sa.hi[g] = (uint8_t)(hi & ((1u << hps) - 1u)); }
-			else if (hot || eq > 1) sa_set(O.sa, g, r[k] & ((1ull << O.pb) - 1));       // only k_tie_fix / the fallback read positions
+			const uint64_t pos = r[k] & ((1ull << O.pb) - 1);
+			if (!WRITE_SA && (hot || eq > 1)) sa_set(O.sa, g, pos);       // only k_tie_fix / the fallback read positions
 			if (prev && !hot) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
-			if (lo32 == (uint32_t)O.start && (r[k] & ((1ull << O.pb) - 1)) == O.start) *O.p0 = g;
+			if (pos == O.start) *O.p0 = g;
 		}
-	}
+		if (valid) {
+			obwt[apad + dp] = (uint8_t)((hi >> hps) & 7u);       // hot bins: overwritten by the fallback's emit
+			if (WRITE_SA) { osa[dp] = lo32; if (O.sa.hi) O.sa.hi[s0 + dp] = (uint8_t)(hi & ((1u << hps) - 1u)); }
+		}
+	};
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) { if ((uint32_t)k < kfull) rank_drop(k, false); else rank_drop(k, true); }
 	__syncthreads();
 	{
 		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);
