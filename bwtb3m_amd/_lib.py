@@ -36,6 +36,7 @@ class Result(ctypes.Structure):
         ("ms_total", ctypes.c_double), ("ms_sort", ctypes.c_double), ("ms_gap", ctypes.c_double),
         ("ms_interleave", ctypes.c_double),
         ("slice_offset", ctypes.c_uint64), ("slice_len", ctypes.c_uint64), ("has_p0", ctypes.c_uint64),
+        ("tie_overhang", ctypes.c_uint64), ("tie_slow", ctypes.c_uint64),
     ]
 
 

@@ -153,6 +153,9 @@ struct BlockSortOut {
 	uint32_t *tie_U = nullptr, *tie_gid = nullptr;
 	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
+	bool want_ext = false;            // a block of a merge tree with long ties: sort it again together with an overhang (block_sort does)
+	uint64_t slow_ties = 0;           // slots that prefix doubling inside the block's domain could not finish (repeat longer than the overhang)
+	uint64_t overhang = 0;            // symbols behind the block that were sorted with it
 	uint64_t kept_len = 0;            // suffixes sorted here (= len unless this is a suffix-range shard)
 	uint64_t slice_offset = 0;        // global rank of the first of them
 };
@@ -162,10 +165,17 @@ struct BlockSortOut {
 // rank falls into the shard's range are sorted; out.kept_len / out.slice_offset describe the slice
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s,
                 Timeline *tl, BlockSortOut &out, uint8_t *d_bwt, uint32_t *d_p0, int shard = 0, int nshards = 1, bool need_sa = true);
-void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out);
+// own / allow_ext: see tie_rounds_domain.  own = 0: every suffix of [start, start+len) belongs to the block
+void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out, uint64_t own = 0, bool allow_ext = false);
 bool msd_applicable(const TextView &T, uint64_t len);
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa);
+                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own = 0, bool allow_ext = false);
+// prefix doubling for the ties of a block of a merge tree, inside the domain [start, start+D) (the block's `own` suffixes + overhang)
+uint64_t tie_rounds_domain(uint32_t *idx, uint64_t u, uint64_t *kx, uint64_t *ky, uint32_t *B[6], uint32_t *scan_ws, RadixWs &radix,
+                           uint64_t start, uint64_t D, uint64_t own, uint32_t *isa, uint64_t h0, hipStream_t s, uint64_t *left, uint64_t *h_blocked);
+void isa_from_sa_rel(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t *d_isa, hipStream_t s);
+bool no_tree_doubling();          // B3M_NO_TREE_DOUBLING=1: key-extension rounds only (measurement switch)
+uint64_t block_overhang();        // symbols of overhang a plan leaves room for (B3M_OVERHANG, default 2^20)
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
                     uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0);

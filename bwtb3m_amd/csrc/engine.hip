@@ -300,8 +300,11 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint64_t o_bwt0 = take(bwt_cap + 16), o_bwt1 = take(B > 1 ? n + 16 : 16);
 	p->gt_words = (n + 1 + 31) / 32 + 2;
 	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
-	const uint64_t sort_cap = sharded_sort ? p->shard_cap : p->blocksize;
-	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, p->blocksize));
+	// blocks of a merge tree are sorted with room for an overhang behind them (long repeats: tie_rounds_domain)
+	const uint64_t ovh = (B > 1 && !sharded_sort) ? std::min(block_overhang(), p->blocksize / 8) : 0;
+	const uint64_t sort_cap = sharded_sort ? p->shard_cap : p->blocksize + ovh;
+	const uint64_t sort_span = std::max(p->blocksize, sort_cap);
+	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, sort_span));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
 	uint64_t nbk = rank_blocks(maxL);
@@ -339,7 +342,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
 	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
-	blocksort_ws_carve(p->bs, A + o_bs, sort_cap, p->blocksize);
+	blocksort_ws_carve(p->bs, A + o_bs, sort_cap, sort_span);
 	if (B > 1) {
 		p->d_rank_blocks = (uint32_t *)(A + o_rb); p->d_rank_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 		p->d_ranks[0] = (uint32_t *)(A + o_r0); p->d_ranks[1] = (uint32_t *)(A + o_r1);
@@ -465,6 +468,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			B3M_REQUIRE(!(so.tie_left && p->seq_shards > 1), "internal: deferred ties in a sequential shard");
 			p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 			p->res.tie_elements += so.tie_elements;
+			p->res.tie_overhang = std::max<uint64_t>(p->res.tie_overhang, so.overhang);
+			p->res.tie_slow += so.slow_ties;
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a, so.slice_offset);
 			if (!so.symhist_done && (sh == 0 || p->seq_shards == 1)) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
@@ -818,8 +823,9 @@ int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
 	PaddedText pt(d_text, n, inputtype, s);
-	DevBuf ws(blocksort_ws_bytes(len));
-	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
+	const uint64_t cap = len + std::min(std::min(block_overhang(), len / 8), n - (start + len));     // room for an overhang behind the block (tie_rounds_domain)
+	DevBuf ws(blocksort_ws_bytes(cap));
+	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, cap);
 	BlockSortOut so;
 	DevBuf sc(64), bwt_tmp(d_bwt_out ? 16 : len);
 	uint8_t *bw = d_bwt_out ? d_bwt_out : bwt_tmp.as<uint8_t>();
@@ -1075,8 +1081,9 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
 	PaddedText pt(d_text, n, inputtype, s);
-	DevBuf ws(blocksort_ws_bytes(len));
-	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, len);
+	const uint64_t cap = len + std::min(std::min(block_overhang(), len / 8), n - (start + len));     // room for an overhang behind the block (tie_rounds_domain)
+	DevBuf ws(blocksort_ws_bytes(cap));
+	BlockSortWs bs; blocksort_ws_carve(bs, ws.p, cap);
 	BlockSortOut so;
 	DevBuf sc(64);     // [0] p0 u32, [2..3] p0 pair u64, [4] end rank, [6..7] end position u64
 	uint32_t *d_p0 = sc.as<uint32_t>();
@@ -1205,7 +1212,8 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
 	const uint64_t nbk = rank_blocks(max_L ? max_L : 1);
 	const uint64_t chains_max = max_R / 32 + 2;
-	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(max_leaf)), o_rb = take(64 * nbk), o_rs = take(64 * nbk + 64),
+	const uint64_t leaf_cap = max_leaf + (max_leaf < n ? std::min(block_overhang(), max_leaf / 8) : 0);      // room for an overhang (tie_rounds_domain)
+	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(leaf_cap)), o_rb = take(64 * nbk), o_rs = take(64 * nbk + 64),
 	         o_sw = take(4 * scan_ws_elems(nbk) + 64), o_r0 = take(4 * (max_R + max_R / 8 + 256)), o_r1 = take(4 * (max_R + max_R / 8 + 256)), o_rx = take(radix_ws_bytes(max_R + max_R / 8 + 256)),
 	         o_tq = take(4 * (interleave_tiles(max_L + max_R + 1) + 2)), o_an = take(4 * chains_max), o_sm = take(8 * DIST_SMALL), o_p0 = take(64);
 	p->ws_bytes = off;
@@ -1215,7 +1223,7 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	B3M_HIP(hipMalloc((void **)&p->arena, off));
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text;
-	blocksort_ws_carve(p->bs, A + o_bs, max_leaf);
+	blocksort_ws_carve(p->bs, A + o_bs, leaf_cap);
 	p->d_blocks = (uint32_t *)(A + o_rb); p->d_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 	p->d_r0 = (uint32_t *)(A + o_r0); p->d_r1 = (uint32_t *)(A + o_r1);
 	radix_ws_carve(p->radix, A + o_rx, max_R + max_R / 8 + 256);

@@ -384,12 +384,176 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 	if (left) *left = u;
 	return rounds;
 }
+// ------------------------------------------------------------------------------------------------
+// Ties of a block of a merge tree (the bound on a block's repeat cost the reference
+// gets from lcpnext / largelcpthres, src/bwtb3m.cpp:55).  The block [start, start+own) is sorted together
+// with an overhang [start+own, start+D) of the text behind it; after a few key-extension rounds the tied
+// suffixes are finished by prefix doubling INSIDE that domain: the key of suffix i is the current rank of
+// suffix i+h if i+h lies in the domain and that rank is usable.  Where it is not:
+//   * an overhang suffix simply leaves the list ("dead": it is only there to lend ranks, it is filtered out
+//     of the result) and its rank becomes unknown for whoever refers to it later;
+//   * a group with a suffix of the block among them stops doubling as a whole ("blocked": its members' ranks
+//     become unknown as well, so nothing that refers to them advances past what is known) and is finished by
+//     the key-extension rounds afterwards.  That needs a repeat that reaches from the block to within its own
+//     length of the domain's end, i.e. one longer than the overhang.
+// isa is indexed by position - start.  Keys: 0 = blocked group, 1 + rank, D + 1 = dead.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t ISA_UNKNOWN = 0xFFFFFFFFu;
+__global__ void k_isa_init_rel(const uint32_t *sa, uint64_t len, uint64_t start, uint32_t *isa)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < len) isa[sa[r] - start] = (uint32_t)r;
+}
+__global__ void k_isa_list_rel(const uint32_t *U, const uint32_t *hid, const uint32_t *idx, uint64_t u, uint64_t start, uint32_t *isa)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) isa[idx[U[s]] - start] = U[hid[s]];
+}
+__device__ inline uint32_t dom_ref(const uint32_t *isa, uint64_t i_rel, uint64_t h, uint64_t D)
+{
+	const uint64_t q = i_rel + h;
+	return q < D ? isa[q] : ISA_UNKNOWN;
+}
+__global__ void k_dom_clear(const uint32_t *gid, uint64_t u, uint32_t *mark)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < u) mark[gid[s]] = 0;
+}
+// mark[label] = 1 for the groups that stop doubling: a member of the block whose reference is unknown, or a member whose own rank was given up earlier
+__global__ void k_dom_mark(const uint32_t *isa, uint64_t start, uint64_t h, uint64_t D, uint64_t own, const uint32_t *U, const uint32_t *gid, const uint32_t *idx,
+                           uint64_t u, uint32_t *mark, uint32_t *any)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint64_t i = (uint64_t)idx[U[s]] - start;
+	if (isa[i] == ISA_UNKNOWN || (i < own && dom_ref(isa, i, h, D) == ISA_UNKNOWN)) { mark[gid[s]] = 1; *any = 1; }
+}
+__device__ inline uint64_t dom_key(const uint32_t *isa, uint64_t i_rel, uint64_t h, uint64_t D, uint32_t blocked)
+{
+	if (blocked) return 0;
+	const uint32_t r = dom_ref(isa, i_rel, h, D);
+	return r == ISA_UNKNOWN ? D + 1 : (uint64_t)r + 1;
+}
+__global__ void k_dom_keys(const uint32_t *isa, uint64_t start, uint64_t h, uint64_t D, const uint32_t *U, const uint32_t *gid, const uint32_t *idx, uint64_t u,
+                           const uint32_t *mark, uint64_t *nk, uint32_t *slot)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	nk[s] = dom_key(isa, (uint64_t)idx[U[s]] - start, h, D, mark[gid[s]]);
+	slot[s] = (uint32_t)s;
+}
+// (the sorted group labels equal the old ones slot by slot: gid[s] is the label of whoever ends up in slot s)
+__global__ void k_dom_gather(const uint32_t *isa, uint64_t start, uint64_t h, uint64_t D, const uint32_t *U, const uint32_t *gid, const uint32_t *idx,
+                             const uint32_t *slot_final, uint64_t u, const uint32_t *mark, uint32_t *tmp_idx, uint64_t *tmp_key)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t i = idx[U[slot_final[s]]];
+	tmp_idx[s] = i;
+	tmp_key[s] = dom_key(isa, (uint64_t)i - start, h, D, mark[gid[s]]);
+}
+// ranks of the listed suffixes after the round: first slot of their group; unknown for the dead and the blocked
+__global__ void k_dom_isa_list(const uint32_t *U, const uint32_t *hid, const uint32_t *idx, const uint64_t *tmp_key, uint64_t D, uint64_t u, uint64_t start, uint32_t *isa)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint64_t k = tmp_key[s];
+	isa[idx[U[s]] - start] = (k == 0 || k == D + 1) ? ISA_UNKNOWN : U[hid[s]];
+}
+// who stays on the list: members of groups of >= 2 that are not dead
+__global__ void k_dom_flags(const uint32_t *hid, const uint64_t *tmp_key, uint64_t D, uint64_t u, uint32_t *flag)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > u) return;
+	if (s == u) { flag[s] = 0; return; }
+	bool h0 = hid[s] == (uint32_t)s, h1 = (s + 1 == u) ? true : (hid[s + 1] == (uint32_t)(s + 1));
+	flag[s] = ((h0 && h1) || tmp_key[s] == D + 1) ? 0u : 1u;
+}
+__global__ void k_dom_compact(const uint32_t *flag_scan, const uint32_t *label, const uint32_t *U, uint64_t u, uint32_t *U2, uint32_t *gid2)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t p = flag_scan[s];
+	if (flag_scan[s + 1] != p) { U2[p] = U[s]; gid2[p] = label[s]; }
+}
+// the overhang leaves the list before the key-extension rounds: only the block's own suffixes must end up ordered
+__global__ void k_dom_own_flags(const uint32_t *U, const uint32_t *idx, uint64_t start, uint64_t own, uint64_t u, uint32_t *flag)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > u) return;
+	flag[s] = (s < u && (uint64_t)idx[U[s]] - start < own) ? 1u : 0u;
+}
+// Returns the rounds run; *left = slots still listed (blocked groups, the block's own suffixes only), in B[0]/B[1];
+// *h_blocked = symbols every group left on the list agrees on.
+uint64_t tie_rounds_domain(uint32_t *idx, uint64_t u, uint64_t *kx, uint64_t *ky, uint32_t *B[6], uint32_t *scan_ws, RadixWs &radix,
+                           uint64_t start, uint64_t D, uint64_t own, uint32_t *isa, uint64_t h0, hipStream_t s, uint64_t *left, uint64_t *h_blocked)
+{
+	int gbits = 1; while ((1ull << gbits) < D + 2 && gbits < 33) ++gbits;
+	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
+	uint64_t rounds = 0, hb = 0;
+	uint32_t h_u = 0, h_any = 0;
+	// ranks of the listed suffixes: first slot of their group
+	hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+	inclusive_max_u32(hid, u, scan_ws, s);
+	hipLaunchKernelGGL(k_isa_list_rel, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, start, isa);
+	for (uint64_t h = h0; u > 0 && h < D; h *= 2) {
+		++rounds;
+		B3M_HIP(hipMemsetAsync(flag, 0, 4, s));
+		hipLaunchKernelGGL(k_dom_clear, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+		hipLaunchKernelGGL(k_dom_mark, dim3(nblk(u)), dim3(256), 0, s, isa, start, h, D, own, U, gid, idx, u, hid, flag);
+		B3M_HIP(hipMemcpyAsync(&h_any, flag, 4, hipMemcpyDeviceToHost, s));
+		hipLaunchKernelGGL(k_dom_keys, dim3(nblk(u)), dim3(256), 0, s, isa, start, h, D, U, gid, idx, u, hid, kx, vx);
+		uint64_t *rk; uint32_t *rv;
+		radix_sort_u64(kx, vx, ky, vy, u, gbits, radix, s, nullptr, &rk, &rv);
+		uint64_t *gk = (rk == kx) ? ky : kx;
+		uint32_t *vidle = (rv == vx) ? vy : vx;
+		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, gid, rv, u, gk);
+		uint64_t *rk2; uint32_t *rv2;
+		radix_sort_u64(gk, rv, rk, vidle, u, 32, radix, s, nullptr, &rk2, &rv2);
+		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
+		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
+		hipLaunchKernelGGL(k_dom_gather, dim3(nblk(u)), dim3(256), 0, s, isa, start, h, D, U, gid, idx, rv2, u, hid, tmp_idx, tmp_key);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, tmp_key, u, idx, hid);
+		inclusive_max_u32(hid, u, scan_ws, s);
+		hipLaunchKernelGGL(k_dom_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, tmp_key, D, u, start, isa);
+		hipLaunchKernelGGL(k_dom_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, tmp_key, D, u, flag);
+		exclusive_sum_u32(flag, u + 1, scan_ws, s);
+		B3M_HIP(hipMemcpyAsync(&h_u, flag + u, 4, hipMemcpyDeviceToHost, s));
+		uint32_t *U2 = vx, *gid2 = vy;
+		hipLaunchKernelGGL(k_dom_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, U, u, U2, gid2);
+		B3M_HIP(hipStreamSynchronize(s));
+		vx = U; vy = gid; U = U2; gid = gid2;
+		u = h_u;
+		if (h_any && !hb) hb = h;
+	}
+	if (u) {
+		// what is left stopped doubling: only the block's own suffixes go on
+		hipLaunchKernelGGL(k_dom_own_flags, dim3(nblk(u + 1)), dim3(256), 0, s, U, idx, start, own, u, flag);
+		exclusive_sum_u32(flag, u + 1, scan_ws, s);
+		B3M_HIP(hipMemcpyAsync(&h_u, flag + u, 4, hipMemcpyDeviceToHost, s));
+		hipLaunchKernelGGL(k_dom_compact, dim3(nblk(u)), dim3(256), 0, s, flag, gid, U, u, vx, vy);
+		B3M_HIP(hipStreamSynchronize(s));
+		std::swap(U, vx); std::swap(gid, vy);
+		u = h_u;
+	}
+	B[0] = U; B[1] = gid; B[2] = vx; B[3] = vy;
+	if (left) *left = u;
+	if (h_blocked) *h_blocked = hb ? hb : h0;
+	return rounds;
+}
+void isa_from_sa_rel(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t *d_isa, hipStream_t s)
+{
+	if (len) hipLaunchKernelGGL(k_isa_init_rel, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, start, d_isa);
+}
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s)
 {
 	if (len) hipLaunchKernelGGL(k_isa_init, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, d_isa);
 }
 
-void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out)
+bool no_tree_doubling() { const char *e = getenv("B3M_NO_TREE_DOUBLING"); return e && atoi(e) != 0; }
+uint64_t block_overhang() { const char *e = getenv("B3M_OVERHANG"); return e ? strtoull(e, nullptr, 10) : (1ull << 20); }
+
+void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out, uint64_t own, bool allow_ext)
 {
 	// K1 keys
 	{
@@ -427,8 +591,18 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 		uint64_t left = 0;
 		// whole text in one block: a few key-extension rounds, then prefix doubling (see tie_rounds)
 		const bool whole = start == 0 && len == T.n;
+		const bool tree = !whole && !no_tree_doubling();       // a block of a merge tree: tie_rounds_domain
 		const uint64_t R0 = 4;
-		out.tie_rounds = tie_rounds(T, v, h_u, 1, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left, whole ? R0 : 0);
+		out.tie_rounds = tie_rounds(T, v, h_u, 1, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left, (whole || tree) ? R0 : 0);
+		if (left && tree && out.tie_rounds >= R0) {
+			if (allow_ext) { out.want_ext = true; out.d_sa = v; return; }
+			const uint64_t K = (uint64_t)key_symbols(T.type);
+			uint64_t h0 = 1; while (2 * h0 <= (R0 + 1) * K) h0 *= 2;
+			uint64_t hb = 0;
+			isa_from_sa_rel(v, len, start, ws.t[5], s);
+			out.tie_rounds += tie_rounds_domain(v, left, k, k_other, B, ws.scan_ws, ws.radix, start, len, own ? own : len, ws.t[5], h0, s, &left, &hb);
+			if (left) { out.slow_ties = left; out.tie_rounds += tie_rounds(T, v, left, hb / K, k, k_other, B, ws.scan_ws, ws.radix, len, s, &left, 0); }
+		}
 		if (left && whole && out.tie_rounds >= R0) {
 			uint64_t h0 = 1; while (2 * h0 <= (R0 + 1) * (uint64_t)key_symbols(T.type)) h0 *= 2;
 			isa_from_sa(v, len, ws.t[5], s);
@@ -439,6 +613,19 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 	out.d_sa = v;
 }
 
+// overhang filter: flag[r] = 1 if sa[r] belongs to the block (position < end); after the scan the block's suffixes are copied in order
+__global__ void k_own_flags(const uint32_t *sa, uint64_t len, uint64_t end, uint32_t *flag)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r <= len) flag[r] = (r < len && (uint64_t)sa[r] < end) ? 1u : 0u;
+}
+__global__ void k_own_compact(const uint32_t *sa, const uint32_t *flag_scan, uint64_t len, uint32_t *out)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= len) return;
+	const uint32_t p = flag_scan[r];
+	if (flag_scan[r + 1] != p) out[p] = sa[r];
+}
 void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                 uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa)
 {
@@ -447,11 +634,35 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	B3M_REQUIRE(T.n < (1ull << 32) || msd_applicable(T, len), "texts of 2^32 symbols and more need a pac/pacterm input (record sort with 36-bit positions)");
 	out = BlockSortOut();
 	if (len == 0) return;
-	if (msd_applicable(T, len)) {
-		block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards, need_sa);
+	// a block of a merge tree may be sorted together with an overhang of the text behind it (tie_rounds_domain): as much as the workspace has room for
+	const bool tree = nshards <= 1 && !(start == 0 && len == T.n) && T.n < (1ull << 32);
+	const uint64_t H = tree ? std::min(std::min<uint64_t>(ws.cap - len, T.n - (start + len)), block_overhang()) : 0;
+	const bool msd = msd_applicable(T, len);
+	if (msd) block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards, need_sa, 0, H > 0);
+	else block_sort_lsd(T, start, len, ws, s, tl, out, 0, H > 0);
+	if (out.want_ext) {
+		// long ties: the block and its overhang as one block (suffix array kept, BWT into scratch), then the overhang is filtered out
+		const uint64_t first_rounds = out.tie_rounds, first_elems = out.tie_elements;
+		uint64_t *hist_keep = ws.d_symhist_out; ws.d_symhist_out = nullptr;      // the histogram of the block was added by the first pass (MSD) or is the caller's business
+		const bool hist_done = out.symhist_done;
+		BlockSortOut o2;
+		if (msd) block_sort_msd(T, start, len + H, ws, s, tl, o2, reinterpret_cast<uint8_t *>(ws.t[1]), d_p0, 0, 1, true, len, false);
+		else block_sort_lsd(T, start, len + H, ws, s, tl, o2, len, false);
+		ws.d_symhist_out = hist_keep;
+		Scope sc(tl, KF_EMIT, 14 * (len + H));
+		uint32_t *flag = ws.t[3], *sa_own = ws.t[2];
+		B3M_REQUIRE(o2.d_sa != nullptr && o2.d_sa != sa_own && o2.d_sa != flag, "internal: buffers of the overhang filter");
+		hipLaunchKernelGGL(k_own_flags, dim3(nblk(len + H + 1)), dim3(256), 0, s, o2.d_sa, len + H, start + len, flag);
+		exclusive_sum_u32(flag, len + H + 1, ws.scan_ws, s);
+		hipLaunchKernelGGL(k_own_compact, dim3(nblk(len + H)), dim3(256), 0, s, o2.d_sa, flag, len + H, sa_own);
+		B3M_HIP(hipMemsetAsync(d_p0, 0xFF, 4, s));
+		emit_bwt(T, sa_own, len, start, d_bwt, d_p0, s);
+		out = o2;
+		out.d_sa = sa_own; out.d_sa_hi = nullptr; out.kept_len = len; out.slice_offset = 0; out.overhang = H; out.want_ext = false;
+		out.tie_rounds += first_rounds; out.tie_elements = first_elems; out.symhist_done = hist_done; out.late_writes = true;
 		return;
 	}
-	block_sort_lsd(T, start, len, ws, s, tl, out);
+	if (msd) return;
 	out.kept_len = len;
 	Scope sc(tl, KF_EMIT, 6 * len);
 	emit_bwt(T, out.d_sa, len, start, d_bwt, d_p0, s);

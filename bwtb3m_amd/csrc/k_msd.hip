@@ -1375,7 +1375,7 @@ __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, ui
 }
 
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
-                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa)
+                    uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own, bool allow_ext)
 {
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
@@ -1629,7 +1629,20 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// (b3m_plan_tie_export / b3m_plan_tie_finish): O(log longest repeat) rounds there too
 		const bool defer = nshards > 1 && start == 0 && len_in == T.n;
 		const uint64_t R0 = 4;
-		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer) ? R0 : 0);
+		// a block of a merge tree: the same few rounds, then prefix doubling inside the block and its overhang (tie_rounds_domain):
+		// the first time round the caller is asked to sort the block again with the overhang behind it (out.want_ext)
+		const bool tree = !whole && !defer && !no_tree_doubling();
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree) ? R0 : 0);
+		if (left && tree && out.tie_rounds >= R0) {
+			if (allow_ext) { out.want_ext = true; goto leave_fallback; }
+			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
+			const uint64_t K = (uint64_t)key_symbols(T.type);
+			uint64_t h0 = 1; while (2 * h0 <= R0 * K) h0 *= 2;
+			uint64_t hb = 0;
+			isa_from_sa_rel(sa.lo, len, start, ws.t[5], s);
+			out.tie_rounds += tie_rounds_domain(sa.lo, left, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, start, len, own ? own : len, ws.t[5], h0, s, &left, &hb);
+			if (left) { out.slow_ties = left; out.tie_rounds += tie_rounds(T, sa.lo, left, hb / K, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0); }
+		}
 		if (left && defer && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1];
@@ -1646,7 +1659,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s);
 		leave_fallback:;
 	}
-	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true); return; }   // the histogram was added by this pass already
+	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true, own, allow_ext); return; }   // the histogram was added by this pass already
 	B3M_HIP(hipGetLastError());
 	out.d_sa = need_sa ? sa.lo : nullptr;      // without need_sa only the entries of tied / overflow records were written
 	out.d_sa_hi = need_sa ? sa.hi : nullptr;

@@ -152,6 +152,8 @@ typedef struct b3m_result {
 	double   ms_total, ms_sort, ms_gap, ms_interleave;   /* HIP-event times of the last run */
 	uint64_t slice_offset, slice_len;   /* suffix-range shard: global rank of the first symbol written, and how many (else 0, n) */
 	uint64_t has_p0;                    /* 0 if the rotation starting at 0 lies in another shard */
+	uint64_t tie_overhang;              /* blocks of a merge tree with long repeats: symbols behind the block sorted with it (max; 0 = no block needed it) */
+	uint64_t tie_slow;                  /* suffixes whose repeat reached past the overhang: finished by key-extension rounds (sum) */
 } b3m_result;
 int b3m_plan_result(const b3m_plan *p, b3m_result *out);
 /* copies min(cap, num_samples) (rank,pos) u64 pairs to host memory, in position order (pos = 0, rate, 2*rate, ...) */

@@ -911,3 +911,45 @@ def test_long_repeats_in_suffix_range_shards(gpu, oracle):
     assert len(p0s) == 1 and int(got[p0s[0]]) == 0
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("overhang", [None, 3000, 0])
+@pytest.mark.parametrize("itype", ["pacterm", "pac", "bytestream"])
+def test_long_repeats_in_blocks_of_a_merge_tree(gpu, oracle, itype, overhang, monkeypatch):
+    """row a6 for blocks of a merge tree: the reference bounds what a repeat costs a block with lcpnext / largelcpthres
+    (/root/reference/src/bwtb3m.cpp:55, ChangeLog:205-211).  Here a block whose ties survive four key-extension rounds is sorted again together
+    with an overhang of the text behind it and finished by prefix doubling inside that domain: O(log longest repeat) rounds.  Repeats that reach
+    further past the block than the overhang (overhang 3000 / 0) fall back to key-extension rounds for the affected groups only: still exact."""
+    if overhang is not None:
+        monkeypatch.setenv("B3M_OVERHANG", str(overhang))
+    rng = np.random.default_rng(62)
+    if itype == "bytestream":
+        nb, bs = 200_000, 50_000
+        b = rng.integers(65, 91, nb, dtype=np.uint8)
+        b[20000:32000] = b[5000:17000]; b[26000] ^= 1           # a 12-kb copy inside block 0
+        b[46000:56000] = b[33000:43000]                         # a 10-kb copy that straddles the border of blocks 0 / 1, its twin inside block 0: ties reach 6 kb past the block
+        b[97000:101500] = np.resize(b[97000:97300], 4500)       # tandem array across the border of blocks 1 / 2
+        b[160000:172000] = 66                                   # a homopolymer run in the last block
+        buf, s = b, b
+    else:
+        nb, bs = (1 << 20) + 4 * 300 + 55, (1 << 18) + 300
+        b = rng.integers(0, 4, nb, dtype=np.uint8)
+        b[100000:140000] = b[20000:60000]; b[110000] ^= 1; b[125000] ^= 2      # 40-kb copy inside block 0, two substitutions
+        e0 = -(-nb // 5)                                                         # the balanced tree makes 5 blocks of this size
+        b[e0 - 15000:e0 + 15000] = b[150000:180000]                              # a 30-kb copy across the border of blocks 0 / 1, its twin inside block 0: ties reach 15 kb past the block
+        b[2 * e0 - 20000:2 * e0 + 10000] = np.resize(b[2 * e0 - 20000:2 * e0 - 17000], 30000)   # tandem array across the border of blocks 1 / 2
+        b[nb - 60000:nb - 40000] = 0                                             # 20 kb of A in the last block
+        buf = _pac(oracle, b)
+        s = oracle.symbols_from_file_bytes(buf, itype)
+    out, res, plan = _plan_bwt(gpu, buf, itype, blocksize=bs)
+    assert res["num_blocks"] == (4 if itype == "bytestream" else 5)
+    assert np.array_equal(out, oracle.bwt(s))
+    if overhang is None:
+        # 4 local rounds + log2(40000 / 64) doubling rounds (twice: the first pass and the pass with the overhang), not 40000 / 21 = 1900
+        assert 4 < res["tie_rounds"] <= 2 * 4 + 24, res["tie_rounds"]
+        assert res["tie_overhang"] >= (4500 if itype == "bytestream" else 15000) and res["tie_slow"] == 0, res      # (blocks are balanced: blocksize/8 of the balanced size)
+    elif overhang == 3000:
+        assert res["tie_overhang"] == 3000 and res["tie_slow"] > 0, res      # the copy across a border reaches 12-15 kb past its block
+    else:
+        assert res["tie_overhang"] == 0 and res["tie_slow"] > 0, res
+    plan.close()

@@ -28,20 +28,21 @@ def make(n, seed):
     return b
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+blocksize = int(float(sys.argv[2])) if len(sys.argv) > 2 else 0      # > 0: blocks of a merge tree (B3M_NO_TREE_DOUBLING=1 for the rounds without doubling)
 b = make(n, 7)
 buf = O.pac_encode(b) if hasattr(O, "pac_encode") else None
 if buf is None:
     raise SystemExit("no pac encoder")
 d_text = torch.from_numpy(np.asarray(buf)).cuda()
 nsym = n + 1
-plan = engine.Plan(nsym, "pacterm", isasamplingrate=1 << 16)
+plan = engine.Plan(nsym, "pacterm", isasamplingrate=1 << 16, blocksize=blocksize)
 out = torch.empty(nsym, dtype=torch.uint8, device="cuda")
 for it in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     plan.run(d_text, out)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     r = plan.result()
-    print("run %d: %.1f ms  tie_rounds %d tie_elements %d" % (it, dt * 1e3, r["tie_rounds"], r["tie_elements"]), flush=True)
+    print("run %d: %.1f ms  blocks %d tie_rounds %d tie_elements %d overhang %d slow %d" % (it, dt * 1e3, r["num_blocks"], r["tie_rounds"], r["tie_elements"], r["tie_overhang"], r["tie_slow"]), flush=True)
     print({k["name"]: round(k["ms"], 2) for k in plan.kernel_times() if k["ms"] > 0.05}, flush=True)
 m0, m1, _ = plan.lf_walk(out, sarate=0)
 print("LF check mismatches:", m0, m1)
