@@ -107,27 +107,43 @@ def verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize)
             % (rate, n, (time.perf_counter() - t0) * 1e3))
 
 
-def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps):
+def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
     """input in host memory (page cache) -> BWT symbols in host memory, through PCIe both ways.
-    Pinned host buffers; the BWT leaves the device in slices while later buckets are still being sorted."""
+    Pinned host buffers; the BWT leaves the device in slices while later buckets are still being sorted.  Two forms of the
+    hand-over: one byte per symbol, and (2-bit inputs) packed like the input, a quarter of the bytes (b3m_plan_set_packed_output)."""
+    from bwtb3m_amd import engine
     h_text = d_text.cpu().pin_memory()
-    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
-    plan.run_host(h_text, h_out)                       # warm-up (first touch of the pinned pages)
-    acc = {"h2d_ms": 0.0, "construct_ms": 0.0, "d2h_tail_ms": 0.0, "total_ms": 0.0}
-    streamed = 0
-    for _ in range(steps):
-        t = plan.run_host(h_text, h_out)
-        for k in acc:
-            acc[k] += t[k]
-        streamed = t["streamed_bytes"]
-    torch.cuda.synchronize()
-    ok = bool(torch.equal(h_out, d_out.cpu()))
-    assert ok, "bench e2e: the BWT that arrived in host memory differs from the device-resident result"
-    res = {k: round(v / steps, 3) for k, v in acc.items()}
-    res.update({"value_e2e": round(nbases / (acc["total_ms"] / steps) / 1e6, 4), "unit": "Gbase/s", "steps": steps,
-                "bytes_in": int(h_text.numel()), "bytes_out": int(n), "streamed_bytes": int(streamed), "equals_device_result": ok,
-                "what": "pinned host text -> HBM (PCIe) -> construction -> BWT bytes in pinned host memory (PCIe), wall clock of "
-                        "b3m_plan_run_host; RL file writing is separate (DESIGN.md 4)"})
+    out = {}
+    for packed in ((False, True) if itype in ("pac", "pacterm") else (False,)):
+        nbytes = (n + 3) // 4 if packed else n
+        h_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        plan.run_host(h_text, h_out, packed=packed)    # warm-up (first touch of the pinned pages)
+        acc = {"h2d_ms": 0.0, "construct_ms": 0.0, "d2h_tail_ms": 0.0, "total_ms": 0.0}
+        streamed = 0
+        for _ in range(steps):
+            t = plan.run_host(h_text, h_out, packed=packed)
+            for k in acc:
+                acc[k] += t[k]
+            streamed = t["streamed_bytes"]
+        torch.cuda.synchronize()
+        if packed:
+            want = torch.cat([engine.Plan.pack_pac(c, itype == "pacterm") for c in torch.split(d_out, 1 << 28)]).cpu()   # (1 << 28 is a multiple of 4)
+        else:
+            want = d_out.cpu()
+        ok = bool(torch.equal(h_out, want))
+        assert ok, "bench e2e: the BWT that arrived in host memory differs from the device-resident result"
+        res = {k: round(v / steps, 3) for k, v in acc.items()}
+        res.update({"value_e2e": round(nbases / (acc["total_ms"] / steps) / 1e6, 4), "unit": "Gbase/s", "steps": steps,
+                    "bytes_in": int(h_text.numel()), "bytes_out": int(nbytes), "streamed_bytes": int(streamed), "equals_device_result": ok})
+        out["packed" if packed else "bytes"] = res
+        del h_out
+    best = out.get("packed", out["bytes"])
+    res = dict(best)
+    res["hand_over"] = "2 bits per symbol (.pac layout)" if "packed" in out else "1 byte per symbol"
+    if "packed" in out:
+        res["one_byte_per_symbol"] = out["bytes"]
+    res["what"] = ("pinned host text -> HBM (PCIe) -> construction -> BWT symbols in pinned host memory (PCIe), wall clock of "
+                   "b3m_plan_run_host; RL file writing is separate (DESIGN.md 4)")
     return res
 
 
@@ -191,7 +207,7 @@ def main():
     }
     out["config"]["value_is"] = "device-resident: packed text in HBM -> BWT bytes in HBM (SURVEY 8d end-to-end figure: `e2e`)"
     if a.e2e_steps > 0:
-        out["e2e"] = measure_e2e(torch, plan, d_text, d_out, n, nbases, a.e2e_steps)
+        out["e2e"] = measure_e2e(torch, plan, d_text, d_out, n, nbases, a.e2e_steps, itype)
     if a.verify:
         from oracle import oracle as O
         sym = O.symbols_from_file_bytes(d_text.cpu().numpy(), itype)

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("b3m_plan_text_bytes", _u64, [_p]),
     ("b3m_plan_run", _i, [_p, _p, _p, _p]),
     ("b3m_plan_run_host", _i, [_p, _p, _p, ctypes.POINTER(E2ETimes), _p]),
+    ("b3m_plan_set_packed_output", _i, [_p, _i]),
     ("b3m_host_alloc", _p, [_u64]),
     ("b3m_host_free", None, [_p]),
     ("b3m_compact_info", _i, [_p, _u64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),

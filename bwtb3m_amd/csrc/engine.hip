@@ -146,6 +146,8 @@ struct b3m_plan {
 	uint64_t tie_left = 0; uint32_t *tie_U = nullptr, *tie_gid = nullptr;   // suffix-range shard: what its local rounds left tied (b3m_plan_tie_*)
 	uint32_t *d_sa_slice = nullptr; uint64_t slice_off = 0, slice_len = 0;
 	hipStream_t copy_stream = nullptr;     // host-memory runs: slices of the BWT leave on this stream while later buckets sort
+	int packed_out = 0;                    // host-memory runs hand the BWT over 2-bit packed (b3m_plan_set_packed_output)
+	uint8_t *d_pack = nullptr;             // its device image
 	b3m_e2e_times e2e{};
 };
 
@@ -381,6 +383,7 @@ void b3m_plan_destroy(b3m_plan *p)
 {
 	if (!p) return;
 	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+	if (p->d_pack) (void)hipFree(p->d_pack);
 	if (p->arena) (void)hipFree(p->arena);
 	delete p;
 }
@@ -389,16 +392,47 @@ uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 
 uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
 
 namespace {
+// BWT symbols -> the .pac layout (4 symbols per byte, the first in the top bits); sub = 1 for pacterm (symbols 1..4 -> 0..3, the
+// terminator's slot reads 0).  One thread per 16 symbols = 4 output bytes.
+__global__ void k_pack_pac(const uint8_t *bwt, uint64_t w_first, uint64_t w_last, uint32_t sub, uint8_t *out)
+{
+	const uint64_t w = w_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= w_last) return;
+	const uint4 v = reinterpret_cast<const uint4 *>(bwt)[w];
+	const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+	uint32_t o = 0;
+	for (int k = 0; k < 4; ++k) {
+		uint32_t b = 0;
+		for (int j = 0; j < 4; ++j) {
+			uint32_t c = (in[k] >> (8 * j)) & 0xFFu;
+			c = c >= sub ? c - sub : 0u;
+			b |= (c & 3u) << (6 - 2 * j);
+		}
+		o |= b << (8 * k);
+	}
+	reinterpret_cast<uint32_t *>(out)[w] = o;
+}
 struct HostSink {            // SliceHook context of a host-memory run
 	b3m_plan *p; hipStream_t s; uint8_t *d_bwt; uint8_t *h_bwt; std::vector<hipEvent_t> evs; uint64_t copied = 0;
+	// symbols [first, last) are final on the device: pack them if asked for, then send them off on the copy stream
 	static void slice(void *ctx, uint64_t first, uint64_t last)
 	{
 		HostSink *k = (HostSink *)ctx;
 		if (last <= first) return;
-		hipEvent_t e = k->p->tl.get();
+		b3m_plan *p = k->p;
+		uint64_t b0 = first, b1 = last;                 // byte range that leaves
+		const uint8_t *src = k->d_bwt;
+		if (p->packed_out) {
+			// whole bytes of four symbols; the byte that straddles `first` was left to this slice by the one before
+			b0 = first / 4; b1 = last == p->n ? (p->n + 3) / 4 : last / 4;
+			if (b1 > b0) hipLaunchKernelGGL(k_pack_pac, dim3((uint32_t)(((b1 + 3) / 4 - b0 / 4 + 255) / 256)), dim3(256), 0, k->s, k->d_bwt, b0 / 4, (b1 + 3) / 4,
+			                                p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack);
+			src = p->d_pack;
+		}
+		hipEvent_t e = p->tl.get();
 		B3M_HIP(hipEventRecord(e, k->s));
-		B3M_HIP(hipStreamWaitEvent(k->p->copy_stream, e, 0));
-		B3M_HIP(hipMemcpyAsync(k->h_bwt + first, k->d_bwt + first, last - first, hipMemcpyDeviceToHost, k->p->copy_stream));
+		B3M_HIP(hipStreamWaitEvent(p->copy_stream, e, 0));
+		if (b1 > b0) B3M_HIP(hipMemcpyAsync(k->h_bwt + b0, src + b0, b1 - b0, hipMemcpyDeviceToHost, p->copy_stream));
 		k->evs.push_back(e); k->copied += last - first;
 	}
 };
@@ -419,6 +453,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		if (!p->copy_stream) B3M_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
 		d_bwt_out = p->d_bwt[0];                    // one block: the leaf sort writes here; several: the last level is copied here
 		sink.d_bwt = d_bwt_out;
+		if (p->packed_out && !p->d_pack) B3M_HIP(hipMalloc((void **)&p->d_pack, (((p->n + 3) / 4 + 15) & ~15ull) + 16));
 		p->e2e = b3m_e2e_times{};
 	}
 	const uint64_t n = p->n, B = p->leaves.size();
@@ -579,7 +614,12 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		B3M_HIP(hipEventRecord(evh2, s));                                   // construction done
 		if (sink.copied != n) {                                                 // nothing streamed (several blocks, small input) or rewritten slices: one copy of the whole result
 			B3M_HIP(hipStreamSynchronize(p->copy_stream));
-			B3M_HIP(hipMemcpyAsync(h_bwt_out, B > 1 ? p->d_bwt[cur] : d_bwt_out, n, hipMemcpyDeviceToHost, s));
+			const uint8_t *src = B > 1 ? p->d_bwt[cur] : d_bwt_out;
+			if (p->packed_out) {
+				const uint64_t nb4 = (n + 3) / 4;
+				hipLaunchKernelGGL(k_pack_pac, dim3((uint32_t)(((nb4 + 3) / 4 + 255) / 256)), dim3(256), 0, s, src, (uint64_t)0, (nb4 + 3) / 4, p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack);
+				B3M_HIP(hipMemcpyAsync(h_bwt_out, p->d_pack, nb4, hipMemcpyDeviceToHost, s));
+			} else B3M_HIP(hipMemcpyAsync(h_bwt_out, src, n, hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipEventRecord(evh3, s));
 		} else {
 			B3M_HIP(hipEventRecord(evh3, p->copy_stream));
@@ -602,7 +642,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		float a = 0, b = 0, c = 0;
 		(void)hipEventElapsedTime(&a, evh0, evh1); (void)hipEventElapsedTime(&b, evh1, evh2); (void)hipEventElapsedTime(&c, evh2, evh3);
 		p->e2e.h2d_ms = a; p->e2e.construct_ms = b; p->e2e.d2h_tail_ms = c > 0 ? c : 0; p->e2e.total_ms = wall1 - wall0;
-		p->e2e.streamed_bytes = sink.copied == n ? n : 0;
+		p->e2e.streamed_bytes = sink.copied == n ? (p->packed_out ? (n + 3) / 4 : n) : 0;
 		for (auto e : sink.evs) tl->pool.push_back(e);
 		tl->pool.push_back(evh0); tl->pool.push_back(evh1); tl->pool.push_back(evh2); tl->pool.push_back(evh3);
 	}
@@ -638,6 +678,15 @@ int b3m_plan_run_host(b3m_plan *p, const void *h_text, uint8_t *h_bwt_out, b3m_e
 	int rc = plan_run_impl(p, nullptr, h_text, nullptr, h_bwt_out, stream);
 	if (rc == 0 && times) *times = p->e2e;
 	return rc;
+}
+int b3m_plan_set_packed_output(b3m_plan *p, int on)
+{
+	B3M_TRY
+	B3M_REQUIRE(p != nullptr, "b3m_plan_set_packed_output: null plan");
+	B3M_REQUIRE(!on || p->type == B3M_INPUT_PAC || p->type == B3M_INPUT_PACTERM, "a 2-bit packed BWT needs a pac/pacterm input");
+	p->packed_out = on ? 1 : 0;
+	return 0;
+	B3M_CATCH(1)
 }
 void *b3m_host_alloc(uint64_t bytes)
 {

@@ -63,7 +63,9 @@ class Plan:
             lib().b3m_plan_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:          # (module globals are gone when the interpreter shuts down)
+            self.close()
 
     @property
     def num_blocks(self):
@@ -93,13 +95,26 @@ class Plan:
             return d_out[: self.result()["slice_len"]]
         return d_out
 
-    def run_host(self, h_text, h_out):
+    def run_host(self, h_text, h_out, packed=False):
         """the same pass from host memory to host memory (b3m_plan_run_host): h_text / h_out are CPU uint8 tensors, pinned
-        for asynchronous copies.  Returns the HIP-event / wall-clock splits of the run."""
-        assert not h_text.is_cuda and not h_out.is_cuda and h_text.numel() >= self.text_bytes and h_out.numel() >= self.n
+        for asynchronous copies.  packed: the BWT arrives 2 bits per symbol in the .pac layout ((n+3)//4 bytes, b3m_plan_set_packed_output).
+        Returns the HIP-event / wall-clock splits of the run."""
+        check(lib().b3m_plan_set_packed_output(self._h, 1 if packed else 0))
+        assert not h_text.is_cuda and not h_out.is_cuda and h_text.numel() >= self.text_bytes
+        assert h_out.numel() >= ((self.n + 3) // 4 if packed else self.n)
         t = _lib.E2ETimes()
         check(lib().b3m_plan_run_host(self._h, _ptr(h_text), _ptr(h_out), ctypes.byref(t), _stream()))
         return {k: getattr(t, k) for k, _ in _lib.E2ETimes._fields_}
+
+    @staticmethod
+    def pack_pac(bwt, pacterm):
+        """what a packed hand-over of the BWT tensor `bwt` (uint8 symbols, any device) holds: see b3m_plan_set_packed_output"""
+        v = bwt.to(torch.int16)
+        if pacterm:
+            v = torch.clamp(v - 1, min=0)
+        n = v.numel()
+        v = torch.nn.functional.pad(v & 3, (0, (-n) % 4)).view(-1, 4)
+        return ((v[:, 0] << 6) | (v[:, 1] << 4) | (v[:, 2] << 2) | v[:, 3]).to(torch.uint8)
 
     # ---- suffix-range shards and long repeats (b3m_plan_tie_*): see finish_shard_ties() ----
     def keep_sa(self, on=True):

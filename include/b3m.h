@@ -120,6 +120,11 @@ typedef struct b3m_e2e_times {
 	uint64_t streamed_bytes; /* bytes of the BWT that left in slices during construction (0: one copy at the end) */
 } b3m_e2e_times;
 int   b3m_plan_run_host(b3m_plan *p, const void *h_text, uint8_t *h_bwt_out, b3m_e2e_times *times, void *stream);
+/* pac / pacterm plans: b3m_plan_run_host hands the BWT over as it takes the text, 2 bits per symbol in the .pac layout (4 symbols per
+ * byte, the first in the top two bits: h_bwt_out then holds (n+3)/4 bytes).  pac: the symbol values; pacterm: symbol - 1, and the one
+ * slot that holds the terminator (rank b3m_result.p0) reads 0.  A quarter of the bytes cross PCIe; the encoder behind the hand-off
+ * (RLEncoderStd, /root/reference/src/lcpbit.cpp:3677-3681) consumes symbols either way. */
+int   b3m_plan_set_packed_output(b3m_plan *p, int on);
 void *b3m_host_alloc(uint64_t bytes);     /* pinned host memory (hipHostMalloc) */
 void  b3m_host_free(void *p);
 

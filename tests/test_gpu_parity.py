@@ -953,3 +953,61 @@ def test_long_repeats_in_blocks_of_a_merge_tree(gpu, oracle, itype, overhang, mo
     else:
         assert res["tie_overhang"] == 0 and res["tie_slow"] > 0, res
     plan.close()
+
+
+@pytest.mark.parametrize("case", ["one_block_30m", "one_block_30m_pac", "repeats_30m", "blocks_small", "bytes_small"])
+def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
+    """SURVEY.md 8(d) end to end: b3m_plan_run_host takes the text from host memory and leaves the BWT in host memory, in slices while later
+    buckets are still being sorted (30 M symbols: 8 slices), one byte per symbol or packed like the input (b3m_plan_set_packed_output).  What
+    arrives must equal the device-resident run; repeats make listed buckets rewrite slices that have left (copied again), several blocks and
+    small inputs take the one-copy path.  Role: the hand-offs around BwtMergeSort::computeBwt, /root/reference/src/bwtb3m.cpp:63."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    rng = np.random.default_rng(63)
+    bs = 0
+    if case == "bytes_small":
+        itype = "bytestream"
+        buf = rng.integers(32, 127, 70001, dtype=np.uint8)
+        n = len(buf)
+    else:
+        itype = "pac" if case.endswith("pac") else "pacterm"
+        nb = {"one_block_30m": 30_000_001, "one_block_30m_pac": 30_000_003, "repeats_30m": 30_000_002, "blocks_small": 100_003}[case]
+        b = rng.integers(0, 4, nb, dtype=np.uint8)
+        if case == "repeats_30m":
+            b[5_000_000:5_300_000] = 0
+            b[9_000_000:9_200_000] = b[1_000_000:1_200_000]
+        if case == "blocks_small":
+            bs = 30000
+        buf = _pac(oracle, b)
+        n = nb + (1 if itype == "pacterm" else 0)
+    d_text = torch.from_numpy(np.asarray(buf)).cuda()
+    plan = engine.Plan(n, itype, blocksize=bs)
+    d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    plan.run(d_text, d_out)
+    if n < 200_000:
+        assert np.array_equal(d_out.cpu().numpy(), oracle.bwt(oracle.symbols_from_file_bytes(buf, itype)))
+    h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory()
+    h_text[:len(buf)] = torch.from_numpy(np.asarray(buf))
+    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    t = plan.run_host(h_text, h_out)
+    assert torch.equal(h_out, d_out.cpu())
+    if case in ("one_block_30m", "one_block_30m_pac"):
+        assert t["streamed_bytes"] == n
+    if itype != "bytestream":
+        h_pk = torch.empty((n + 3) // 4, dtype=torch.uint8).pin_memory()
+        t = plan.run_host(h_text, h_pk, packed=True)
+        assert torch.equal(h_pk, engine.Plan.pack_pac(d_out, itype == "pacterm").cpu())
+        if case in ("one_block_30m", "one_block_30m_pac"):
+            assert t["streamed_bytes"] == (n + 3) // 4
+        if itype == "pacterm":
+            p0 = plan.result()["p0"]
+            assert int(d_out[p0]) == 0                                   # the terminator's slot: reads 0 in the packed form
+            assert (int(h_pk[p0 // 4]) >> (6 - 2 * (p0 % 4))) & 3 == 0
+        # and back to one byte per symbol on the same plan
+        h_out.zero_()
+        plan.run_host(h_text, h_out)
+        assert torch.equal(h_out, d_out.cpu())
+    else:
+        with pytest.raises(Exception):
+            plan.run_host(h_text, h_out, packed=True)
+    plan.close()
