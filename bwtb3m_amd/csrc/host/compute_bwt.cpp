@@ -39,8 +39,8 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		const char *tname = (o->inputtype && *o->inputtype) ? o->inputtype : "bytestream";
 		int type = b3m_parse_input_type(tname);
 		if (type < 0) throw std::runtime_error(b3m_last_error());
-		if (type != B3M_INPUT_BYTESTREAM && type != B3M_INPUT_PAC && type != B3M_INPUT_PACTERM && type != B3M_INPUT_COMPACTSTREAM)
-			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, compactstream, pac, pacterm)");
+		if (type != B3M_INPUT_BYTESTREAM && type != B3M_INPUT_PAC && type != B3M_INPUT_PACTERM && type != B3M_INPUT_COMPACTSTREAM && type != B3M_INPUT_UTF8)
+			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, compactstream, pac, pacterm, utf-8)");
 		std::string outfn = (o->output_fn && *o->output_fn) ? o->output_fn : (std::string((o->tmpprefix && *o->tmpprefix) ? o->tmpprefix : "bwtb3m_out") + ".bwt");
 		std::string prefix = b3m::clip_off(outfn, ".bwt");
 		double t0 = now();
@@ -48,11 +48,29 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		uint64_t n;
 		// compactstream (row f4): 2-bit files are a .pac payload behind a 32-byte header; other widths are decoded to bytes on the device
 		uint32_t cbits = 0; uint64_t coff = 0; const int filetype = type;
+		int64_t symmap_store[256]; const int64_t *symmap = nullptr;
 		if (type == B3M_INPUT_COMPACTSTREAM) {
 			if (b3m_compact_info(file.data(), file.size(), &cbits, &n, &coff)) throw std::runtime_error(b3m_last_error());
 			file.erase(file.begin(), file.begin() + (long)coff);
 			file.resize(file.size() + 16, 0);
 			type = cbits == 2 ? B3M_INPUT_PAC : B3M_INPUT_BYTESTREAM;
+		} else if (type == B3M_INPUT_UTF8) {
+			// utf-8 (row f4): the text is the sequence of code points.  The code points that occur are ranked (order kept) into a byte
+			// alphabet, the ranks are sorted and merged as a bytestream, and the files name the code points again (symmap).
+			std::vector<uint32_t> cps = b3m::utf8_decode(file);
+			std::vector<uint8_t> seen(0x110000, 0);
+			for (uint32_t c : cps) seen[c] = 1;
+			std::vector<int32_t> rank(0x110000, -1);
+			uint32_t k = 0;
+			for (uint32_t c = 0; c < 0x110000; ++c) if (seen[c]) { if (k < 256) symmap_store[k] = (int64_t)c; rank[c] = (int32_t)k++; }
+			if (k > 256) throw std::runtime_error("inputtype=utf-8: the text has " + std::to_string(k) + " distinct code points; this engine ranks them into a byte alphabet and supports at most 256");
+			for (uint32_t j = k; j < 256; ++j) symmap_store[j] = (int64_t)0x110000 + j;      // (unused ranks: never written)
+			file.resize(cps.size());
+			for (size_t i = 0; i < cps.size(); ++i) file[i] = (uint8_t)rank[cps[i]];
+			n = cps.size();
+			symmap = symmap_store;
+			type = B3M_INPUT_BYTESTREAM;
+			file.resize(file.size() + 16, 0);
 		} else if (type == B3M_INPUT_BYTESTREAM) n = file.size();
 		else {
 			if (file.size() < 2 || file.back() > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
@@ -98,10 +116,10 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		    res.ms_interleave, n / (t2 - t1) / 1e9);
 		std::vector<uint8_t> bwt(n);
 		HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
-		b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, o->numthreads ? o->numthreads : 1);
+		b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, o->numthreads ? o->numthreads : 1, symmap);
 		uint64_t hist[256];
 		b3m_plan_histogram(plan, hist);
-		b3m::write_hist(prefix + ".hist", hist);
+		b3m::write_hist(prefix + ".hist", hist, symmap);
 		std::vector<uint64_t> pairs(2 * res.num_samples);
 		if (res.num_samples) b3m_plan_samples(plan, pairs.data(), res.num_samples);
 		b3m::write_meta(prefix + ".meta", {n, res.num_blocks, res.levels, res.p0, isarate});

@@ -151,7 +151,7 @@ struct Canon {
 
 static const uint64_t RL_ESCAPE = 256;   // run lengths >= 256 are coded as escape + elias(len)
 
-static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out)
+static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out, const int64_t *symmap)
 {
 	BitWriter w(out);
 	// symbols are bytes and coded lengths are 1..256 (256 = escape): flat counters and code tables
@@ -171,7 +171,11 @@ static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &o
 	out.reserve(out.size() + nr / 2 + 4096);
 	w.elias(nr);
 	w.put(esc ? 1 : 0, 1);
-	sc.serialise(w); cc.serialise(w);
+	if (symmap) {          // the table names the mapped symbols (the map is monotone: the canonical order is the same)
+		w.elias(sc.syms.size());
+		for (auto &s : sc.syms) { w.elias((uint64_t)symmap[s.first]); w.elias((uint64_t)s.second); }
+	} else sc.serialise(w);
+	cc.serialise(w);
 	w.align();
 	for (uint64_t i = 0; i < nr; ++i) { uint8_t s = (uint8_t)runs[i].sym; w.put(scode[s], slen[s]); }
 	w.align();
@@ -181,7 +185,7 @@ static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &o
 	w.align();
 }
 
-void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads)
+void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap)
 {
 	if (!runs_per_block) runs_per_block = 64 * 1024;
 	if (!numthreads) numthreads = 1;
@@ -246,7 +250,7 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 					i = j;
 				}
 				bsyms[b] = syms; bruns[b] = runs.size();
-				encode_block(runs.data(), runs.size(), bufs[b]);
+				encode_block(runs.data(), runs.size(), bufs[b], symmap);
 			}
 		};
 		std::vector<std::thread> th;
@@ -374,13 +378,34 @@ uint64_t rl_decode_array(const std::string &fn, uint8_t *out, uint64_t cap, unsi
 }
 
 // ---- siblings -----------------------------------------------------------------------------------------
-void write_hist(const std::string &fn, const uint64_t hist256[256])
+void write_hist(const std::string &fn, const uint64_t hist256[256], const int64_t *symmap)
 {
 	std::vector<uint8_t> o; uint64_t cnt = 0;
 	for (int i = 0; i < 256; ++i) cnt += hist256[i] != 0;
 	put_be64(o, cnt);
-	for (int i = 0; i < 256; ++i) if (hist256[i]) { put_be64(o, (uint64_t)i); put_be64(o, hist256[i]); }
+	for (int i = 0; i < 256; ++i) if (hist256[i]) { put_be64(o, (uint64_t)(symmap ? symmap[i] : i)); put_be64(o, hist256[i]); }
 	write_file(fn, o.data(), o.size());
+}
+std::vector<uint32_t> utf8_decode(const std::vector<uint8_t> &f)
+{
+	std::vector<uint32_t> out; out.reserve(f.size());
+	const size_t n = f.size();
+	auto bad = [&](size_t i) { throw std::runtime_error("utf-8 input: invalid byte sequence at offset " + std::to_string(i)); };
+	for (size_t i = 0; i < n;) {
+		const uint8_t c = f[i];
+		uint32_t cp; int k;
+		if (c < 0x80) { cp = c; k = 0; }
+		else if (c >= 0xC2 && c <= 0xDF) { cp = c & 0x1Fu; k = 1; }
+		else if (c >= 0xE0 && c <= 0xEF) { cp = c & 0x0Fu; k = 2; }
+		else if (c >= 0xF0 && c <= 0xF4) { cp = c & 0x07u; k = 3; }
+		else { bad(i); return out; }
+		if (i + k >= n + (k ? 0 : 1)) bad(i);
+		for (int j = 1; j <= k; ++j) { const uint8_t d = f[i + j]; if ((d & 0xC0u) != 0x80u) bad(i); cp = (cp << 6) | (d & 0x3Fu); }
+		if ((k == 2 && cp < 0x800u) || (k == 3 && cp < 0x10000u) || cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) bad(i);
+		out.push_back(cp);
+		i += (size_t)k + 1;
+	}
+	return out;
 }
 std::map<int64_t, uint64_t> read_hist(const std::string &fn)
 {
@@ -420,6 +445,18 @@ int b3m_rl_read(const char *fn, uint8_t *symbols_out, uint64_t cap, uint64_t *n_
 		uint64_t n = b3m::rl_decode_array(fn, symbols_out, cap, std::max(1u, std::thread::hardware_concurrency()), &bad);
 		if (n_out) *n_out = n;
 		if (bad) { b3m::set_error("symbol outside 0..255"); return 1; }
+		return 0;
+	} catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
+}
+int b3m_rl_read_symbols(const char *fn, int64_t *symbols_out, uint64_t cap, uint64_t *n_out)
+{
+	try {
+		struct Ctx { int64_t *out; uint64_t cap, at; } c{symbols_out, cap, 0};
+		uint64_t n = b3m::rl_decode_file(fn, [](void *q, int64_t sym, uint64_t len) {
+			Ctx *k = (Ctx *)q;
+			for (uint64_t i = 0; i < len; ++i, ++k->at) if (k->out && k->at < k->cap) k->out[k->at] = sym;
+		}, &c);
+		if (n_out) *n_out = n;
 		return 0;
 	} catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
 }

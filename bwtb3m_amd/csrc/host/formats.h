@@ -22,7 +22,8 @@ bool file_exists(const std::string &fn);
 //   index: per block (u64 BE file offset, u64 BE runs, u64 BE symbols), u64 BE numblocks
 //   u64 BE  offset of the index            (last 8 bytes of the file)
 struct RLRun { int64_t sym; uint64_t len; };
-void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads);
+// symmap (may be null): the symbol value written for byte b is symmap[b] (monotone; utf-8 input: code points ranked into a byte alphabet)
+void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap = nullptr);
 // decodeRun() stream: calls sink(sym,len) per run; returns n
 uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx);
 uint64_t rl_length(const std::string &fn);
@@ -34,7 +35,7 @@ std::vector<RLIndexEntry> rl_index(const std::string &fn);
 // ---- siblings -------------------------------------------------------------------------------------
 // X.hist: NumberMapSerialisation::serialiseMap<int64,uint64> (reader at
 // /root/reference/src/bwtdecodeblock.cpp:150-173): u64 BE count, then (i64 BE key, u64 BE value)
-void write_hist(const std::string &fn, const uint64_t hist256[256]);
+void write_hist(const std::string &fn, const uint64_t hist256[256], const int64_t *symmap = nullptr);
 std::map<int64_t, uint64_t> read_hist(const std::string &fn);
 // X.preisa: raw host-endian u64 pairs (rank,pos) (/root/reference/src/hwtPreIsaToIsa.cpp:64-77)
 void write_preisa(const std::string &fn, const uint64_t *pairs, uint64_t count);
@@ -42,6 +43,10 @@ void write_preisa(const std::string &fn, const uint64_t *pairs, uint64_t count);
 void write_sampled(const std::string &fn, uint64_t rate, const std::vector<uint64_t> &values);
 // X.meta: 8-byte big-endian numbers (NumberSerialisation); content is engine-specific
 void write_meta(const std::string &fn, const std::vector<uint64_t> &numbers);
+
+// inputtype=utf-8: the text is the file's sequence of Unicode code points (strict decoding: no overlong forms, surrogates,
+// values above U+10FFFF or truncated sequences); throws with the byte offset of the first bad sequence
+std::vector<uint32_t> utf8_decode(const std::vector<uint8_t> &file);
 
 // clipOff(bwtname, ".bwt")  (/root/reference/src/checkbwt.cpp:31)
 std::string clip_off(const std::string &s, const std::string &suffix);

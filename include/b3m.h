@@ -42,7 +42,7 @@ enum {
 	B3M_INPUT_PAC = 2,
 	B3M_INPUT_PACTERM = 3,
 	B3M_INPUT_LZ4 = 4,           /* parsed, not yet constructed */
-	B3M_INPUT_UTF8 = 5           /* parsed, not yet constructed */
+	B3M_INPUT_UTF8 = 5           /* b3m_compute_bwt: texts of at most 256 distinct code points (ranked into a byte alphabet); plans take the ranked bytes as bytestream */
 };
 
 int         b3m_version(void);
@@ -277,6 +277,8 @@ int b3m_rl_write(const char *fn, const uint8_t *symbols, uint64_t n, uint64_t ru
 /* decodeRun() loop of /root/reference/src/bwtb3mdecoderl.cpp:34: n_out = symbol count;
  * symbols_out may be NULL to query the length only */
 int b3m_rl_read(const char *fn, uint8_t *symbols_out, uint64_t cap, uint64_t *n_out);
+/* the same with the symbols as the file names them (inputtype=utf-8: Unicode code points): the (sym:int64, len) pairs of decodeRun() expanded */
+int b3m_rl_read_symbols(const char *fn, int64_t *symbols_out, uint64_t cap, uint64_t *n_out);
 int b3m_rl_length(const char *fn, uint64_t *n_out);           /* RLDecoder::getLength, checkbwt.cpp:57 */
 
 #ifdef __cplusplus

@@ -248,7 +248,38 @@ def symbols_from_file_bytes(buf, inputtype):
     if inputtype == "pacterm":
         b = pac_decode(buf)
         return np.concatenate([b + 1, np.zeros(1, dtype=np.uint8)]).astype(np.uint8)
+    if inputtype == "utf-8":
+        # the text is the file's sequence of Unicode code points (role of libmaus2's utf-8 input wrapper; decoder call site
+        # /root/reference/src/bwtb3mdecoderl.cpp:47-57 writes them back with UTF8::encodeUTF8)
+        return np.frombuffer(bytes(np.asarray(buf, dtype=np.uint8)).decode("utf-8").encode("utf-32-le"), dtype="<u4").astype(np.int64)
     raise ValueError("oracle: unsupported inputtype " + inputtype)
+
+
+def bwt_wide(sym):
+    """BWT (rotation order, README.md:55-59) of a text over any integer alphabet, as int64.  Texts of <= 256 distinct symbols go through the
+    byte BWT on their ranks (order-preserving); larger alphabets through a plain prefix-doubling suffix sort in numpy."""
+    sym = np.asarray(sym, dtype=np.int64)
+    n = len(sym)
+    if n == 0:
+        return sym.copy()
+    vals, rk = np.unique(sym, return_inverse=True)
+    if len(vals) <= 256:
+        return vals[bwt(rk.astype(np.uint8)).astype(np.int64)]
+    r = rk.astype(np.int64)
+    h = 1
+    idx = np.arange(n, dtype=np.int64)
+    while True:
+        key2 = r[(idx + h) % n]
+        order = np.lexsort((key2, r))
+        a, b = r[order], key2[order]
+        newr = np.empty(n, dtype=np.int64)
+        newr[order] = np.concatenate([[0], np.cumsum((a[1:] != a[:-1]) | (b[1:] != b[:-1]))])
+        r = newr
+        h *= 2
+        if r.max() == n - 1 or h >= n:
+            break
+    order = np.argsort(r, kind="stable")
+    return sym[(order - 1) % n]
 
 
 # --- deterministic synthetic inputs (SURVEY.md 8d: splitmix64, seed 0xB3B3B3B3 + cfg) ----------

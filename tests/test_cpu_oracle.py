@@ -143,3 +143,15 @@ def test_compactstream_codec_round_trip():
     # 2-bit compact words are a .pac payload: same bit order
     b = rng.integers(0, 4, 1001, dtype=np.uint8)
     assert np.array_equal(O.compact_encode(b, 2)[32:32 + 250], O.pac_encode(b)[:250])
+
+
+def test_utf8_symbols_and_wide_bwt():
+    # row f4: inputtype=utf-8 makes the code points the text; bwt_wide against sorted rotations (README.md:55-59), both of its paths
+    from oracle import oracle as O
+    txt = "a\u00f1b \u00f1and\u00fa \u03b1\u03b2\u03b3 a\u00f1b \u00f1and\u00fa \U0001F600 a\u00f1b"
+    s = O.symbols_from_file_bytes(np.frombuffer(txt.encode("utf-8"), dtype=np.uint8), "utf-8")
+    assert list(s) == [ord(c) for c in txt]
+    rng = np.random.default_rng(2)
+    for w in (s, rng.integers(0, 1000, 2000), rng.integers(0, 3, 500) * 100000, np.array([7, 7, 7, 7])):
+        rot = sorted(range(len(w)), key=lambda i: list(w[i:]) + list(w[:i]))
+        assert np.array_equal(O.bwt_wide(w), np.array([w[(i - 1) % len(w)] for i in rot]))

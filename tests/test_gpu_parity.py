@@ -1011,3 +1011,49 @@ def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
         with pytest.raises(Exception):
             plan.run_host(h_text, h_out, packed=True)
     plan.close()
+
+
+def test_cli_utf8(gpu, oracle, tmp_path):
+    """row f4, inputtype=utf-8: the text is the file's sequence of code points (here Latin, Greek, Cyrillic, CJK and an emoji: one to four
+    bytes each); the .bwt names the code points, `bwtb3mdecoderl inputtype=utf-8` writes them as UTF-8 (/root/reference/src/bwtb3mdecoderl.cpp:47-57),
+    X.hist is keyed by code point (reader /root/reference/src/bwtdecodeblock.cpp:150-173).  More than 256 distinct code points and invalid
+    UTF-8 are refused with a message."""
+    import ctypes, os, subprocess
+    from bwtb3m_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(64)
+    words = ["ma\u00f1ana ", "\u03b1\u03b2\u03b3\u03b4 ", "\u043f\u0440\u0438\u0432\u0435\u0442 ", "\u65e5\u672c\u8a9e ", "\U0001F600 ", "plain ascii ", "\u00e9t\u00e9\n"]
+    txt = "".join(words[i] for i in rng.integers(0, len(words), 6000))
+    txt = txt[:20000] + txt[3000:9000] + txt[20000:]                # a 6000-code-point repeat
+    fn = tmp_path / "in.txt"
+    fn.write_bytes(txt.encode("utf-8"))
+    cps = np.array([ord(c) for c in txt], dtype=np.int64)
+    ref = oracle.bwt_wide(cps)
+    for extra in (["bwtonly=1"], ["bwtonly=0", "isasamplingrate=256", "sasamplingrate=16"]):
+        outfn = tmp_path / "out.bwt"
+        r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % outfn] + extra + [str(fn)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        n = ctypes.c_uint64(0)
+        got = np.zeros(len(cps), dtype=np.int64)
+        assert _lib.lib().b3m_rl_read_symbols(str(outfn).encode(), got.ctypes.data, len(got), ctypes.byref(n)) == 0 and n.value == len(cps)
+        assert np.array_equal(got, ref)
+        d = subprocess.run([os.path.join(root, "bin", "bwtb3mdecoderl"), "inputtype=utf-8", str(outfn)], capture_output=True)
+        assert d.returncode == 0 and d.stdout.decode("utf-8") == "".join(chr(int(c)) for c in ref)
+        # the byte-mode decoder refuses code points above 255, as the reference's does (:36-42)
+        d = subprocess.run([os.path.join(root, "bin", "bwtb3mdecoderl"), str(outfn)], capture_output=True)
+        assert d.returncode != 0 and b"unsupported character value" in d.stderr
+        hist = np.frombuffer((tmp_path / "out.hist").read_bytes(), dtype=">u8")
+        assert int(hist[0]) == len(set(txt)) and {int(k): int(v) for k, v in zip(hist[1::2], hist[2::2])} == {ord(c): txt.count(c) for c in set(txt)}
+    if True:
+        # sampled suffix array of the second run (bwtonly=0): positions are code point indices
+        sa = np.frombuffer((tmp_path / "out.sa").read_bytes(), dtype=np.uint64)
+        full = oracle.sa_circular(np.unique(cps, return_inverse=True)[1].astype(np.uint8))
+        assert int(sa[0]) == 16 and np.array_equal(sa[2:].astype(np.int64), full[::16])
+    big = tmp_path / "big.txt"
+    big.write_bytes("".join(chr(0x4E00 + i) for i in range(300)).encode("utf-8"))
+    r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % (tmp_path / "b.bwt"), str(big)], capture_output=True)
+    assert r.returncode != 0 and b"300 distinct code points" in r.stderr
+    bad = tmp_path / "bad.txt"
+    bad.write_bytes(b"abc\xc3\x28def")
+    r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % (tmp_path / "c.bwt"), str(bad)], capture_output=True)
+    assert r.returncode != 0 and b"invalid byte sequence at offset 3" in r.stderr
