@@ -166,9 +166,9 @@ struct L0Args {
 	TextView T; uint64_t start, len;
 	uint64_t P0;                 // absolute position of item 0 of tile 0 (multiple of 16)
 	uint64_t *rec_out;
-	uint32_t *hist;              // COUNT_ONLY: counts out [digit][tile] ; else scanned offsets in
-	int D;                       // digit bits
-	uint32_t keep_lo, keep_hi;   // scatter: only records with keep_lo <= digit < keep_hi are kept (suffix-range shard)
+	uint32_t *hist;              // COUNT_ONLY: counts out [bin][tile] ; else scanned offsets in
+	int D;                       // digit bits (up to 15: a suffix-range shard splits its digit range further)
+	uint32_t keep_lo, keep_hi;   // only positions with keep_lo <= digit < keep_hi take part; bin = digit - keep_lo, at most MAXBINS bins
 	int pb;                      // position bits of a record
 };
 
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	__shared__ uint32_t stext[WORDS + 4];                        // [0] = the word before the chunk
 	__shared__ uint32_t wsum[W0_THREADS / 64];
 	const uint32_t tid = threadIdx.x;
-	const int bins = 1 << A.D;
+	const int bins = (int)(A.keep_hi - A.keep_lo);           // bin = digit - keep_lo; digits outside [keep_lo, keep_hi) are not this sort's (suffix-range shard)
+	const uint32_t klo = A.keep_lo, nbin = (uint32_t)bins;
 	const int dsh = 64 - A.D, dsh32 = 32 - A.D;
 	const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
 	const uint64_t end = A.start + A.len;
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					uint32_t dgt = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
-					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cur[dgt], 1u);
+					const uint32_t bin = ((s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32) - klo;
+					if (bin < nbin) atomicAdd(&cur[bin], 1u);
 				}
 			}
 		} else {
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
-					uint32_t dgt = (uint32_t)(x >> dsh);
-					if (COUNT_ONLY || (dgt >= A.keep_lo && dgt < A.keep_hi)) atomicAdd(&cur[dgt], 1u);
+					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
+					if (bin < nbin) atomicAdd(&cur[bin], 1u);
 				}
 			}
 		}
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					uint32_t dgt = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
-					if (dgt >= A.keep_lo && dgt < A.keep_hi) sidx[atomicAdd(&cur[dgt], 1u)] = (uint16_t)(w * 16 + s);
+					const uint32_t bin = ((s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32) - klo;
+					if (bin < nbin) sidx[atomicAdd(&cur[bin], 1u)] = (uint16_t)(w * 16 + s);
 				}
 			}
 		} else {
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
-					uint32_t dgt = (uint32_t)(x >> dsh);
-					if (dgt >= A.keep_lo && dgt < A.keep_hi) sidx[atomicAdd(&cur[dgt], 1u)] = (uint16_t)li;
+					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
+					if (bin < nbin) sidx[atomicAdd(&cur[bin], 1u)] = (uint16_t)li;
 				}
 			}
 		}
@@ -301,8 +302,9 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
 				r = make_rec(x, A.D, pr, cpos + li, &dgt, A.pb);
 			}
-			const uint32_t rs = dgt ? cur[dgt - 1] : 0u;          // start of run dgt
-			A.rec_out[(uint64_t)gbase[dgt] + (q - rs)] = r;
+			const uint32_t bin = dgt - klo;
+			const uint32_t rs = bin ? cur[bin - 1] : 0u;          // start of run bin
+			A.rec_out[(uint64_t)gbase[bin] + (q - rs)] = r;
 		}
 		__syncthreads();
 		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cur[b] - (b ? cur[b - 1] : 0u);
@@ -476,6 +478,14 @@ __global__ void k_next_starts(const uint32_t *scanned, const uint32_t *bucket_ta
 	uint32_t b = g >> D, d = g & ((1u << D) - 1);
 	uint32_t nt = bucket_tab[2 * nb + b];
 	out[g] = nt ? scanned[bucket_tab[nb + b] + (uint64_t)d * nt] : bucket_tab[b];
+}
+
+// starts of the nb buckets leaving level 0 (nb need not be a power of two); out[nb] = len
+__global__ void k_l0_starts(const uint32_t *scanned, uint32_t ntiles, uint32_t nb, uint32_t len, uint32_t *out)
+{
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g > nb) return;
+	out[g] = g == nb ? len : scanned[(uint64_t)g * ntiles];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1392,10 +1402,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// ---- level 0: text -> records (keyA), partitioned by the first D0 bits ----
 	const uint64_t P0 = start & ~15ull;
 	const uint64_t span = start + len_in - P0;
-	const bool geoA = dg.D0 <= 11;
-	const uint64_t tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
-	const uint32_t ntA = (uint32_t)((span + tile0 - 1) / tile0);
-	const uint32_t bins0 = 1u << dg.D0;
+	bool geoA = dg.D0 <= 11;
+	uint64_t tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
+	uint32_t ntA = (uint32_t)((span + tile0 - 1) / tile0);
+	uint32_t bins0 = 1u << dg.D0;          // buckets leaving level 0 (a shard: the bins of its own digit range, see below)
+	int D0e = dg.D0;                        // digit bits of level 0 as it finally runs
+	uint32_t *hist0 = M.hist;               // row 0 of the [bin][tile] matrix of that pass
 	B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
 	L0Args A{};
 	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_out = ws.keyA; A.hist = M.hist; A.D = dg.D0;
@@ -1430,19 +1442,38 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			return d;
 		};
 		uint32_t lo = bound(shard), hi = bound(shard + 1);
-		A.keep_lo = lo; A.keep_hi = hi;
 		out.slice_offset = cum[lo];
 		len = cum[hi] - cum[lo];
 		B3M_REQUIRE(len <= ws.cap && len < (1ull << 32), "suffix-range shard larger than the workspace (skewed input): use block mode or fewer shards");
-		if (lo) B3M_HIP(hipMemsetAsync(M.hist, 0, 4ull * lo * ntA, s));
-		if (hi < bins0) B3M_HIP(hipMemsetAsync(M.hist + (uint64_t)hi * ntA, 0, 4ull * (bins0 - hi) * ntA, s));
+		// The shard's level 0 only has bins for its own digits [lo, hi).  Where the text is so long that D0 + D1 bits leave final
+		// buckets above the LDS sort's size (n > ~6 G: 30 Gbase has 2^23 of them), the shard spends the bins it does not need for
+		// other shards' digits on S more bits of its own: one more counting pass over the text, and level 0 partitions by D0 + S bits.
+		int t = 0; while ((len_in >> t) > (uint64_t)F_AVG) ++t;
+		int S = 0;
+		while (hi > lo && S < t - dg.D0 - dg.D1 && dg.D0 + S < 15 && ((uint64_t)(hi - lo) << (S + 1)) <= (uint64_t)W0_MAXBINS) ++S;
+		static const int no_fine = getenv("B3M_NO_FINE_SHARDS") ? atoi(getenv("B3M_NO_FINE_SHARDS")) : 0;      // measurement switch
+		if (no_fine) S = 0;
+		{ const char *e = getenv("B3M_FINE_MAXS"); if (e && S > atoi(e)) S = atoi(e); }
+		A.keep_lo = lo << S; A.keep_hi = hi << S; A.D = dg.D0 + S; D0e = dg.D0 + S;
+		bins0 = (hi - lo) << S;
+		if (S == 0) hist0 = M.hist + (uint64_t)lo * ntA;      // the rows of the first count serve
+		else if (bins0) {
+			geoA = bins0 <= (uint32_t)W0A_BINS;
+			tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
+			ntA = (uint32_t)((span + tile0 - 1) / tile0);
+			B3M_REQUIRE((uint64_t)bins0 * ntA <= M.hist_cap, "MSD histogram workspace too small");
+			Scope sc(tl, KF_MSD_HIST, span / 4);
+			if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+			else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		}
+		A.hist = hist0;
 	}
 	out.kept_len = len;
 	B3M_REQUIRE(len < (1ull << 32), "more than 2^32 suffixes in one sort: use suffix-range shards");
 	if (len == 0) { out.d_sa = sa.lo; out.d_sa_hi = sa.hi; return; }          // empty shard (one huge digit took the neighbours' share)
 	{
 		Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
-		exclusive_sum_u32(M.hist, (uint64_t)bins0 * ntA, M.scan_ws, s);
+		exclusive_sum_u32(hist0, (uint64_t)bins0 * ntA, M.scan_ws, s);
 	}
 	{
 		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
@@ -1454,7 +1485,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab0, 12, hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));
 	}
-	const uint32_t eq_syms = (uint32_t)((dg.D0 + REC_KEY_BITS) / 2);    // symbols known equal when key fields tie
+	const uint32_t eq_syms = (uint32_t)((D0e + REC_KEY_BITS) / 2);       // symbols known equal when key fields tie
 	uint32_t *d_tiebits = ws.t[0];      // tie bitmap: len bits
 	const uint64_t *cur = ws.keyA; uint64_t *other = ws.keyB;
 	uint32_t nbF = bins0;               // final buckets
@@ -1464,11 +1495,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	FS.bstart = M.lvl_start;
 	bool gather = false;
 	if (dg.D1 == 0) {
-		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.lvl_start);
+		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.lvl_start);
 		FS.rec = ws.keyA;
 	} else {
 		// ---- level 1: every chunk of L1_CHUNK records of a level-0 bucket sorted in LDS, in place; tiles of <= L1_TCH chunks built on the host ----
-		hipLaunchKernelGGL(k_next_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, M.hist, M.bucket_tab, 1u, dg.D0, (uint32_t)len, M.sub_start);
+		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.sub_start);
 		std::vector<uint32_t> st(bins0 + 1);
 		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
