@@ -116,7 +116,7 @@ struct MsdWs {
 	uint32_t *overflow = nullptr; uint64_t overflow_cap = 0; // [0] = count, then (start, size) pairs
 	uint32_t *biglist = nullptr; uint64_t big_cap = 0;       // [0] = count, then ids of final buckets above the LDS capacity
 	uint32_t *hugelist = nullptr; uint64_t huge_cap = 0;     // [0] = count, then ids of final buckets above F_HUGE records
-	uint32_t *midlist = nullptr;                             // [0] = count, then ids of final buckets of 1x..2x the LDS capacity (big_cap entries)
+	uint32_t *midlist = nullptr; uint64_t mid_cap = 0;       // [0] = count, then ids of final buckets for the 1024-thread finish: 1x..2x the LDS capacity, or listed by the gathering finishes
 	void *lists = nullptr;                                   // two FinishLists structs (device): what the finish kernels read when they must list a bucket
 	uint32_t *runpre = nullptr;                              // the same rows as start | records before the run << 14 (for the gathering finish)
 	uint32_t *runtab = nullptr; uint64_t runtab_cap = 0;     // level-1 run table: row (level-0 bucket, digit), column = chunk: start | length << 16

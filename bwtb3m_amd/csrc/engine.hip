@@ -752,7 +752,7 @@ int b3m_plan_tie_pending(const b3m_plan *p, uint64_t *count_out)
 int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs_out, void *stream)
 {
 	B3M_TRY
-	B3M_REQUIRE(p && d_sa_slice_out, "b3m_plan_tie_export: null argument");
+	B3M_REQUIRE(p && (d_sa_slice_out || p->slice_len == 0), "b3m_plan_tie_export: null argument");
 	B3M_REQUIRE(p->nshards > 1 && p->n < (1ull << 32), "tie export: suffix-range shards of a text below 2^32 symbols only");
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(p->d_sa_slice || p->slice_len == 0, "tie export: the shard kept no suffix array: b3m_plan_set_keep_sa(plan, 1) and run it again");
@@ -770,7 +770,7 @@ int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs
 int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pairs_all, uint64_t total, uint64_t my_first, uint8_t *d_bwt_slice, void *stream)
 {
 	B3M_TRY
-	B3M_REQUIRE(p && d_sa_global && d_pairs_all && d_bwt_slice, "b3m_plan_tie_finish: null argument");
+	B3M_REQUIRE(p && d_sa_global && d_pairs_all && (d_bwt_slice || p->slice_len == 0), "b3m_plan_tie_finish: null argument");      // (an empty shard takes part with an empty slice)
 	B3M_REQUIRE(p->nshards > 1 && p->n < (1ull << 32), "tie finish: suffix-range shards of a text below 2^32 symbols only");
 	hipStream_t s = (hipStream_t)stream;
 	const uint64_t n = p->n;

@@ -82,6 +82,12 @@ static MsdDigits msd_digits(uint64_t len)
 	MsdDigits d;
 	if (t <= W0_MAXBITS) { d.D0 = std::max(t, 1); d.D1 = 0; }
 	else { d.D0 = 11; d.D1 = t - d.D0; if (d.D1 > MSD_MAXBITS) { d.D1 = MSD_MAXBITS; d.D0 = std::min(W0_MAXBITS, t - d.D1); } }
+	// test switch: B3M_MSD_D1=k gives level 1 k bits whatever the size, so that small inputs (which the oracle can check) run the
+	// kernels of the large geometries (k_l1_local, the gathering finishes, k_finish_fast from 4 bits on)
+	if (const char *e = getenv("B3M_MSD_D1")) {
+		const int k = atoi(e);
+		if (k >= 1 && k <= MSD_MAXBITS && t > k) { d.D1 = k; d.D0 = std::min(W0_MAXBITS, t - k); }
+	}
 	return d;
 }
 
@@ -106,7 +112,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + 2 * al(4 * (msd_big_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (MSD_TAB_MAX + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096;
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -121,7 +127,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.overflow = (uint32_t *)p; ws.overflow_cap = msd_ovf_cap(cap); p += al(4 * (2 * ws.overflow_cap + 4));
 	ws.biglist = (uint32_t *)p; ws.big_cap = msd_big_cap(cap); p += al(4 * (ws.big_cap + 2));
 	ws.hugelist = (uint32_t *)p; ws.huge_cap = cap / F_HUGE + 16; p += al(4 * (ws.huge_cap + 2));
-	ws.midlist = (uint32_t *)p; p += al(4 * (ws.big_cap + 2));
+	ws.midlist = (uint32_t *)p; ws.mid_cap = MSD_TAB_MAX; p += al(4 * (ws.mid_cap + 2));       // any final bucket can be listed here (skew, sparse buckets), each at most once
 	ws.runtab = (uint32_t *)p; ws.runtab_cap = msd_runtab_cap(cap); p += al(4 * ws.runtab_cap);
 	ws.runpre = (uint32_t *)p; p += al(4 * ws.runtab_cap);
 	ws.lists = p; p += 256;
@@ -1065,20 +1071,21 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		__syncthreads();
 		uint32_t run = inc - sum;
 		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
-		if (cmax > (uint32_t)LS_TIE_CAP) {                      // a 16-mer repeated inside the bucket: that bin goes to the overflow list on its own
-			uint32_t st = run;
-			#pragma unroll 1
-			for (int k = 0; k < WPT; ++k) { if (w[k] > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, w[k]); st += w[k]; }
-		}
 		#pragma unroll
 		for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k]; w[k] = run | (c << 16); run += c; }
 		#pragma unroll
 		for (int q = 0; q < WPT / 4; ++q) reinterpret_cast<uint4 *>(tab)[tid * (WPT / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-	}
-	__syncthreads();
-	if (s_slow) {
-		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
-		return;
+		__syncthreads();
+		if (s_slow) {
+			if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+			return;
+		}
+		// a 16-mer repeated inside the bucket: that bin goes to the overflow list on its own -- only once the bucket is known to stay
+		// here (a bucket handed to the slower path lists its bins there: pushed from both places, the list would hold the slots twice)
+		if (cmax > (uint32_t)LS_TIE_CAP) {
+			#pragma unroll 1
+			for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k] >> 16; if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + (w[k] & 0xFFFFu), c); }
+		}
 	}
 	// ---- entries into bin order ----
 	uint32_t tb[F_PER];                                           // start | count << 16 of the record's bin
@@ -1192,10 +1199,10 @@ __device__ __forceinline__ void compact_segments(const uint32_t b, const FinishS
 		__syncthreads();
 	}
 }
-__global__ __launch_bounds__(256) void k_compact_listed(FinishSrc S, uint64_t *out, const uint32_t *midlist, const uint32_t *biglist, uint32_t list_cap,
+__global__ __launch_bounds__(256) void k_compact_listed(FinishSrc S, uint64_t *out, const uint32_t *midlist, uint32_t mid_cap, const uint32_t *biglist, uint32_t list_cap,
                                                          const uint32_t *hugelist, uint32_t huge_cap)
 {
-	uint32_t nm = midlist[0]; if (nm > list_cap) nm = list_cap;
+	uint32_t nm = midlist[0]; if (nm > mid_cap) nm = mid_cap;
 	uint32_t nbg = biglist[0]; if (nbg > list_cap) nbg = list_cap;
 	for (uint32_t it = blockIdx.x; it < nm + nbg; it += gridDim.x)
 		compact_segments(it < nm ? midlist[1 + it] : biglist[1 + it - nm], S, out, 0, 1);
@@ -1551,7 +1558,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
 		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
-		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.big_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap},
+		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap},
 		                           {nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap}};
 		FinishLists *dl = reinterpret_cast<FinishLists *>(M.lists);       // [0]: first launch (lists mid / big / huge), [1]: the mid launch
 		B3M_HIP(hipMemcpyAsync(dl, hl, sizeof hl, hipMemcpyHostToDevice, s));
@@ -1592,7 +1599,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (gather) {
 			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
 			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
-			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
+			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
 		}
 		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
@@ -1621,9 +1628,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		Scope sc(tl, KF_TIES, len / 8);
 		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
 	}
-	uint32_t nov = 0;
+	uint32_t nov = 0, nlist[3] = {0, 0, 0};
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(&nlist[0], M.midlist, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(&nlist[1], M.biglist, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(&nlist[2], M.hugelist, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
+	if (getenv("B3M_DEBUG")) fprintf(stderr, "[b3m] block_sort_msd len %llu D0 %d D1 %d: listed mid %u big %u huge %u (caps %llu %llu %llu), overflow ranges %u\n",
+	                                 (unsigned long long)len, D0e, dg.D1, nlist[0], nlist[1], nlist[2], (unsigned long long)M.mid_cap, (unsigned long long)M.big_cap, (unsigned long long)M.huge_cap, nov);
+	// a list that ran over would have dropped buckets silently
+	B3M_REQUIRE(nlist[0] <= M.mid_cap && nlist[1] <= M.big_cap && nlist[2] <= M.huge_cap, "internal: a bucket list of the MSD finish ran over");
 	out.msd_overflow_buckets = nov;
 	if (nov) out.late_writes = true;
 	bool rerun_with_sa = false;

@@ -329,7 +329,13 @@ def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("itype", ["pac", "pacterm"])
 @pytest.mark.parametrize("kind", ["uniform", "repeat", "polyA", "periodic", "twosym"])
-def test_msd_block_sort_paths(gpu, oracle, itype, kind):
+@pytest.mark.parametrize("d1", [0, 4, 6, 8])
+def test_msd_block_sort_paths(gpu, oracle, itype, kind, d1, monkeypatch):
+    """d1 > 0: B3M_MSD_D1 gives level 1 that many bits whatever the size, so that these half-megabase inputs, which the oracle can check, run
+    the kernels of the large geometries: chunk-local level 1, the gathering finishes and (from 4 bits on) k_finish_fast, with their
+    listed-bucket, hot-bin and tie paths.  (At their natural size those kernels are only reached by inputs the oracle cannot sort.)"""
+    if d1:
+        monkeypatch.setenv("B3M_MSD_D1", str(d1))
     nb = (1 << 19) + 12345
     if kind == "uniform":
         b = oracle.synth_bases(nb, 31)
@@ -345,11 +351,13 @@ def test_msd_block_sort_paths(gpu, oracle, itype, kind):
         b = (oracle.synth_bases(nb, 34) & 1).astype(np.uint8)   # only A/C: half-empty bucket space
     buf = _pac(oracle, b)
     s = oracle.symbols_from_file_bytes(buf, itype)
-    out, res, plan = _plan_bwt(gpu, buf, itype)
-    assert np.array_equal(out, oracle.bwt(s)), kind
-    if itype == "pacterm":
-        assert out[res["p0"]] == 0
-    plan.close()
+    ref = oracle.bwt(s)
+    for isarate in ((0, 4096) if d1 else (0,)):          # BWT only / suffix array kept: two instantiations of every finish kernel
+        out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate)
+        assert np.array_equal(out, ref), (kind, isarate)
+        if itype == "pacterm":
+            assert out[res["p0"]] == 0
+        plan.close()
 
 
 @pytest.mark.parametrize("itype,isarate", [("pacterm", 0), ("pacterm", 4096), ("pac", 0), ("bytestream", 0)])
@@ -1057,3 +1065,47 @@ def test_cli_utf8(gpu, oracle, tmp_path):
     bad.write_bytes(b"abc\xc3\x28def")
     r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % (tmp_path / "c.bwt"), str(bad)], capture_output=True)
     assert r.returncode != 0 and b"invalid byte sequence at offset 3" in r.stderr
+
+
+def test_repeat_rich_100mbase_one_block_lf_verified(gpu):
+    """A genome-like 100 Mbase text (interspersed 300-bp and 6-kb repeats, 200-kb segmental duplications, microsatellites, a satellite array) as
+    ONE block: the size where level 1 has 4 bits and k_finish_fast runs with sparse buckets, hot bins and listed buckets at once (a bucket that
+    was handed to the slower path after its hot bins had been listed once put slots on the overflow list twice: round 2, found by this input).
+    Verified by the on-device LF walk (/root/reference/src/checkbwt.cpp:176-243) and against the same text sorted as four blocks of a merge tree."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    from oracle import oracle as O
+    n = 100_000_000
+    rng = np.random.default_rng(7)
+    b = rng.integers(0, 4, n, dtype=np.uint8)
+    def mutate(seg, rate):
+        t = seg.copy(); k = int(len(t) * rate)
+        if k:
+            idx = rng.integers(0, len(t), k); t[idx] = (t[idx] + rng.integers(1, 4, k)) & 3
+        return t
+    alu = rng.integers(0, 4, 300, dtype=np.uint8)
+    for p in rng.integers(0, n - 300, n // 3000):
+        b[p:p + 300] = mutate(alu, 0.10)
+    l1 = rng.integers(0, 4, 6000, dtype=np.uint8)
+    for p in rng.integers(0, n - 6000, n // 120000):
+        b[p:p + 6000] = mutate(l1, 0.03)
+    sd = rng.integers(0, 4, 200000, dtype=np.uint8)
+    for p in rng.integers(0, n - 200000, 6):
+        b[p:p + 200000] = mutate(sd, 0.001)
+    for p in rng.integers(0, n - 1300, n // 100000):
+        u = int(rng.integers(1, 7)); c = int(rng.integers(20, 200))
+        b[p:p + u * c] = np.resize(rng.integers(0, 4, u, dtype=np.uint8), u * c)
+    p = int(rng.integers(0, n - 171 * 3000))
+    b[p:p + 171 * 3000] = mutate(np.resize(rng.integers(0, 4, 171, dtype=np.uint8), 171 * 3000), 0.01)
+    d_text = torch.from_numpy(np.asarray(O.pac_encode(b))).cuda()
+    outs = []
+    for bs in (0, 26_000_000):
+        plan = engine.Plan(n + 1, "pacterm", isasamplingrate=1 << 16, blocksize=bs)
+        out = plan.run(d_text).clone()
+        torch.cuda.synchronize()
+        r = plan.result()
+        assert plan.lf_walk(out, sarate=0)[:2] == (0, 0), (bs, r)
+        assert r["tie_rounds"] <= 2 * 4 + 24 and r["tie_slow"] == 0, r          # doubling: not (200 kb / 21) rounds, in either form
+        assert int(out[r["p0"]]) == 0
+        outs.append(out); plan.close()
+    assert torch.equal(outs[0], outs[1])

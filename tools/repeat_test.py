@@ -46,3 +46,30 @@ for it in range(2):
     print({k["name"]: round(k["ms"], 2) for k in plan.kernel_times() if k["ms"] > 0.05}, flush=True)
 m0, m1, _ = plan.lf_walk(out, sarate=0)
 print("LF check mismatches:", m0, m1)
+
+# ---- the same text as suffix-range shards (what each GPU of an N-GPU run does; here one after the other on one GPU) ----
+nsh = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if nsh > 1:
+    plan.close()
+    plans, slices, t_run = [], [], []
+    for k in range(nsh):
+        p = engine.Plan(nsym, "pacterm", shard=k, nshards=nsh, isasamplingrate=1 << 16)
+        p.run(d_text); torch.cuda.synchronize()
+        t0 = time.perf_counter(); sl = p.run(d_text).clone(); torch.cuda.synchronize(); t_run.append(time.perf_counter() - t0)
+        plans.append(p); slices.append(sl)
+    pend = [p.tie_pending() for p in plans]
+    print("shards %d: local sort max %.1f ms (rounds %d), pending ties %s" % (nsh, max(t_run) * 1e3, max(p.result()["tie_rounds"] for p in plans), pend), flush=True)
+    t_fin = []
+    if sum(pend):
+        exported = [p.tie_export("cuda") for p in plans]
+        sa_all = torch.cat([e[0] for e in exported]); pairs_all = torch.cat([e[1] for e in exported])
+        for k, p in enumerate(plans):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            engine.finish_shard_ties(p, slices[k], lambda sa: sa_all.clone(), lambda pr, k=k: (pairs_all, sum(pend[:k])))
+            torch.cuda.synchronize(); t_fin.append(time.perf_counter() - t0)
+        print("collective finish per shard max %.1f ms (rounds in all %d)" % (max(t_fin) * 1e3, max(p.result()["tie_rounds"] for p in plans)), flush=True)
+    print("=> per GPU %.1f ms (local sort + finish; the all-gather of %d suffix array entries is not in it)" % ((max(t_run) + (max(t_fin) if t_fin else 0)) * 1e3, nsym), flush=True)
+    whole = torch.cat(slices)
+    chk = engine.Plan(nsym, "pacterm", isasamplingrate=1 << 16)
+    ref = chk.run(d_text)
+    print("equals the single-block BWT:", bool(torch.equal(whole, ref)))
