@@ -88,6 +88,9 @@ static MsdDigits msd_digits(uint64_t len)
 		const int k = atoi(e);
 		if (k >= 1 && k <= MSD_MAXBITS && t > k) { d.D1 = k; d.D0 = std::min(W0_MAXBITS, t - k); }
 	}
+	// test switch: B3M_MSD_D0=k caps level 0 at k bits (with B3M_MSD_D1: fewer partition bits than the size asks for, which is
+	// what a 30 Gbase text has; a suffix-range shard then takes the fine level 0 of block_sort_msd on an input the oracle can check)
+	if (const char *e = getenv("B3M_MSD_D0")) { const int k = atoi(e); if (k >= 1 && k < d.D0) d.D0 = k; }
 	return d;
 }
 

@@ -529,6 +529,37 @@ def _run_mode(job, d_text, steps, warmup, dev, fam_of=None):
     return float(dt[0]), out, off, p0, fam
 
 
+def _check_slices(out, off, p0, d_text, n, itype, dev):
+    """size-independent properties of a distributed result (what the N>1 bench can afford at full size): the slices tile the rank space,
+    their symbol histograms add up to the text's (computed with torch alone), and for pacterm the slot p0 holds the one terminator.
+    Collective; returns a description or raises."""
+    from . import benchutil
+    info = _all_gather_i64([int(off), int(out.numel())], None, dev)
+    pos = 0
+    for o, ln in sorted((int(x[0]), int(x[1])) for x in info):
+        if o != pos:
+            raise RuntimeError("slices do not tile the rank space: a slice starts at %d, expected %d" % (o, pos))
+        pos += ln
+    if pos != n:
+        raise RuntimeError("slices cover %d of %d ranks" % (pos, n))
+    h = torch.zeros(256, dtype=torch.int64, device=dev)
+    for o in range(0, out.numel(), 1 << 28):
+        h += torch.bincount(out[o:o + (1 << 28)].to(torch.int64), minlength=256)
+    _all_reduce_sum(h)
+    want = benchutil.text_histogram(d_text, n, itype)
+    if h.cpu().tolist() != want:
+        raise RuntimeError("symbol histogram of the slices differs from the text's")
+    term = ""
+    if itype == "pacterm":
+        mine = p0 is not None and int(off) <= int(p0) < int(off) + out.numel()      # (a shard without the rotation starting at 0 reports None)
+        ok = torch.tensor([1 if (mine and int(out[int(p0) - int(off)]) == 0) else 0], dtype=torch.int64, device=dev)
+        _all_reduce_sum(ok)
+        if int(ok[0]) != 1:
+            raise RuntimeError("BWT[p0] is not the terminator")
+        term = "; BWT[p0]=terminator"
+    return "slices of all %d ranks tile [0, n); sum of their symbol histograms == histogram(text)%s" % (dist.get_world_size(), term)
+
+
 def bench_main(a, rank, local_rank, world):
     """N>1 leg of bench.py: one process per GPU (torchrun), RCCL process group.  Headline = the mode asked for (default:
     suffix-range shards); the other mode runs too (one step) and both are in the ONE JSON line (`config.modes`).  Any failure
@@ -570,10 +601,11 @@ def bench_main(a, rank, local_rank, world):
         try:
             job = make(m)
             dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times()) if m != "blocks" else None)
+            checked = _check_slices(out, off, p0, d_text, n, itype, dev) if getattr(a, "check", True) else None
             del out
             phases = {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}
             levels = len(job.plan.levels) if m == "blocks" else 0
-            return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job}
+            return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job, "checked": checked}
         finally:
             wd.cancel()
 
@@ -596,7 +628,7 @@ def bench_main(a, rank, local_rank, world):
     if rank == 0:
         def summary(r):
             return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
-                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"]}
+                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"]}
         dt, steps, fam, levels = res_main["dt"], res_main["steps"], res_main["fam"], res_main["levels"]
         alg_job = nbases * (9.5 + 41.0 * levels)
         if fam:
@@ -617,7 +649,7 @@ def bench_main(a, rank, local_rank, world):
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
-                       "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes,
+                       "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes, "checked": res_main["checked"],
                        "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices in HBM"},
             "roofline": roof,
         }

@@ -435,9 +435,14 @@ def _run_all_shards(torch, engine, d_text, n, itype, nshards, isarate):
 
 @pytest.mark.parametrize("itype,kind,nshards", [("pacterm", "uniform", 2), ("pacterm", "uniform", 8), ("pac", "uniform", 3),
                                                  ("pacterm", "repeat", 4), ("pac", "twosym", 4)])
-def test_suffix_range_shards(gpu, oracle, itype, kind, nshards):
+@pytest.mark.parametrize("geometry", ["natural", "fine"])
+def test_suffix_range_shards(gpu, oracle, itype, kind, nshards, geometry, monkeypatch):
+    """geometry "fine": B3M_MSD_D0=2 / B3M_MSD_D1=3 leave fewer partition bits than the size asks for, as at 30 Gbase, so that every shard's level 0
+    takes the extra counting pass and partitions its own digit range by up to 3 more bits (block_sort_msd), on an input the oracle can check."""
     torch = gpu
     from bwtb3m_amd import engine
+    if geometry == "fine":
+        monkeypatch.setenv("B3M_MSD_D0", "2"); monkeypatch.setenv("B3M_MSD_D1", "3")
     nb = (1 << 19) + 4321
     if kind == "uniform":
         b = oracle.synth_bases(nb, 51)
@@ -823,6 +828,9 @@ def test_bench_two_ranks_on_one_gpu_reports_both_modes_and_fails_loudly(gpu, tmp
     assert j["n_gpus"] == 2 and set(j["config"]["modes"]) == {"prefix", "blocks"}
     assert j["config"]["modes"]["blocks"]["merge_levels"] == 1 and j["config"]["modes"]["blocks"]["ms_per_step"] > 0
     assert set(j["config"]["modes"]["blocks"]["rank0_phase_s"]) >= {"leaf", "walk", "exchange", "interleave"}
+    for m in ("prefix", "blocks"):       # both modes check what they timed: slices tile the rank space, histograms add up, BWT[p0] = terminator
+        assert "tile [0, n)" in j["config"]["modes"][m]["checked"] and "terminator" in j["config"]["modes"][m]["checked"]
+    assert j["config"]["checked"] == j["config"]["modes"]["prefix"]["checked"]
     # block mode on a byte alphabet is refused by the library: the run must fail, not report
     cmd_bad = cmd[:-4] + ["--config", "c1", "--mode", "blocks"]
     r = subprocess.run(cmd_bad, env=env, capture_output=True, text=True, timeout=600, cwd=root)

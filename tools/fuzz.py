@@ -1,7 +1,7 @@
 """Randomised parity sweep against the oracle (GPU box): sizes around the path switches (2^18 = MSD threshold,
 block edges not aligned to words / chunks), all input types, random blockings, low-entropy and repeat-rich texts.
 python tools/fuzz.py [iterations] [seed]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo")
 from bwtb3m_amd import engine
@@ -27,8 +27,12 @@ for it in range(iters):
         buf = O.pac_encode(b); s = O.symbols_from_file_bytes(buf, itype)
     n = len(s)
     bs = 0
-    if itype != "bytestream" and rng.integers(0, 2) and n > 20:
+    if rng.integers(0, 2) and n > 20:              # blocks of a merge tree (2-bit and byte alphabets)
         bs = int(rng.integers(max(8, n // 9), n))
+    # level-1 width forced on half of the cases: small inputs through the kernels of the large geometries (B3M_MSD_D1, see k_msd.hip)
+    d1 = int([0, 0, 0, 2, 4, 5, 6, 8][int(rng.integers(0, 8))])
+    if d1: os.environ["B3M_MSD_D1"] = str(d1)
+    else: os.environ.pop("B3M_MSD_D1", None)
     isar = int([0, 64, 4096][int(rng.integers(0, 3))])
     try:
         out, res, plan = engine.bwt_device(buf, itype, blocksize=bs, isasamplingrate=isar)
@@ -42,7 +46,7 @@ for it in range(iters):
         ok = False; print("EXC", repr(ex)[:200])
     if not ok:
         bad += 1
-        print("MISMATCH it=%d type=%s nb=%d kind=%d bs=%d isar=%d" % (it, itype, nb, kind, bs, isar), flush=True)
+        print("MISMATCH it=%d type=%s nb=%d kind=%d bs=%d isar=%d d1=%d" % (it, itype, nb, kind, bs, isar, d1), flush=True)
     if it % 25 == 24: print("%d iterations, %d bad, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
 print("done: %d iterations, %d bad" % (iters, bad))
 sys.exit(1 if bad else 0)
