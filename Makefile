@@ -7,7 +7,7 @@ CSRC       := bwtb3m_amd/csrc
 OBJDIR     := build
 LIB        := bwtb3m_amd/libb3m.so
 
-HIP_SRCS   := $(CSRC)/k_scan_radix.hip $(CSRC)/k_blocksort.hip $(CSRC)/k_msd.hip $(CSRC)/k_merge.hip $(CSRC)/engine.hip
+HIP_SRCS   := $(CSRC)/k_scan_radix.hip $(CSRC)/k_blocksort.hip $(CSRC)/k_msd.hip $(CSRC)/k_merge.hip $(CSRC)/k_rlenc.hip $(CSRC)/engine.hip
 HOST_SRCS  := $(wildcard $(CSRC)/host/*.cpp)
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
 HOST_OBJS  := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(filter-out $(CSRC)/host/cli_%.cpp,$(HOST_SRCS)))

@@ -106,6 +106,7 @@ SYMBOLS = [
     ("b3m_dist_interleave", _i, [_p, _p, _p, _u64, _p, _u64, _p, _p]),
     ("b3m_rl_write", _i, [_cp, _p, _u64, _u64]),
     ("b3m_rl_read", _i, [_cp, _p, _u64, ctypes.POINTER(_u64)]),
+    ("b3m_rl_write_device", _i, [_cp, _p, _u64, _u64, _p]),
     ("b3m_rl_read_symbols", _i, [_cp, _p, _u64, ctypes.POINTER(_u64)]),
     ("b3m_rl_length", _i, [_cp, ctypes.POINTER(_u64)]),
 ]

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <unistd.h>
@@ -114,9 +115,14 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		b3m_result res; b3m_plan_result(plan, &res);
 		log("[V] constructed BWT in %.3f s (sort %.1f ms, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, res.ms_sort, res.ms_gap,
 		    res.ms_interleave, n / (t2 - t1) / 1e9);
-		std::vector<uint8_t> bwt(n);
-		HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
-		b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, o->numthreads ? o->numthreads : 1, symmap);
+		// X.bwt: written from the BWT in HBM (runs, frequencies and code streams on the device); the host encoder takes what that
+		// one does not (2^32 symbols and more) and B3M_HOST_RL=1 asks for it (both write the same bytes)
+		const unsigned enc_threads = o->numthreads ? o->numthreads : 1;
+		if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, d_bwt, n, 64 * 1024, enc_threads, symmap, nullptr)) {
+			std::vector<uint8_t> bwt(n);
+			HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
+			b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, enc_threads, symmap);
+		}
 		uint64_t hist[256];
 		b3m_plan_histogram(plan, hist);
 		b3m::write_hist(prefix + ".hist", hist, symmap);

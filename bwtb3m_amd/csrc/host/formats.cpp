@@ -151,38 +151,63 @@ struct Canon {
 
 static const uint64_t RL_ESCAPE = 256;   // run lengths >= 256 are coded as escape + elias(len)
 
-static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out, const int64_t *symmap)
+// header of one block (run count, escape flag, the two code tables, byte-aligned) and its code tables, from the block's frequencies:
+// sf[s] = runs of byte symbol s, cf[l] = runs of length l (1..255), cf[256] = runs of 256 and more (escape + Elias-coded length).
+// Shared by the host encoder below and the device encoder (k_rlenc.hip), which packs the code streams on the GPU.
+void rl_block_header(const uint32_t *sf, const uint32_t *cf, uint64_t nr, const int64_t *symmap, std::vector<uint8_t> &header, RLBlockTables &t)
 {
-	BitWriter w(out);
-	// symbols are bytes and coded lengths are 1..256 (256 = escape): flat counters and code tables
-	uint64_t sf[256] = {0}, cf[RL_ESCAPE + 1] = {0};
-	bool esc = false;
-	for (uint64_t i = 0; i < nr; ++i) {
-		sf[(uint8_t)runs[i].sym]++;
-		if (runs[i].len >= RL_ESCAPE) { esc = true; cf[RL_ESCAPE]++; } else cf[runs[i].len]++;
-	}
 	std::map<int64_t, uint64_t> sh, ch;
 	for (int s = 0; s < 256; ++s) if (sf[s]) sh[s] = sf[s];
 	for (uint64_t l = 0; l <= RL_ESCAPE; ++l) if (cf[l]) ch[(int64_t)l] = cf[l];
 	Canon sc = Canon::from_freq(sh), cc = Canon::from_freq(ch);
-	uint64_t scode[256]; int slen[256]; uint64_t ccode[RL_ESCAPE + 1]; int clen[RL_ESCAPE + 1];
-	for (auto &kv : sc.enc) { scode[kv.first] = kv.second.first; slen[kv.first] = kv.second.second; }
-	for (auto &kv : cc.enc) { ccode[kv.first] = kv.second.first; clen[kv.first] = kv.second.second; }
-	out.reserve(out.size() + nr / 2 + 4096);
+	memset(&t, 0, sizeof t);
+	for (auto &kv : sc.enc) { t.scode[kv.first] = kv.second.first; t.slen[kv.first] = (uint8_t)kv.second.second; }
+	for (auto &kv : cc.enc) { t.ccode[kv.first] = kv.second.first; t.clen[kv.first] = (uint8_t)kv.second.second; }
+	header.clear();
+	BitWriter w(header);
 	w.elias(nr);
-	w.put(esc ? 1 : 0, 1);
+	w.put(cf[RL_ESCAPE] ? 1 : 0, 1);
 	if (symmap) {          // the table names the mapped symbols (the map is monotone: the canonical order is the same)
 		w.elias(sc.syms.size());
 		for (auto &s : sc.syms) { w.elias((uint64_t)symmap[s.first]); w.elias((uint64_t)s.second); }
 	} else sc.serialise(w);
 	cc.serialise(w);
 	w.align();
-	for (uint64_t i = 0; i < nr; ++i) { uint8_t s = (uint8_t)runs[i].sym; w.put(scode[s], slen[s]); }
+}
+
+static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &out, const int64_t *symmap)
+{
+	// symbols are bytes and coded lengths are 1..256 (256 = escape): flat counters and code tables
+	uint32_t sf[256] = {0}, cf[RL_ESCAPE + 1] = {0};
+	for (uint64_t i = 0; i < nr; ++i) {
+		sf[(uint8_t)runs[i].sym]++;
+		if (runs[i].len >= RL_ESCAPE) cf[RL_ESCAPE]++; else cf[runs[i].len]++;
+	}
+	RLBlockTables t;
+	rl_block_header(sf, cf, nr, symmap, out, t);
+	BitWriter w(out);
+	out.reserve(out.size() + nr / 2 + 4096);
+	for (uint64_t i = 0; i < nr; ++i) { uint8_t s = (uint8_t)runs[i].sym; w.put(t.scode[s], t.slen[s]); }
 	w.align();
 	for (uint64_t i = 0; i < nr; ++i) {
-		if (runs[i].len >= RL_ESCAPE) { w.put(ccode[RL_ESCAPE], clen[RL_ESCAPE]); w.elias(runs[i].len); } else w.put(ccode[runs[i].len], clen[runs[i].len]);
+		if (runs[i].len >= RL_ESCAPE) { w.put(t.ccode[RL_ESCAPE], t.clen[RL_ESCAPE]); w.elias(runs[i].len); } else w.put(t.ccode[runs[i].len], t.clen[runs[i].len]);
 	}
 	w.align();
+}
+
+void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index)
+{
+	FILE *f = fopen(fn.c_str(), "wb");
+	if (!f) throw std::runtime_error("cannot open " + fn + " for writing");
+	std::vector<uint8_t> head; put_be64(head, n);
+	fwrite(head.data(), 1, head.size(), f);
+	if (blocks_bytes && fwrite(blocks, 1, blocks_bytes, f) != blocks_bytes) { fclose(f); throw std::runtime_error("short write to " + fn); }
+	std::vector<uint8_t> tail;
+	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
+	put_be64(tail, index.size());
+	put_be64(tail, 8 + blocks_bytes);
+	fwrite(tail.data(), 1, tail.size(), f);
+	if (fclose(f)) throw std::runtime_error("error closing " + fn);
 }
 
 void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap)

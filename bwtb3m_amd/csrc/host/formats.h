@@ -30,6 +30,14 @@ uint64_t rl_length(const std::string &fn);
 // decode into out[0..cap) with the blocks in parallel; returns n
 uint64_t rl_decode_array(const std::string &fn, uint8_t *out, uint64_t cap, unsigned numthreads, bool *bad_symbol);
 struct RLIndexEntry { uint64_t pos, runs, syms; };
+// pieces shared with the device encoder (csrc/k_rlenc.hip): code tables + header bytes of one block from its frequencies, and the container
+// around already encoded blocks (index entries: file position, runs, symbols of every block)
+struct RLBlockTables { uint64_t scode[256]; uint8_t slen[256]; uint64_t ccode[257]; uint8_t clen[257]; };
+void rl_block_header(const uint32_t *sf256, const uint32_t *cf257, uint64_t nr, const int64_t *symmap, std::vector<uint8_t> &header, RLBlockTables &t);
+// the same file written from symbols that are still in HBM (csrc/k_rlenc.hip): runs, frequencies and both code streams on the device, tables
+// and headers here.  false: not an input for it (empty, 2^32 symbols or more, a code above 32 bits): use rl_encode_file
+bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream);
+void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index);
 std::vector<RLIndexEntry> rl_index(const std::string &fn);
 
 // ---- siblings -------------------------------------------------------------------------------------

@@ -1,0 +1,259 @@
+// k_rlenc.hip -- the RL .bwt container written from a BWT that is still in HBM (role of
+// libmaus2::huffman::RLEncoderStd, usage /root/reference/src/lcpbit.cpp:3677-3681).  The host encoder (host/formats.cpp)
+// spends its time finding runs and writing two Huffman code streams per block bit by bit: 5.5 s at 3 Gbase.  Here the
+// device finds the runs, counts every block's symbol / run-length frequencies, and packs both code streams of every block at
+// their final byte offsets; the host only builds the per-block code tables and headers from the frequencies (the SAME code as
+// the host encoder: the files are byte-identical) and writes the file.
+//   1. k_rl_count  : run heads per tile of 4096 symbols              (one read of the BWT)
+//   2. k_rl_runs   : start position and symbol of every run           (second read; 5 B per run written)
+//   3. k_rl_hist   : per block of `rpb` runs: symbol counts, length counts (1..255, 256 = escape), Elias bits of the escaped lengths, symbols
+//      host        : code tables + header per block (rl_block_header), sizes of the two streams from the counts, byte offsets
+//   4. k_rl_pack   : one workgroup per block: bit offsets by a scan over its runs' code lengths, codes OR-ed into the zeroed output
+// Bit order MSB first (a stream is bytes; the 32-bit words the kernel ORs are byte-swapped).
+#include "b3m_internal.h"
+#include "host/formats.h"
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+namespace b3m {
+
+static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
+namespace {
+struct Buf {
+	void *p = nullptr;
+	explicit Buf(uint64_t bytes) { B3M_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
+	~Buf() { if (p) (void)hipFree(p); }
+	template <class X> X *as() { return (X *)p; }
+	Buf(const Buf &) = delete; Buf &operator=(const Buf &) = delete;
+};
+}
+
+constexpr int RL_TILE = 4096;            // symbols per workgroup in the run search (256 threads x 16)
+constexpr int RL_HIST = 516;             // per block: [0,256) symbol counts, [256,513) length counts (index 256 + min(len,256)), [513] Elias bits, [514] symbols lo, [515] symbols hi
+
+__device__ __forceinline__ uint32_t elias_bits(uint64_t x)
+{
+	const uint64_t y = x + 1;
+	const int N = 63 - __clzll((long long)y);
+	const int L = 31 - __clz(N + 1);
+	return (uint32_t)(2 * L + 1 + N);
+}
+
+__device__ __forceinline__ uint32_t wave_incl(uint32_t v)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o, 64); if (lane >= (uint32_t)o) v += t; }
+	return v;
+}
+
+// heads of tile t: positions i with i == 0 or bwt[i] != bwt[i-1]
+__global__ __launch_bounds__(256) void k_rl_count(const uint8_t *bwt, uint64_t n, uint32_t *tile_heads)
+{
+	__shared__ uint32_t ws[4];
+	const uint64_t base = (uint64_t)blockIdx.x * RL_TILE + (uint64_t)threadIdx.x * 16;
+	uint32_t c = 0;
+	if (base < n) {
+		uint8_t prev = base ? bwt[base - 1] : (uint8_t)~bwt[0];
+		#pragma unroll
+		for (int j = 0; j < 16; ++j) { if (base + j < n) { const uint8_t v = bwt[base + j]; c += v != prev; prev = v; } }
+	}
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) tile_heads[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// run r: rstart[r] = position of its first symbol, rsym[r] = the symbol; rstart[R] = n
+__global__ __launch_bounds__(256) void k_rl_runs(const uint8_t *bwt, uint64_t n, const uint32_t *tile_first, uint64_t R, uint32_t *rstart, uint8_t *rsym)
+{
+	__shared__ uint32_t ws[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint64_t base = (uint64_t)blockIdx.x * RL_TILE + (uint64_t)tid * 16;
+	uint8_t v[16]; uint32_t heads = 0, c = 0;
+	if (base < n) {
+		uint8_t prev = base ? bwt[base - 1] : (uint8_t)~bwt[0];
+		#pragma unroll
+		for (int j = 0; j < 16; ++j) { v[j] = base + j < n ? bwt[base + j] : prev; if (base + j < n && v[j] != prev) { heads |= 1u << j; ++c; } prev = v[j]; }
+	}
+	const uint32_t inc = wave_incl(c);
+	if (lane == 63) ws[wave] = inc;
+	__syncthreads();
+	uint64_t r = (uint64_t)tile_first[blockIdx.x] + inc - c;
+	for (uint32_t i = 0; i < wave; ++i) r += ws[i];
+	#pragma unroll
+	for (int j = 0; j < 16; ++j) if (heads & (1u << j)) { rstart[r] = (uint32_t)(base + j); rsym[r] = v[j]; ++r; }
+	if (blockIdx.x == 0 && tid == 0) rstart[R] = (uint32_t)n;       // (n < 2^32)
+}
+
+__global__ __launch_bounds__(256) void k_rl_hist(const uint32_t *rstart, const uint8_t *rsym, uint64_t R, uint32_t rpb, uint32_t *hist)
+{
+	__shared__ uint32_t h[RL_HIST];
+	const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+	for (uint32_t i = threadIdx.x; i < (uint32_t)RL_HIST; i += 256) h[i] = 0;
+	__syncthreads();
+	for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+		const uint32_t len = rstart[r + 1] - rstart[r];
+		atomicAdd(&h[rsym[r]], 1u);
+		if (len >= 256u) { atomicAdd(&h[256 + 256], 1u); atomicAdd(&h[513], elias_bits(len)); } else atomicAdd(&h[256 + len], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { const uint64_t syms = (uint64_t)rstart[r1] - rstart[r0]; h[514] = (uint32_t)syms; h[515] = (uint32_t)(syms >> 32); }
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < (uint32_t)RL_HIST; i += 256) hist[(uint64_t)blockIdx.x * RL_HIST + i] = h[i];
+}
+
+// appends `bits` (<= 32) bits of v to a stream that starts at bit `bitpos` of `out` (bytes, MSB first); words are OR-ed in
+struct BitSink {
+	uint32_t *out; uint64_t w; uint64_t acc; int fill;
+	__device__ void open(uint8_t *base, uint64_t bitpos) { out = reinterpret_cast<uint32_t *>(base); w = bitpos >> 5; fill = (int)(bitpos & 31); acc = 0; }
+	__device__ void put(uint64_t v, int bits)
+	{
+		if (bits == 0) return;
+		acc = (acc << bits) | (v & (bits >= 64 ? ~0ull : ((1ull << bits) - 1)));
+		fill += bits;
+		while (fill >= 32) {
+			const uint32_t word = (uint32_t)(acc >> (fill - 32));
+			if (word) atomicOr(&out[w], __builtin_bswap32(word));
+			++w; fill -= 32;
+		}
+	}
+	__device__ void close() { if (fill > 0) { const uint32_t word = (uint32_t)(acc << (32 - fill)); if (word) atomicOr(&out[w], __builtin_bswap32(word)); } }
+};
+
+// tables: per block 513 entries (code << 8 | length): [0,256) symbols, [256,513) lengths (256 + min(len,256))
+__global__ __launch_bounds__(256) void k_rl_pack(const uint32_t *rstart, const uint8_t *rsym, uint64_t R, uint32_t rpb, const uint64_t *tables,
+                                                 const uint64_t *off_sym, const uint64_t *off_len, uint8_t *out)
+{
+	__shared__ uint64_t tab[513];
+	__shared__ uint32_t ws1[4], ws2[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint64_t r0 = (uint64_t)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+	for (uint32_t i = tid; i < 513u; i += 256) tab[i] = tables[(uint64_t)blockIdx.x * 513 + i];
+	__syncthreads();
+	const uint32_t per = (rpb + 255) / 256;                   // consecutive runs per thread
+	const uint64_t a = r0 + (uint64_t)tid * per, b = a + per < r1 ? a + per : r1;
+	uint32_t b1 = 0, b2 = 0;
+	for (uint64_t r = a; r < b; ++r) {
+		const uint32_t len = rstart[r + 1] - rstart[r];
+		b1 += (uint32_t)(tab[rsym[r]] & 255u);
+		if (len >= 256u) b2 += (uint32_t)(tab[512] & 255u) + elias_bits(len); else b2 += (uint32_t)(tab[256 + len] & 255u);
+	}
+	const uint32_t i1 = wave_incl(b1), i2 = wave_incl(b2);
+	if (lane == 63) { ws1[wave] = i1; ws2[wave] = i2; }
+	__syncthreads();
+	uint64_t p1 = i1 - b1, p2 = i2 - b2;
+	for (uint32_t i = 0; i < wave; ++i) { p1 += ws1[i]; p2 += ws2[i]; }
+	BitSink s1, s2;
+	s1.open(out, off_sym[blockIdx.x] * 8 + p1);
+	s2.open(out, off_len[blockIdx.x] * 8 + p2);
+	for (uint64_t r = a; r < b; ++r) {
+		const uint32_t len = rstart[r + 1] - rstart[r];
+		const uint64_t e = tab[rsym[r]];
+		s1.put(e >> 8, (int)(e & 255u));
+		if (len >= 256u) {
+			const uint64_t c = tab[512];
+			s2.put(c >> 8, (int)(c & 255u));
+			const uint64_t y = (uint64_t)len + 1;
+			const int N = 63 - __clzll((long long)y), L = 31 - __clz(N + 1);
+			s2.put((uint64_t)(N + 1), 2 * L + 1);           // L zeros, then N + 1 in L + 1 bits
+			s2.put(y & ((1ull << N) - 1), N);
+		} else { const uint64_t c = tab[256 + len]; s2.put(c >> 8, (int)(c & 255u)); }
+	}
+	s1.close(); s2.close();
+}
+
+// d_symbols: n bytes in HBM (n < 2^32).  Writes the same file as rl_encode_file.  Returns false if this input is not for the device
+// encoder (a code longer than 32 bits, n out of range): the caller uses the host encoder then.
+bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream)
+{
+	hipStream_t s = (hipStream_t)hip_stream;
+	if (!runs_per_block) runs_per_block = 64 * 1024;
+	if (!numthreads) numthreads = 1;
+	if (n == 0 || n >= (1ull << 32) || runs_per_block > (1u << 24)) return false;
+	const uint32_t rpb = (uint32_t)runs_per_block;
+	const uint64_t ntiles = (n + RL_TILE - 1) / RL_TILE;
+	Buf tiles(4 * (ntiles + 1)), scan_ws(4 * scan_ws_elems(ntiles + 1));
+	hipLaunchKernelGGL(k_rl_count, dim3((uint32_t)ntiles), dim3(256), 0, s, d_symbols, n, tiles.as<uint32_t>());
+	B3M_HIP(hipMemsetAsync(tiles.as<uint32_t>() + ntiles, 0, 4, s));
+	exclusive_sum_u32(tiles.as<uint32_t>(), ntiles + 1, scan_ws.as<uint32_t>(), s);
+	uint32_t R32 = 0;
+	B3M_HIP(hipMemcpyAsync(&R32, tiles.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	const uint64_t R = R32;
+	B3M_REQUIRE(R >= 1, "internal: no runs found");
+	const uint64_t nblocks = (R + rpb - 1) / rpb;
+	Buf rstart(4 * (R + 2)), rsym(R + 16), hist(4ull * RL_HIST * nblocks);
+	hipLaunchKernelGGL(k_rl_runs, dim3((uint32_t)ntiles), dim3(256), 0, s, d_symbols, n, tiles.as<uint32_t>(), R, rstart.as<uint32_t>(), rsym.as<uint8_t>());
+	hipLaunchKernelGGL(k_rl_hist, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, hist.as<uint32_t>());
+	std::vector<uint32_t> h((size_t)RL_HIST * nblocks);
+	B3M_HIP(hipMemcpyAsync(h.data(), hist.p, 4ull * RL_HIST * nblocks, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	// ---- host: tables, headers, sizes ----
+	std::vector<uint64_t> tables(513 * nblocks), off_sym(nblocks), off_len(nblocks), bytes1(nblocks), bytes2(nblocks);
+	std::vector<std::vector<uint8_t>> headers(nblocks);
+	std::atomic<uint64_t> next(0); std::atomic<bool> too_long(false);
+	auto work = [&]() {
+		RLBlockTables t;
+		for (;;) {
+			const uint64_t b = next.fetch_add(1);
+			if (b >= nblocks) return;
+			const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
+			const uint64_t nr = std::min<uint64_t>(rpb, R - b * rpb);
+			rl_block_header(hb, hb + 256, nr, symmap, headers[b], t);
+			uint64_t s1 = 0, s2 = hb[513];
+			uint64_t *tb = tables.data() + 513 * b;
+			for (int c = 0; c < 256; ++c) { tb[c] = (t.scode[c] << 8) | t.slen[c]; s1 += (uint64_t)hb[c] * t.slen[c]; if (t.slen[c] > 32) too_long = true; }
+			for (int l = 0; l <= 256; ++l) { tb[256 + l] = (t.ccode[l] << 8) | t.clen[l]; s2 += (uint64_t)hb[256 + l] * t.clen[l]; if (t.clen[l] > 32) too_long = true; }
+			bytes1[b] = (s1 + 7) / 8; bytes2[b] = (s2 + 7) / 8;
+		}
+	};
+	{
+		std::vector<std::thread> th;
+		const unsigned T = (unsigned)std::min<uint64_t>(numthreads, nblocks);
+		for (unsigned i = 1; i < T; ++i) th.emplace_back(work);
+		work();
+		for (auto &x : th) x.join();
+	}
+	if (too_long) return false;
+	std::vector<RLIndexEntry> index(nblocks);
+	uint64_t pos = 0;                                   // offsets inside the block area (the file adds 8 bytes in front)
+	for (uint64_t b = 0; b < nblocks; ++b) {
+		const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
+		index[b] = {8 + pos, std::min<uint64_t>(rpb, R - b * rpb), (uint64_t)hb[514] | ((uint64_t)hb[515] << 32)};
+		off_sym[b] = pos + headers[b].size();
+		off_len[b] = off_sym[b] + bytes1[b];
+		pos = off_len[b] + bytes2[b];
+	}
+	const uint64_t total = pos;
+	Buf d_out(((total + 3) & ~3ull) + 16), d_tab(8 * tables.size()), d_o1(8 * nblocks), d_o2(8 * nblocks);
+	B3M_HIP(hipMemsetAsync(d_out.p, 0, ((total + 3) & ~3ull) + 16, s));
+	B3M_HIP(hipMemcpyAsync(d_tab.p, tables.data(), 8 * tables.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(d_o1.p, off_sym.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(d_o2.p, off_len.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_rl_pack, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, d_tab.as<uint64_t>(),
+	                   d_o1.as<uint64_t>(), d_o2.as<uint64_t>(), d_out.as<uint8_t>());
+	std::vector<uint8_t> blocks(total + 16);
+	B3M_HIP(hipMemcpyAsync(blocks.data(), d_out.p, total, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	for (uint64_t b = 0; b < nblocks; ++b) std::copy(headers[b].begin(), headers[b].end(), blocks.begin() + (long)(index[b].pos - 8));
+	rl_write_container(fn, n, blocks.data(), total, index);
+	return true;
+}
+
+}  // namespace b3m
+
+extern "C" int b3m_rl_write_device(const char *fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, void *stream)
+{
+	try {
+		int cnt = 0;
+		if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) throw b3m::Error("no HIP device: this library has no CPU fallback");
+		if (!fn || !d_symbols) throw b3m::Error("b3m_rl_write_device: null argument");
+		if (!b3m::rl_encode_device(fn, d_symbols, n, runs_per_block, std::max(1u, std::thread::hardware_concurrency()), nullptr, stream))
+			throw b3m::Error("b3m_rl_write_device: this input needs the host encoder (b3m_rl_write): empty, 2^32 symbols or more, or a code longer than 32 bits");
+		return 0;
+	} catch (const std::exception &e) { b3m::set_error(e.what()); return 1; }
+}

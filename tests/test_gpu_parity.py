@@ -1117,3 +1117,33 @@ def test_repeat_rich_100mbase_one_block_lf_verified(gpu):
         assert int(out[r["p0"]]) == 0
         outs.append(out); plan.close()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kind", ["dna", "dna_runs", "one_symbol", "bytes256", "tiny", "escapes"])
+def test_rl_container_written_from_hbm_equals_the_host_encoder(gpu, kind, tmp_path):
+    """row a11 (RLEncoderStd, /root/reference/src/lcpbit.cpp:3677-3681): b3m_rl_write_device finds the runs, counts the frequencies and packs the
+    Huffman code streams of every block on the device; the file must equal the host encoder's byte for byte (same tables, same layout), for
+    whole and ragged blocks, run lengths with and without the escape, one to 256 symbols."""
+    import ctypes
+    torch = gpu
+    from bwtb3m_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(65)
+    cases = {
+        "dna": [(rng.integers(1, 5, 5_000_001, dtype=np.uint8), 65536), (rng.integers(0, 4, 300_007, dtype=np.uint8), 1000)],
+        "dna_runs": [(np.repeat(rng.integers(0, 5, 400_000, dtype=np.uint8), rng.integers(1, 40, 400_000)), 4096)],
+        "one_symbol": [(np.full(1_000_003, 7, dtype=np.uint8), 65536), (np.full(5, 0, dtype=np.uint8), 3)],
+        "bytes256": [(rng.integers(0, 256, 2_000_000, dtype=np.uint8), 65536), (np.repeat(np.arange(256, dtype=np.uint8), 3), 100)],
+        "tiny": [(np.array([3], dtype=np.uint8), 65536), (np.array([1, 1], dtype=np.uint8), 1), (np.array([1, 2, 2, 3, 3, 3], dtype=np.uint8), 2)],
+        "escapes": [(np.repeat(rng.integers(0, 4, 3000, dtype=np.uint8), rng.integers(1, 3000, 3000)), 256),
+                    (np.concatenate([np.zeros(70_000, np.uint8), np.ones(255, np.uint8), np.full(256, 2, np.uint8), np.full(257, 3, np.uint8), np.zeros(1, np.uint8)]), 2)],
+    }[kind]
+    for k, (a, rpb) in enumerate(cases):
+        fh, fd = str(tmp_path / ("h%d.bwt" % k)).encode(), str(tmp_path / ("d%d.bwt" % k)).encode()
+        assert L.b3m_rl_write(fh, a.ctypes.data, len(a), rpb) == 0, L.b3m_last_error()
+        d = torch.from_numpy(a).cuda()
+        assert L.b3m_rl_write_device(fd, ctypes.c_void_p(d.data_ptr()), len(a), rpb, None) == 0, L.b3m_last_error()
+        hb, db = open(fh, "rb").read(), open(fd, "rb").read()
+        assert len(hb) == len(db) and hb == db, (kind, k, len(hb), len(db))
+        out = np.zeros(len(a), dtype=np.uint8); n = ctypes.c_uint64(0)
+        assert L.b3m_rl_read(fd, out.ctypes.data, len(a), ctypes.byref(n)) == 0 and n.value == len(a) and np.array_equal(out, a)
