@@ -65,16 +65,16 @@ struct Timeline {
 	std::vector<Ev> evs;
 	std::vector<hipEvent_t> pool;
 	hipEvent_t get();
-	void begin(int fam, uint64_t alg_bytes);
-	void end();
+	size_t begin(int fam, uint64_t alg_bytes);     // -> index of the entry (scopes may nest or live on different streams)
+	void end(size_t idx);
 	void collect(double ms[KF_COUNT], uint64_t launches[KF_COUNT], uint64_t bytes[KF_COUNT]);
 	void reset();
 	~Timeline();
 };
 struct Scope {
-	Timeline *t;
-	Scope(Timeline *tl, int fam, uint64_t bytes = 0) : t(tl) { if (t && t->enabled) t->begin(fam, bytes); }
-	~Scope() { if (t && t->enabled) t->end(); }
+	Timeline *t; size_t idx = 0;
+	Scope(Timeline *tl, int fam, uint64_t bytes = 0) : t(tl) { if (t && t->enabled) idx = t->begin(fam, bytes); }
+	~Scope() { if (t && t->enabled) t->end(idx); }
 };
 
 // ---- device helpers (launchers defined in the .hip files) ------------------------------------------

@@ -22,13 +22,14 @@ hipEvent_t Timeline::get()
 	if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
 	hipEvent_t e; B3M_HIP(hipEventCreate(&e)); return e;
 }
-void Timeline::begin(int fam, uint64_t bytes)
+size_t Timeline::begin(int fam, uint64_t bytes)
 {
 	Ev e; e.a = get(); e.b = get(); e.fam = fam; e.bytes = bytes;
 	B3M_HIP(hipEventRecord(e.a, stream));
 	evs.push_back(e);
+	return evs.size() - 1;
 }
-void Timeline::end() { B3M_HIP(hipEventRecord(evs.back().b, stream)); }
+void Timeline::end(size_t idx) { B3M_HIP(hipEventRecord(evs[idx].b, stream)); }
 void Timeline::collect(double ms[KF_COUNT], uint64_t launches[KF_COUNT], uint64_t bytes[KF_COUNT])
 {
 	for (int i = 0; i < KF_COUNT; ++i) { ms[i] = 0; launches[i] = 0; bytes[i] = 0; }
