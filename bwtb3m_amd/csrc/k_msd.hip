@@ -960,7 +960,6 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];
 	__shared__ __attribute__((aligned(16))) uint32_t tab[TAB_N];
 	__shared__ __attribute__((aligned(16))) uint8_t obwt[OBWT_N];
-	__shared__ uint32_t osa[WRITE_SA ? F_CAP : 1];
 	__shared__ uint32_t wsum[F_WAVES];
 	__shared__ __attribute__((aligned(8))) uint2 rr[G_NCH + 1];
 	__shared__ uint16_t gfirst[GF_N];
@@ -1107,6 +1106,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	// the bin's first value B: below the own offset <=> sorts before me.  Everything rare (bins above four entries, ties, the
 	// block's first suffix) sits behind ONE branch per record. ----
 	const uint32_t start_lo = (uint32_t)O.start;
+	uint32_t dpv[WRITE_SA ? F_PER : 1];                          // WRITE_SA: the record's place; its position goes through `ent` once every entry has been read
 	auto rank_drop = [&](const int k, const bool guard) {
 		const uint32_t hi = (uint32_t)(r[k] >> 32), e = k * F_THREADS + tid;
 		const bool valid = !guard || e < m;
@@ -1136,9 +1136,10 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 			if (prev && !hot) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
 			if (pos == O.start) *O.p0 = g;
 		}
+		if (WRITE_SA) dpv[k] = valid ? dp : 0xFFFFFFFFu;
 		if (valid) {
 			obwt[apad + dp] = (uint8_t)((hi >> hps) & 7u);       // hot bins: overwritten by the fallback's emit
-			if (WRITE_SA) { osa[dp] = lo32; if (O.sa.hi) O.sa.hi[s0 + dp] = (uint8_t)(hi & ((1u << hps) - 1u)); }
+			if (WRITE_SA && O.sa.hi) O.sa.hi[s0 + dp] = (uint8_t)(hi & ((1u << hps) - 1u));
 		}
 	};
 	#pragma unroll
@@ -1154,8 +1155,12 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		}
 	}
 	if (WRITE_SA) {
+		// the positions in place order through the entry array (dead now: an extra 24 KB of LDS for them halved the occupancy)
 		#pragma unroll
-		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa.lo[s0 + e] = osa[e]; }
+		for (int k = 0; k < F_PER; ++k) if (dpv[k] != 0xFFFFFFFFu) ent[dpv[k]] = (uint32_t)r[k];
+		__syncthreads();
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) { uint32_t e = k * F_THREADS + tid; if (e < m) O.sa.lo[s0 + e] = ent[e]; }
 	}
 }
 
