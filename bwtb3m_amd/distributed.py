@@ -231,6 +231,24 @@ def _all_to_all_v(send, send_counts, recv_counts, group):
     return recv.to(dev) if st else recv
 
 
+class _PendingA2A:
+    """an all-to-all(v) in flight (dist.all_to_all_single(async_op=True)): RCCL runs it on its own stream while this rank's next kernels
+    (the next tile of the chain walk) run on the compute stream; result() waits and hands the received elements over"""
+
+    def __init__(self, send, send_counts, recv_counts, group):
+        self.dev = send.device
+        self.staged = _staged(send)
+        self.src = (send.cpu() if self.staged else send).contiguous()          # kept alive until the collective is through
+        self.recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=self.src.device)
+        self.work = dist.all_to_all_single(self.recv, self.src, output_split_sizes=[int(x) for x in recv_counts],
+                                           input_split_sizes=[int(x) for x in send_counts], group=group, async_op=True)
+
+    def result(self):
+        self.work.wait()
+        self.src = None
+        return self.recv.to(self.dev) if self.staged else self.recv
+
+
 def _broadcast(t, src, group):
     if _staged(t):
         h = t.cpu()
@@ -382,24 +400,36 @@ class DistributedBwt:
         be.build_dict(parts, m, p0L)
         cb = split_even(mg.num_chains, gs)
         c0, c1 = cb[gi], cb[gi + 1]
-        anc = h_anchors[mg.anchor_off + c0: mg.anchor_off + c1]
         lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
-        sr_mine, cut, gt_out = be.walk(a, m, mr, self._symstart(mg.L.ranks), gt_cur, anc, c0, c1 - c0, mg.chain_len, lam)
+        # my chain range goes in tiles: while tile t+1 walks, the gap buckets of tile t are already on their way (all-to-all(v) of
+        # the ranks, cut on the device at the borders of the group's rank slices; RCCL runs it on its own stream)
+        ntile = max(1, min(int(os.environ.get("B3M_DIST_TILES", "2")), c1 - c0))
+        tb = split_even(c1 - c0, ntile)
+        symstart = self._symstart(mg.L.ranks)
+        flights, rc, oseg = [], None, None
+        for t in range(ntile):
+            ca, cz = c0 + tb[t], c0 + tb[t + 1]
+            anc = h_anchors[mg.anchor_off + ca: mg.anchor_off + cz]
+            sr_t, cut, gt_out = be.walk(a, m, mr, symstart, gt_cur, anc, ca, cz - ca, mg.chain_len, lam)
+            seg = gt_out[w0:w1]
+            oseg = seg.clone() if oseg is None else oseg | seg          # new gt bits of the walked positions (disjoint between tiles and walkers)
+            del gt_out
+            send_counts = np.diff(cut)
+            rc_t = _all_gather_i64(list(send_counts), grp, dev)          # rc_t[i][j] = i sends to j in this tile
+            flights.append(_PendingA2A(sr_t, send_counts, rc_t[:, gi], grp))
+            rc = rc_t if rc is None else rc + rc_t
         del parts
         t2 = time.perf_counter()
         tm["walk"] += t2 - t1
         # new gt bits of R's positions relative to S_a: union over walkers (disjoint positions)
-        oseg = gt_out[w0:w1].contiguous()
+        oseg = oseg.contiguous()
         _all_reduce_sum(oseg, grp)
-        del gt_out
         gt_new = gt_cur                               # L's bits (a, rbeg) stay; R's become relative to S_a
         _replace_bits_seg(gt_new, oseg, w0, rbeg, rend)
         _set_bit(gt_new, rend, 1 if int(h_anchors[mg.anchor_off]) > p0L else 0)
-        # 5. all-to-all of gap buckets by owning slice of the rank space [0, m]
-        send_counts = np.diff(cut)
-        rc = _all_gather_i64(list(send_counts), grp, dev)          # rc[i][j] = i sends to j
-        recv_counts = rc[:, gi]
-        got = _all_to_all_v(sr_mine, send_counts, recv_counts, grp)
+        # 5. the gap buckets of my slice of the rank space [0, m], from every walker and tile
+        got = torch.cat([f.result() for f in flights]) if len(flights) > 1 else flights[0].result()
+        del flights
         nbits = max(1, int(m + 1).bit_length())
         sr_slice = be.sort_u32(got, min(32, nbits))
         # 6. which range of BWT(R) falls into my slice
