@@ -14,9 +14,7 @@
 
 static std::string format_time(double s)
 {
-	std::ostringstream o;
-	uint64_t is = (uint64_t)s;
-	if (is >= 3600) o << is / 3600 << ":";
+	const uint64_t is = (uint64_t)s;
 	char buf[64]; snprintf(buf, sizeof buf, "%02llu:%02llu:%02llu.%03llu", (unsigned long long)(is / 3600), (unsigned long long)((is / 60) % 60),
 	                       (unsigned long long)(is % 60), (unsigned long long)((s - (double)is) * 1000));
 	return buf;
