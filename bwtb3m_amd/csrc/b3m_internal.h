@@ -121,6 +121,11 @@ struct MsdWs {
 	uint32_t *runpre = nullptr;                              // the same rows as start | records before the run << 14 (for the gathering finish)
 	uint32_t *runtab = nullptr; uint64_t runtab_cap = 0;     // level-1 run table: row (level-0 bucket, digit), column = chunk: start | length << 16
 	uint32_t *scan_ws = nullptr;
+	// chunk-local level 0: run table (row = digit, column = chunk), the rows' prefixes, first runs of level 1's chunks, gather tiles
+	uint32_t *tab0 = nullptr, *pre0 = nullptr; uint64_t tab0_cap = 0;
+	uint32_t *tile_fr = nullptr; uint64_t tile_fr_cap = 0;
+	void *gtiles = nullptr; uint64_t gtiles_cap = 0;
+	uint32_t *tfirst = nullptr;
 };
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span);
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);

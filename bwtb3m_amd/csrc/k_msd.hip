@@ -108,6 +108,13 @@ static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap,
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
 static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 33 + 4096; }                   // (start, size) pairs: every listed bin holds > 32 records
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
+// entries of the chunk-local level 0's run table: 2048 rows x (whole tiles of 4 chunks of 65,280 positions); 0 = no such path (small blocks, 2^32 and more)
+static uint64_t msd_local0_cap(uint64_t cap)
+{
+	if (cap < MSD_MIN_LEN || cap >= (1ull << 32)) return 0;
+	const uint64_t tile = (uint64_t)W0A_CHUNK * W0A_TCH;
+	return (uint64_t)W0A_BINS * (((cap + 16 + tile - 1) / tile) * W0A_TCH);
+}
 static uint64_t msd_runtab_cap(uint64_t cap) { return (cap / L1_CHUNK + MSD_L0_MAX) * (uint64_t)MSD_MAXBINS; }   // one column per chunk, 2^D1 rows per level-0 bucket
 
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
@@ -115,7 +122,8 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	if (cap < MSD_MIN_LEN) return 4096;
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
-	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (MSD_TAB_MAX + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096;
+	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (MSD_TAB_MAX + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096
+	     + (msd_local0_cap(cap) ? 2 * al(4 * msd_local0_cap(cap)) + al(4 * (cap / L1_CHUNK + 2 * MSD_L0_MAX)) + al(32 * msd_tiles_cap(cap)) + al(4 * MSD_L0_MAX) : 0);
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -134,7 +142,17 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.runtab = (uint32_t *)p; ws.runtab_cap = msd_runtab_cap(cap); p += al(4 * ws.runtab_cap);
 	ws.runpre = (uint32_t *)p; p += al(4 * ws.runtab_cap);
 	ws.lists = p; p += 256;
-	ws.scan_ws = (uint32_t *)p;
+	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(hist));
+	// chunk-local level 0 (whole blocks below 2^32): its run table and the rows' prefixes, level 1's gather tiles
+	ws.tab0 = nullptr; ws.pre0 = nullptr; ws.tab0_cap = 0;
+	if (msd_local0_cap(cap)) {
+		ws.tab0_cap = msd_local0_cap(cap);
+		ws.tab0 = (uint32_t *)p; p += al(4 * ws.tab0_cap);
+		ws.pre0 = (uint32_t *)p; p += al(4 * ws.tab0_cap);
+		ws.tile_fr_cap = cap / L1_CHUNK + 2 * MSD_L0_MAX; ws.tile_fr = (uint32_t *)p; p += al(4 * ws.tile_fr_cap);
+		ws.gtiles_cap = msd_tiles_cap(cap); ws.gtiles = p; p += al(32 * ws.gtiles_cap);
+		ws.tfirst = (uint32_t *)p; p += al(4 * MSD_L0_MAX);
+	}
 }
 
 // 64 bits = the 32 bases from `pos` on, with the bucketing convention for the end of the text:
@@ -179,6 +197,8 @@ struct L0Args {
 	int D;                       // digit bits (up to 15: a suffix-range shard splits its digit range further)
 	uint32_t keep_lo, keep_hi;   // only positions with keep_lo <= digit < keep_hi take part; bin = digit - keep_lo, at most MAXBINS bins
 	int pb;                      // position bits of a record
+	uint32_t *runtab0;           // LOCAL: row (digit) x column (chunk): start inside the chunk | length << 16
+	uint32_t nchunks0;           // LOCAL: columns
 };
 
 // window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
@@ -193,13 +213,16 @@ __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t 
 // Two geometries: 65,280-position chunks for up to 2048 bins (32-record runs on average at 11 bits; the
 // index array alone is 128 KB of LDS, everything else is squeezed into the rest) and 32,768-position
 // chunks for 4096 bins.
-template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS>
+// LOCAL (whole-text blocks, no shard): the chunk's records go out in digit order to the chunk's OWN index range of the record buffer,
+// a stream of whole lines instead of 2048 scattered 32-record runs, and where digit d sits inside chunk c is one entry of a run table
+// (row d, column c); no counting pass and no [digit][tile] offsets are needed.  Level 1 gathers a bucket from its row's runs.
+template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false>
 __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 {
 	constexpr int WORDS = CHUNK / 16;
 	static_assert(CHUNK % 16 == 0 && CHUNK <= 65536, "chunk-local positions are 16-bit");
 	__shared__ uint32_t cur[MAXBINS];                            // count, then exclusive start, then end of every digit run
-	__shared__ uint32_t gbase[COUNT_ONLY ? 1 : MAXBINS];
+	__shared__ uint32_t gbase[(COUNT_ONLY || LOCAL) ? 1 : MAXBINS];
 	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : CHUNK];            // chunk-local positions in digit order
 	__shared__ uint32_t stext[WORDS + 4];                        // [0] = the word before the chunk
 	__shared__ uint32_t wsum[W0_THREADS / 64];
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
 	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
-	else { for (int b = tid; b < bins; b += W0_THREADS) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
+	else if (!LOCAL) { for (int b = tid; b < bins; b += W0_THREADS) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
 	__syncthreads();
 	for (int c = 0; c < TCH; ++c) {
 		const uint64_t cpos = A.P0 + (uint64_t)tile * (TCH * CHUNK) + (uint64_t)c * CHUNK;
@@ -311,9 +334,16 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
 				r = make_rec(x, A.D, pr, cpos + li, &dgt, A.pb);
 			}
+			if (LOCAL) { A.rec_out[(cpos - A.P0) + q] = r; continue; }
 			const uint32_t bin = dgt - klo;
 			const uint32_t rs = bin ? cur[bin - 1] : 0u;          // start of run bin
 			A.rec_out[(uint64_t)gbase[bin] + (q - rs)] = r;
+		}
+		if (LOCAL) {
+			const uint32_t col = tile * TCH + c;
+			for (int b = tid; b < bins; b += W0_THREADS) { const uint32_t st0 = b ? cur[b - 1] : 0u; A.runtab0[(uint64_t)b * A.nchunks0 + col] = st0 | ((cur[b] - st0) << 16); }
+			__syncthreads();
+			continue;
 		}
 		__syncthreads();
 		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cur[b] - (b ? cur[b - 1] : 0u);
@@ -401,6 +431,185 @@ __global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 	}
 	__syncthreads();
 	// the tile's columns of the run table: digit d -> nchunks consecutive entries of row d
+	for (int d = tid; d < bins; d += THREADS) {
+		uint32_t *row = A.runtab + (uint64_t)tile.hist_base + (uint64_t)d * tile.stride;
+		for (uint32_t c = 0; c < nchunks; ++c) row[c] = tabst[c][d];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunk-local level 0: its run table (row = digit, column = chunk of W0A_CHUNK positions) -> bucket sizes, then the prefix of
+// every run inside its row and, for every 16 Ki-record chunk of level 1, the run its first slot lies in.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows0_totals(const uint32_t *tab0, uint32_t nchunks0, unsigned long long *tot)
+{
+	__shared__ unsigned long long ws[4];
+	const uint32_t *row = tab0 + (uint64_t)blockIdx.x * nchunks0;
+	unsigned long long c = 0;
+	for (uint32_t i = threadIdx.x; i < nchunks0; i += 256) c += row[i] >> 16;
+	#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) tot[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// pre0[d][c] = records of row d in the chunks before c; tile_fr[tfirst[d] + k] = the run that holds slot k * L1_CHUNK of bucket d
+// (k < chunks of the bucket), tile_fr[tfirst[d] + chunks] = nchunks0
+__global__ __launch_bounds__(256) void k_rows0_prefix(const uint32_t *tab0, uint32_t nchunks0, uint32_t *pre0, const uint32_t *tfirst, uint32_t *tile_fr)
+{
+	__shared__ uint32_t ws[4];
+	const uint32_t d = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t *row = tab0 + (uint64_t)d * nchunks0;
+	uint32_t *prow = pre0 + (uint64_t)d * nchunks0;
+	uint32_t *fr = tile_fr + tfirst[d];
+	uint32_t run = 0;
+	for (uint32_t i0 = 0; i0 < nchunks0; i0 += 256) {
+		const uint32_t i = i0 + tid;
+		const uint32_t len = i < nchunks0 ? row[i] >> 16 : 0u;
+		const uint32_t inc = wave_incl_sum(len);
+		__syncthreads();
+		if (lane == 63) ws[wave] = inc;
+		__syncthreads();
+		uint32_t pre = run + inc - len;
+		for (uint32_t w = 0; w < wave; ++w) pre += ws[w];
+		if (i < nchunks0) {
+			prow[i] = pre;
+			for (uint32_t k = (pre + (uint32_t)L1_CHUNK - 1) / (uint32_t)L1_CHUNK; (uint64_t)k * L1_CHUNK < (uint64_t)pre + len; ++k) fr[k] = i;
+		}
+		run += ws[0] + ws[1] + ws[2] + ws[3];
+	}
+	if (tid == 0) fr[(run + (uint32_t)L1_CHUNK - 1) / (uint32_t)L1_CHUNK] = nchunks0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level 1 behind a chunk-local level 0: the same chunk-local sort as k_l1_local, but the 16 Ki records of a chunk are GATHERED from
+// the runs of the bucket's row (~512 runs of ~32 records on uniform input) through the slot -> run map of the gathering finish
+// (group descriptors of up to four runs per 64 slots; a lane of a group with more searches the run list), and written contiguously
+// to the bucket's own range of the output buffer.
+// ------------------------------------------------------------------------------------------------
+struct L1GTile { uint32_t out_off, count, hist_base, stride, d, tfr, slot0, pad; };    // tfr: index into tile_fr of the tile's first chunk; slot0: its first slot in the bucket
+struct L1GArgs {
+	const uint64_t *rec_in; uint64_t *rec_out;
+	const L1GTile *tiles;
+	uint32_t *runtab;            // this level's run table (as k_l1_local)
+	const uint32_t *tab0, *pre0, *tile_fr; uint32_t nchunks0; uint32_t chunk0;      // level 0's table, row prefixes, first runs; index stride of a level-0 chunk
+	int D, shift;
+};
+constexpr int L1G_RUNS = 1536;       // runs of one chunk kept in LDS (uniform input: ~512); more: every lane searches the row in HBM
+
+template <int THREADS, int TCH>
+__global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
+{
+	constexpr int CHUNK = THREADS * MSD_ITEMS;
+	constexpr int NG = CHUNK / 64;
+	__shared__ uint32_t cnt[MSD_MAXBINS];
+	__shared__ uint32_t binstart[MSD_MAXBINS];
+	__shared__ uint32_t tabst[TCH][MSD_MAXBINS];
+	__shared__ __attribute__((aligned(16))) uint64_t srec[CHUNK];
+	__shared__ uint32_t wsum[THREADS / 64];
+	__shared__ __attribute__((aligned(8))) uint2 rr[L1G_RUNS + 2];       // x = first slot of the run inside the chunk, y = index of its first record taken
+	__shared__ uint16_t gfirst[NG + 2];
+	__shared__ __attribute__((aligned(16))) uint4 gda[NG], gdb[NG];      // {o1, o2, o3, A} and {B - o1, C - o2, D - o3, more than four runs}
+	static_assert(THREADS >= MSD_MAXBINS && NG <= THREADS, "one bin / one group per thread");
+	const uint32_t tid = threadIdx.x, wave = tid >> 6;
+	const int bins = 1 << A.D;
+	const L1GTile tile = A.tiles[blockIdx.x];
+	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;       // <= TCH
+	const uint32_t *row0 = A.tab0 + (uint64_t)tile.d * A.nchunks0, *prow = A.pre0 + (uint64_t)tile.d * A.nchunks0;
+	uint64_t rec[MSD_ITEMS];
+	// the 16 records of a thread = slots s * THREADS + tid of chunk c of the tile (all loads back to back, clamped slot).  Barriers inside:
+	// every thread calls it.  The map (rr, gfirst, gda, gdb) is only needed until the loads are issued.
+	auto load_chunk = [&](const uint32_t c) {
+		const uint32_t cbase = c * CHUNK;
+		const uint32_t nv = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
+		const uint32_t S0 = tile.slot0 + cbase;
+		const uint32_t fr = A.tile_fr[tile.tfr + c];
+		uint32_t fre = A.tile_fr[tile.tfr + c + 1]; if (fre >= A.nchunks0) fre = A.nchunks0 - 1;
+		const uint32_t nr = fre - fr + 1;
+		const uint32_t glast = (nv - 1) >> 6;
+		if (nr > (uint32_t)L1G_RUNS) {
+			// (skew: the bucket is rare, its chunk spans more level-0 chunks than the list holds) every lane searches the row's prefixes in HBM
+			#pragma unroll                                          // (a loop with a dynamic index would put rec[] into scratch memory)
+			for (int s = 0; s < MSD_ITEMS; ++s) {
+				uint32_t e = s * THREADS + tid; e = e < nv ? e : nv - 1;
+				const uint32_t slot = S0 + e;
+				uint32_t lo = fr, hi = fre + 1;                       // largest i in [fr, fre] with prow[i] <= slot
+				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prow[mid] <= slot) lo = mid; else hi = mid; }
+				rec[s] = A.rec_in[(uint64_t)lo * A.chunk0 + (row0[lo] & 0xFFFFu) + (slot - prow[lo])];
+			}
+			return;
+		}
+		__syncthreads();                                              // (the map of the chunk before is no longer read)
+		for (uint32_t j = tid; j < nr; j += THREADS) {
+			const uint32_t e = row0[fr + j], pre = prow[fr + j], len = e >> 16;
+			const uint32_t lo = pre > S0 ? pre - S0 : 0u, skip = S0 > pre ? S0 - pre : 0u;
+			uint32_t hi = pre + len > S0 ? pre + len - S0 : 0u; hi = hi < nv ? hi : nv;
+			rr[j] = make_uint2(lo < nv ? lo : nv, (fr + j) * A.chunk0 + (e & 0xFFFFu) + skip);
+			for (uint32_t g = (lo + 63) >> 6; (g << 6) < hi; ++g) gfirst[g] = (uint16_t)j;
+		}
+		if (tid == 0) { rr[nr] = make_uint2(nv, 0u); rr[nr + 1] = make_uint2(nv, 0u); gfirst[glast + 1] = (uint16_t)(nr - 1); }
+		__syncthreads();
+		if (tid <= glast) {
+			const uint32_t sl = tid << 6;
+			const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
+			const uint2 q0 = rr[j0];
+			uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
+			for (uint32_t i = j0 + 1; i <= j1 && i < nr; ++i) {
+				const uint2 qi = rr[i];
+				if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
+				const uint32_t oo = qi.x - sl, bb = qi.y - oo;
+				if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
+				++found;
+			}
+			gda[tid] = make_uint4(o1, o2, o3, q0.y + (sl - q0.x));
+			gdb[tid] = make_uint4(b1, b2, b3, found > 3 ? 1u : 0u);
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) {
+			uint32_t e = s * THREADS + tid; e = e < nv ? e : nv - 1;
+			const uint32_t g = e >> 6, x = e & 63u;
+			const uint4 da = gda[g], db = gdb[g];
+			uint32_t adr = (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
+			if (db.w) {                                             // more than four runs in these 64 slots: search the list
+				uint32_t lo = gfirst[g], hi = nr;                   // largest j with rr[j].x <= e
+				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rr[mid].x <= e) lo = mid; else hi = mid; }
+				adr = rr[lo].y + (e - rr[lo].x);
+			}
+			rec[s] = A.rec_in[adr];
+		}
+	};
+	load_chunk(0);
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const uint32_t cbase = c * CHUNK;
+		const uint32_t nvalid = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
+		for (int b = tid; b < bins; b += THREADS) cnt[b] = 0;
+		__syncthreads();
+		uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS];
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) dg[s] = (uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1);
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) slot[s] = atomicAdd(&cnt[dg[s]], 1u);
+		__syncthreads();
+		{
+			const uint32_t v = (int)tid < bins ? cnt[tid] : 0u;
+			uint32_t inc = wave_incl_sum(v);
+			uint32_t l = tid & 63;
+			if (l == 63) wsum[wave] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+			if ((int)tid < bins) { binstart[tid] = pre + inc - v; tabst[c][tid] = (pre + inc - v) | (v << 16); }
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) srec[binstart[dg[s]] + slot[s]] = rec[s];
+		if (c + 1 < nchunks) load_chunk(c + 1);                       // issued before this chunk is copied out: read and write streams overlap
+		__syncthreads();
+		uint64_t *out = A.rec_out + (uint64_t)tile.out_off + cbase;
+		for (uint32_t p = tid; p < nvalid; p += THREADS) out[p] = srec[p];
+	}
+	__syncthreads();
 	for (int d = tid; d < bins; d += THREADS) {
 		uint32_t *row = A.runtab + (uint64_t)tile.hist_base + (uint64_t)d * tile.stride;
 		for (uint32_t c = 0; c < nchunks; ++c) row[c] = tabst[c][d];
@@ -1427,14 +1636,31 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	L0Args A{};
 	A.T = T; A.start = start; A.len = len; A.P0 = P0; A.rec_out = ws.keyA; A.hist = M.hist; A.D = dg.D0;
 	A.keep_lo = 0; A.keep_hi = bins0; A.pb = pb;
-	{
+	// Chunk-local level 0 (unsharded blocks with a level 1, 32-bit positions): no counting pass, the records of a chunk stay in the
+	// chunk's own index range, level 1 gathers (k_l0_pass<.., LOCAL>, k_l1_gather).  B3M_L0_LOCAL=0: the scattering form.
+	static const int l0_local_on = getenv("B3M_L0_LOCAL") ? atoi(getenv("B3M_L0_LOCAL")) : 1;
+	const uint32_t nchunks0 = (uint32_t)((span + W0A_CHUNK - 1) / W0A_CHUNK);
+	const bool local0 = l0_local_on && nshards <= 1 && geoA && dg.D1 > 0 && !big && span <= ws.cap && M.tab0 != nullptr
+	                    && (uint64_t)bins0 * ((uint64_t)ntA * W0A_TCH) <= M.tab0_cap && span < (1ull << 32);
+	const uint32_t ncol0 = ntA * (uint32_t)W0A_TCH;             // columns of the level-0 run table (whole tiles)
+	(void)nchunks0;
+	unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
+	if (local0) {
+		{
+			Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
+			B3M_HIP(hipMemsetAsync(M.tab0, 0, 4ull * bins0 * ncol0, s));
+			A.runtab0 = M.tab0; A.nchunks0 = ncol0;
+			hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		}
+		Scope sc(tl, KF_SCAN, 4ull * bins0 * ncol0);
+		hipLaunchKernelGGL(k_rows0_totals, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, d_tot);
+	} else {
 		Scope sc(tl, KF_MSD_HIST, span / 4);
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
-	unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
 	if (ws.d_symhist_out && dg.D0 >= 2) {
-		hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		if (!local0) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
 		hipLaunchKernelGGL(k_symhist_from_totals, dim3(1), dim3(256), 0, s, d_tot, bins0, dg.D0, T.type == B3M_INPUT_PACTERM ? 1 : 0,
 		                   (T.type == B3M_INPUT_PACTERM && start + len_in == T.n) ? 1 : 0, reinterpret_cast<unsigned long long *>(ws.d_symhist_out));
 		out.symhist_done = true;
@@ -1486,11 +1712,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	out.kept_len = len;
 	B3M_REQUIRE(len < (1ull << 32), "more than 2^32 suffixes in one sort: use suffix-range shards");
 	if (len == 0) { out.d_sa = sa.lo; out.d_sa_hi = sa.hi; return; }          // empty shard (one huge digit took the neighbours' share)
-	{
-		Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
-		exclusive_sum_u32(hist0, (uint64_t)bins0 * ntA, M.scan_ws, s);
-	}
-	{
+	if (!local0) {
+		{
+			Scope sc(tl, KF_SCAN, 8ull * bins0 * ntA);
+			exclusive_sum_u32(hist0, (uint64_t)bins0 * ntA, M.scan_ws, s);
+		}
 		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<false, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
@@ -1514,11 +1740,25 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		FS.rec = ws.keyA;
 	} else {
 		// ---- level 1: every chunk of L1_CHUNK records of a level-0 bucket sorted in LDS, in place; tiles of <= L1_TCH chunks built on the host ----
-		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.sub_start);
 		std::vector<uint32_t> st(bins0 + 1);
-		B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
-		B3M_HIP(hipStreamSynchronize(s));
+		if (local0) {
+			// bucket sizes = row sums of level 0's run table; their prefix is uploaded where the scattering form computes it
+			std::vector<unsigned long long> tot(bins0);
+			B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			uint64_t acc = 0;
+			for (uint32_t b = 0; b < bins0; ++b) { st[b] = (uint32_t)acc; acc += tot[b]; }
+			st[bins0] = (uint32_t)acc;
+			B3M_REQUIRE(acc == len, "internal: level 0's run table does not add up to the block");
+			B3M_HIP(hipMemcpyAsync(M.sub_start, st.data(), 4ull * (bins0 + 1), hipMemcpyHostToDevice, s));
+		} else {
+			hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.sub_start);
+			B3M_HIP(hipMemcpyAsync(st.data(), M.sub_start, 4ull * (bins0 + 1), hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+		}
 		std::vector<MsdTile> tiles;
+		std::vector<L1GTile> gtiles;
+		std::vector<uint32_t> tfirst(local0 ? bins0 + 1 : 0);
 		std::vector<uint32_t> tab(3ull * bins0);
 		uint64_t toff = 0;
 		const uint32_t TILE = (uint32_t)L1_CHUNK * L1_TCH;
@@ -1526,7 +1766,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			const uint32_t sz = st[b + 1] - st[b];
 			const uint32_t nch = (sz + L1_CHUNK - 1) / L1_CHUNK;
 			tab[b] = st[b]; tab[bins0 + b] = (uint32_t)toff; tab[2ull * bins0 + b] = nch;
+			if (local0) tfirst[b] = b ? tfirst[b - 1] + (st[b] - st[b - 1] + (uint32_t)L1_CHUNK - 1) / (uint32_t)L1_CHUNK + 1 : 0u;
 			for (uint32_t j = 0; j * TILE < sz; ++j) {
+				if (local0) {
+					L1GTile t{}; t.out_off = st[b] + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
+					t.hist_base = (uint32_t)(toff + (uint64_t)j * L1_TCH); t.stride = nch; t.d = b; t.tfr = tfirst[b] + j * (uint32_t)L1_TCH; t.slot0 = j * TILE;
+					gtiles.push_back(t);
+					continue;
+				}
 				MsdTile t; t.in_off = st[b] + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
 				t.hist_base = (uint32_t)(toff + (uint64_t)j * L1_TCH); t.stride = nch;
 				tiles.push_back(t);
@@ -1534,13 +1781,30 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			toff += ((uint64_t)1 << dg.D1) * nch;
 		}
 		B3M_REQUIRE(toff <= M.runtab_cap && tiles.size() <= M.tiles_cap && toff < (1ull << 32), "MSD workspace too small");
-		B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
 		B3M_HIP(hipMemcpyAsync(M.bucket_tab, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
-		B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
-		L1Args Bq{};
-		Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = dg.D1; Bq.shift = 64 - dg.D1;
-		const uint32_t ntB = (uint32_t)tiles.size();
-		{
+		uint32_t ntB = 0;
+		if (local0) {
+			tfirst[bins0] = tfirst[bins0 - 1] + (st[bins0] - st[bins0 - 1] + (uint32_t)L1_CHUNK - 1) / (uint32_t)L1_CHUNK + 1;
+			B3M_REQUIRE(gtiles.size() <= M.gtiles_cap && tfirst[bins0] <= M.tile_fr_cap, "MSD workspace too small");
+			B3M_HIP(hipMemcpyAsync(M.gtiles, gtiles.data(), sizeof(L1GTile) * gtiles.size(), hipMemcpyHostToDevice, s));
+			B3M_HIP(hipMemcpyAsync(M.tfirst, tfirst.data(), 4ull * (bins0 + 1), hipMemcpyHostToDevice, s));
+			B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
+			{
+				Scope sc(tl, KF_SCAN, 8ull * bins0 * ncol0);
+				hipLaunchKernelGGL(k_rows0_prefix, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, M.pre0, M.tfirst, M.tile_fr);
+			}
+			L1GArgs Gq{};
+			Gq.rec_in = ws.keyA; Gq.rec_out = ws.keyB; Gq.tiles = reinterpret_cast<const L1GTile *>(M.gtiles); Gq.runtab = M.runtab;
+			Gq.tab0 = M.tab0; Gq.pre0 = M.pre0; Gq.tile_fr = M.tile_fr; Gq.nchunks0 = ncol0; Gq.chunk0 = (uint32_t)W0A_CHUNK; Gq.D = dg.D1; Gq.shift = 64 - dg.D1;
+			ntB = (uint32_t)gtiles.size();
+			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
+			hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
+		} else {
+			B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
+			B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
+			L1Args Bq{};
+			Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = dg.D1; Bq.shift = 64 - dg.D1;
+			ntB = (uint32_t)tiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
 			hipLaunchKernelGGL((k_l1_local<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Bq);
 		}
