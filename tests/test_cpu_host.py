@@ -199,7 +199,7 @@ def test_bench_roofline_helper():
           {"name": "scan", "ms": 0.3, "launches": 6, "alg_bytes": 1000}]
     benchutil.add_kernel_times(fam, kt); benchutil.add_kernel_times(fam, kt)
     r = benchutil.dominant_roofline(fam, 2, 0.104, 3_000_000_000, 0, 0, "/nonexistent")
-    assert r["family"] == "msd_scatter" and r["kernel"] == "b3m::k_l1_local<1024, 4>" and r["bound"] == "hbm"
+    assert r["family"] == "msd_scatter" and r["kernel"] == "b3m::k_l1_gather<1024, 4>" and r["bound"] == "hbm"
     assert abs(r["achieved"] - 3000.0) < 1.0 and abs(r["frac"] - 0.375) < 1e-3 and r["traffic"] is None
     assert r["launches_per_step"] == 1 and r["alg_bytes_per_launch"] == 48_000_000_016
     assert abs(r["job_frac"] - 28.5e9 / 0.052 / 1e9 / 8000.0) < 1e-4
