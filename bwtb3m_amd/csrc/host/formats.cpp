@@ -320,6 +320,90 @@ uint64_t rl_length(const std::string &fn)
 	return get_be64(b);
 }
 
+// runs of ONE block of the container (the block that starts at file offset `pos`): what a seek through the trailing index decodes
+static void rl_decode_block_at(const std::vector<uint8_t> &d, uint64_t pos, uint64_t ipos, std::vector<RLRun> &runs)
+{
+	if (pos < 8 || pos >= ipos) throw std::runtime_error("RL decoder: block offset outside the file");
+	BitReader r(d.data() + pos, d.data() + ipos);
+	const uint64_t nr = r.elias();
+	const bool esc = r.bit();
+	Canon sc = Canon::deserialise(r), cc = Canon::deserialise(r);
+	r.align();
+	runs.resize(nr);
+	for (uint64_t i = 0; i < nr; ++i) runs[i].sym = sc.get(r);
+	r.align();
+	for (uint64_t i = 0; i < nr; ++i) {
+		const int64_t c = cc.get(r);
+		runs[i].len = (esc && c == (int64_t)RL_ESCAPE) ? r.elias() : (uint64_t)c;
+	}
+}
+
+// ---- X.bwt.sparserank + LF steps on the container (role of RLDecoder::getBlockSymHistograms and of the SparseRank consumer,
+// /root/reference/src/bwtdecodeblock.cpp:134-365): per block of the container the counts of the symbols minsym..maxsym BEFORE the
+// block, (maxsym - minsym + 1) 8-byte big-endian numbers per block (reader: :228-236) ----
+void rl_block_sym_histograms(const std::string &bwtfn, const std::string &outfn, int64_t minsym, int64_t maxsym)
+{
+	if (maxsym < minsym) throw std::runtime_error("sparserank: empty symbol range");
+	std::vector<uint8_t> d = read_file(bwtfn);
+	std::vector<RLIndexEntry> idx = rl_index_of(d, bwtfn);
+	const uint64_t ipos = get_be64(d.data() + d.size() - 8);
+	const uint64_t k = (uint64_t)(maxsym - minsym + 1);
+	std::vector<uint64_t> H(k, 0);
+	std::vector<uint8_t> o; o.reserve(idx.size() * k * 8);
+	std::vector<RLRun> runs;
+	for (auto &e : idx) {
+		for (uint64_t c = 0; c < k; ++c) put_be64(o, H[c]);
+		rl_decode_block_at(d, e.pos, ipos, runs);
+		for (auto &r : runs) {
+			if (r.sym < minsym || r.sym > maxsym) throw std::runtime_error("sparserank: symbol outside [minsym,maxsym]");
+			H[(uint64_t)(r.sym - minsym)] += r.len;
+		}
+	}
+	write_file(outfn, o.data(), o.size());
+}
+
+RLSparseRank::RLSparseRank(const std::string &bwtfn, const std::string &histfn, int64_t mins, int64_t maxs)
+	: data(read_file(bwtfn)), minsym(mins), maxsym(maxs)
+{
+	index = rl_index_of(data, bwtfn);
+	ipos = get_be64(data.data() + data.size() - 8);
+	n = get_be64(data.data());
+	sparse = read_file(bwtfn + ".sparserank");
+	const uint64_t k = (uint64_t)(maxsym - minsym + 1);
+	if (sparse.size() != index.size() * k * 8) throw std::runtime_error(bwtfn + ".sparserank does not fit the index of " + bwtfn);
+	vstart.resize(index.size() + 1, 0);
+	for (size_t b = 0; b < index.size(); ++b) vstart[b + 1] = vstart[b] + index[b].syms;
+	std::map<int64_t, uint64_t> hm = read_hist(histfn);
+	if (!hm.empty() && hm.begin()->first >= 0) {           // D[sym] = symbols smaller than sym (bwtdecodeblock.cpp:150-173)
+		D.assign((size_t)hm.rbegin()->first + 1, 0);
+		uint64_t acc = 0;
+		for (auto &kv : hm) { D[(size_t)kv.first] = acc; acc += kv.second; }
+	}
+	cached = ~0ull;
+}
+// symbol at rank i and the number of its occurrences before i
+std::pair<int64_t, uint64_t> RLSparseRank::inverse_select(uint64_t i)
+{
+	if (i >= n) throw std::runtime_error("sparserank: rank out of range");
+	const size_t b = (size_t)(std::upper_bound(vstart.begin(), vstart.end(), i) - vstart.begin()) - 1;      // findVBlock
+	if (cached != b) { rl_decode_block_at(data, index[b].pos, ipos, runs); cached = b; }
+	const uint64_t k = (uint64_t)(maxsym - minsym + 1);
+	std::vector<uint64_t> H(k);
+	for (uint64_t c = 0; c < k; ++c) H[c] = get_be64(sparse.data() + (b * k + c) * 8);
+	uint64_t offset = i - vstart[b];
+	for (auto &r : runs) {
+		if (offset >= r.len) { H[(uint64_t)(r.sym - minsym)] += r.len; offset -= r.len; }
+		else { H[(uint64_t)(r.sym - minsym)] += offset; return {r.sym, H[(uint64_t)(r.sym - minsym)]}; }
+	}
+	throw std::runtime_error("sparserank: block shorter than its index entry says");
+}
+std::pair<int64_t, uint64_t> RLSparseRank::lf(uint64_t i)
+{
+	std::pair<int64_t, uint64_t> p = inverse_select(i);
+	if (p.first < 0 || (size_t)p.first >= D.size()) throw std::runtime_error("sparserank: symbol missing in the histogram");
+	return {p.first, D[(size_t)p.first] + p.second};
+}
+
 uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx)
 {
 	std::vector<uint8_t> d = read_file(fn);

@@ -40,6 +40,17 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index);
 std::vector<RLIndexEntry> rl_index(const std::string &fn);
 
+// ---- consumers of the container's seek index (role of RLDecoder::getBlockSymHistograms / SparseRank, /root/reference/src/bwtdecodeblock.cpp:134-365) ----
+// X.bwt.sparserank: per block of the container, the counts of minsym..maxsym BEFORE the block, 8-byte big-endian each
+void rl_block_sym_histograms(const std::string &bwtfn, const std::string &outfn, int64_t minsym, int64_t maxsym);
+struct RLSparseRank {
+	std::vector<uint8_t> data, sparse; std::vector<RLIndexEntry> index; std::vector<uint64_t> vstart, D; uint64_t ipos = 0, n = 0;
+	int64_t minsym, maxsym; std::vector<RLRun> runs; uint64_t cached;
+	RLSparseRank(const std::string &bwtfn, const std::string &histfn, int64_t minsym, int64_t maxsym);      // reads bwtfn + ".sparserank"
+	std::pair<int64_t, uint64_t> inverse_select(uint64_t i);     // (symbol at rank i, its occurrences before i)
+	std::pair<int64_t, uint64_t> lf(uint64_t i);                 // (symbol at rank i, rank of the suffix one position to the left)
+};
+
 // ---- siblings -------------------------------------------------------------------------------------
 // X.hist: NumberMapSerialisation::serialiseMap<int64,uint64> (reader at
 // /root/reference/src/bwtdecodeblock.cpp:150-173): u64 BE count, then (i64 BE key, u64 BE value)

@@ -286,3 +286,42 @@ def test_bench_line_contract(gpu):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+@pytest.mark.gpu
+def test_seek_index_consumers_sortpreisa_and_bwtdecodeblock(gpu, oracle, tmp_path):
+    """row f4, consumers of the container's seek index: X.preisa -> sorted isa (/root/reference/src/sortPreIsa.cpp:62,95-96), then text[low, low+len)
+    out of X.bwt by LF steps from the nearest sample through X.bwt.sparserank (/root/reference/src/bwtdecodeblock.cpp:134-365: findVBlock, the
+    per-block symbol counts, inverseSelect, lf, decode; arguments :324-333); the decoder itself compares with the compact text file (:371-386)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(66)
+    nb = 150_001
+    b = rng.integers(0, 4, nb, dtype=np.uint8)
+    b[70_000:71_000] = 0                                         # a homopolymer run: long runs in the BWT, escapes in the container
+    pac = tmp_path / "t.pac"
+    oracle.pac_encode(b).tofile(pac)
+    sym = np.concatenate([b + 1, np.zeros(1, dtype=np.uint8)])   # the text as the index sees it: bases 1..4, terminator 0
+    comp = tmp_path / "t.compact"
+    oracle.compact_encode(sym, 3).tofile(comp)
+    out = tmp_path / "t.bwt"
+    r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=1", "isasamplingrate=4096", "outputfilename=%s" % out, str(pac)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    sisa = tmp_path / "t.sisa"
+    r = subprocess.run([os.path.join(root, "bin", "sortPreIsa"), str(tmp_path / "t.preisa"), str(sisa)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    w = np.frombuffer(sisa.read_bytes(), dtype=">u8").reshape(-1, 2)
+    assert np.all(np.diff(w[:, 0].astype(np.int64)) > 0)
+    sa = oracle.sa_circular(sym)
+    assert np.array_equal(sa[w[:, 1].astype(np.int64)], w[:, 0].astype(sa.dtype))          # (pos, rank) pairs
+    text = "".join("\nACGT"[int(c)] for c in sym)
+    n = len(sym)
+    for low, ln in ((0, 100), (5000, 3000), (69_500, 2100), (n - 700, 700), (n - 5000, 4999), (12345, 1)):
+        d = subprocess.run([os.path.join(root, "bin", "bwtdecodeblock"), str(out), str(tmp_path / "t.hist"), str(sisa), str(comp), str(low), str(ln)], capture_output=True)
+        assert d.returncode == 0, d.stderr[-500:]
+        assert d.stdout.decode() == text[low:low + ln], (low, ln)
+    assert os.path.exists(str(out) + ".sparserank")
+    idx_blocks = len(open(str(out) + ".sparserank", "rb").read()) // (5 * 8)
+    assert idx_blocks >= 1
+    d = subprocess.run([os.path.join(root, "bin", "bwtdecodeblock"), str(out), str(tmp_path / "t.hist"), str(sisa), str(comp), str(n - 10), "11"], capture_output=True)
+    assert d.returncode != 0 and b"low+len=" in d.stderr
