@@ -1549,23 +1549,14 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // does not decide.  Groups are at most LS_TIE_CAP long (longer ones are on the overflow list and
 // set no bits); the length guard only keeps a corrupt bitmap from running away.
 // The launch covers the records [lo, hi) (tie groups never cross a bucket, so slices of whole buckets are independent).
-__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+__device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tiebits, uint64_t len, uint64_t q, uint32_t eq_syms, const SaOut &sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
 {
-	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if ((w << 5) >= hi) return;
-	uint32_t bits = tiebits[w];
-	if (!bits) return;
-	uint32_t prevbit = w ? (tiebits[w - 1] >> 31) : 0u;
-	uint32_t starts = bits & ~((bits << 1) | prevbit);          // set bits whose predecessor bit is clear
-	if ((w << 5) < lo) starts &= ~((1u << (lo - (w << 5))) - 1u);             // runs of the neighbouring slices are theirs
-	if ((w << 5) + 32 > hi) starts &= (1u << (hi - (w << 5))) - 1u;
-	while (starts) {
-		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
-		uint64_t q = (w << 5) + k;                               // first tied record; head = q-1
-		uint64_t pos = q - 1;
+	{
+		{
+		uint64_t pos = q - 1;                                    // q = first tied record; head = q-1
 		uint32_t g = 2;
 		for (uint64_t z = q + 1; z < len && g <= (uint32_t)LS_TIE_CAP && ((tiebits[z >> 5] >> (z & 31)) & 1u); ++z) ++g;
-		if (g > (uint32_t)LS_TIE_CAP) continue;   // cannot happen (see above)
+		if (g > (uint32_t)LS_TIE_CAP) return;     // cannot happen (see above)
 		for (uint32_t a = 1; a < g; ++a) {
 			uint64_t x = sa_get(sa, pos + a); uint8_t bx = bwt[pos + a];
 			bool ex = (uint64_t)x + eq_syms + 32 <= T.nbases;
@@ -1584,7 +1575,70 @@ __global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uin
 			sa_set(sa, pos + j, x); bwt[pos + j] = bx;
 		}
 		for (uint32_t a = 0; a < g; ++a) if (sa_get(sa, pos + a) == start) *p0 = (uint32_t)(pos + a);
+		}
 	}
+}
+// starts of the tie groups of a word of the bitmap: set bits whose predecessor bit is clear, inside [lo, hi)
+__device__ __forceinline__ uint32_t tie_starts(const uint32_t *tiebits, uint64_t w, uint64_t lo, uint64_t hi)
+{
+	const uint32_t bits = tiebits[w];
+	if (!bits) return 0u;
+	const uint32_t prevbit = w ? (tiebits[w - 1] >> 31) : 0u;
+	uint32_t starts = bits & ~((bits << 1) | prevbit);
+	if ((w << 5) < lo) starts &= ~((1u << (lo - (w << 5))) - 1u);             // runs of the neighbouring slices are theirs
+	if ((w << 5) + 32 > hi) starts &= (1u << (hi - (w << 5))) - 1u;
+	return starts;
+}
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+{
+	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if ((w << 5) >= hi) return;
+	uint32_t starts = tie_starts(tiebits, w, lo, hi);
+	while (starts) {
+		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
+		tie_group(T, tiebits, len, (w << 5) + k, eq_syms, sa, bwt, start, p0);
+	}
+}
+// The same in two steps (whole blocks): the groups are few (0.3 % of the records) and each costs a chain of dependent gathers, so a
+// thread per bitmap word keeps every wave alive for one lane's sake.  Step 1 lists the group starts (a stream over the bitmap, one
+// atomic per wave), step 2 runs one group per lane, densely.
+constexpr int TIE_WPT = 32;                   // bitmap words per thread of k_tie_collect: one atomic on the list counter per 8192 words
+__global__ __launch_bounds__(256) void k_tie_collect(const uint32_t *tiebits, uint64_t len, uint32_t *list, uint32_t cap, uint32_t *counter)
+{
+	__shared__ uint32_t ws[4];
+	__shared__ uint32_t s_base;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint64_t w0 = (uint64_t)blockIdx.x * (256 * TIE_WPT);
+	uint32_t c = 0;
+	#pragma unroll 4
+	for (int i = 0; i < TIE_WPT; ++i) { const uint64_t w = w0 + (uint64_t)i * 256 + tid; if ((w << 5) < len) c += __popc(tie_starts(tiebits, w, 0, len)); }
+	uint32_t inc = c;
+	#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += t; }
+	if (lane == 63) ws[wave] = inc;
+	__syncthreads();
+	if (tid == 0) { const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3]; s_base = total ? atomicAdd(counter, total) : 0u; }
+	__syncthreads();
+	uint32_t at = s_base + inc - c;
+	for (uint32_t i = 0; i < wave; ++i) at += ws[i];
+	if (c == 0) return;
+	for (int i = 0; i < TIE_WPT; ++i) {
+		const uint64_t w = w0 + (uint64_t)i * 256 + tid;
+		if ((w << 5) >= len) break;
+		uint32_t starts = tie_starts(tiebits, w, 0, len);
+		while (starts) {
+			const uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
+			if (at < cap) list[at] = (uint32_t)((w << 5) + k);
+			++at;
+		}
+	}
+}
+__global__ __launch_bounds__(256) void k_tie_fix_list(TextView T, const uint32_t *tiebits, uint64_t len, const uint32_t *list, const uint32_t *counter, uint32_t cap,
+                                                      uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+{
+	uint32_t cnt = *counter; cnt = cnt < cap ? cnt : cap;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
+		tie_group(T, tiebits, len, list[i], eq_syms, sa, bwt, start, p0);
 }
 
 // sorted (size << 32 | start) pairs -> sizes (scanned into list offsets by the caller) and starts
@@ -1898,7 +1952,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	if (!sliced || out.late_writes) {
 		Scope sc(tl, KF_TIES, len / 8);
-		hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
+		static const int tie_two_step = getenv("B3M_TIE_TWO_STEP") ? atoi(getenv("B3M_TIE_TWO_STEP")) : 1;      // measurement switch
+		if (tie_two_step && len >= (1ull << 22) && len < (1ull << 32)) {
+			// both record buffers are free by now: the list of group starts goes into one of them
+			uint32_t *glist = reinterpret_cast<uint32_t *>(ws.keyB), *gcnt = reinterpret_cast<uint32_t *>(M.lists) + 60;
+			const uint32_t gcap = (uint32_t)std::min<uint64_t>(2 * ws.cap, 0xFFFFFFF0ull);
+			B3M_HIP(hipMemsetAsync(gcnt, 0, 4, s));
+			hipLaunchKernelGGL(k_tie_collect, dim3(nblk((len + 31) / 32, 256 * TIE_WPT)), dim3(256), 0, s, ws.t[0], len, glist, gcap, gcnt);
+			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0);
+		} else
+			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
 	}
 	uint32_t nov = 0, nlist[3] = {0, 0, 0};
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
