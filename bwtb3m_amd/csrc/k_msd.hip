@@ -238,6 +238,12 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	__syncthreads();
 	for (int c = 0; c < TCH; ++c) {
 		const uint64_t cpos = A.P0 + (uint64_t)tile * (TCH * CHUNK) + (uint64_t)c * CHUNK;
+		if (LOCAL && (cpos >= end || cpos + CHUNK <= A.start)) {
+			// a chunk outside the block: its column of the run table is empty (written here: the table is not cleared beforehand)
+			const uint32_t col = tile * TCH + c;
+			for (int b = tid; b < bins; b += W0_THREADS) A.runtab0[(uint64_t)b * A.nchunks0 + col] = 0u;
+			continue;
+		}
 		if (cpos >= end) break;
 		if (cpos + CHUNK <= A.start) continue;
 		// the whole chunk inside the block, every window inside the text, a word in front of it
@@ -1702,8 +1708,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	if (local0) {
 		{
 			Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
-			B3M_HIP(hipMemsetAsync(M.tab0, 0, 4ull * bins0 * ncol0, s));
-			A.runtab0 = M.tab0; A.nchunks0 = ncol0;
+			A.runtab0 = M.tab0; A.nchunks0 = ncol0;                  // (every column is written by its chunk, empty ones too)
 			hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		}
 		Scope sc(tl, KF_SCAN, 4ull * bins0 * ncol0);
