@@ -6,20 +6,25 @@
 //        [ 29 key bits | 3 bits predecessor symbol | 32 bits position ]
 // and the passes are (C3: 3 Gbase, D0 = 11, D1 = 8, 2^19 final buckets of ~5.7 K records):
 //
-//   level 0 (k_l0_pass)       : text -> records, partitioned by the first D0 <= 12 bits.  The
-//                               records do not exist yet, so a wide fan-out is cheap: a chunk of
-//                               32 Ki POSITIONS is counting-sorted as 16-bit indices inside LDS
-//                               (text of the chunk: 8 KB) and the records are generated in
-//                               bucket order, every digit leaving the CU as one contiguous run.
-//   level 1 (k_msd_pass)      : records of every level-0 bucket partitioned by the next D1 <= 8
-//                               bits (chunks of 4096 records through LDS; wider fan-outs break
-//                               the 128-byte runs and halve the write bandwidth).
-//   finish  (k_finish_lds)    : one workgroup per final bucket: read ONCE into registers, counting
-//                               sort on 13 more key bits in LDS, rank inside the bin, BWT byte
-//                               (+ SA entry) dropped at the final place, key ties marked.
-//   ties    (k_tie_fix)       : runs of equal 29+D0 known bits ordered from the text.
+//   level 0 (k_l0_pass)       : text -> records, by the first D0 <= 12 bits.  The records do not exist yet, so a wide
+//                               fan-out is cheap: a chunk of 65,280 POSITIONS is counting-sorted as 16-bit indices inside
+//                               LDS (text of the chunk: 16 KB) and the records are generated in digit order.  Whole blocks:
+//                               CHUNK-LOCAL (template flag LOCAL): the chunk's records go to the chunk's own index range, a
+//                               stream of whole lines, and a run table (row = digit, column = chunk) says where each digit
+//                               sits; no counting pass.  Suffix-range shards (they keep 1/N of every chunk) and texts of
+//                               2^32 symbols and more: the scattering form (counting pass, [digit][tile] scan, one run per
+//                               digit and chunk written to the digit's bucket).
+//   level 1 (k_l1_gather /    : the next D1 <= 8 bits, chunk-local too: 16 Ki records of ONE level-0 bucket are sorted by
+//            k_l1_local)        their digit in LDS and written contiguously to the bucket's range (its rank range); behind a
+//                               chunk-local level 0 they are gathered from the bucket's row of runs (slot -> run map in LDS),
+//                               behind the scattering one they are a stream copy.  Its own run table for the finish.
+//   finish  (k_finish_fast /  : one workgroup per final bucket: its ~90 runs of ~64 records gathered ONCE into registers,
+//            finish_bucket)     counting sort on 13 more key bits in LDS, rank inside the bin, BWT byte (+ SA entry) dropped
+//                               at the final place, key ties marked.
+//   ties    (k_tie_collect,   : runs of equal 29+D0 known bits ordered from the text.
+//            k_tie_fix_list)
 //
-// HBM traffic per suffix: 0.5 (text, twice) + 8 | 8 + 16 | 8 + 1 (+4) = ~41 B.
+// HBM traffic per suffix: 0.25 (text) + 8 | 8 (+4 of unaligned runs) + 8 | 8 (+2) + 1 (+4) = ~43 B (PMC: 128 GB per 3 Gbase step).
 // Buckets above the LDS capacity (skewed input) take k_bucket_finish: one more 8-bit partition
 // through HBM, then one wave per sub-bucket.  Bins / tie groups above 32 records (repeats), sub-
 // buckets above 512 and buckets above 2^20 records go to the overflow list and are finished by the
