@@ -616,7 +616,10 @@ def test_low_complexity_bucket_above_a_million_records(gpu, oracle):
     plan.close()
 
 
-@pytest.mark.parametrize("nb", [24_000_000, 50_000_000, 100_000_000, 200_000_000])
+@pytest.mark.parametrize("nb", [24_000_000, 50_000_000, 100_000_000, 200_000_000,
+                                # the edges of the chunk-local level 0: just above the size where a level 1 exists, whole tiles of 4 x 65,280
+                                # positions exactly / one more / one less (pacterm adds the terminator), a whole level-1 chunk count
+                                23_592_961, 100 * 4 * 65280 - 1, 100 * 4 * 65280, 100 * 4 * 65280 + 1, 2048 * 16384 - 1])
 def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
     # sizes whose level-1 digit is 1..5 bits wide (the oracle is too slow here): the on-device LF walk
     # re-derives the text from the BWT (checkbwt, /root/reference/src/checkbwt.cpp:176-243)
