@@ -66,6 +66,7 @@ SYMBOLS = [
     ("b3m_plan_num_blocks", _u64, [_p]),
     ("b3m_plan_workspace_bytes", _u64, [_p]),
     ("b3m_plan_text_bytes", _u64, [_p]),
+    ("b3m_plan_text_buffer", _p, [_p]),
     ("b3m_plan_run", _i, [_p, _p, _p, _p]),
     ("b3m_plan_run_host", _i, [_p, _p, _p, ctypes.POINTER(E2ETimes), _p]),
     ("b3m_plan_set_packed_output", _i, [_p, _i]),

@@ -391,6 +391,7 @@ void b3m_plan_destroy(b3m_plan *p)
 uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 0; }
 uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 0; }
 uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
+void *b3m_plan_text_buffer(b3m_plan *p) { return p ? (void *)p->d_text : nullptr; }
 
 namespace {
 // BWT symbols -> the .pac layout (4 symbols per byte, the first in the top bits); sub = 1 for pacterm (symbols 1..4 -> 0..3, the
@@ -470,9 +471,14 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	B3M_HIP(hipEventRecord(ev0, s));
 	// resident, padded copy of the packed text
 	uint64_t tb = packed_text_bytes(n, p->type);
-	B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
-	if (host) { B3M_HIP(hipMemcpyAsync(p->d_text, h_text_in, tb, hipMemcpyHostToDevice, s)); B3M_HIP(hipEventRecord(evh1, s)); }
-	else B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+	if (!host && d_text_in == (const void *)p->d_text) {
+		// the caller loaded the text into the plan's own buffer (b3m_plan_text_buffer): used in place, only the padding is cleared
+		B3M_HIP(hipMemsetAsync(p->d_text + tb, 0, p->text_cap - tb, s));
+	} else {
+		B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
+		if (host) { B3M_HIP(hipMemcpyAsync(p->d_text, h_text_in, tb, hipMemcpyHostToDevice, s)); B3M_HIP(hipEventRecord(evh1, s)); }
+		else B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+	}
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
 	B3M_HIP(hipMemsetAsync(p->d_hist, 0, 8 * 256 * B, s));
 	B3M_HIP(hipMemsetAsync(p->d_anchors, 0, 4 * (p->total_anchors + 1), s));

@@ -83,6 +83,15 @@ class Plan:
     def slice_capacity(self):
         return int(lib().b3m_plan_slice_capacity(self._h))
 
+    def text_buffer(self):
+        """the plan's own resident text buffer as a uint8 CUDA tensor (a view, b3m_plan_text_buffer): a text copied in here and passed to
+        run() is used in place"""
+        ptr = lib().b3m_plan_text_buffer(self._h)
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (self.text_bytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_View(), device="cuda")
+
     def run(self, d_text, d_out=None):
         """one pass of the hot path.  Sharded plans return the view of their slice (see result())."""
         assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.numel() >= self.text_bytes

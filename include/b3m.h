@@ -101,6 +101,9 @@ void      b3m_plan_destroy(b3m_plan *p);
 uint64_t  b3m_plan_num_blocks(const b3m_plan *p);
 uint64_t  b3m_plan_workspace_bytes(const b3m_plan *p);
 uint64_t  b3m_plan_text_bytes(const b3m_plan *p);            /* packed input size in bytes */
+/* the plan's own resident text buffer (device memory, b3m_plan_text_bytes() bytes and padding behind them): a text loaded HERE and passed
+ * to b3m_plan_run as d_text is used in place (no copy into the plan: 0.75 GB read + written at 3 Gbase); any other d_text is copied here */
+void     *b3m_plan_text_buffer(b3m_plan *p);
 
 /* d_text: packed input exactly as in the file (bytestream: n bytes; pac/pacterm: BWA .pac
  * payload, base i in byte i>>2 at bit ((~i)&3)<<1), b3m_plan_text_bytes() readable bytes.

@@ -1150,3 +1150,26 @@ def test_rl_container_written_from_hbm_equals_the_host_encoder(gpu, kind, tmp_pa
         assert len(hb) == len(db) and hb == db, (kind, k, len(hb), len(db))
         out = np.zeros(len(a), dtype=np.uint8); n = ctypes.c_uint64(0)
         assert L.b3m_rl_read(fd, out.ctypes.data, len(a), ctypes.byref(n)) == 0 and n.value == len(a) and np.array_equal(out, a)
+
+
+def test_text_in_the_plans_own_buffer_is_used_in_place(gpu, oracle):
+    """b3m_plan_text_buffer: a text loaded into the plan's resident buffer and passed to run() is not copied; the result is the same, run after
+    run, and a foreign buffer afterwards is copied in as before."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    for itype, nb in (("pacterm", 700_001), ("pac", 300_003), ("bytestream", 70_000)):
+        rng = np.random.default_rng(nb)
+        if itype == "bytestream":
+            buf = rng.integers(0, 256, nb, dtype=np.uint8); sym = buf
+        else:
+            buf = _pac(oracle, rng.integers(0, 4, nb, dtype=np.uint8)); sym = oracle.symbols_from_file_bytes(buf, itype)
+        ref = oracle.bwt(sym)
+        plan = engine.Plan(len(sym), itype, blocksize=0 if itype != "pac" else 100_000)
+        tb = plan.text_buffer()
+        assert tb.is_cuda and tb.numel() == plan.text_bytes
+        tb.copy_(torch.from_numpy(np.ascontiguousarray(buf[:tb.numel()])))
+        for _ in range(2):
+            assert np.array_equal(plan.run(tb).cpu().numpy(), ref)
+        other = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
+        assert np.array_equal(plan.run(other).cpu().numpy(), ref)
+        plan.close()
