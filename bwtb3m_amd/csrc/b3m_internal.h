@@ -132,6 +132,10 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);
 // a caller that streams the BWT away while it is being made: the MSD finish runs in `nslices` slices of whole level-0
 // buckets and calls fn(ctx, first, last) on the host once the kernels that make bwt[first, last) final are enqueued
 struct SliceHook { int nslices; void (*fn)(void *ctx, uint64_t first, uint64_t last); void *ctx; };
+// a text that is still arriving (host-to-host runs: the H2D copy goes out in pieces on another stream): after event i the first
+// bytes_ready[i] bytes of the packed text are in place.  The chunk-local level 0 needs no global pass over the text before it starts,
+// so it runs piece by piece behind the copy; every other path waits for the last event first.
+struct TextArrival { int n; hipEvent_t ev[16]; uint64_t bytes_ready[16]; };
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
@@ -143,6 +147,7 @@ struct BlockSortWs {
 	MsdWs msd;
 	uint32_t *d_scalars = nullptr;    // small device scalars
 	const SliceHook *slice_hook = nullptr;
+	const TextArrival *arrival = nullptr;
 	uint64_t *d_symhist_out = nullptr; // optional: the MSD path adds the block's symbol histogram here (it falls out of the level-0 digit counts)
 };
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)

@@ -462,6 +462,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	Timeline *tl = &p->tl;
 	tl->reset(); tl->stream = s; tl->enabled = true;
 	hipEvent_t ev0 = tl->get(), ev1 = tl->get();
+	TextArrival arrival{}; bool streaming_text = false;
 	if (host) {
 		evh0 = tl->get(); evh1 = tl->get(); evh2 = tl->get(); evh3 = tl->get();
 		B3M_HIP(hipStreamSynchronize(s));
@@ -475,9 +476,29 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		// the caller loaded the text into the plan's own buffer (b3m_plan_text_buffer): used in place, only the padding is cleared
 		B3M_HIP(hipMemsetAsync(p->d_text + tb, 0, p->text_cap - tb, s));
 	} else {
-		B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
-		if (host) { B3M_HIP(hipMemcpyAsync(p->d_text, h_text_in, tb, hipMemcpyHostToDevice, s)); B3M_HIP(hipEventRecord(evh1, s)); }
-		else B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+		if (host) {
+			// the text arrives in pieces on the copy stream; a single-block sort starts its (chunk-local) level 0 behind the first piece,
+			// everything else waits for the last one (TextArrival)
+			hipEvent_t e0 = tl->get();
+			B3M_HIP(hipEventRecord(e0, s));
+			B3M_HIP(hipStreamWaitEvent(p->copy_stream, e0, 0));
+			tl->pool.push_back(e0);
+			B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), p->copy_stream));
+			const int np = tb >= (64ull << 20) ? 8 : 1;
+			arrival.n = np;
+			for (int i = 0; i < np; ++i) {
+				const uint64_t a0 = (tb * (uint64_t)i / np) & ~255ull, a1 = i + 1 == np ? tb : (tb * (uint64_t)(i + 1) / np) & ~255ull;
+				B3M_HIP(hipMemcpyAsync(p->d_text + a0, (const uint8_t *)h_text_in + a0, a1 - a0, hipMemcpyHostToDevice, p->copy_stream));
+				arrival.ev[i] = i + 1 == np ? evh1 : tl->get();
+				B3M_HIP(hipEventRecord(arrival.ev[i], p->copy_stream));
+				arrival.bytes_ready[i] = a1;
+			}
+			streaming_text = B == 1 && p->nshards == 1 && p->seq_shards <= 1;
+			if (!streaming_text) B3M_HIP(hipStreamWaitEvent(s, evh1, 0));
+		} else {
+			B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));
+			B3M_HIP(hipMemcpyAsync(p->d_text, d_text_in, tb, hipMemcpyDeviceToDevice, s));
+		}
 	}
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
 	B3M_HIP(hipMemsetAsync(p->d_hist, 0, 8 * 256 * B, s));
@@ -501,8 +522,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			// one block: its BWT is the result and goes straight to the caller's buffer
 			p->bs.d_symhist_out = (sh == 0 || p->seq_shards == 1) ? p->d_hist + 256 * k : nullptr;      // the histogram of the whole block falls out of every shard's level-0 totals: taken once
 			p->bs.slice_hook = (host && B == 1 && nsh == 1) ? &hook : nullptr;
+			p->bs.arrival = streaming_text ? &arrival : nullptr;
 			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a, p->d_p0tmp + k, sh, nsh, need_sa);
-			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr;
+			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr; p->bs.arrival = nullptr;
 			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
@@ -652,6 +674,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		p->e2e.streamed_bytes = sink.copied == n ? (p->packed_out ? (n + 3) / 4 : n) : 0;
 		for (auto e : sink.evs) tl->pool.push_back(e);
 		tl->pool.push_back(evh0); tl->pool.push_back(evh1); tl->pool.push_back(evh2); tl->pool.push_back(evh3);
+		for (int i = 0; i + 1 < arrival.n; ++i) tl->pool.push_back(arrival.ev[i]);
 	}
 	tl->collect(p->kms, p->klaunch, p->kbytes);
 	tl->pool.push_back(ev0); tl->pool.push_back(ev1);

@@ -638,6 +638,7 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	const bool tree = nshards <= 1 && !(start == 0 && len == T.n) && T.n < (1ull << 32);
 	const uint64_t H = tree ? std::min(std::min<uint64_t>(ws.cap - len, T.n - (start + len)), block_overhang()) : 0;
 	const bool msd = msd_applicable(T, len);
+	if (!msd && ws.arrival) for (int i = 0; i < ws.arrival->n; ++i) B3M_HIP(hipStreamWaitEvent(s, ws.arrival->ev[i], 0));      // only the MSD path starts behind a text that is still arriving
 	if (msd) block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards, need_sa, 0, H > 0);
 	else block_sort_lsd(T, start, len, ws, s, tl, out, 0, H > 0);
 	if (out.want_ext) {

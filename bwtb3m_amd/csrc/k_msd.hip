@@ -204,6 +204,7 @@ struct L0Args {
 	int pb;                      // position bits of a record
 	uint32_t *runtab0;           // LOCAL: row (digit) x column (chunk): start inside the chunk | length << 16
 	uint32_t nchunks0;           // LOCAL: columns
+	uint32_t tile_base;          // LOCAL: first tile of this launch (the text may arrive in pieces: one launch per piece)
 };
 
 // window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	const int bins = (int)(A.keep_hi - A.keep_lo);           // bin = digit - keep_lo; digits outside [keep_lo, keep_hi) are not this sort's (suffix-range shard)
 	const uint32_t klo = A.keep_lo, nbin = (uint32_t)bins;
 	const int dsh = 64 - A.D, dsh32 = 32 - A.D;
-	const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
+	const uint32_t tile = (LOCAL ? A.tile_base : 0u) + blockIdx.x, ntiles = gridDim.x;
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
 	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
@@ -1710,11 +1711,30 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const uint32_t ncol0 = ntA * (uint32_t)W0A_TCH;             // columns of the level-0 run table (whole tiles)
 	(void)nchunks0;
 	unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
+	if (!local0 && ws.arrival) for (int i = 0; i < ws.arrival->n; ++i) B3M_HIP(hipStreamWaitEvent(s, ws.arrival->ev[i], 0));
 	if (local0) {
 		{
 			Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
 			A.runtab0 = M.tab0; A.nchunks0 = ncol0;                  // (every column is written by its chunk, empty ones too)
-			hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+			// a text that is still arriving: tiles go out as the bytes they read (their positions, a word in front, 48 bases behind) are in place
+			uint32_t t_done = 0;
+			if (ws.arrival) {
+				for (int i = 0; i < ws.arrival->n && t_done < ntA; ++i) {
+					const uint64_t bytes = ws.arrival->bytes_ready[i];
+					const uint64_t pos_ok = bytes >= 32 ? (bytes - 32) * 4 : 0;                       // positions whose windows are complete
+					uint32_t t_end = i + 1 == ws.arrival->n ? ntA : (uint32_t)std::min<uint64_t>(ntA, pos_ok > P0 ? (pos_ok - P0) / tile0 : 0);
+					B3M_HIP(hipStreamWaitEvent(s, ws.arrival->ev[i], 0));
+					if (t_end > t_done) {
+						A.tile_base = t_done;
+						hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true>), dim3(t_end - t_done), dim3(W0_THREADS), 0, s, A);
+						t_done = t_end;
+					}
+				}
+			}
+			if (t_done < ntA) {
+				A.tile_base = t_done;
+				hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true>), dim3(ntA - t_done), dim3(W0_THREADS), 0, s, A);
+			}
 		}
 		Scope sc(tl, KF_SCAN, 4ull * bins0 * ncol0);
 		hipLaunchKernelGGL(k_rows0_totals, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, d_tot);
