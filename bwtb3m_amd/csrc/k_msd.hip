@@ -346,7 +346,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
 				r = make_rec(x, A.D, pr, cpos + li, &dgt, A.pb);
 			}
-			if (LOCAL) { A.rec_out[(cpos - A.P0) + q] = r; continue; }
+			if (LOCAL) { __builtin_nontemporal_store(r, &A.rec_out[(cpos - A.P0) + q]); continue; }
 			const uint32_t bin = dgt - klo;
 			const uint32_t rs = bin ? cur[bin - 1] : 0u;          // start of run bin
 			A.rec_out[(uint64_t)gbase[bin] + (q - rs)] = r;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 		if (c + 1 < nchunks) load_chunk(c + 1);                       // issued before this chunk is copied out: read and write streams overlap
 		__syncthreads();
 		uint64_t *out = A.rec_out + (uint64_t)tile.out_off + cbase;
-		for (uint32_t p = tid; p < nvalid; p += THREADS) out[p] = srec[p];
+		for (uint32_t p = tid; p < nvalid; p += THREADS) __builtin_nontemporal_store(srec[p], &out[p]);
 	}
 	__syncthreads();
 	for (int d = tid; d < bins; d += THREADS) {
