@@ -439,7 +439,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_local(L1Args A)
 		}
 		__syncthreads();
 		uint64_t *out = A.rec_out + (uint64_t)tile.in_off + cbase;
-		for (uint32_t p = tid; p < nvalid; p += THREADS) out[p] = srec[p];
+		for (uint32_t p = tid; p < nvalid; p += THREADS) __builtin_nontemporal_store(srec[p], &out[p]);
 	}
 	__syncthreads();
 	// the tile's columns of the run table: digit d -> nchunks consecutive entries of row d
