@@ -261,18 +261,26 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
 		__syncthreads();
 		// ---- count ----
+		// a suffix-range shard keeps 1/N of the positions: the count remembers WHICH (16 bits per word of 16 positions, in registers: the
+		// same thread takes the same words in the place phase) so that the place phase only visits those
+		constexpr int NJ = (WORDS + W0_THREADS - 1) / W0_THREADS;
+		uint32_t km[(COUNT_ONLY || LOCAL) ? 1 : (NJ + 1) / 2];
+		const bool sparse = !COUNT_ONLY && !LOCAL && 2u * nbin <= (1u << A.D);
+		if (!COUNT_ONLY && !LOCAL) { for (int j = 0; j < (NJ + 1) / 2; ++j) km[j] = 0u; }
 		if (fast) {
 			#pragma unroll
-			for (int j = 0; j < (WORDS + W0_THREADS - 1) / W0_THREADS; ++j) {
+			for (int j = 0; j < NJ; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
 				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
 				// the digit needs <= 12 bits of the window: 32-bit funnel shifts of two words do
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
+				uint32_t mk = 0;
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
 					const uint32_t bin = ((s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32) - klo;
-					if (bin < nbin) atomicAdd(&cur[bin], 1u);
+					if (bin < nbin) { atomicAdd(&cur[bin], 1u); mk |= 1u << s; }
 				}
+				if (!COUNT_ONLY && !LOCAL) km[j >> 1] |= mk << (16 * (j & 1));
 			}
 		} else {
 			#pragma nounroll
@@ -304,9 +312,23 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		}
 		__syncthreads();
 		// ---- place the chunk-local positions in digit order (order inside a digit is irrelevant) ----
-		if (fast) {
+		if (fast && sparse) {
 			#pragma unroll
-			for (int j = 0; j < (WORDS + W0_THREADS - 1) / W0_THREADS; ++j) {
+			for (int j = 0; j < NJ; ++j) {
+				const uint32_t w = j * W0_THREADS + tid;
+				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
+				uint32_t mk = (km[(COUNT_ONLY || LOCAL) ? 0 : (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+				if (mk == 0) continue;
+				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
+				while (mk) {
+					const uint32_t sft = (uint32_t)__ffs(mk) - 1u; mk &= mk - 1u;
+					const uint32_t bin = (__funnelshift_l(w1, w0, 2u * sft) >> dsh32) - klo;       // (a shift of 0 returns w0)
+					sidx[atomicAdd(&cur[bin], 1u)] = (uint16_t)(w * 16 + sft);
+				}
+			}
+		} else if (fast) {
+			#pragma unroll
+			for (int j = 0; j < NJ; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
 				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
