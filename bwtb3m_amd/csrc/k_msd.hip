@@ -1765,8 +1765,10 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
+	bool totals_ready = local0;             // d_tot holds this pass's digit totals (NOT out.symhist_done: a pass that starts over with the suffix array kept inherits that flag, while d_tot has been overwritten since)
 	if (ws.d_symhist_out && dg.D0 >= 2) {
 		if (!local0) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		totals_ready = true;
 		hipLaunchKernelGGL(k_symhist_from_totals, dim3(1), dim3(256), 0, s, d_tot, bins0, dg.D0, T.type == B3M_INPUT_PACTERM ? 1 : 0,
 		                   (T.type == B3M_INPUT_PACTERM && start + len_in == T.n) ? 1 : 0, reinterpret_cast<unsigned long long *>(ws.d_symhist_out));
 		out.symhist_done = true;
@@ -1776,7 +1778,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// suffix-range shard: this rank keeps the level-0 digits [lo, hi) holding the ranks
 		// [shard*n/N, (shard+1)*n/N) as evenly as whole digits allow.  The totals come from the
 		// text alone, so every rank derives the same boundaries without talking to anyone.
-		if (!out.symhist_done) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+		if (!totals_ready) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
 		std::vector<unsigned long long> tot(bins0);
 		B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
@@ -1791,7 +1793,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		uint32_t lo = bound(shard), hi = bound(shard + 1);
 		out.slice_offset = cum[lo];
 		len = cum[hi] - cum[lo];
-		B3M_REQUIRE(len <= ws.cap && len < (1ull << 32), "suffix-range shard larger than the workspace (skewed input): use block mode or fewer shards");
+		if (!(len <= ws.cap && len < (1ull << 32))) {
+			uint64_t mx = 0; for (uint32_t d = lo; d < hi; ++d) mx = std::max<uint64_t>(mx, tot[d]);
+			throw Error("suffix-range shard larger than the workspace (skewed input): shard " + std::to_string(shard) + " of " + std::to_string(nshards) + " would hold " +
+			            std::to_string(len) + " suffixes (level-0 digits " + std::to_string(lo) + ".." + std::to_string(hi) + ", the heaviest has " + std::to_string(mx) +
+			            "), the workspace " + std::to_string(ws.cap) + ": use block mode or fewer shards");
+		}
 		// The shard's level 0 only has bins for its own digits [lo, hi).  Where the text is so long that D0 + D1 bits leave final
 		// buckets above the LDS sort's size (n > ~6 G: 30 Gbase has 2^23 of them), the shard spends the bins it does not need for
 		// other shards' digits on S more bits of its own: one more counting pass over the text, and level 0 partitions by D0 + S bits.

@@ -1173,3 +1173,38 @@ def test_text_in_the_plans_own_buffer_is_used_in_place(gpu, oracle):
         other = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
         assert np.array_equal(plan.run(other).cpu().numpy(), ref)
         plan.close()
+
+
+def test_long_repeats_in_suffix_range_shards_30mbase_bwt_only(gpu):
+    """The same at a size with a level 1 (30 Mbase) and BWT-only shard plans: a shard whose local rounds leave ties starts over with the suffix
+    array kept, inside the same call; that second pass used the digit totals of the first, which level 1 had overwritten by then (wrong shard
+    borders or a refusal; found by tools/fuzz_large.py in round 2).  The shards' slices, finished collectively, must equal the one-block BWT."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    nb = 30_000_003
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    b = torch.randint(0, 4, (nb,), device="cuda", dtype=torch.uint8, generator=g)
+    b[1_000_000:1_200_000] = 2                                              # homopolymer run
+    b[9_000_000:9_100_000] = b[9_000_000:9_000_100].repeat(1000)            # tandem array
+    b[20_000_000:20_150_000] = b[3_000_000:3_150_000].clone()               # a 150-kb copy
+    pad = (-nb) % 4
+    bb = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device="cuda")]).view(-1, 4)
+    pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
+    d_text = torch.cat([pac, torch.tensor([nb % 4], dtype=torch.uint8, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    n = nb + 1
+    plan = engine.Plan(n, "pacterm", isasamplingrate=1 << 16)
+    one = plan.run(d_text).clone()
+    torch.cuda.synchronize()
+    assert plan.lf_walk(one, sarate=0)[:2] == (0, 0)
+    plan.close()
+    for nshards in (4, 7):
+        plans, slices = _run_all_shards(torch, engine, d_text, n, "pacterm", nshards, 0)
+        off = 0
+        for p, sl in zip(plans, slices):
+            r = p.result()
+            assert r["slice_offset"] == off and r["slice_len"] == sl.numel()
+            off += sl.numel()
+        assert off == n and torch.equal(torch.cat(slices), one)
+        assert max(p.result()["tie_rounds"] for p in plans) <= 4 + 24
+        for p in plans:
+            p.close()

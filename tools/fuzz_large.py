@@ -1,0 +1,76 @@
+"""Randomised sweep at sizes the oracle cannot sort (24 M - 400 M bases): random composition (uniform, AT-rich, two symbols), planted repeats
+(copies, tandem arrays, homopolymer runs), one block / a few blocks of a merge tree / suffix-range shards; every result is verified by the
+on-device LF walk (/root/reference/src/checkbwt.cpp:176-243 semantics) and block / shard forms must equal the one-block BWT.
+python tools/fuzz_large.py [iterations] [seed]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from bwtb3m_amd import engine
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+bad = 0; t0 = time.time()
+for it in range(iters):
+    nb = int(rng.integers(24_000_000, 400_000_000))
+    comp = int(rng.integers(0, 4))
+    g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1, 1 << 40)))
+    if comp == 0: b = torch.randint(0, 4, (nb,), device="cuda", dtype=torch.uint8, generator=g)
+    elif comp == 1:
+        p = torch.tensor([0.33, 0.17, 0.17, 0.33], device="cuda")          # AT 66 %
+        b = torch.multinomial(p, nb, replacement=True, generator=g).to(torch.uint8)
+    elif comp == 2: b = torch.randint(0, 2, (nb,), device="cuda", dtype=torch.uint8, generator=g) * 3
+    else:
+        p = torch.tensor([0.7, 0.1, 0.1, 0.1], device="cuda")
+        b = torch.multinomial(p, nb, replacement=True, generator=g).to(torch.uint8)
+    for _ in range(int(rng.integers(0, 6))):           # planted repeats
+        kind = int(rng.integers(0, 3)); ln = int(rng.integers(100, 300_000)); dst = int(rng.integers(0, nb - ln))
+        if kind == 0: src = int(rng.integers(0, nb - ln)); b[dst:dst + ln] = b[src:src + ln].clone()
+        elif kind == 1: u = int(rng.integers(1, 200)); b[dst:dst + ln] = b[dst:dst + u].repeat((ln + u - 1) // u)[:ln]
+        else: b[dst:dst + ln] = int(rng.integers(0, 4))
+    itype = ["pac", "pacterm"][int(rng.integers(0, 2))]
+    # .pac image on the device
+    pad = (-nb) % 4
+    bb = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device="cuda")]).view(-1, 4)
+    pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
+    tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device="cuda")
+    d_text = torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    n = nb + (1 if itype == "pacterm" else 0)
+    form = int(rng.integers(0, 3))
+    ok = True; msg = ""
+    try:
+        plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
+        one = plan.run(d_text).clone(); torch.cuda.synchronize()
+        lf = plan.lf_walk(one, sarate=0)[:2] if itype == "pacterm" or True else (0, 0)
+        ok &= lf == (0, 0); msg = "LF %s rounds %d" % (lf, plan.result()["tie_rounds"])
+        plan.close()
+        if form == 1:
+            nblk = int(rng.integers(2, 6))
+            plan = engine.Plan(n, itype, isasamplingrate=1 << 16, blocksize=(n + nblk - 1) // nblk)
+            out = plan.run(d_text); torch.cuda.synchronize()
+            ok &= bool(torch.equal(out, one)); msg += " blocks %d eq %s" % (plan.result()["num_blocks"], ok)
+            plan.close()
+        elif form == 2:
+            ns = int(rng.integers(2, 9))
+            plans, slices = [], []
+            for k in range(ns):
+                p = engine.Plan(n, itype, shard=k, nshards=ns); slices.append(p.run(d_text).clone()); plans.append(p)
+            pend = [p.tie_pending() for p in plans]
+            if sum(pend):                              # long repeats: the collective finish over all shards' suffix arrays
+                for k, p in enumerate(plans):
+                    if not p.has_sa():
+                        sl = torch.empty(p.slice_capacity, dtype=torch.uint8, device="cuda")
+                        engine.rerun_for_ties(p, d_text, sl); slices[k] = sl[: p.result()["slice_len"]].clone()
+                pend = [p.tie_pending() for p in plans]
+                exported = [p.tie_export("cuda") for p in plans]
+                sa_all = torch.cat([e[0] for e in exported]); pairs_all = torch.cat([e[1] for e in exported])
+                for k, p in enumerate(plans):
+                    engine.finish_shard_ties(p, slices[k], lambda sa: sa_all.clone(), lambda pr, k=k: (pairs_all, sum(pend[:k])))
+            ok &= bool(torch.equal(torch.cat(slices), one)); msg += " shards %d eq %s (ties %d)" % (ns, ok, sum(pend))
+            for p in plans: p.close()
+    except Exception as ex:   # noqa: BLE001
+        ok = False; msg += " EXC " + repr(ex)[:400]
+    print("%s it=%d n=%d %s comp=%d form=%d %s  %.0f s" % ("ok " if ok else "BAD", it, n, itype, comp, form, msg, time.time() - t0), flush=True)
+    bad += 0 if ok else 1
+    del d_text, b, pac, one
+    torch.cuda.empty_cache()
+print("done: %d iterations, %d bad" % (iters, bad))
+sys.exit(1 if bad else 0)
