@@ -493,7 +493,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 				B3M_HIP(hipEventRecord(arrival.ev[i], p->copy_stream));
 				arrival.bytes_ready[i] = a1;
 			}
-			streaming_text = B == 1 && p->nshards == 1 && p->seq_shards <= 1;
+			// (pacterm only: in a circular pac text the BWT symbol of position 0 is the text's LAST symbol, which the first tile would read before it has arrived)
+			streaming_text = B == 1 && p->nshards == 1 && p->seq_shards <= 1 && p->type == B3M_INPUT_PACTERM;
 			if (!streaming_text) B3M_HIP(hipStreamWaitEvent(s, evh1, 0));
 		} else {
 			B3M_HIP(hipMemsetAsync(p->d_text + (tb & ~63ull), 0, p->text_cap - (tb & ~63ull), s));

@@ -1701,6 +1701,13 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 {
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
+	// B3M_DEBUG=2: the stream is drained after every stage and the stage is named on stderr (which kernel a fault belongs to)
+	static const int dbg_stages = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	auto stage = [&](const char *name) {
+		if (dbg_stages < 2) return;
+		B3M_HIP(hipStreamSynchronize(s));
+		fprintf(stderr, "[b3m] stage done: %s (start %llu len %llu)\n", name, (unsigned long long)start, (unsigned long long)len_in);
+	};
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
 	const MsdDigits dg = msd_digits(len_in);
 	B3M_REQUIRE(dg.D0 >= 1 && dg.D0 <= W0_MAXBITS && dg.D1 >= 0 && dg.D1 <= MSD_MAXBITS, "internal: MSD digit split");
@@ -1759,6 +1766,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			}
 		}
 		Scope sc(tl, KF_SCAN, 4ull * bins0 * ncol0);
+		stage("level 0 (chunk-local)");
 		hipLaunchKernelGGL(k_rows0_totals, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, d_tot);
 	} else {
 		Scope sc(tl, KF_MSD_HIST, span / 4);
@@ -1906,12 +1914,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				Scope sc(tl, KF_SCAN, 8ull * bins0 * ncol0);
 				hipLaunchKernelGGL(k_rows0_prefix, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, M.pre0, M.tfirst, M.tile_fr);
 			}
+			stage("rows0 prefix");
 			L1GArgs Gq{};
 			Gq.rec_in = ws.keyA; Gq.rec_out = ws.keyB; Gq.tiles = reinterpret_cast<const L1GTile *>(M.gtiles); Gq.runtab = M.runtab;
 			Gq.tab0 = M.tab0; Gq.pre0 = M.pre0; Gq.tile_fr = M.tile_fr; Gq.nchunks0 = ncol0; Gq.chunk0 = (uint32_t)W0A_CHUNK; Gq.D = dg.D1; Gq.shift = 64 - dg.D1;
 			ntB = (uint32_t)gtiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
 			hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
+			stage("level 1 (gather)");
 		} else {
 			B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));
 			B3M_HIP(hipStreamSynchronize(s));      // host vectors must outlive the copies
@@ -1927,6 +1937,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			Scope sc(tl, KF_SCAN, 4ull * toff);
 			hipLaunchKernelGGL(k_run_totals, dim3(bins0), dim3(256), 0, s, M.runtab, M.runpre, M.bucket_tab, bins0, dg.D1, (uint32_t)len, M.lvl_start);
 		}
+		stage("level 1 + run totals");
 		FS.rec = ws.keyB; FS.runtab = M.runtab; FS.runpre = M.runpre; FS.btab = M.bucket_tab; FS.nb0 = bins0; FS.D1 = dg.D1; FS.chunk = (uint32_t)L1_CHUNK;
 		gather = true;
 	}
@@ -1981,14 +1992,17 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				ws.slice_hook->fn(ws.slice_hook->ctx, ra, rb);
 			}
 		}
+		stage("first finish launch");
 		if (gather) {
 			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
 			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
 			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
+			stage("compact listed");
 		}
 		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
 		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
+		stage("mid finish");
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa, pb);
@@ -1997,6 +2011,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
 		else
 			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+		stage("big / huge finish");
 		sliced = nsl > 1;
 	}
 	if (sliced) {
@@ -2022,6 +2037,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		} else
 			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
 	}
+	stage("tie fix");
 	uint32_t nov = 0, nlist[3] = {0, 0, 0};
 	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipMemcpyAsync(&nlist[0], M.midlist, 4, hipMemcpyDeviceToHost, s));
@@ -2055,6 +2071,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		const uint64_t total = total32;
 		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[0], Bf[1]);
+		stage("overflow list filled");
 		B3M_HIP(hipStreamSynchronize(s));
 		uint64_t left = 0;
 		out.tie_elements = total;
@@ -2096,6 +2113,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[5], (uint32_t *)nullptr);
 		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s);
+		stage("fallback rounds + emit");
 		leave_fallback:;
 	}
 	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true, own, allow_ext); return; }   // the histogram was added by this pass already

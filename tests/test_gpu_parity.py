@@ -974,7 +974,7 @@ def test_long_repeats_in_blocks_of_a_merge_tree(gpu, oracle, itype, overhang, mo
     plan.close()
 
 
-@pytest.mark.parametrize("case", ["one_block_30m", "one_block_30m_pac", "repeats_30m", "blocks_small", "bytes_small"])
+@pytest.mark.parametrize("case", ["one_block_30m", "one_block_30m_pac", "repeats_30m", "blocks_small", "bytes_small", "pieces_300m", "pieces_300m_pac"])
 def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
     """SURVEY.md 8(d) end to end: b3m_plan_run_host takes the text from host memory and leaves the BWT in host memory, in slices while later
     buckets are still being sorted (30 M symbols: 8 slices), one byte per symbol or packed like the input (b3m_plan_set_packed_output).  What
@@ -990,7 +990,10 @@ def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
         n = len(buf)
     else:
         itype = "pac" if case.endswith("pac") else "pacterm"
-        nb = {"one_block_30m": 30_000_001, "one_block_30m_pac": 30_000_003, "repeats_30m": 30_000_002, "blocks_small": 100_003}[case]
+        # pieces_*: above 64 MB of packed text the H2D copy goes out in 8 pieces and (pacterm) level 0 runs behind it; a circular pac text
+        # must not: the BWT symbol of position 0 is the text's last symbol (a wrong byte there was found by tools/fuzz_large.py)
+        nb = {"one_block_30m": 30_000_001, "one_block_30m_pac": 30_000_003, "repeats_30m": 30_000_002, "blocks_small": 100_003,
+              "pieces_300m": 300_000_001, "pieces_300m_pac": 300_000_002}[case]
         b = rng.integers(0, 4, nb, dtype=np.uint8)
         if case == "repeats_30m":
             b[5_000_000:5_300_000] = 0
@@ -1005,6 +1008,10 @@ def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
     plan.run(d_text, d_out)
     if n < 200_000:
         assert np.array_equal(d_out.cpu().numpy(), oracle.bwt(oracle.symbols_from_file_bytes(buf, itype)))
+    if case.startswith("pieces"):
+        plan.close()
+        plan = engine.Plan(n, itype, blocksize=bs)           # a fresh plan: its text buffer has never held this text
+        plan.text_buffer().fill_(0x5A)
     h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory()
     h_text[:len(buf)] = torch.from_numpy(np.asarray(buf))
     h_out = torch.empty(n, dtype=torch.uint8).pin_memory()

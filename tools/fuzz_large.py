@@ -1,7 +1,7 @@
 """Randomised sweep at sizes the oracle cannot sort (24 M - 400 M bases): random composition (uniform, AT-rich, two symbols), planted repeats
 (copies, tandem arrays, homopolymer runs), one block / a few blocks of a merge tree / suffix-range shards; every result is verified by the
 on-device LF walk (/root/reference/src/checkbwt.cpp:176-243 semantics) and block / shard forms must equal the one-block BWT.
-python tools/fuzz_large.py [iterations] [seed]"""
+python tools/fuzz_large.py [iterations] [seed] [min bases] [max bases]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -10,17 +10,16 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 bad = 0; t0 = time.time()
 for it in range(iters):
-    nb = int(rng.integers(24_000_000, 400_000_000))
+    nb = int(rng.integers(int(float(sys.argv[3])) if len(sys.argv) > 3 else 24_000_000, int(float(sys.argv[4])) if len(sys.argv) > 4 else 400_000_000))
     comp = int(rng.integers(0, 4))
     g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1, 1 << 40)))
-    if comp == 0: b = torch.randint(0, 4, (nb,), device="cuda", dtype=torch.uint8, generator=g)
-    elif comp == 1:
-        p = torch.tensor([0.33, 0.17, 0.17, 0.33], device="cuda")          # AT 66 %
-        b = torch.multinomial(p, nb, replacement=True, generator=g).to(torch.uint8)
-    elif comp == 2: b = torch.randint(0, 2, (nb,), device="cuda", dtype=torch.uint8, generator=g) * 3
-    else:
-        p = torch.tensor([0.7, 0.1, 0.1, 0.1], device="cuda")
-        b = torch.multinomial(p, nb, replacement=True, generator=g).to(torch.uint8)
+    # (chunks of 2^28: torch.multinomial with 1.27 G samples faulted on this box -- in torch, before the library was called)
+    probs = {0: [0.25, 0.25, 0.25, 0.25], 1: [0.33, 0.17, 0.17, 0.33], 2: [0.5, 0.0, 0.0, 0.5], 3: [0.7, 0.1, 0.1, 0.1]}[comp]
+    edges = torch.tensor(np.cumsum(probs)[:3], dtype=torch.float32, device="cuda")
+    b = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for o in range(0, nb, 1 << 28):
+        m_ = min(1 << 28, nb - o)
+        b[o:o + m_] = torch.bucketize(torch.rand(m_, device="cuda", generator=g), edges, right=True).to(torch.uint8)
     for _ in range(int(rng.integers(0, 6))):           # planted repeats
         kind = int(rng.integers(0, 3)); ln = int(rng.integers(100, 300_000)); dst = int(rng.integers(0, nb - ln))
         if kind == 0: src = int(rng.integers(0, nb - ln)); b[dst:dst + ln] = b[src:src + ln].clone()
@@ -34,7 +33,7 @@ for it in range(iters):
     tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device="cuda")
     d_text = torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device="cuda")])
     n = nb + (1 if itype == "pacterm" else 0)
-    form = int(rng.integers(0, 3))
+    form = int(rng.integers(0, 4))
     ok = True; msg = ""
     try:
         plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
@@ -47,6 +46,17 @@ for it in range(iters):
             plan = engine.Plan(n, itype, isasamplingrate=1 << 16, blocksize=(n + nblk - 1) // nblk)
             out = plan.run(d_text); torch.cuda.synchronize()
             ok &= bool(torch.equal(out, one)); msg += " blocks %d eq %s" % (plan.result()["num_blocks"], ok)
+            plan.close()
+        elif form == 3:
+            # host memory to host memory (text arriving in pieces, BWT leaving in slices), one byte per symbol and packed
+            plan = engine.Plan(n, itype, isasamplingrate=0)
+            h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory(); h_text.copy_(d_text[:plan.text_bytes].cpu())
+            h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+            plan.run_host(h_text, h_out)
+            ok &= bool(torch.equal(h_out, one.cpu()))
+            h_pk = torch.empty((n + 3) // 4, dtype=torch.uint8).pin_memory()
+            plan.run_host(h_text, h_pk, packed=True)
+            ok &= bool(torch.equal(h_pk, engine.Plan.pack_pac(one, itype == "pacterm").cpu())); msg += " host runs eq %s" % ok
             plan.close()
         elif form == 2:
             ns = int(rng.integers(2, 9))
