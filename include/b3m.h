@@ -114,7 +114,8 @@ int b3m_plan_run(b3m_plan *p, const void *d_text, uint8_t *d_bwt_out, void *stre
  * host memory; role of the file -> memory and memory -> encoder hand-offs around BwtMergeSort::computeBwt,
  * /root/reference/src/bwtb3m.cpp:63).  h_text: b3m_plan_text_bytes() bytes, h_bwt_out: n bytes; pinned memory (b3m_host_alloc) makes
  * both copies asynchronous.  One block: the BWT leaves the device in slices of whole buckets, in rank order, while later buckets are
- * still being sorted.  times (may be NULL): HIP-event splits of this run. */
+ * still being sorted; a pacterm text of 64 MB and more arrives in 8 pieces and the (chunk-local) level 0 of the sort runs behind the copy,
+ * piece by piece.  times (may be NULL): HIP-event splits of this run. */
 typedef struct b3m_e2e_times {
 	double h2d_ms;         /* packed text, host -> HBM */
 	double construct_ms;   /* first kernel .. last kernel (slices of the BWT already leave during this) */
