@@ -285,7 +285,10 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		uint64_t b = n;
 		// byte alphabets: count rows of BWT(L), 16 B per symbol of the largest left side, instead of 0.33 B
 		const uint64_t merge_part = inputtype == B3M_INPUT_BYTESTREAM ? 9 * n / 2 + 9 * n : 9 * n / 2;
-		while (b > 1024 && fixed + blocksort_ws_bytes(b) + (b < n ? merge_part : 0) > budget) b = (b + 1) / 2;
+		// (a budget below the fixed part -- text, two BWT arrays, gt bits, the ranks of a merge -- cannot be met by smaller blocks: the split
+		// stops at 1024 leaf blocks instead of going down to 1 Ki-symbol blocks, which is correct but takes minutes)
+		const uint64_t bmin = std::max<uint64_t>(1024, n / 1024);
+		while (b > bmin && fixed + blocksort_ws_bytes(b) + (b < n ? merge_part : 0) > budget) b = (b + 1) / 2;
 		blocksize = b;
 	}
 	if (blocksize > n) blocksize = n;

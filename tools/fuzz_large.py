@@ -33,7 +33,7 @@ for it in range(iters):
     tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device="cuda")
     d_text = torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device="cuda")])
     n = nb + (1 if itype == "pacterm" else 0)
-    form = int(rng.integers(0, 4))
+    form = int(rng.integers(0, 5))
     ok = True; msg = ""
     try:
         plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
@@ -42,10 +42,17 @@ for it in range(iters):
         ok &= lf == (0, 0); msg = "LF %s rounds %d" % (lf, plan.result()["tie_rounds"])
         plan.close()
         if form == 1:
-            nblk = int(rng.integers(2, 6))
+            nblk = int(rng.integers(2, 6)) if rng.integers(0, 3) else int(rng.integers(6, 41))          # a few blocks, or many (more merge levels)
             plan = engine.Plan(n, itype, isasamplingrate=1 << 16, blocksize=(n + nblk - 1) // nblk)
             out = plan.run(d_text); torch.cuda.synchronize()
             ok &= bool(torch.equal(out, one)); msg += " blocks %d eq %s" % (plan.result()["num_blocks"], ok)
+            plan.close()
+        elif form == 4:
+            # the memory budget picks the block size (mem=: /root/reference/README.md:42), aiming at 2..12 blocks
+            want = int(rng.integers(2, 13))
+            plan = engine.Plan(n, itype, isasamplingrate=1 << 16, mem=int(n * 8 + n * 52 / want) + (128 << 20))
+            out = plan.run(d_text); torch.cuda.synchronize()
+            ok &= bool(torch.equal(out, one)); msg += " mem-> blocks %d eq %s" % (plan.result()["num_blocks"], ok)
             plan.close()
         elif form == 3:
             # host memory to host memory (text arriving in pieces, BWT leaving in slices), one byte per symbol and packed
@@ -59,7 +66,7 @@ for it in range(iters):
             ok &= bool(torch.equal(h_pk, engine.Plan.pack_pac(one, itype == "pacterm").cpu())); msg += " host runs eq %s" % ok
             plan.close()
         elif form == 2:
-            ns = int(rng.integers(2, 9))
+            ns = int(rng.integers(2, 17))
             plans, slices = [], []
             for k in range(ns):
                 p = engine.Plan(n, itype, shard=k, nshards=ns); slices.append(p.run(d_text).clone()); plans.append(p)
