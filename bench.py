@@ -36,9 +36,13 @@ def parse():
     ap.add_argument("--no-also-blocks", dest="also_blocks", action="store_false",
                     help="N>1: skip the extra pass of the block-merge mode after the headline line")
     ap.add_argument("--blocks-timeout", type=int, default=90)
+    ap.add_argument("--isasamplingrate", type=int, default=0, help="the option as given to bwtb3m (0 = the mode's default, 262144)")
+    ap.add_argument("--bwtonly", type=int, default=0, help="the option as given to bwtb3m")
+    ap.add_argument("--no-bwt-only", dest="bwt_only", action="store_false",
+                    help="skip the extra leg that times a plan without (rank,pos) samples (`config.bwt_only`)")
     ap.add_argument("--no-check", dest="check", action="store_false",
-                    help="skip the verification after the timed loop (default: the timed isasamplingrate=0 result is compared with an "
-                         "isasamplingrate>0 run that is LF-walk-verified against the text, checkbwt semantics)")
+                    help="skip the verification after the timed loop (default: the timed output is LF-walked on the device against the "
+                         "text from the timed plan's own (rank,pos) samples, checkbwt semantics)")
     ap.add_argument("--verify", action="store_true", help="check the result against the oracle (small sizes only)")
     ap.add_argument("--copy-text", action="store_true", help="pass the text in a buffer of the caller's (copied into the plan every step) instead of the plan's own text buffer")
     ap.add_argument("--e2e-steps", type=int, default=3, help="host-memory runs (pinned input -> pinned BWT bytes) reported as `e2e`; 0 = skip")
@@ -75,37 +79,50 @@ def cpu_baseline(buf, itype, sample, blocks):
                       % (len(sym), B, cores, dt, st[0], st[1], st[2])}
 
 
-def verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize):
-    """After the timed loop: prove that what was timed (the isasamplingrate=0 plan) is the BWT.  A second plan
-    with (rank,pos) samples constructs it again, that result is LF-walked against the text on the device
-    (every symbol, every chain closure: /root/reference/src/checkbwt.cpp:176-243), and the timed output must
-    equal it byte for byte; out[p0] is the terminator and the symbol histogram equals the text's."""
+def verify_timed_result(torch, plan, d_text, d_out, n, itype):
+    """After the timed loop: prove that what was timed IS the BWT.  The timed plan carries the (rank,pos) samples the shipped
+    path emits (b3m_plan_sampling_rate), so its own output is LF-walked on the device against the text (every symbol, every chain
+    closure: /root/reference/src/checkbwt.cpp:176-243); out[p0] is the terminator and the symbol histograms of the BWT, of the
+    text (torch alone) and of the engine's .hist agree."""
     t0 = time.perf_counter()
     res0 = plan.result()
     from bwtb3m_amd import benchutil
     hist_text = benchutil.text_histogram(d_text, n, itype)          # torch only, independent of the engine
     assert plan.histogram().astype("int64").tolist() == hist_text, "bench check: the engine's symbol histogram (.hist) differs from the text's"
-    plan.close()
-    rate = 1 << 16 if n > (1 << 24) else 64
-    vplan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=rate)
-    d_ref = torch.empty(n, dtype=torch.uint8, device=d_out.device)
-    vplan.run(d_text, d_ref)
-    torch.cuda.synchronize()
-    m0, m1, _ = vplan.lf_walk(d_ref, sarate=0)
+    m0, m1, _ = plan.lf_walk(d_out, sarate=0)
     assert (m0, m1) == (0, 0), "bench check: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
-    assert torch.equal(d_out, d_ref), "bench check: the timed isasamplingrate=0 result differs from the LF-walk-verified one"
-    r1 = vplan.result()
-    assert r1["p0"] == res0["p0"], "bench check: p0 differs between the two variants"
     if itype == "pacterm":
         assert int(d_out[res0["p0"]]) == 0, "bench check: BWT[p0] is not the terminator"
     hb = torch.zeros(256, dtype=torch.int64, device=d_out.device)
     for o in range(0, n, 1 << 28):      # in slices: an int64 copy of 3 G symbols at once would be 24 GB
         hb += torch.bincount(d_out[o:o + (1 << 28)].to(torch.int64), minlength=256)
     assert hb.cpu().numpy().tolist() == hist_text, "bench check: symbol histogram of the BWT differs from the text's"
-    vplan.close()
-    return ("timed isasamplingrate=0 output == isasamplingrate=%d output, which the on-device LF walk verified against the text over all "
-            "%d symbols (0 symbol / 0 chain mismatches); BWT[p0]=terminator; histogram(BWT)==histogram(text); %.0f ms"
-            % (rate, n, (time.perf_counter() - t0) * 1e3))
+    return ("the timed output, LF-walked on the device against the text from the timed plan's own %d (rank,pos) samples over all "
+            "%d symbols: 0 symbol / 0 chain mismatches; BWT[p0]=terminator; histogram(BWT)==histogram(text)==.hist; %.0f ms"
+            % (res0["num_samples"], n, (time.perf_counter() - t0) * 1e3))
+
+
+def time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, steps):
+    """the same workload through a plan without (rank,pos) samples (isasamplingrate=0: nothing b3m_compute_bwt ever creates): reported
+    beside the headline, never instead of it; its output must equal the verified one"""
+    plan0 = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=0)
+    buf = plan0.text_buffer()
+    buf[:d_text.numel()].copy_(d_text[:buf.numel()])
+    d0 = torch.empty(n, dtype=torch.uint8, device=d_out.device)
+    plan0.run(buf, d0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan0.run(buf, d0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = bool(torch.equal(d0, d_out))
+    assert same, "bench: the isasamplingrate=0 plan's output differs from the shipped plan's"
+    del buf
+    plan0.close()
+    nbases = n - 1 if itype == "pacterm" else n
+    return {"ms_per_step": round(dt / steps * 1e3, 3), "value": round(nbases * steps / dt / 1e9, 4), "unit": "Gbase/s", "steps": steps,
+            "equals_shipped_output": same, "what": "plan without (rank,pos) samples: BWT bytes only, not what b3m_compute_bwt runs"}
 
 
 def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
@@ -178,7 +195,10 @@ def main():
     blocksize = int(a.blocksize)
     if a.blocks > 0:
         blocksize = (n + a.blocks - 1) // a.blocks
-    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=0)        # the timed variant: BWT only, no (rank,pos) samples
+    # the timed plan is the one b3m_compute_bwt creates for these options (same rule, b3m_plan_sampling_rate): BWT + (rank,pos) samples
+    from bwtb3m_amd import _lib
+    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(a.isasamplingrate, a.bwtonly))
+    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=plan_rate)
     d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
     d_text_gen = d_text
     if not a.copy_text:
@@ -214,7 +234,10 @@ def main():
                    "parallelism": "1 GPU", "input_gen_s": round(gen_s, 2)},
         "roofline": roof,
     }
-    out["config"]["value_is"] = "device-resident: packed text in HBM -> BWT bytes in HBM (SURVEY 8d end-to-end figure: `e2e`)"
+    out["config"]["isasamplingrate"] = {"option": a.isasamplingrate or (64 if a.bwtonly else 262144), "bwtonly": a.bwtonly, "plan": plan_rate,
+                                        "samples": res["num_samples"],
+                                        "what": "the plan b3m_compute_bwt creates for these options (b3m_plan_sampling_rate); the samples are emitted by the sort itself"}
+    out["config"]["value_is"] = "device-resident: packed text in HBM -> BWT bytes + (rank,pos) samples in HBM (SURVEY 8d end-to-end figure: `e2e`)"
     out["config"]["text"] = ("in a buffer of the caller's, copied into the plan every step" if a.copy_text
                              else "in the plan's own text buffer (b3m_plan_text_buffer), used in place")
     if a.e2e_steps > 0:
@@ -225,7 +248,10 @@ def main():
         assert np.array_equal(d_out.cpu().numpy(), O.bwt(sym)), "bench --verify: BWT differs from the oracle"
         out["config"]["verified"] = True
     if a.check:
-        out["config"]["checked"] = verify_timed_result(torch, engine, plan, d_text, d_out, n, itype, blocksize)
+        out["config"]["checked"] = verify_timed_result(torch, plan, d_text, d_out, n, itype)
+    plan.close()
+    if a.bwt_only:
+        out["config"]["bwt_only"] = time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, max(1, min(a.steps, 10)))
     if not a.no_cpu_baseline:
         sample = int(min(a.cpu_sample, n))
         # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)

@@ -105,6 +105,22 @@ bool sort_u32_msd(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, uint32_t *s
 void radix_sort_u32(uint32_t *kA, uint32_t *kB, uint64_t n, int nbits, RadixWs &ws, hipStream_t s,
                     Timeline *tl, uint32_t **k_res, bool rank_list = false);
 
+// ---- (rank,pos) samples written where a suffix is finally placed ---------------------------------
+// The MSD sort of a whole-text block (or of a suffix-range shard of one) emits the sample of position x = k * rate into the fixed
+// slot k - first the moment it knows the suffix's final rank: in the finish kernels for records alone in their key, in the tie fix
+// and in the list-based rounds' emit for the others.  No suffix array has to be kept for the sake of one entry in `rate`
+// (row a12: the reference always writes .preisa, /root/reference/src/checkbwt.cpp:131-148).
+// Divisibility of a 32-bit position without a division: low tz bits zero and (x >> tz) * inv <= lim (inv = inverse of the odd
+// part of the rate modulo 2^32); positions above 2^32 need a power-of-two rate (sample_in_kernel_ok).
+struct SampleOut {
+	uint64_t *pairs = nullptr;       // null: no samples
+	uint64_t rank_off = 0;           // global rank of the sort's first slot (suffix-range shards)
+	uint64_t first = 0, cap = 0;     // slots [first, first + cap) are this block's
+	uint32_t rate = 1, tz = 0, pmask = 0xFFFFFFFFu, inv = 1, lim = 0xFFFFFFFFu, pow2 = 1;
+};
+SampleOut make_sample_out(uint64_t *pairs, uint64_t rate, uint64_t first, uint64_t cap);
+bool sample_in_kernel_ok(uint64_t rate, uint64_t n);
+
 // ---- block sort (row a7) ---------------------------------------------------------------------
 struct MsdTile { uint32_t in_off, count, hist_base, stride; };
 struct MsdWs {
@@ -149,6 +165,7 @@ struct BlockSortWs {
 	const SliceHook *slice_hook = nullptr;
 	const TextArrival *arrival = nullptr;
 	uint64_t *d_symhist_out = nullptr; // optional: the MSD path adds the block's symbol histogram here (it falls out of the level-0 digit counts)
+	const SampleOut *samples = nullptr; // optional (whole-text blocks / their shards, MSD path): (rank,pos) samples are emitted by the sort itself (out.samples_done)
 };
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
 uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0);
@@ -163,6 +180,7 @@ struct BlockSortOut {
 	uint32_t *tie_U = nullptr, *tie_gid = nullptr;
 	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
+	bool samples_done = false;        // ws.samples was served: every sample of a suffix sorted here sits in its slot
 	bool want_ext = false;            // a block of a merge tree with long ties: sort it again together with an overhang (block_sort does)
 	uint64_t slow_ties = 0;           // slots that prefix doubling inside the block's domain could not finish (repeat longer than the overhang)
 	uint64_t overhang = 0;            // symbols behind the block that were sorted with it
@@ -190,7 +208,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
                     uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0);
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
-void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s);
+void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,
+                   const SampleOut *smp = nullptr);
 // products of a sorted block
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt,
               uint32_t *d_p0 /*device scalar*/, hipStream_t s);

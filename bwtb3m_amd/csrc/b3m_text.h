@@ -85,6 +85,21 @@ __device__ inline int compare_rotations(const TextView &T, uint64_t x, uint64_t 
 	return 0;
 }
 
+// ---- (rank,pos) samples (SampleOut, b3m_internal.h) ------------------------------------------------
+// is the position with these low 32 bits a multiple of the rate?  (sampling off: pmask is all ones, only 0 passes and sample_put drops it)
+__device__ __forceinline__ bool sample_hit(const SampleOut &S, uint32_t lo32)
+{
+	bool h = (lo32 & S.pmask) == 0u;
+	if (!S.pow2) h = h && (lo32 >> S.tz) * S.inv <= S.lim;
+	return h;
+}
+__device__ __forceinline__ void sample_put(const SampleOut &S, uint64_t rank, uint64_t pos)
+{
+	if (!S.pairs) return;
+	const uint64_t k = (S.pow2 ? pos >> S.tz : pos / S.rate) - S.first;
+	if (k < S.cap) { S.pairs[2 * k] = rank + S.rank_off; S.pairs[2 * k + 1] = pos; }
+}
+
 // ---- wave helpers (64 lanes) -----------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 

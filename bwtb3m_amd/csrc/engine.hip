@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <cstdio>
+#include <exception>
 
 namespace b3m {
 
@@ -399,7 +400,7 @@ void *b3m_plan_text_buffer(b3m_plan *p) { return p ? (void *)p->d_text : nullptr
 namespace {
 // BWT symbols -> the .pac layout (4 symbols per byte, the first in the top bits); sub = 1 for pacterm (symbols 1..4 -> 0..3, the
 // terminator's slot reads 0).  One thread per 16 symbols = 4 output bytes.
-__global__ void k_pack_pac(const uint8_t *bwt, uint64_t w_first, uint64_t w_last, uint32_t sub, uint8_t *out)
+__global__ void k_pack_pac(const uint8_t *bwt, uint64_t w_first, uint64_t w_last, uint32_t sub, uint8_t *out, uint64_t n)
 {
 	const uint64_t w = w_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= w_last) return;
@@ -410,6 +411,7 @@ __global__ void k_pack_pac(const uint8_t *bwt, uint64_t w_first, uint64_t w_last
 		uint32_t b = 0;
 		for (int j = 0; j < 4; ++j) {
 			uint32_t c = (in[k] >> (8 * j)) & 0xFFu;
+			if (16 * w + 4 * k + j >= n) c = sub;                 // padding slots behind the last symbol read 0 whatever the buffer holds there
 			c = c >= sub ? c - sub : 0u;
 			b |= (c & 3u) << (6 - 2 * j);
 		}
@@ -431,7 +433,7 @@ struct HostSink {            // SliceHook context of a host-memory run
 			// whole bytes of four symbols; the byte that straddles `first` was left to this slice by the one before
 			b0 = first / 4; b1 = last == p->n ? (p->n + 3) / 4 : last / 4;
 			if (b1 > b0) hipLaunchKernelGGL(k_pack_pac, dim3((uint32_t)(((b1 + 3) / 4 - b0 / 4 + 255) / 256)), dim3(256), 0, k->s, k->d_bwt, b0 / 4, (b1 + 3) / 4,
-			                                p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack);
+			                                p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack, p->n);
 			src = p->d_pack;
 		}
 		hipEvent_t e = p->tl.get();
@@ -452,6 +454,16 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	hipEvent_t evh0 = nullptr, evh1 = nullptr, evh2 = nullptr, evh3 = nullptr;
 	HostSink sink{p, s, nullptr, h_bwt_out, {}, 0};
 	SliceHook hook{8, &HostSink::slice, &sink};
+	// whatever way this function is left: the sort workspace must not keep pointers into this stack frame, and no copy of a
+	// host-memory run may still be in flight into the caller's buffers
+	struct Guard {
+		b3m_plan *p; bool host;
+		~Guard()
+		{
+			p->bs.slice_hook = nullptr; p->bs.arrival = nullptr; p->bs.samples = nullptr; p->bs.d_symhist_out = nullptr;
+			if (host && p->copy_stream && std::uncaught_exceptions()) (void)hipStreamSynchronize(p->copy_stream);
+		}
+	} guard{p, h_text_in != nullptr};
 	double wall0 = 0;
 	if (host) {
 		B3M_REQUIRE(p->nshards == 1, "host-memory runs need an unsharded plan");
@@ -517,7 +529,12 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	for (uint64_t k = 0; k < B; ++k) {
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
-		const bool need_sa = B > 1 || p->isarate != 0 || p->keep_sa;       // anchors / samples / the tie export read the suffix array
+		// (rank,pos) samples of a whole-text block (or its shards) are written by the sort itself, where each suffix is finally placed
+		// (SampleOut): no suffix array is kept for them.  Blocks of a merge tree keep theirs anyway (anchors), the LSD path always has one.
+		const bool smp_in_kernel = B == 1 && p->isarate != 0 && sample_in_kernel_ok(p->isarate, n);
+		const bool need_sa = B > 1 || p->keep_sa || (p->isarate != 0 && !smp_in_kernel);       // anchors / the tie export / samples the kernels cannot test for read the suffix array
+		SampleOut smp_cfg;
+		if (smp_in_kernel) smp_cfg = make_sample_out(p->d_samples + 2 * p->sample_off[k], p->isarate, (lf.a + p->isarate - 1) / p->isarate, p->sample_off[k + 1] - p->sample_off[k]);
 		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
 		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
 		if (p->isarate && nsh > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
@@ -527,8 +544,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			p->bs.d_symhist_out = (sh == 0 || p->seq_shards == 1) ? p->d_hist + 256 * k : nullptr;      // the histogram of the whole block falls out of every shard's level-0 totals: taken once
 			p->bs.slice_hook = (host && B == 1 && nsh == 1) ? &hook : nullptr;
 			p->bs.arrival = streaming_text ? &arrival : nullptr;
+			p->bs.samples = smp_in_kernel ? &smp_cfg : nullptr;
 			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a, p->d_p0tmp + k, sh, nsh, need_sa);
-			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr; p->bs.arrival = nullptr;
+			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr; p->bs.arrival = nullptr; p->bs.samples = nullptr;
 			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
@@ -541,9 +559,11 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a, so.slice_offset);
 			if (!so.symhist_done && (sh == 0 || p->seq_shards == 1)) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
-			if (p->isarate)
+			if (p->isarate && !so.samples_done) {
+				B3M_REQUIRE(so.d_sa != nullptr || so.kept_len == 0, "internal: samples asked for, but the sort kept no suffix array");
 				emit_samples(so.d_sa, so.d_sa_hi, so.kept_len, p->isarate, so.slice_offset, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,
 				             p->sample_off[k + 1] - p->sample_off[k], s);
+			}
 			acc += so.kept_len;
 		}
 		if (p->seq_shards > 1) { B3M_REQUIRE(acc == lf.m, "internal: suffix-range shards do not cover the block"); p->res.slice_offset = 0; p->res.slice_len = acc; }
@@ -650,7 +670,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			const uint8_t *src = B > 1 ? p->d_bwt[cur] : d_bwt_out;
 			if (p->packed_out) {
 				const uint64_t nb4 = (n + 3) / 4;
-				hipLaunchKernelGGL(k_pack_pac, dim3((uint32_t)(((nb4 + 3) / 4 + 255) / 256)), dim3(256), 0, s, src, (uint64_t)0, (nb4 + 3) / 4, p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack);
+				hipLaunchKernelGGL(k_pack_pac, dim3((uint32_t)(((nb4 + 3) / 4 + 255) / 256)), dim3(256), 0, s, src, (uint64_t)0, (nb4 + 3) / 4, p->type == B3M_INPUT_PACTERM ? 1u : 0u, p->d_pack, p->n);
 				B3M_HIP(hipMemcpyAsync(h_bwt_out, p->d_pack, nb4, hipMemcpyDeviceToHost, s));
 			} else B3M_HIP(hipMemcpyAsync(h_bwt_out, src, n, hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipEventRecord(evh3, s));

@@ -31,6 +31,13 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 }
 
+extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly)
+{
+	const uint64_t isarate = isasamplingrate ? isasamplingrate : (bwtonly ? 64 : 262144);
+	if (!bwtonly && isarate > 1024 && isarate % 1024 == 0) return 1024;
+	return isarate;
+}
+
 extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 {
 	void *d_text = nullptr; uint8_t *d_bwt = nullptr; b3m_plan *plan = nullptr;
@@ -79,14 +86,12 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		}
 		if (n == 0) throw std::runtime_error("input is empty");
 		log("[V] input %s type %s symbols %llu\n", o->input_fn, tname, (unsigned long long)n);
-		uint64_t isarate = o->isasamplingrate ? o->isasamplingrate : 262144;
+		// bwtonly=1 lowers the default ISA sampling rate to 64 (/root/reference/ChangeLog:281); 0 means "default for the mode"
+		uint64_t isarate = o->isasamplingrate ? o->isasamplingrate : (o->bwtonly ? 64 : 262144);
 		uint64_t sarate = o->sasamplingrate ? o->sasamplingrate : 32;
-		// bwtonly=1 lowers the default ISA sampling rate to 64 (/root/reference/ChangeLog:281);
-		// the caller passes the effective value, 0 means "default for the mode"
 		const bool want_sa = !o->bwtonly;                     // sampled SA/ISA stage (byte alphabets walk the LF array)
 		// anchors of the LF walks: a divisor of the output rate, dense enough to fill the GPU
-		uint64_t anchor_rate = isarate;
-		if (want_sa && isarate > 1024 && isarate % 1024 == 0) anchor_rate = 1024;
+		const uint64_t anchor_rate = b3m_plan_sampling_rate(o->isasamplingrate, (int)o->bwtonly);
 		// byte alphabets are sorted as ONE block (no byte-alphabet merge): a memory target that would force several
 		// blocks (the reference's scripts pass mem= for host RAM) is not applied to them
 		uint64_t mem = o->mem;

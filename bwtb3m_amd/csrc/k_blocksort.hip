@@ -160,7 +160,7 @@ __global__ void k_tie_apply(const uint32_t *U, const uint32_t *gid, const uint32
 	bool head = (s == 0) || gid[s] != gid[s - 1] || tmp_key[s] != tmp_key[s - 1];
 	hid[s] = head ? (uint32_t)s : 0u;
 }
-__global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, uint64_t start, uint8_t *bwt, uint32_t *p0)
+__global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, uint64_t start, uint8_t *bwt, uint32_t *p0, SampleOut smp)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
@@ -169,6 +169,7 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 	uint64_t j = i ? i - 1 : T.n - 1;
 	bwt[r] = (uint8_t)sym_at(T, j);
 	if (i == start) *p0 = r;
+	if (sample_hit(smp, (uint32_t)i)) sample_put(smp, r, i);      // the listed slots are final here: their samples could not be written earlier
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,9 +670,10 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	emit_bwt(T, out.d_sa, len, start, d_bwt, d_p0, s);
 }
 
-void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)
+void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,
+                   const SampleOut *smp)
 {
-	if (u) hipLaunchKernelGGL(k_emit_bwt_list, dim3(nblk(u)), dim3(256), 0, s, T, U, u, d_sa, start, d_bwt, d_p0);
+	if (u) hipLaunchKernelGGL(k_emit_bwt_list, dim3(nblk(u)), dim3(256), 0, s, T, U, u, d_sa, start, d_bwt, d_p0, smp ? *smp : SampleOut());
 }
 
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)
@@ -686,6 +688,26 @@ void emit_samples(const uint32_t *d_sa, const uint8_t *d_sa_hi, uint64_t len, ui
 {
 	B3M_REQUIRE(rate < (1ull << 32), "sampling rate out of range");
 	if (len && rate) hipLaunchKernelGGL(k_emit_samples, dim3(nblk(len)), dim3(256), 0, s, d_sa, d_sa_hi, len, rate, rank_off, d_pairs, first, cap);
+}
+// in-kernel sampling (SampleOut): any rate below 2^32 for 32-bit positions; texts of 2^32 symbols and more need a power of two
+bool sample_in_kernel_ok(uint64_t rate, uint64_t n)
+{
+	if (rate == 0 || rate >= (1ull << 32)) return false;
+	return n < (1ull << 32) || (rate & (rate - 1)) == 0;
+}
+SampleOut make_sample_out(uint64_t *pairs, uint64_t rate, uint64_t first, uint64_t cap)
+{
+	B3M_REQUIRE(rate >= 1 && rate < (1ull << 32), "sampling rate out of range");
+	SampleOut S;
+	S.pairs = pairs; S.first = first; S.cap = cap; S.rate = (uint32_t)rate;
+	uint32_t odd = (uint32_t)rate; S.tz = 0;
+	while (!(odd & 1u)) { odd >>= 1; ++S.tz; }
+	S.pmask = (uint32_t)((1ull << S.tz) - 1);
+	S.pow2 = odd == 1u;
+	uint32_t inv = odd;                                           // Newton: inv * odd == 1 (mod 2^32)
+	for (int i = 0; i < 5; ++i) inv *= 2u - odd * inv;
+	S.inv = inv; S.lim = 0xFFFFFFFFu / odd;
+	return S;
 }
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum, hipStream_t s)

@@ -754,7 +754,7 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct SortOut { SaOut sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; int pb; };
+struct SortOut { SaOut sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; int pb; SampleOut smp; };
 
 // a sub-bucket the in-kernel sort cannot finish: (start, size) goes to the overflow list (lane 0 only)
 __device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m)
@@ -865,6 +865,7 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 				if (WRITE_SA || sp || sn) sa_set(sa, b0 + e, i);       // without consumers only k_tie_fix reads positions
 				bwt[b0 + e] = (uint8_t)((q >> O.pb) & 7u);
 				if (i == start) *p0 = b0 + e;
+				if (!(sp || sn) && sample_hit(O.smp, (uint32_t)i)) sample_put(O.smp, b0 + e, i);     // (tied records: k_tie_fix, once their order is known)
 			}
 		}
 	}
@@ -1125,6 +1126,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 			else if (dest[k] & (3u << 29)) sa_set(O.sa, g, i);       // without consumers only k_tie_fix / the fallback read positions
 			if (dest[k] & (1u << 31)) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
 			if (i == O.start) *O.p0 = g;
+			if (!(dest[k] & (3u << 29)) && sample_hit(O.smp, (uint32_t)i)) sample_put(O.smp, g, i);     // (tied / hot records: where they are finally placed)
 		}
 	}
 	__syncthreads();
@@ -1362,7 +1364,8 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		uint32_t eq = (t0 < 8192u ? 1u : 0u) + (t1 < 8192u ? 1u : 0u) + (t2 < 8192u ? 1u : 0u) + (t3 < 8192u ? 1u : 0u);
 		const uint32_t lo32 = (uint32_t)r[k];
 		uint32_t dp = st + lt;
-		if (valid && (eq > 1 || c > 4 || lo32 == start_lo)) {    // rare
+		const bool smp = sample_hit(O.smp, lo32);
+		if (valid && (eq > 1 || c > 4 || lo32 == start_lo || smp)) {    // rare
 			bool prev = t0 < e || t1 < e || t2 < e || t3 < e;
 			const bool hot = c > (uint32_t)LS_TIE_CAP;
 			if (c > 4 && !hot) {
@@ -1378,6 +1381,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 			if (!WRITE_SA && (hot || eq > 1)) sa_set(O.sa, g, pos);       // only k_tie_fix / the fallback read positions
 			if (prev && !hot) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
 			if (pos == O.start) *O.p0 = g;
+			if (smp && !hot && eq <= 1) sample_put(O.smp, g, pos);            // (rank,pos) sample of a record alone in its key: its place is final
 		}
 		if (WRITE_SA) dpv[k] = valid ? dp : 0xFFFFFFFFu;
 		if (valid) {
@@ -1583,7 +1587,8 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // does not decide.  Groups are at most LS_TIE_CAP long (longer ones are on the overflow list and
 // set no bits); the length guard only keeps a corrupt bitmap from running away.
 // The launch covers the records [lo, hi) (tie groups never cross a bucket, so slices of whole buckets are independent).
-__device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tiebits, uint64_t len, uint64_t q, uint32_t eq_syms, const SaOut &sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+__device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tiebits, uint64_t len, uint64_t q, uint32_t eq_syms, const SaOut &sa, uint8_t *bwt, uint64_t start, uint32_t *p0,
+                                          const SampleOut &smp)
 {
 	{
 		{
@@ -1608,7 +1613,11 @@ __device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tie
 			}
 			sa_set(sa, pos + j, x); bwt[pos + j] = bx;
 		}
-		for (uint32_t a = 0; a < g; ++a) if (sa_get(sa, pos + a) == start) *p0 = (uint32_t)(pos + a);
+		for (uint32_t a = 0; a < g; ++a) {
+			const uint64_t x = sa_get(sa, pos + a);
+			if (x == start) *p0 = (uint32_t)(pos + a);
+			if (sample_hit(smp, (uint32_t)x)) sample_put(smp, pos + a, x);
+		}
 		}
 	}
 }
@@ -1623,14 +1632,14 @@ __device__ __forceinline__ uint32_t tie_starts(const uint32_t *tiebits, uint64_t
 	if ((w << 5) + 32 > hi) starts &= (1u << (hi - (w << 5))) - 1u;
 	return starts;
 }
-__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp)
 {
 	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if ((w << 5) >= hi) return;
 	uint32_t starts = tie_starts(tiebits, w, lo, hi);
 	while (starts) {
 		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
-		tie_group(T, tiebits, len, (w << 5) + k, eq_syms, sa, bwt, start, p0);
+		tie_group(T, tiebits, len, (w << 5) + k, eq_syms, sa, bwt, start, p0, smp);
 	}
 }
 // The same in two steps (whole blocks): the groups are few (0.3 % of the records) and each costs a chain of dependent gathers, so a
@@ -1668,11 +1677,11 @@ __global__ __launch_bounds__(256) void k_tie_collect(const uint32_t *tiebits, ui
 	}
 }
 __global__ __launch_bounds__(256) void k_tie_fix_list(TextView T, const uint32_t *tiebits, uint64_t len, const uint32_t *list, const uint32_t *counter, uint32_t cap,
-                                                      uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0)
+                                                      uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp)
 {
 	uint32_t cnt = *counter; cnt = cnt < cap ? cnt : cap;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
-		tie_group(T, tiebits, len, list[i], eq_syms, sa, bwt, start, p0);
+		tie_group(T, tiebits, len, list[i], eq_syms, sa, bwt, start, p0, smp);
 }
 
 // sorted (size << 32 | start) pairs -> sizes (scanned into list offsets by the caller) and starts
@@ -1945,7 +1954,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
 	B3M_REQUIRE(fbits >= 1 && fbits <= REC_KEY_BITS && fbits - std::min(fbits, F_BINBITS) <= 16, "internal: free key bits of the finish");
 	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
-	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits, pb};
+	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits, pb, SampleOut()};
+	if (ws.samples) {
+		// (rank,pos) samples leave with the records: only sorts of the whole text (or of a suffix-range shard of it) know global ranks
+		B3M_REQUIRE(start == 0 && len_in == T.n && !allow_ext && own == 0, "internal: in-kernel samples need a whole-text block");
+		B3M_REQUIRE(sample_in_kernel_ok(ws.samples->rate, T.n), "internal: sampling rate the kernels cannot test");
+		O.smp = *ws.samples; O.smp.rank_off = out.slice_offset;
+		out.samples_done = true;
+	}
 	{
 		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
 		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
@@ -1988,7 +2004,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, dl, O);
 			}
 			if (nsl > 1) {
-				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0);
+				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0, O.smp);
 				ws.slice_hook->fn(ws.slice_hook->ctx, ra, rb);
 			}
 		}
@@ -2033,9 +2049,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			const uint32_t gcap = (uint32_t)std::min<uint64_t>(2 * ws.cap, 0xFFFFFFF0ull);
 			B3M_HIP(hipMemsetAsync(gcnt, 0, 4, s));
 			hipLaunchKernelGGL(k_tie_collect, dim3(nblk((len + 31) / 32, 256 * TIE_WPT)), dim3(256), 0, s, ws.t[0], len, glist, gcap, gcnt);
-			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0);
+			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0, O.smp);
 		} else
-			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0);
+			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0, O.smp);
 	}
 	stage("tie fix");
 	uint32_t nov = 0, nlist[3] = {0, 0, 0};
@@ -2112,7 +2128,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// BWT symbols (and p0) of the slots finished here
 		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[5], (uint32_t *)nullptr);
-		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s);
+		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s, &O.smp);
 		stage("fallback rounds + emit");
 		leave_fallback:;
 	}

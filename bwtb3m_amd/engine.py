@@ -226,13 +226,15 @@ def finish_shard_ties(plan, out_slice, gather_sa, gather_pairs):
         plan.tie_finish(sa_global.contiguous(), pairs_all.contiguous(), my_first, out_slice)
 
 
-def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0):
-    """convenience: host packed bytes -> (bwt numpy, result dict)"""
+def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0, keep_sa=False):
+    """convenience: host packed bytes -> (bwt numpy, result dict, plan); keep_sa: the sort keeps its whole suffix array (b3m_plan_set_keep_sa)"""
     fb = np.ascontiguousarray(file_bytes, dtype=np.uint8)
     if _type_id(inputtype) == INPUT_TYPES["compactstream"]:
         itype, d, n = compact_to_plan_input(fb)
         plan = Plan(n, itype, blocksize=blocksize, isasamplingrate=isasamplingrate)
         try:
+            if keep_sa:
+                plan.keep_sa(True)
             out = plan.run(d)
             torch.cuda.synchronize()
             return out.cpu().numpy(), plan.result(), plan
@@ -242,6 +244,8 @@ def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0):
     n = num_symbols(fb, inputtype)
     plan = Plan(n, inputtype, blocksize=blocksize, isasamplingrate=isasamplingrate)
     try:
+        if keep_sa:
+            plan.keep_sa(True)
         d = torch.from_numpy(fb).cuda()
         out = plan.run(d)
         torch.cuda.synchronize()

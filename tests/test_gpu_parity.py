@@ -13,10 +13,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _plan_bwt(torch, file_bytes, inputtype, blocksize=0, isarate=0):
+def _plan_bwt(torch, file_bytes, inputtype, blocksize=0, isarate=0, keep_sa=False):
     from bwtb3m_amd import engine
-    out, res, plan = engine.bwt_device(file_bytes, inputtype, blocksize=blocksize, isasamplingrate=isarate)
+    out, res, plan = engine.bwt_device(file_bytes, inputtype, blocksize=blocksize, isasamplingrate=isarate, keep_sa=keep_sa)
     return out, res, plan
+
+
+def _check_samples(plan, sa, n, rate):
+    """the plan's (rank,pos) samples: one per multiple of the rate, each rank the suffix's place in the oracle's suffix array"""
+    smp = plan.samples()
+    assert len(smp) == (n + rate - 1) // rate, (len(smp), n, rate)
+    assert np.array_equal(np.sort(smp[:, 1]), np.arange(0, n, rate).astype(np.uint64))
+    assert np.array_equal(sa[smp[:, 0].astype(np.int64)].astype(np.uint64), smp[:, 1])
 
 
 def _pac(O, bases):
@@ -352,11 +360,15 @@ def test_msd_block_sort_paths(gpu, oracle, itype, kind, d1, monkeypatch):
     buf = _pac(oracle, b)
     s = oracle.symbols_from_file_bytes(buf, itype)
     ref = oracle.bwt(s)
-    for isarate in ((0, 4096) if d1 else (0,)):          # BWT only / suffix array kept: two instantiations of every finish kernel
-        out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate)
+    sa = oracle.sa_circular(s) if d1 else None
+    # BWT only / BWT + samples written by the sort itself / the same with the suffix array kept: both instantiations of every finish kernel
+    for isarate, keep in (((0, False), (4096, False), (96, True)) if d1 else ((0, False),)):
+        out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate, keep_sa=keep)
         assert np.array_equal(out, ref), (kind, isarate)
         if itype == "pacterm":
             assert out[res["p0"]] == 0
+        if isarate:
+            _check_samples(plan, sa, len(s), isarate)
         plan.close()
 
 
@@ -386,6 +398,36 @@ def test_deep_repeats_use_prefix_doubling(gpu, oracle, itype, isarate):
         smp = plan.samples()
         assert np.array_equal(sa[smp[:, 0].astype(np.int64)], smp[:, 1].astype(sa.dtype))
     plan.close()
+
+
+@pytest.mark.parametrize("itype", ["pac", "pacterm"])
+@pytest.mark.parametrize("kind", ["uniform", "repeat", "polyA"])
+def test_samples_are_emitted_where_suffixes_are_placed(gpu, oracle, itype, kind, monkeypatch):
+    """Row a12 inside the fast path: a whole-text block writes its (rank,pos) samples from the finish kernels (records alone in their key),
+    from the tie fix (key ties) and from the list-based rounds' emit (hot bins, oversized buckets), without keeping a suffix array:
+    power-of-two rates (a mask test), other rates (multiplicative divisibility test), rate 1 (every suffix: the whole inverse suffix
+    array), rates above the text length (the one sample of position 0), at the natural geometry and with k_finish_fast forced."""
+    nb = (1 << 18) + 54321
+    if kind == "uniform":
+        b = oracle.synth_bases(nb, 91)
+    elif kind == "repeat":
+        b = oracle.synth_repeat_bases(nb, 92, unit=23, copies=3)
+    else:
+        b = oracle.synth_bases(nb, 93).copy()
+        b[1000:90000] = 0
+        b[-40:] = 0
+    buf = _pac(oracle, b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    for d1 in (0, 5):
+        if d1:
+            monkeypatch.setenv("B3M_MSD_D1", str(d1))
+        for rate in (1, 7, 64, 1000, 12288, 262144, (1 << 20) + 3):
+            out, res, plan = _plan_bwt(gpu, buf, itype, isarate=rate)
+            assert np.array_equal(out, ref), (kind, d1, rate)
+            _check_samples(plan, sa, len(s), rate)
+            plan.close()
 
 
 @pytest.mark.parametrize("itype", ["pac", "pacterm"])
