@@ -141,7 +141,10 @@ struct b3m_plan {
 	uint64_t total_samples = 0;
 	// results
 	b3m_result res{};
-	std::vector<uint64_t> h_samples;
+	std::vector<uint64_t> h_samples;       // (rank,pos) pairs in position order; filled on demand from h_raw (samples_of)
+	uint64_t *h_raw = nullptr;             // pinned image of d_samples, copied on the run's own stream (a pageable copy of 47 MB cost 30 ms per C3 step)
+	bool h_raw_pinned = false;
+	bool samples_pending = false;          // h_raw is newer than h_samples
 	std::vector<uint64_t> h_hist;          // 256
 	Timeline tl;
 	double kms[KF_COUNT]{}; uint64_t klaunch[KF_COUNT]{}; uint64_t kbytes[KF_COUNT]{};
@@ -370,6 +373,11 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	B3M_HIP(hipMemcpy(p->d_anchor_pos, ap.data(), 8 * ap.size(), hipMemcpyHostToDevice));
 	B3M_HIP(hipMemcpy(p->d_endpos, ep.data(), 8 * B, hipMemcpyHostToDevice));
 	p->h_hist.assign(256, 0);
+	if (nsamp) {
+		// pinned if the host can spare it (a dense sampling of a long text may not fit what the driver is willing to pin)
+		if (hipHostMalloc((void **)&p->h_raw, 16 * nsamp, hipHostMallocDefault) == hipSuccess) p->h_raw_pinned = true;
+		else { (void)hipGetLastError(); p->h_raw = (uint64_t *)malloc(16 * nsamp); B3M_REQUIRE(p->h_raw != nullptr, "out of host memory for the (rank,pos) samples"); }
+	}
 	return p;
 	B3M_CATCH((b3m_plan_destroy(p), (b3m_plan *)nullptr))
 }
@@ -387,6 +395,7 @@ uint64_t b3m_plan_slice_capacity(const b3m_plan *p) { return p ? (p->nshards > 1
 void b3m_plan_destroy(b3m_plan *p)
 {
 	if (!p) return;
+	if (p->h_raw) { if (p->h_raw_pinned) (void)hipHostFree(p->h_raw); else free(p->h_raw); }
 	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
 	if (p->d_pack) (void)hipFree(p->d_pack);
 	if (p->arena) (void)hipFree(p->arena);
@@ -443,6 +452,23 @@ struct HostSink {            // SliceHook context of a host-memory run
 		k->evs.push_back(e); k->copied += last - first;
 	}
 };
+}
+
+// the run's samples as a host list, in position order (slot k of the pinned image holds position k * rate); a shard keeps only the
+// samples of its own suffixes (the other slots still read "empty"; ranks are global already)
+static const std::vector<uint64_t> &samples_of(b3m_plan *p)
+{
+	if (p->samples_pending) {
+		p->h_samples.clear();
+		const uint64_t *raw = p->h_raw;
+		if (p->nshards > 1) {
+			for (uint64_t i = 0; i < p->total_samples; ++i)
+				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
+		} else p->h_samples.assign(raw, raw + 2 * p->total_samples);
+		p->res.num_samples = p->h_samples.size() / 2;
+		p->samples_pending = false;
+	}
+	return p->h_samples;
 }
 
 static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_in, uint8_t *d_bwt_out, uint8_t *h_bwt_out, void *stream)
@@ -681,6 +707,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	}
 	uint64_t p0pair[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
+	// the samples leave on the same stream into pinned memory; the host-side list is made from them when somebody asks (samples_of)
+	if (p->isarate && p->total_samples) B3M_HIP(hipMemcpyAsync(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipEventRecord(ev1, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
@@ -706,17 +734,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	               + p->kms[KF_MSD_HIST] + p->kms[KF_MSD_SCATTER] + p->kms[KF_MSD_SCATTER_TEXT] + p->kms[KF_LDS_SORT];
 	p->res.ms_gap = p->kms[KF_RANKBUILD] + p->kms[KF_ANCHOR] + p->kms[KF_GAPWALK];
 	p->res.ms_interleave = p->kms[KF_INTERLEAVE];
-	// samples -> host, in position order (slot k holds position k*rate); a shard keeps only its own
 	p->h_samples.clear();
-	if (p->isarate && p->total_samples) {
-		std::vector<uint64_t> raw(2 * p->total_samples);
-		B3M_HIP(hipMemcpy(raw.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
-		if (p->nshards > 1) {            // a shard keeps the samples of its own suffixes (ranks are global already)
-			for (uint64_t i = 0; i < p->total_samples; ++i)
-				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
-		} else p->h_samples.swap(raw);
-	}
-	p->res.num_samples = p->h_samples.size() / 2;
+	p->samples_pending = p->isarate && p->total_samples;
+	p->res.num_samples = p->nshards > 1 ? 0 : p->total_samples;      // (a shard's own count: samples_of)
 	return 0;
 	B3M_CATCH(1)
 }
@@ -861,11 +881,8 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 	B3M_HIP(hipGetLastError());
 	if (p0pair[0] != ~0ull) { p->res.p0 = p0pair[0]; p->res.has_p0 = 1; }
 	if (mine && p->isarate && p->total_samples) {
-		std::vector<uint64_t> raw(2 * p->total_samples);
-		B3M_HIP(hipMemcpy(raw.data(), p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
-		p->h_samples.clear();
-		for (uint64_t i = 0; i < p->total_samples; ++i) if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
-		p->res.num_samples = p->h_samples.size() / 2;
+		B3M_HIP(hipMemcpy(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		p->samples_pending = true;
 	}
 	p->tie_left = 0;
 	return 0;
@@ -875,13 +892,15 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 int b3m_plan_result(const b3m_plan *p, b3m_result *out)
 {
 	if (!p || !out) { set_error("null argument"); return 1; }
+	if (p->samples_pending && p->nshards > 1) (void)samples_of(const_cast<b3m_plan *>(p));      // a shard's sample count is known once its slots have been looked at
 	*out = p->res; return 0;
 }
 int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap)
 {
 	if (!p || !pairs_out) { set_error("null argument"); return 1; }
-	uint64_t c = std::min<uint64_t>(cap, p->h_samples.size() / 2);
-	memcpy(pairs_out, p->h_samples.data(), 16 * c);
+	const std::vector<uint64_t> &h = samples_of(const_cast<b3m_plan *>(p));
+	uint64_t c = std::min<uint64_t>(cap, h.size() / 2);
+	memcpy(pairs_out, h.data(), 16 * c);
 	return 0;
 }
 int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256)
@@ -1224,7 +1243,7 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	B3M_TRY
 	B3M_REQUIRE(p && d_bwt && mismatches_out, "b3m_plan_lf_walk: null argument");
 	B3M_REQUIRE(p->nshards == 1, "the LF walk needs the whole BWT (unsharded plan)");
-	B3M_REQUIRE(p->isarate && !p->h_samples.empty(), "the plan has no (rank,pos) samples: create it with isasamplingrate > 0 and run it");
+	B3M_REQUIRE(p->isarate && !samples_of(p).empty(), "the plan has no (rank,pos) samples: create it with isasamplingrate > 0 and run it");
 	hipStream_t s = (hipStream_t)stream;
 	const uint64_t n = p->n;
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};

@@ -349,7 +349,7 @@ uint64_t gap_walk_slots(uint64_t num_chains, uint64_t chain_len) { return num_ch
 void gap_walk(const GapWalkArgs &A, hipStream_t s)
 {
 	if (!A.num_chains) return;
-	static const int one_lane = getenv("B3M_WALK_ONE_LANE") ? atoi(getenv("B3M_WALK_ONE_LANE")) : 0;   // measurement switch
+	const int one_lane = getenv("B3M_WALK_ONE_LANE") ? atoi(getenv("B3M_WALK_ONE_LANE")) : 0;   // measurement switch
 	if (one_lane) {
 		// the one-lane kernel fills [chain_len][num_chains]; the rest of the padded table must read as unused
 		const uint64_t used = A.num_chains * A.chain_len, all = gap_walk_slots(A.num_chains, A.chain_len);

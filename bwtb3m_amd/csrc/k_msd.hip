@@ -883,10 +883,13 @@ __device__ __forceinline__ void wave_sort_bucket(uint32_t b0, uint32_t m, int so
 // between 6144 and 12288 records that the first launch listed (`midlist`; skewed base composition makes many),
 // one workgroup per CU.
 // debug build (-DB3M_CHECK_LDS, `make debug`): every LDS index of the finish is checked against its array and traps
+// ... and so is every bucket id taken from a list and every bucket's record range (GLB_CHK)
 #ifdef B3M_CHECK_LDS
 #define LDS_CHK(idx, cap) do { if ((uint32_t)(idx) >= (uint32_t)(cap)) __builtin_trap(); } while (0)
+#define GLB_CHK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
 #else
 #define LDS_CHK(idx, cap) do { } while (0)
+#define GLB_CHK(cond) do { } while (0)
 #endif
 
 constexpr int G_NCH = 512;               // runs (chunks of the level-0 bucket) a gathering finish maps in LDS
@@ -900,6 +903,7 @@ struct FinishSrc {
 	const uint32_t *runpre;      // GATHER: the same rows as start | records before the run << 14 (k_run_totals)
 	const uint32_t *btab;        // GATHER: {start[nb0], tab_off[nb0], nch[nb0]} of the level-0 buckets
 	uint32_t nb0; int D1; uint32_t chunk;
+	uint32_t nbF, nrec;          // number of final buckets and of records (bounds of every bucket id / record range: checked in the debug build)
 };
 struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; };
 
@@ -1148,19 +1152,25 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 }
 
 template <bool WRITE_SA, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, uint32_t b_first, const uint32_t *todo, const FinishLists *L, SortOut O)
+__global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbits, uint32_t b_first, const uint32_t *todo, uint32_t todo_cap, const FinishLists *L, SortOut O)
 {
 	const RowBucket RB{0u, 0u, 0u}; const RowAhead RA{0u, 0u, 0u};
 	if (!todo) {
 		const uint32_t b = b_first + blockIdx.x;
+		GLB_CHK(b < S.nbF);
 		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		GLB_CHK(s0 <= S.nrec && m <= S.nrec - s0);
 		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O); return;
 	}
-	// listed buckets: a fixed grid strides over the list (an empty list costs nothing)
-	const uint32_t cnt = todo[0];
+	// listed buckets: a fixed grid strides over the list (an empty list costs nothing).  The count is what the listing kernels asked for;
+	// what the list HOLDS is at most its capacity (the round-2 abort of `d1.log`: 126 buckets asked for 102 slots, this loop read the
+	// 24 ids behind the list -- run-table words -- and S.bstart[] of those faulted: profiles/NOTES_r03.md)
+	uint32_t cnt = todo[0]; cnt = cnt < todo_cap ? cnt : todo_cap;
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
 		const uint32_t b = todo[1 + it];
+		GLB_CHK(b < S.nbF);
 		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		GLB_CHK(s0 <= S.nrec && m <= S.nrec - s0);
 		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O);
 		__syncthreads();
 	}
@@ -1175,7 +1185,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbi
 	const uint32_t tid = threadIdx.x, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
 	const RowBucket RB{S.btab[2 * S.nb0 + b0], S.btab[S.nb0 + b0], S.btab[b0]};
+	GLB_CHK(b < S.nbF && b0 < S.nb0);
 	const uint32_t s0 = S.bstart[b], s1 = S.bstart[b + 1];
+	GLB_CHK(s0 <= s1 && s1 <= S.nrec);
 	if (s1 == s0) return;                                      // empty (a suffix-range shard keeps a digit range; nch may be 0)
 	const uint32_t tc = tid < RB.nch ? tid : RB.nch - 1, tn = tc + 1 < RB.nch ? tc + 1 : tc;
 	const uint32_t *row = S.runpre + RB.tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * RB.nch;
@@ -1214,6 +1226,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
 	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+	GLB_CHK(b < S.nbF && b0 < S.nb0 && s0 <= S.nrec && m <= S.nrec - s0);
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
 		if (tid == 0) {
@@ -1421,6 +1434,7 @@ __device__ __forceinline__ void compact_segments(const uint32_t b, const FinishS
 	__shared__ uint32_t s_src[256];
 	__shared__ uint32_t red[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	GLB_CHK(b < S.nbF);
 	const uint32_t b0 = b >> S.D1, nch = S.btab[2 * S.nb0 + b0];
 	const uint32_t *row = S.runtab + S.btab[S.nb0 + b0] + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
 	const uint32_t dst0 = S.bstart[b], cbase = S.btab[b0];
@@ -1571,10 +1585,10 @@ __device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec
 }
 
 template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist,
+__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist, uint32_t big_cap,
                                                                  int D, int shift, int sortbits, SortOut O)
 {
-	const uint32_t cnt = biglist[0];
+	uint32_t cnt = biglist[0]; cnt = cnt < big_cap ? cnt : big_cap;          // (what the list holds, not what was asked for)
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {        // a fixed grid strides over the list
 		big_bucket<WRITE_SA>(biglist[1 + it], rec_in, rec_tmp, bstart, D, shift, sortbits, O);
 		__syncthreads();
@@ -1711,12 +1725,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
 	// B3M_DEBUG=2: the stream is drained after every stage and the stage is named on stderr (which kernel a fault belongs to)
-	static const int dbg_stages = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	const int dbg_stages = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	// (a GPU memory fault ends the process inside the runtime: the last "stage done" line then names the stage BEFORE the faulting one)
 	auto stage = [&](const char *name) {
 		if (dbg_stages < 2) return;
-		B3M_HIP(hipStreamSynchronize(s));
-		fprintf(stderr, "[b3m] stage done: %s (start %llu len %llu)\n", name, (unsigned long long)start, (unsigned long long)len_in);
+		const hipError_t e = hipStreamSynchronize(s);
+		fprintf(stderr, "[b3m] stage %s: %s (start %llu len %llu)\n", e == hipSuccess ? "done" : "FAILED", name, (unsigned long long)start, (unsigned long long)len_in);
+		fflush(stderr);
+		B3M_HIP(e);
 	};
+	stage("enter block_sort_msd");
 	B3M_REQUIRE(M.hist != nullptr, "MSD workspace missing");
 	const MsdDigits dg = msd_digits(len_in);
 	B3M_REQUIRE(dg.D0 >= 1 && dg.D0 <= W0_MAXBITS && dg.D1 >= 0 && dg.D1 <= MSD_MAXBITS, "internal: MSD digit split");
@@ -1742,7 +1760,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	A.keep_lo = 0; A.keep_hi = bins0; A.pb = pb;
 	// Chunk-local level 0 (unsharded blocks with a level 1, 32-bit positions): no counting pass, the records of a chunk stay in the
 	// chunk's own index range, level 1 gathers (k_l0_pass<.., LOCAL>, k_l1_gather).  B3M_L0_LOCAL=0: the scattering form.
-	static const int l0_local_on = getenv("B3M_L0_LOCAL") ? atoi(getenv("B3M_L0_LOCAL")) : 1;
+	const int l0_local_on = getenv("B3M_L0_LOCAL") ? atoi(getenv("B3M_L0_LOCAL")) : 1;
 	const uint32_t nchunks0 = (uint32_t)((span + W0A_CHUNK - 1) / W0A_CHUNK);
 	const bool local0 = l0_local_on && nshards <= 1 && geoA && dg.D1 > 0 && !big && span <= ws.cap && M.tab0 != nullptr
 	                    && (uint64_t)bins0 * ((uint64_t)ntA * W0A_TCH) <= M.tab0_cap && span < (1ull << 32);
@@ -1822,7 +1840,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		int t = 0; while ((len_in >> t) > (uint64_t)F_AVG) ++t;
 		int S = 0;
 		while (hi > lo && S < t - dg.D0 - dg.D1 && dg.D0 + S < 15 && ((uint64_t)(hi - lo) << (S + 1)) <= (uint64_t)W0_MAXBINS) ++S;
-		static const int no_fine = getenv("B3M_NO_FINE_SHARDS") ? atoi(getenv("B3M_NO_FINE_SHARDS")) : 0;      // measurement switch
+		const int no_fine = getenv("B3M_NO_FINE_SHARDS") ? atoi(getenv("B3M_NO_FINE_SHARDS")) : 0;      // measurement switch
 		if (no_fine) S = 0;
 		{ const char *e = getenv("B3M_FINE_MAXS"); if (e && S > atoi(e)) S = atoi(e); }
 		A.keep_lo = lo << S; A.keep_hi = hi << S; A.D = dg.D0 + S; D0e = dg.D0 + S;
@@ -1951,6 +1969,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		gather = true;
 	}
 	// ---- finish: every final bucket sorted inside LDS; compulsory traffic = records in, BWT byte (+ SA entry) out ----
+	FS.nbF = nbF; FS.nrec = (uint32_t)len;
 	const int fbits = REC_KEY_BITS - consumed;            // free key bits of a record entering the finish
 	B3M_REQUIRE(fbits >= 1 && fbits <= REC_KEY_BITS && fbits - std::min(fbits, F_BINBITS) <= 16, "internal: free key bits of the finish");
 	const uint32_t ovf_cap = (uint32_t)M.overflow_cap;
@@ -1992,7 +2011,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			const uint32_t bfa = nsl > 1 ? l0a << dg.D1 : 0u, bfb = nsl > 1 ? l0b << dg.D1 : nbF;
 			const uint64_t ra = nsl > 1 ? lvl0[sl] : 0, rb = nsl > 1 ? lvl0[sl + 1] : len;
 			if (bfb == bfa) continue;
-			static const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
+			const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
 			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
@@ -2000,8 +2019,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else {
-				if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, dl, O);
-				else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, dl, O);
+				if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, 0u, dl, O);
+				else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, 0u, dl, O);
 			}
 			if (nsl > 1) {
 				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0, O.smp);
@@ -2016,17 +2035,17 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
 			stage("compact listed");
 		}
-		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
-		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, dl + 1, O);
+		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, (uint32_t)M.mid_cap, dl + 1, O);
+		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, (uint32_t)M.mid_cap, dl + 1, O);
 		stage("mid finish");
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
 		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
 		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa, pb);
 		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 2048);
 		if (need_sa)
-			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
 		else
-			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, 8, 64 - consumed - 8, fbits - 8, O);
+			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
 		stage("big / huge finish");
 		sliced = nsl > 1;
 	}
@@ -2042,7 +2061,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	if (!sliced || out.late_writes) {
 		Scope sc(tl, KF_TIES, len / 8);
-		static const int tie_two_step = getenv("B3M_TIE_TWO_STEP") ? atoi(getenv("B3M_TIE_TWO_STEP")) : 1;      // measurement switch
+		const int tie_two_step = getenv("B3M_TIE_TWO_STEP") ? atoi(getenv("B3M_TIE_TWO_STEP")) : 1;      // measurement switch
 		if (tie_two_step && len >= (1ull << 22) && len < (1ull << 32)) {
 			// both record buffers are free by now: the list of group starts goes into one of them
 			uint32_t *glist = reinterpret_cast<uint32_t *>(ws.keyB), *gcnt = reinterpret_cast<uint32_t *>(M.lists) + 60;

@@ -1,0 +1,247 @@
+"""Randomised cases shared by the fixed-seed slices in tests/test_gpu_fuzz.py and the long sweeps in tools/fuzz*.py.
+
+Each case_* function draws ONE case from the numpy generator it is given, runs it through the C ABI (bwtb3m_amd.engine) and returns
+(ok, description).  Small cases are checked against the oracle; cases the oracle cannot sort are verified by the on-device LF walk
+(checkbwt semantics, /root/reference/src/checkbwt.cpp:176-243) and by comparing the forms (one block / merge tree / shards / host to
+host) with each other.  The alternative code paths of the library (environment switches, tools/README.md) are drawn too.
+"""
+import os
+
+import numpy as np
+
+
+def _set_env(**kv):
+    for k, v in kv.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+
+
+def clear_switches():
+    _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None)
+
+
+def case_small(rng, O, engine):
+    """all input types, sizes around the path switches (2^18 = record sort, block edges off word / chunk borders), random blockings and
+    sampling rates (powers of two and not), forced digit widths, low-entropy and repeat-rich texts: against the oracle"""
+    itype = ["pac", "pacterm", "bytestream"][int(rng.integers(0, 3))]
+    pick = rng.integers(0, 5)
+    nb = int([rng.integers(1, 2000), rng.integers(260000, 270000), rng.integers(250000, 700000), rng.integers(1, 100000), rng.integers(520000, 1100000)][pick])
+    kind = int(rng.integers(0, 4))
+    if itype == "bytestream":
+        sig = int([256, 4, 2, 26][kind])
+        t = rng.integers(0, sig, nb, dtype=np.uint8)
+        if kind == 3 and nb > 100:
+            k = int(rng.integers(1, nb // 2)); t[nb - k:] = t[:k]
+        buf, s = t, t
+    else:
+        b = rng.integers(0, [4, 4, 2, 4][kind], nb, dtype=np.uint8)
+        if kind == 1 and nb > 100:
+            k = int(rng.integers(1, nb // 2)); p = int(rng.integers(0, nb - k)); b[p:p + k] = 0
+        if kind == 3 and nb > 100:
+            k = int(rng.integers(1, nb // 2)); b[nb - k:] = b[:k]
+        buf = O.pac_encode(b); s = O.symbols_from_file_bytes(buf, itype)
+    n = len(s)
+    bs = 0
+    if rng.integers(0, 2) and n > 20:              # blocks of a merge tree (2-bit and byte alphabets)
+        bs = int(rng.integers(max(8, n // 9), n))
+    d1 = int([0, 0, 0, 2, 4, 5, 6, 8][int(rng.integers(0, 8))])
+    _set_env(B3M_MSD_D1=d1 or None, B3M_L0_LOCAL=[None, None, 0][int(rng.integers(0, 3))], B3M_NO_FAST_FINISH=[None, None, 1][int(rng.integers(0, 3))])
+    isar = int([0, 64, 4096, 1000, 7][int(rng.integers(0, 5))])
+    keep = bool(rng.integers(0, 4) == 0)
+    desc = "small type=%s nb=%d kind=%d bs=%d isar=%d keep_sa=%d d1=%d" % (itype, nb, kind, bs, isar, keep, d1)
+    try:
+        out, res, plan = engine.bwt_device(buf, itype, blocksize=bs, isasamplingrate=isar, keep_sa=keep)
+        ok = bool(np.array_equal(out, O.bwt(s)))
+        if ok and isar:
+            sa = O.sa_circular(s); smp = plan.samples()
+            ok = len(smp) == (n + isar - 1) // isar and bool(np.array_equal(sa[smp[:, 0].astype(np.int64)], smp[:, 1].astype(sa.dtype)))
+        plan.close()
+    except Exception as ex:   # noqa: BLE001
+        ok = False; desc += " EXC " + repr(ex)[:300]
+    finally:
+        clear_switches()
+    return ok, desc
+
+
+def run_shards(torch, engine, d_text, n, itype, ns, isarate=0):
+    """all ns suffix-range shards of a text on this one GPU, as the ranks of a multi-GPU run would: each plan runs, and if any shard's local
+    rounds left suffixes tied (long repeats) all of them finish collectively over the gathered suffix arrays"""
+    plans, slices = [], []
+    for k in range(ns):
+        plan = engine.Plan(n, itype, shard=k, nshards=ns, isasamplingrate=isarate)
+        slices.append(plan.run(d_text).clone()); plans.append(plan)
+    torch.cuda.synchronize()
+    pend = [p.tie_pending() for p in plans]
+    if sum(pend):
+        for k, p in enumerate(plans):              # BWT-only runs kept no suffix array
+            if not p.has_sa():
+                sl = torch.empty(p.slice_capacity, dtype=torch.uint8, device="cuda")
+                engine.rerun_for_ties(p, d_text, sl)
+                slices[k] = sl[: p.result()["slice_len"]].clone()
+        pend = [p.tie_pending() for p in plans]
+        exported = [p.tie_export("cuda") for p in plans]
+        sa_all = torch.cat([e[0] for e in exported]); pairs_all = torch.cat([e[1] for e in exported])
+        assert sa_all.numel() == n
+        for k, p in enumerate(plans):
+            engine.finish_shard_ties(p, slices[k], lambda sa: sa_all.clone(), lambda pr, k=k: (pairs_all, sum(pend[:k])))
+    return plans, slices, sum(pend)
+
+
+def case_shards(rng, O, engine, torch):
+    """2..8 suffix-range shards of a 0.26..0.9 Mbase text must tile the oracle's BWT (forced digit widths: the large geometries, the fine level 0)"""
+    itype = ["pac", "pacterm"][int(rng.integers(0, 2))]
+    nb = int(rng.integers(262200, 900000))
+    kind = int(rng.integers(0, 3))
+    b = rng.integers(0, [4, 4, 2][kind], nb, dtype=np.uint8)
+    if kind == 1:
+        k = int(rng.integers(1, nb // 3)); p = int(rng.integers(0, nb - k)); b[p:p + k] = b[:k]
+    buf = O.pac_encode(b); s = O.symbols_from_file_bytes(buf, itype); n = len(s)
+    ns = int(rng.integers(2, 9))
+    geo = int(rng.integers(0, 4))
+    isar = int([0, 256, 1000][int(rng.integers(0, 3))])
+    _set_env(B3M_MSD_D0=[None, None, "2", "3"][geo], B3M_MSD_D1=[None, "4", "3", "4"][geo])
+    desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d" % (itype, nb, kind, ns, geo, isar)
+    try:
+        d_text = torch.from_numpy(np.asarray(buf)).cuda()
+        plans, slices, _ = run_shards(torch, engine, d_text, n, itype, ns, isar)
+        off, ok, smp = 0, True, []
+        for p, sl in zip(plans, slices):
+            r = p.result()
+            ok &= r["slice_offset"] == off and r["slice_len"] == sl.numel()
+            off += sl.numel()
+            if isar:
+                smp.append(p.samples())
+        ok &= off == n and bool(np.array_equal(torch.cat(slices).cpu().numpy(), O.bwt(s)))
+        if ok and isar:
+            smp = np.concatenate(smp); sa = O.sa_circular(s)
+            ok = len(smp) == (n + isar - 1) // isar and bool(np.array_equal(sa[smp[:, 0].astype(np.int64)], smp[:, 1].astype(sa.dtype)))
+        for p in plans:
+            p.close()
+    except Exception as ex:   # noqa: BLE001
+        ok = False; desc += " EXC " + repr(ex)[:300]
+    finally:
+        clear_switches()
+    return ok, desc
+
+
+def device_dna(rng, torch, nb, comp):
+    """nb bases on the device with one of four base compositions and 0..5 planted repeats (copies, tandem arrays, homopolymer runs)"""
+    g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1, 1 << 40)))
+    probs = {0: [0.25, 0.25, 0.25, 0.25], 1: [0.33, 0.17, 0.17, 0.33], 2: [0.5, 0.0, 0.0, 0.5], 3: [0.7, 0.1, 0.1, 0.1]}[comp]
+    edges = torch.tensor(np.cumsum(probs)[:3], dtype=torch.float32, device="cuda")
+    b = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for o in range(0, nb, 1 << 28):
+        m_ = min(1 << 28, nb - o)
+        b[o:o + m_] = torch.bucketize(torch.rand(m_, device="cuda", generator=g), edges, right=True).to(torch.uint8)
+    planted = []
+    for _ in range(int(rng.integers(0, 6))):
+        kind = int(rng.integers(0, 3)); ln = int(rng.integers(100, 300_000)); dst = int(rng.integers(0, nb - ln))
+        if kind == 0:
+            src = int(rng.integers(0, nb - ln)); b[dst:dst + ln] = b[src:src + ln].clone(); planted.append((0, ln, dst, src))
+        elif kind == 1:
+            u = int(rng.integers(1, 200)); b[dst:dst + ln] = b[dst:dst + u].repeat((ln + u - 1) // u)[:ln]; planted.append((1, ln, dst, u))
+        else:
+            v = int(rng.integers(0, 4)); b[dst:dst + ln] = v; planted.append((2, ln, dst, v))
+    return b, planted
+
+
+def pac_image(torch, b):
+    """.pac image (+ 64 bytes of padding) of a base tensor on the device"""
+    nb = b.numel()
+    pad = (-nb) % 4
+    bb = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)]).view(-1, 4)
+    pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
+    tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device=b.device)
+    return torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device=b.device)])
+
+
+def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
+    """sizes the oracle cannot sort: the one-block BWT is LF-verified on the device from its own samples, then another form (blocks of
+    a merge tree, mem=-chosen blocks, shards incl. the collective tie finish, host to host byte / packed) must give the same bytes"""
+    nb = int(rng.integers(lo, hi))
+    comp = int(rng.integers(0, 4))
+    b, planted = device_dna(rng, torch, nb, comp)
+    itype = ["pac", "pacterm"][int(rng.integers(0, 2))]
+    d_text = pac_image(torch, b)
+    n = nb + (1 if itype == "pacterm" else 0)
+    form = int(rng.integers(0, 5))
+    alt = int(rng.integers(0, 4))                     # alternative paths of the block sort on a quarter of the cases each
+    _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None)
+    rate = int([1 << 16, 1024, 3000][int(rng.integers(0, 3))])
+    desc = "large n=%d %s comp=%d form=%d alt=%d rate=%d planted=%s" % (n, itype, comp, form, alt, rate, planted)
+    ok = True
+    try:
+        plan = engine.Plan(n, itype, isasamplingrate=rate)
+        one = plan.run(d_text).clone(); torch.cuda.synchronize()
+        lf = plan.lf_walk(one, sarate=0)[:2]
+        ok &= lf == (0, 0); desc += " LF %s rounds %d" % (lf, plan.result()["tie_rounds"])
+        plan.close()
+        if form == 1:
+            nblk = int(rng.integers(2, 6)) if rng.integers(0, 3) else int(rng.integers(6, 41))
+            plan = engine.Plan(n, itype, isasamplingrate=rate, blocksize=(n + nblk - 1) // nblk)
+            out = plan.run(d_text); torch.cuda.synchronize()
+            ok &= bool(torch.equal(out, one)); desc += " blocks %d" % plan.result()["num_blocks"]
+            plan.close()
+        elif form == 4:
+            want = int(rng.integers(2, 13))            # the memory budget picks the block size (mem=: /root/reference/README.md:42)
+            plan = engine.Plan(n, itype, isasamplingrate=rate, mem=int(n * 8 + n * 52 / want) + (128 << 20))
+            out = plan.run(d_text); torch.cuda.synchronize()
+            ok &= bool(torch.equal(out, one)); desc += " mem-> blocks %d" % plan.result()["num_blocks"]
+            plan.close()
+        elif form == 3:
+            plan = engine.Plan(n, itype, isasamplingrate=rate)
+            h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory(); h_text.copy_(d_text[:plan.text_bytes].cpu())
+            h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+            plan.run_host(h_text, h_out)
+            ok &= bool(torch.equal(h_out, one.cpu()))
+            h_pk = torch.empty((n + 3) // 4, dtype=torch.uint8).pin_memory()
+            plan.run_host(h_text, h_pk, packed=True)
+            ok &= bool(torch.equal(h_pk, engine.Plan.pack_pac(one, itype == "pacterm").cpu())); desc += " host runs"
+            plan.close()
+        elif form == 2:
+            ns = int(rng.integers(2, 17))
+            plans, slices, ties = run_shards(torch, engine, d_text, n, itype, ns)
+            ok &= bool(torch.equal(torch.cat(slices), one)); desc += " shards %d (ties %d)" % (ns, ties)
+            for p in plans:
+                p.close()
+    except Exception as ex:   # noqa: BLE001
+        if form == 2 and "suffix-range shard larger than the workspace" in str(ex):
+            desc += " (shards refused: one level-0 digit heavier than a shard's slack -- the documented limit for skewed composition)"
+        else:
+            ok = False; desc += " EXC " + repr(ex)[:400]
+    finally:
+        clear_switches()
+    del d_text, b
+    torch.cuda.empty_cache()
+    return ok, desc
+
+
+def case_bytes_large(rng, engine, torch, lo=5_000_000, hi=80_000_000):
+    """byte alphabets at sizes the oracle cannot sort: the one-block BWT (LF-verified) against blocks of a merge tree"""
+    n = int(rng.integers(lo, hi)); sig = int([2, 4, 26, 64, 256][int(rng.integers(0, 5))])
+    g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1, 1 << 40)))
+    t = torch.randint(0, sig, (n,), device="cuda", dtype=torch.int32, generator=g)
+    if rng.integers(0, 2):
+        t = (t * t) % sig                      # skewed symbol frequencies
+    t = (t + int(rng.integers(0, 256 - sig + 1))).to(torch.uint8)
+    for _ in range(int(rng.integers(0, 4))):
+        ln = int(rng.integers(100, 200_000)); dst = int(rng.integers(0, n - ln))
+        if rng.integers(0, 2):
+            src = int(rng.integers(0, n - ln)); t[dst:dst + ln] = t[src:src + ln].clone()
+        else:
+            u = int(rng.integers(1, 100)); t[dst:dst + ln] = t[dst:dst + u].repeat((ln + u - 1) // u)[:ln]
+    nblk = int(rng.integers(2, 7)); ok = True
+    desc = "bytes n=%d sigma=%d blocks %d" % (n, sig, nblk)
+    try:
+        d_text = torch.cat([t, torch.zeros(64, dtype=torch.uint8, device="cuda")])
+        p1 = engine.Plan(n, "bytestream"); one = p1.run(d_text).clone(); torch.cuda.synchronize(); p1.close()
+        pb = engine.Plan(n, "bytestream", blocksize=(n + nblk - 1) // nblk); out = pb.run(d_text); torch.cuda.synchronize()
+        ok &= bool(torch.equal(out, one)) and bool(torch.equal(torch.bincount(one.to(torch.int64), minlength=256), torch.bincount(t.to(torch.int64), minlength=256)))
+        pb.close()
+    except Exception as ex:   # noqa: BLE001
+        ok = False; desc += " EXC " + repr(ex)[:300]
+    del t
+    torch.cuda.empty_cache()
+    return ok, desc

@@ -683,37 +683,144 @@ def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
     plan.close()
 
 
-def test_config_c3_full_size_3gbase_pacterm(gpu):
-    """BASELINE configs[2] at FULL size (n = 3,000,000,001: level 0 at 11 bits, level 1 at 8 bits, positions above 2^31).
-    The timed variant (isasamplingrate=0, BWT only) must equal the isasamplingrate>0 variant, and that one is verified
-    on the device by LF walks over every symbol against the text (checkbwt, /root/reference/src/checkbwt.cpp:176-243)."""
-    torch = gpu
-    from bwtb3m_amd import benchutil, engine, synth
+def _shipped_rate():
+    from bwtb3m_amd import _lib
+    return int(_lib.lib().b3m_plan_sampling_rate(0, 0))          # the plan b3m_compute_bwt creates by default (isasamplingrate=262144, bwtonly=0)
+
+
+def _c3_one_block(torch, engine, synth):
+    """C3 as ONE block through the plan the boundary function creates; LF-walked from its own samples"""
     itype, d_text, n = synth.config_input_device("c3", device="cuda")
     assert n == 3_000_000_001 and itype == "pacterm"
-    plan = engine.Plan(n, itype, isasamplingrate=0)
+    plan = engine.Plan(n, itype, isasamplingrate=_shipped_rate())
     assert plan.num_blocks == 1
-    timed = torch.empty(n, dtype=torch.uint8, device="cuda")
-    plan.run(d_text, timed)
+    one = torch.empty(n, dtype=torch.uint8, device="cuda")
+    plan.run(d_text, one)
     torch.cuda.synchronize()
-    r0 = plan.result()
-    h0 = plan.histogram().astype(np.int64).tolist()
-    plan.close()
-    plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
-    ref = plan.run(d_text)
-    torch.cuda.synchronize()
+    return itype, d_text, n, plan, one
+
+
+def test_config_c3_full_size_3gbase_pacterm(gpu):
+    """BASELINE configs[2] at full size, through the plan b3m_compute_bwt creates (samples at b3m_plan_sampling_rate): the output is
+    LF-walked on the device against the text from the plan's own samples (checkbwt semantics: every symbol, every chain closure); the
+    BWT-only plan (isasamplingrate=0) gives the same bytes; histograms of the BWT, the text (torch alone) and .hist agree."""
+    torch = gpu
+    from bwtb3m_amd import benchutil, engine, synth
+    itype, d_text, n, plan, one = _c3_one_block(torch, engine, synth)
     r1 = plan.result()
-    m0, m1, _ = plan.lf_walk(ref, sarate=0)
+    assert r1["num_samples"] == (n + _shipped_rate() - 1) // _shipped_rate()
+    m0, m1, _ = plan.lf_walk(one, sarate=0)
     assert (m0, m1) == (0, 0)
-    assert torch.equal(timed, ref)
-    assert r0["p0"] == r1["p0"] and int(timed[r0["p0"]]) == 0
+    assert int(one[r1["p0"]]) == 0
     ht = benchutil.text_histogram(d_text, n, itype)
-    assert h0 == ht
+    assert plan.histogram().astype(np.int64).tolist() == ht
     hb = torch.zeros(256, dtype=torch.int64, device="cuda")
     for o in range(0, n, 1 << 28):
-        hb += torch.bincount(timed[o:o + (1 << 28)].to(torch.int64), minlength=256)
+        hb += torch.bincount(one[o:o + (1 << 28)].to(torch.int64), minlength=256)
     assert hb.cpu().tolist() == ht
     plan.close()
+    plan = engine.Plan(n, itype, isasamplingrate=0)
+    bo = plan.run(d_text)
+    torch.cuda.synchronize()
+    assert torch.equal(bo, one) and plan.result()["p0"] == r1["p0"]
+    plan.close()
+
+
+def test_config_c4_3gbase_as_8_suffix_range_shards(gpu):
+    """BASELINE configs[3]'s workload on one GPU: the 8 suffix-range shards an 8-GPU run would sort, one after the other, concatenate
+    to the one-block BWT byte for byte; exactly one shard holds p0; the shards' (rank,pos) samples together are the one-block plan's."""
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    itype, d_text, n, plan, one = _c3_one_block(torch, engine, synth)
+    r1 = plan.result()
+    smp1 = plan.samples()
+    plan.close()
+    rate = _shipped_rate()
+    off, p0s, parts = 0, [], []
+    for k in range(8):
+        p = engine.Plan(n, itype, shard=k, nshards=8, isasamplingrate=rate)
+        sl = p.run(d_text)
+        torch.cuda.synchronize()
+        r = p.result()
+        assert r["slice_offset"] == off and r["slice_len"] == sl.numel()
+        assert torch.equal(sl, one[off:off + sl.numel()]), "shard %d differs from the one-block BWT" % k
+        if r["has_p0"]:
+            p0s.append(r["p0"])
+        parts.append(p.samples())
+        off += sl.numel()
+        p.close(); del sl
+    assert off == n and p0s == [r1["p0"]]
+    smp8 = np.concatenate(parts)
+    assert len(smp8) == len(smp1)
+    assert np.array_equal(smp8[np.argsort(smp8[:, 1])], smp1[np.argsort(smp1[:, 1])])
+
+
+def test_config_c4_3gbase_as_8_leaf_merge_tree(gpu):
+    """BASELINE configs[3]'s workload through the north-star merge path on one GPU: 8 leaf blocks (blocksize = ceil(n/8)), 3 levels of
+    gap merges; the result equals the one-block BWT byte for byte, p0 and the (rank,pos) samples carried through the merges too."""
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    itype, d_text, n, plan, one = _c3_one_block(torch, engine, synth)
+    r1 = plan.result()
+    smp1 = plan.samples()
+    plan.close()
+    p = engine.Plan(n, itype, blocksize=(n + 7) // 8, isasamplingrate=_shipped_rate())
+    assert p.num_blocks == 8
+    out = p.run(d_text)
+    torch.cuda.synchronize()
+    r = p.result()
+    assert r["levels"] == 3
+    assert torch.equal(out, one), "the 8-leaf merge tree differs from the one-block BWT"
+    assert r["p0"] == r1["p0"]
+    smp = p.samples()
+    assert np.array_equal(smp[np.argsort(smp[:, 1])], smp1[np.argsort(smp1[:, 1])])
+    p.close()
+
+
+def _lf_chain_check(torch, d_text, n, bwt, ranks_by_k, rate, stride):
+    """checkbwt on a subset of the chains, with torch alone (no dictionary of the engine's: 64-bit counts): chain k starts at the sampled
+    rank of position k*rate and makes `rate` LF steps down to position (k-1)*rate; every step's BWT symbol must be the text symbol in
+    front of the position, and the chain must arrive at the sampled rank of (k-1)*rate.  pacterm.  Returns (chains, symbol mismatches,
+    chain mismatches)."""
+    dev = bwt.device
+    CH = 1024
+    nch = (n + CH - 1) // CH
+    cum = torch.zeros((nch + 1, 5), dtype=torch.int64, device=dev)          # cum[j, c] = occurrences of c in bwt[0, j * CH)
+    step_ = 1 << 28
+    for o in range(0, n, step_):
+        e = min(n, o + step_)
+        x = bwt[o:e]
+        pad = (-x.numel()) % CH
+        if pad:
+            x = torch.cat([x, torch.full((pad,), 255, dtype=torch.uint8, device=dev)])
+        x = x.view(-1, CH)
+        j0 = o // CH
+        for c in range(5):
+            cum[j0 + 1: j0 + 1 + x.shape[0], c] = (x == c).sum(1)
+    cum = torch.cumsum(cum, 0)
+    tot = cum[-1]
+    C = torch.zeros(5, dtype=torch.int64, device=dev)
+    C[1:] = torch.cumsum(tot, 0)[:-1]
+    K = len(ranks_by_k)
+    ks = torch.arange(stride, K, stride, device=dev, dtype=torch.int64)
+    rk = torch.from_numpy(ranks_by_k.astype(np.int64)).to(dev)
+    r = rk[ks].clone()
+    pos = ks * rate
+    ar = torch.arange(CH, device=dev, dtype=torch.int64)[None, :]
+    bad_sym = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(rate):
+        c = bwt[r].to(torch.int64)
+        q = pos - 1                                        # pos >= 1 on every step (chains end at (k-1)*rate >= 0)
+        want = ((d_text[q >> 2].to(torch.int64) >> (((~q) & 3) << 1)) & 3) + 1
+        bad_sym += (c != want).sum()
+        ch = r >> 10
+        base = ch << 10
+        win = bwt[torch.clamp(base[:, None] + ar, max=n - 1)].to(torch.int64)
+        inwin = ((win == c[:, None]) & (ar < (r - base)[:, None])).sum(1)
+        r = C[c] + cum[ch, c] + inwin
+        pos = q
+    bad_chain = (r != rk[ks - 1]).sum()
+    return int(ks.numel()), int(bad_sym), int(bad_chain)
 
 
 def _sample_checks(torch, d_text, n, samples, out_slice, slice_offset):
@@ -790,8 +897,11 @@ def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
     ht = benchutil.text_histogram(d_text, n, itype)
     hb = torch.zeros(256, dtype=torch.int64, device="cuda")
     nsh, off, p0s = 8, 0, []
+    rate = 4096
+    full = torch.empty(n, dtype=torch.uint8, device="cuda")          # all eight slices (30 GB), for the LF chains below
+    ranks_by_k = np.full((n + rate - 1) // rate, -1, dtype=np.int64)
     for k in range(nsh):
-        plan = engine.Plan(n, itype, isasamplingrate=1 << 20, shard=k, nshards=nsh)
+        plan = engine.Plan(n, itype, isasamplingrate=rate, shard=k, nshards=nsh)
         sl = plan.run(d_text)
         torch.cuda.synchronize()
         r = plan.result()
@@ -802,11 +912,18 @@ def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
             hb += torch.bincount(sl[o:o + (1 << 28)].to(torch.int64), minlength=256)
         sm = plan.samples()
         assert len(sm) > 1000 and int(sm[:, 0].min()) >= off and int(sm[:, 0].max()) < off + sl.numel()
-        _sample_checks(torch, d_text, n, sm, sl, off)
+        _sample_checks(torch, d_text, n, sm[::64], sl, off)
+        ranks_by_k[(sm[:, 1] // rate).astype(np.int64)] = sm[:, 0].astype(np.int64)
+        full[off:off + sl.numel()] = sl
         off += sl.numel()
         plan.close(); del sl
     assert off == n and len(p0s) == 1
     assert hb.cpu().tolist() == ht
+    # every sampled position got its rank from exactly one shard, and one chain in 256 of the whole BWT closes under LF steps
+    # (/root/reference/src/checkbwt.cpp:176-243 on a subset: 28,610 chains x 4096 steps = 117 M verified symbols, ranks above 2^32)
+    assert int((ranks_by_k < 0).sum()) == 0
+    chains, bad_sym, bad_chain = _lf_chain_check(torch, d_text, n, full, ranks_by_k, rate, 256)
+    assert chains > 28000 and (bad_sym, bad_chain) == (0, 0), (chains, bad_sym, bad_chain)
 
 
 def test_merge_with_skewed_rank_list_40mbase(gpu):

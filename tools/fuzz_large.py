@@ -1,96 +1,20 @@
-"""Randomised sweep at sizes the oracle cannot sort (24 M - 400 M bases): random composition (uniform, AT-rich, two symbols), planted repeats
-(copies, tandem arrays, homopolymer runs), one block / a few blocks of a merge tree / suffix-range shards; every result is verified by the
-on-device LF walk (/root/reference/src/checkbwt.cpp:176-243 semantics) and block / shard forms must equal the one-block BWT.
-python tools/fuzz_large.py [iterations] [seed] [min bases] [max bases]"""
-import sys, time
+"""Randomised sweep at sizes the oracle cannot sort (tests/fuzzlib.py: case_large): random composition, planted repeats, one block /
+blocks of a merge tree / mem=-chosen blocks / suffix-range shards / host-to-host; every result LF-verified on the device, the forms
+compared with each other.  python tools/fuzz_large.py [iterations] [seed] [min bases] [max bases]"""
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fuzzlib
 from bwtb3m_amd import engine
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+lo = int(float(sys.argv[3])) if len(sys.argv) > 3 else 24_000_000
+hi = int(float(sys.argv[4])) if len(sys.argv) > 4 else 400_000_000
 bad = 0; t0 = time.time()
 for it in range(iters):
-    nb = int(rng.integers(int(float(sys.argv[3])) if len(sys.argv) > 3 else 24_000_000, int(float(sys.argv[4])) if len(sys.argv) > 4 else 400_000_000))
-    comp = int(rng.integers(0, 4))
-    g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1, 1 << 40)))
-    # (chunks of 2^28: torch.multinomial with 1.27 G samples faulted on this box -- in torch, before the library was called)
-    probs = {0: [0.25, 0.25, 0.25, 0.25], 1: [0.33, 0.17, 0.17, 0.33], 2: [0.5, 0.0, 0.0, 0.5], 3: [0.7, 0.1, 0.1, 0.1]}[comp]
-    edges = torch.tensor(np.cumsum(probs)[:3], dtype=torch.float32, device="cuda")
-    b = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    for o in range(0, nb, 1 << 28):
-        m_ = min(1 << 28, nb - o)
-        b[o:o + m_] = torch.bucketize(torch.rand(m_, device="cuda", generator=g), edges, right=True).to(torch.uint8)
-    for _ in range(int(rng.integers(0, 6))):           # planted repeats
-        kind = int(rng.integers(0, 3)); ln = int(rng.integers(100, 300_000)); dst = int(rng.integers(0, nb - ln))
-        if kind == 0: src = int(rng.integers(0, nb - ln)); b[dst:dst + ln] = b[src:src + ln].clone()
-        elif kind == 1: u = int(rng.integers(1, 200)); b[dst:dst + ln] = b[dst:dst + u].repeat((ln + u - 1) // u)[:ln]
-        else: b[dst:dst + ln] = int(rng.integers(0, 4))
-    itype = ["pac", "pacterm"][int(rng.integers(0, 2))]
-    # .pac image on the device
-    pad = (-nb) % 4
-    bb = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device="cuda")]).view(-1, 4)
-    pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
-    tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device="cuda")
-    d_text = torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device="cuda")])
-    n = nb + (1 if itype == "pacterm" else 0)
-    form = int(rng.integers(0, 5))
-    ok = True; msg = ""
-    try:
-        plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
-        one = plan.run(d_text).clone(); torch.cuda.synchronize()
-        lf = plan.lf_walk(one, sarate=0)[:2] if itype == "pacterm" or True else (0, 0)
-        ok &= lf == (0, 0); msg = "LF %s rounds %d" % (lf, plan.result()["tie_rounds"])
-        plan.close()
-        if form == 1:
-            nblk = int(rng.integers(2, 6)) if rng.integers(0, 3) else int(rng.integers(6, 41))          # a few blocks, or many (more merge levels)
-            plan = engine.Plan(n, itype, isasamplingrate=1 << 16, blocksize=(n + nblk - 1) // nblk)
-            out = plan.run(d_text); torch.cuda.synchronize()
-            ok &= bool(torch.equal(out, one)); msg += " blocks %d eq %s" % (plan.result()["num_blocks"], ok)
-            plan.close()
-        elif form == 4:
-            # the memory budget picks the block size (mem=: /root/reference/README.md:42), aiming at 2..12 blocks
-            want = int(rng.integers(2, 13))
-            plan = engine.Plan(n, itype, isasamplingrate=1 << 16, mem=int(n * 8 + n * 52 / want) + (128 << 20))
-            out = plan.run(d_text); torch.cuda.synchronize()
-            ok &= bool(torch.equal(out, one)); msg += " mem-> blocks %d eq %s" % (plan.result()["num_blocks"], ok)
-            plan.close()
-        elif form == 3:
-            # host memory to host memory (text arriving in pieces, BWT leaving in slices), one byte per symbol and packed
-            plan = engine.Plan(n, itype, isasamplingrate=0)
-            h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory(); h_text.copy_(d_text[:plan.text_bytes].cpu())
-            h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
-            plan.run_host(h_text, h_out)
-            ok &= bool(torch.equal(h_out, one.cpu()))
-            h_pk = torch.empty((n + 3) // 4, dtype=torch.uint8).pin_memory()
-            plan.run_host(h_text, h_pk, packed=True)
-            ok &= bool(torch.equal(h_pk, engine.Plan.pack_pac(one, itype == "pacterm").cpu())); msg += " host runs eq %s" % ok
-            plan.close()
-        elif form == 2:
-            ns = int(rng.integers(2, 17))
-            plans, slices = [], []
-            for k in range(ns):
-                p = engine.Plan(n, itype, shard=k, nshards=ns); slices.append(p.run(d_text).clone()); plans.append(p)
-            pend = [p.tie_pending() for p in plans]
-            if sum(pend):                              # long repeats: the collective finish over all shards' suffix arrays
-                for k, p in enumerate(plans):
-                    if not p.has_sa():
-                        sl = torch.empty(p.slice_capacity, dtype=torch.uint8, device="cuda")
-                        engine.rerun_for_ties(p, d_text, sl); slices[k] = sl[: p.result()["slice_len"]].clone()
-                pend = [p.tie_pending() for p in plans]
-                exported = [p.tie_export("cuda") for p in plans]
-                sa_all = torch.cat([e[0] for e in exported]); pairs_all = torch.cat([e[1] for e in exported])
-                for k, p in enumerate(plans):
-                    engine.finish_shard_ties(p, slices[k], lambda sa: sa_all.clone(), lambda pr, k=k: (pairs_all, sum(pend[:k])))
-            ok &= bool(torch.equal(torch.cat(slices), one)); msg += " shards %d eq %s (ties %d)" % (ns, ok, sum(pend))
-            for p in plans: p.close()
-    except Exception as ex:   # noqa: BLE001
-        if form == 2 and "suffix-range shard larger than the workspace" in str(ex):
-            msg += " (shards refused: one level-0 digit heavier than a shard's slack -- the documented limit for skewed composition)"
-        else:
-            ok = False; msg += " EXC " + repr(ex)[:400]
-    print("%s it=%d n=%d %s comp=%d form=%d %s  %.0f s" % ("ok " if ok else "BAD", it, n, itype, comp, form, msg, time.time() - t0), flush=True)
+    ok, desc = fuzzlib.case_large(rng, engine, torch, lo, hi)
+    print("%s it=%d %s  %.0f s" % ("ok " if ok else "BAD", it, desc, time.time() - t0), flush=True)
     bad += 0 if ok else 1
-    del d_text, b, pac, one
-    torch.cuda.empty_cache()
 print("done: %d iterations, %d bad" % (iters, bad))
 sys.exit(1 if bad else 0)
