@@ -93,10 +93,12 @@ __device__ __forceinline__ bool sample_hit(const SampleOut &S, uint32_t lo32)
 	if (!S.pow2) h = h && (lo32 >> S.tz) * S.inv <= S.lim;
 	return h;
 }
+// (only for positions sample_hit accepted: the quotient by the odd part of the rate is then the product with its inverse modulo
+// 2^32 -- no division in the kernels; rates that are not powers of two come with 32-bit positions only, sample_in_kernel_ok)
 __device__ __forceinline__ void sample_put(const SampleOut &S, uint64_t rank, uint64_t pos)
 {
 	if (!S.pairs) return;
-	const uint64_t k = (S.pow2 ? pos >> S.tz : pos / S.rate) - S.first;
+	const uint64_t k = (S.pow2 ? pos >> S.tz : (uint64_t)(((uint32_t)pos >> S.tz) * S.inv)) - S.first;
 	if (k < S.cap) { S.pairs[2 * k] = rank + S.rank_off; S.pairs[2 * k + 1] = pos; }
 }
 

@@ -464,7 +464,12 @@ static const std::vector<uint64_t> &samples_of(b3m_plan *p)
 		if (p->nshards > 1) {
 			for (uint64_t i = 0; i < p->total_samples; ++i)
 				if (raw[2 * i] != ~0ull) { p->h_samples.push_back(raw[2 * i]); p->h_samples.push_back(raw[2 * i + 1]); }
-		} else p->h_samples.assign(raw, raw + 2 * p->total_samples);
+		} else {
+			// every multiple of the rate is a suffix of the text: a slot that still reads "empty" means a sort kernel lost a sample
+			for (uint64_t i = 0; i < p->total_samples; ++i)
+				B3M_REQUIRE(raw[2 * i] != ~0ull, "internal: the (rank,pos) sample of position " + std::to_string(i * p->isarate) + " was not written by the sort");
+			p->h_samples.assign(raw, raw + 2 * p->total_samples);
+		}
 		p->res.num_samples = p->h_samples.size() / 2;
 		p->samples_pending = false;
 	}
@@ -563,7 +568,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		if (smp_in_kernel) smp_cfg = make_sample_out(p->d_samples + 2 * p->sample_off[k], p->isarate, (lf.a + p->isarate - 1) / p->isarate, p->sample_off[k + 1] - p->sample_off[k]);
 		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
 		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
-		if (p->isarate && nsh > 1) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));   // slots of other shards stay "empty"
+		// slots of other shards stay "empty"; samples written by the sort itself: a slot nobody wrote is found by samples_of
+		if (p->isarate && (nsh > 1 || smp_in_kernel)) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
 		for (int sh = (p->seq_shards > 1 ? 0 : p->shard); sh < (p->seq_shards > 1 ? p->seq_shards : p->shard + 1); ++sh) {
 			B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
 			// one block: its BWT is the result and goes straight to the caller's buffer
@@ -892,16 +898,20 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 int b3m_plan_result(const b3m_plan *p, b3m_result *out)
 {
 	if (!p || !out) { set_error("null argument"); return 1; }
+	B3M_TRY
 	if (p->samples_pending && p->nshards > 1) (void)samples_of(const_cast<b3m_plan *>(p));      // a shard's sample count is known once its slots have been looked at
 	*out = p->res; return 0;
+	B3M_CATCH(1)
 }
 int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap)
 {
 	if (!p || !pairs_out) { set_error("null argument"); return 1; }
+	B3M_TRY
 	const std::vector<uint64_t> &h = samples_of(const_cast<b3m_plan *>(p));
 	uint64_t c = std::min<uint64_t>(cap, h.size() / 2);
 	memcpy(pairs_out, h.data(), 16 * c);
 	return 0;
+	B3M_CATCH(1)
 }
 int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256)
 {

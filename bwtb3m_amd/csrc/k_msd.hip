@@ -1374,7 +1374,11 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		const uint32_t y0 = ent[st], y1 = ent[st + 1], y2 = ent[st + 2], y3 = ent[st + 3];
 		uint32_t lt = (y0 - B < dx ? 1u : 0u) + (y1 - B < dx ? 1u : 0u) + (y2 - B < dx ? 1u : 0u) + (y3 - B < dx ? 1u : 0u);
 		const uint32_t t0 = y0 - xk0, t1 = y1 - xk0, t2 = y2 - xk0, t3 = y3 - xk0;
-		uint32_t eq = (t0 < 8192u ? 1u : 0u) + (t1 < 8192u ? 1u : 0u) + (t2 < 8192u ? 1u : 0u) + (t3 < 8192u ? 1u : 0u);
+		// (same key <=> t = the other entry's index < F_CAP.  Not "< 8192": the 0xFFFFFFFF padding behind the bucket's last entry reads as
+		// index 8191 of the all-ones key, and a record with that key then looked tied -- harmless until the samples: a "tied" record leaves
+		// its sample to the tie fix, which never saw a group there; 14 of 7.3 M samples at 30 Gbase, found by the C5 test's slot census)
+		constexpr uint32_t SAMEKEY = (uint32_t)F_CAP;
+		uint32_t eq = (t0 < SAMEKEY ? 1u : 0u) + (t1 < SAMEKEY ? 1u : 0u) + (t2 < SAMEKEY ? 1u : 0u) + (t3 < SAMEKEY ? 1u : 0u);
 		const uint32_t lo32 = (uint32_t)r[k];
 		uint32_t dp = st + lt;
 		const bool smp = sample_hit(O.smp, lo32);
@@ -1385,7 +1389,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 				#pragma unroll 1
 				for (uint32_t j = 4; j < c; ++j) {
 					const uint32_t y = ent[st + j], t = y - xk0;
-					lt += y - B < dx ? 1u : 0u; eq += t < 8192u ? 1u : 0u; prev = prev || t < e;
+					lt += y - B < dx ? 1u : 0u; eq += t < SAMEKEY ? 1u : 0u; prev = prev || t < e;
 				}
 			}
 			dp = hot ? st + slot[k] : st + lt;
