@@ -1428,6 +1428,228 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// THE FINISH, third form (sorts that keep no suffix array: what the shipped one-block plan runs).  The same counting sort as
+// k_finish_fast, but no record computes its rank:
+//   * the owner of a record drops a 4-byte ENTRY (low key bits | index | "special" | predecessor symbol) at its bin's start + arrival slot;
+//   * the thread that scanned 16 bins of the table puts those of ITS bins that hold two entries or more (15 % of the bins, 2.5 per
+//     thread) in order, in place, marks key ties and fetches the records of tied entries again (0.3 %) for their suffix array entries;
+//   * the bucket leaves straight from the entry array: four entries = four BWT bytes = one dword store.  An entry flagged special (its
+//     position is a multiple of the sampling rate, or the block's first suffix) fetches its record again and writes the (rank,pos) sample / p0.
+// Against k_finish_fast: no reads of the bin's entries by every record (4 of its ~15 LDS operations per record), no byte staging array,
+// no bin tags (so no aliasing rule, and sparse buckets stay here instead of being listed), about a third fewer vector instructions.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
+{
+	constexpr int F_THREADS = 512, F_CAP = 6144, F_PER = 12, F_WAVES = 8;
+	constexpr int ENT_N = F_CAP + 16, TAB_N = F_BINS + 4, GF_N = F_CAP / 64 + 2;
+	constexpr int E_IDX = 4, E_LOW = 17;                              // entry = low key bits << 17 | index << 4 | special << 3 | predecessor symbol
+	constexpr uint32_t E_SPECIAL = 8u;
+	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];      // entry of the record at place p of the bucket: ent[apad + p] (apad: byte phase of the BWT address)
+	__shared__ __attribute__((aligned(16))) uint32_t tab[TAB_N];
+	__shared__ uint32_t wsum[F_WAVES];
+	__shared__ __attribute__((aligned(8))) uint2 rr[G_NCH + 1];
+	__shared__ uint16_t gfirst[GF_N];
+	__shared__ __attribute__((aligned(16))) uint4 gda[GF_N], gdb[GF_N];
+	__shared__ uint32_t s_slow;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
+	const uint32_t b0 = b >> S.D1;
+	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
+	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+	GLB_CHK(b < S.nbF && b0 < S.nb0 && s0 <= S.nrec && m <= S.nrec - s0);
+	if (m == 0) return;
+	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
+		if (tid == 0) {
+			const FinishLists L = *Lp;
+			if (m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+			else if (m > F_HUGE) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
+			else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
+		}
+		return;
+	}
+	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
+	// ---- slots -> runs (see finish_bucket) ----
+	const uint32_t glast = (m - 1) >> 6;
+	{
+		const uint32_t *row = S.runpre + tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
+		const uint32_t tc = tid < nch ? tid : nch - 1, tn = tc + 1 < nch ? tc + 1 : tc;
+		const uint32_t v = row[tc], vn = tid + 1 < nch ? row[tn] : (m << 14);
+		const uint32_t pre = v >> 14, end = vn >> 14;
+		if (tid < nch) {
+			rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
+			for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
+		}
+		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; }
+		#pragma unroll
+		for (int k = 0; k < F_BINS / F_THREADS; ++k) tab[k * F_THREADS + tid] = 0;
+		if (tid < 4) ent[tid] = 0u;                              // the places in front of the bucket's first and behind its last entry: no symbol, not special
+		if (tid < 12) ent[apad + m + tid] = 0u;
+	}
+	__syncthreads();
+	if (tid <= glast) {
+		const uint32_t sl = tid << 6;
+		const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
+		const uint2 q0 = rr[j0];
+		uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
+		for (uint32_t i = j0 + 1; i <= j1 && i < nch; ++i) {
+			const uint2 qi = rr[i];
+			if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
+			const uint32_t oo = qi.x - sl, bb = qi.y - oo;
+			if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
+			++found;
+		}
+		if (found > 3) s_slow = 1u;
+		gda[tid] = make_uint4(o1, o2, o3, q0.y + (sl - q0.x));
+		gdb[tid] = make_uint4(b1, b2, b3, 0u);
+	}
+	__syncthreads();
+	if (s_slow) {
+		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+		return;
+	}
+	// the record of index e of the bucket (slot e of its rank range before sorting), through the slot -> run map
+	auto rec_adr = [&](const uint32_t e) -> uint32_t {
+		const uint32_t g = e >> 6, x = e & 63u;
+		const uint4 da = gda[g], db = gdb[g];
+		return (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
+	};
+	const uint32_t kfull = m / F_THREADS;                        // items 0 .. kfull-1 have all their 512 slots inside the bucket
+	uint64_t r[F_PER];
+	{
+		uint32_t adr[F_PER];
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) {
+			const uint32_t eu = k * F_THREADS + tid;
+			const uint32_t e = eu < m ? eu : m - 1;
+			uint32_t g = (uint32_t)(k * F_WAVES) + wave; g = g < glast ? g : glast;
+			const uint4 da = gda[g], db = gdb[g];
+			const uint32_t x = e - (g << 6);
+			adr[k] = (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
+		}
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) r[k] = S.rec[adr[k]];
+	}
+	const int lowbits = fbits - F_BINBITS;                       // <= 12
+	const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;
+	const int bsh = hks + lowbits;
+	const uint32_t lmask = (1u << lowbits) - 1u;
+	const uint64_t posmask = (1ull << O.pb) - 1;
+	// ---- count: arrival slot of every record inside its bin ----
+	uint32_t slot[F_PER];
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & (uint32_t)(F_BINS - 1);
+		if ((uint32_t)k < kfull) slot[k] = atomicAdd(&tab[bin], 1u);
+		else { slot[k] = 0; if (k * F_THREADS + tid < m) slot[k] = atomicAdd(&tab[bin], 1u); }
+	}
+	__syncthreads();
+	// ---- scan: thread = 16 consecutive bins; tab[bin] = start | count << 16; multi: which of them hold two entries or more ----
+	uint32_t multi = 0;
+	{
+		constexpr int WPT = F_BINS / F_THREADS;                  // 16
+		uint32_t w[WPT]; uint32_t sum = 0, cmax = 0;
+		#pragma unroll
+		for (int q = 0; q < WPT / 4; ++q) {
+			const uint4 v = reinterpret_cast<const uint4 *>(tab)[tid * (WPT / 4) + q];
+			w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+		}
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { sum += w[k]; cmax = cmax > w[k] ? cmax : w[k]; multi |= (w[k] > 1u ? 1u : 0u) << k; }
+		uint32_t inc = wave_incl_sum(sum);
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		uint32_t run = inc - sum;
+		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k]; w[k] = run | (c << 16); run += c; }
+		#pragma unroll
+		for (int q = 0; q < WPT / 4; ++q) reinterpret_cast<uint4 *>(tab)[tid * (WPT / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+		// a 16-mer repeated inside the bucket: that bin goes to the overflow list on its own
+		if (cmax > (uint32_t)LS_TIE_CAP) {
+			#pragma unroll 1
+			for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k] >> 16; if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + (w[k] & 0xFFFFu), c); }
+		}
+	}
+	__syncthreads();
+	// ---- entries into bin order (arrival order inside a bin) ----
+	const uint32_t start_lo = (uint32_t)O.start;
+	#pragma unroll
+	for (int k = 0; k < F_PER; ++k) {
+		const uint32_t hi = (uint32_t)(r[k] >> 32), lo32 = (uint32_t)r[k], e = k * F_THREADS + tid;
+		const uint32_t tb = tab[(hi >> bsh) & (uint32_t)(F_BINS - 1)];
+		const uint32_t special = (lo32 == start_lo || sample_hit(O.smp, lo32)) ? E_SPECIAL : 0u;
+		const uint32_t x = (((hi >> hks) & lmask) << E_LOW) | (e << E_IDX) | special | ((hi >> hps) & 7u);
+		const uint32_t at = (tb & 0xFFFFu) + slot[k];
+		if ((uint32_t)k < kfull || e < m) {
+			ent[apad + at] = x;
+			if ((tb >> 16) > (uint32_t)LS_TIE_CAP) sa_set(O.sa, s0 + at, r[k] & posmask);     // a hot bin (on the overflow list): the list-based rounds read positions
+		}
+	}
+	__syncthreads();
+	// ---- the bins of this thread with two entries or more: in order, in place; key ties marked for k_tie_fix ----
+	while (multi) {
+		const uint32_t kk = (uint32_t)__ffs(multi) - 1u; multi &= multi - 1u;
+		const uint32_t tw = tab[tid * (F_BINS / F_THREADS) + kk];
+		const uint32_t st = apad + (tw & 0xFFFFu), c = tw >> 16;
+		if (c > (uint32_t)LS_TIE_CAP) continue;                 // hot: left in arrival order for the list-based rounds
+		bool ties = false;
+		if (c == 2) {
+			uint32_t a = ent[st], bb = ent[st + 1];
+			if (bb < a) { const uint32_t t = a; a = bb; bb = t; ent[st] = a; ent[st + 1] = bb; }
+			ties = (a >> E_LOW) == (bb >> E_LOW);
+		} else {
+			#pragma unroll 1
+			for (uint32_t i = 1; i < c; ++i) {
+				const uint32_t x = ent[st + i]; uint32_t j = i;
+				while (j > 0) { const uint32_t y = ent[st + j - 1]; if (y <= x) break; ent[st + j] = y; --j; }
+				ent[st + j] = x;
+			}
+			#pragma unroll 1
+			for (uint32_t i = 1; i < c; ++i) ties = ties || (ent[st + i] >> E_LOW) == (ent[st + i - 1] >> E_LOW);
+		}
+		if (ties) {
+			// equal key fields: bit p of the tie bitmap = "the record at place p has the key field of the one before it"; k_tie_fix orders the run from
+			// the text and needs the positions of all its members (their records are fetched again: 0.3 % of the records); what a tied record has to
+			// say about samples or p0 is said by k_tie_fix, once its place is final
+			#pragma unroll 1
+			for (uint32_t i = 0; i < c; ++i) {
+				const uint32_t x = ent[st + i];
+				const bool tp = i > 0 && (ent[st + i - 1] >> E_LOW) == (x >> E_LOW), tn = i + 1 < c && (ent[st + i + 1] >> E_LOW) == (x >> E_LOW);
+				if (!(tp || tn)) continue;
+				const uint32_t g = s0 + (st - apad) + i;
+				sa_set(O.sa, g, S.rec[rec_adr((x >> E_IDX) & 0x1FFFu)] & posmask);
+				if (tp) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
+				ent[st + i] = x & ~E_SPECIAL;
+			}
+		}
+	}
+	__syncthreads();
+	// ---- the bucket leaves: four entries = four BWT bytes = one dword (partial first / last dword bytewise) ----
+	{
+		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);      // 4-byte aligned (may point before the block's first byte: never written)
+		const uint32_t lo = apad, hi = apad + m;
+		const uint32_t ndw = (hi + 3) >> 2;
+		for (uint32_t j = tid; j < ndw; j += F_THREADS) {
+			const uint4 v = reinterpret_cast<const uint4 *>(ent)[j];
+			const uint32_t bytes = (v.x & 7u) | ((v.y & 7u) << 8) | ((v.z & 7u) << 16) | ((v.w & 7u) << 24);
+			if (4 * j >= lo && 4 * j + 4 <= hi) reinterpret_cast<uint32_t *>(gb)[j] = bytes;
+			else { for (uint32_t q = 4 * j; q < 4 * j + 4; ++q) if (q >= lo && q < hi) gb[q] = (uint8_t)(bytes >> (8 * (q & 3u))); }
+			if ((v.x | v.y | v.z | v.w) & E_SPECIAL) {
+				// a (rank,pos) sample or the block's first suffix, alone in its key: its place is final (entries outside the bucket are zero)
+				const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+				#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					if (!(vv[q] & E_SPECIAL)) continue;
+					const uint64_t pos = S.rec[rec_adr((vv[q] >> E_IDX) & 0x1FFFu)] & posmask;
+					const uint32_t g = s0 + (4 * j + q - apad);
+					if (pos == O.start) *O.p0 = g;
+					if (sample_hit(O.smp, (uint32_t)pos)) sample_put(O.smp, g, pos);
+				}
+			}
+		}
+	}
+}
+
 // Buckets the gathering finish has listed (above its LDS capacity, or spread over more runs than it maps): their runs are
 // copied together into [bstart[b], bstart[b+1]) of `out` (the record buffer level 1 has read and no longer needs), where
 // the mid / big / huge paths find them contiguous.  mid and big buckets (<= 2^20 records): one workgroup each; huge ones:
@@ -2017,7 +2239,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			if (bfb == bfa) continue;
 			const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
 			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
+				const int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;      // measurement switch: 0 = k_finish_fast<false> for sorts that keep no suffix array
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else if (v3) hipLaunchKernelGGL(k_finish_v3, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else if (gather) {
 				if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
