@@ -7,7 +7,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
 KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true>",
-             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048>", "bucket_finish": "b3m::k_finish_fast<false>", "ties": "b3m::k_tie_fix",
+             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048>", "bucket_finish": "b3m::k_finish_v3<3>", "ties": "b3m::k_tie_fix",
              "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk"}
 
 
@@ -26,7 +26,8 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
     # gfx950 FETCH_SIZE correction applied: see the file); only valid for the workload it was taken on
     traffic = None
     try:
-        tj = json.load(open(os.path.join(root, "profiles", "r02_pmc_traffic.json")))
+        import glob
+        tj = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))[-1]))     # the latest round's PMC passes
         kn = KERNEL_OF.get(dname, dname)
         if pmc_n and tj.get("workload_n") == pmc_n and kn in tj["kernels"]:
             traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])

@@ -1432,33 +1432,52 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 // THE FINISH, third form (sorts that keep no suffix array: what the shipped one-block plan runs).  The same counting sort as
 // k_finish_fast, but no record computes its rank:
 //   * the owner of a record drops a 4-byte ENTRY (low key bits | index | "special" | predecessor symbol) at its bin's start + arrival slot;
-//   * the thread that scanned 16 bins of the table puts those of ITS bins that hold two entries or more (15 % of the bins, 2.5 per
-//     thread) in order, in place, marks key ties and fetches the records of tied entries again (0.3 %) for their suffix array entries;
-//   * the bucket leaves straight from the entry array: four entries = four BWT bytes = one dword store.  An entry flagged special (its
-//     position is a multiple of the sampling rate, or the block's first suffix) fetches its record again and writes the (rank,pos) sample / p0.
+//   * the bins that hold two entries or more (15 % of the bins) go on a work list in LDS and are put in order, in place, by ALL threads,
+//     three or four bins each, their table words and entries in flight together, up to four (eight) entries through a sorting network in
+//     registers: no chain of dependent LDS round trips, no imbalance between the threads that scanned many such bins and few;
+//   * key ties (0.3 % of the records) are marked in the tie bitmap; the positions k_tie_fix needs of them are fetched again, by one
+//     thread per tied entry, while the bucket leaves, and stored at the very end;
+//   * the bucket leaves straight from the entry array: four entries = four BWT bytes = one dword store.  A record whose position is a
+//     multiple of the sampling rate, or the block's first suffix, leaves its position in a short list; the thread that sees its (special)
+//     entry at its final place writes the (rank,pos) sample / p0.
 // Against k_finish_fast: no reads of the bin's entries by every record (4 of its ~15 LDS operations per record), no byte staging array,
-// no bin tags (so no aliasing rule, and sparse buckets stay here instead of being listed), about a third fewer vector instructions.
+// no bin tags (so no aliasing rule, and sparse buckets stay here instead of being listed), 16-bit table words (start | count capped at 7),
+// a third of the vector instructions; 51 KB of LDS and 80 registers: three workgroups per CU instead of two.
+// Dense sampling (more specials than the list holds) still works, through fetches of the records, but k_finish_fast is the kernel for it.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
+constexpr int V3_NCH = 256;              // runs a bucket may be spread over (more: listed)
+constexpr int V3_WL = 1536;              // work list: bins with two entries or more (uniform input: 1280 +- 33 of a full bucket's 8192)
+constexpr int V3_TL = 256;               // tied entries whose records are fetched again
+constexpr int V3_SP = 64;                // positions of special records
+constexpr uint64_t V3_MIN_RATE = 256;    // sampling rates below this take k_finish_fast (F_CAP / rate specials per bucket must fit V3_SP)
+
+#define B3M_CE(a, b) { const uint32_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; }
+
+template <int WPC>
+__global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
 {
 	constexpr int F_THREADS = 512, F_CAP = 6144, F_PER = 12, F_WAVES = 8;
-	constexpr int ENT_N = F_CAP + 16, TAB_N = F_BINS + 4, GF_N = F_CAP / 64 + 2;
+	constexpr int ENT_N = F_CAP + 16, TABW_N = F_BINS / 2 + 4, GF_N = F_CAP / 64 + 2;
 	constexpr int E_IDX = 4, E_LOW = 17;                              // entry = low key bits << 17 | index << 4 | special << 3 | predecessor symbol
-	constexpr uint32_t E_SPECIAL = 8u;
+	constexpr uint32_t E_SPECIAL = 8u, T_START = 0x1FFFu;             // table half-word after the scan: start (13 bits) | min(count, 7) << 13
 	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];      // entry of the record at place p of the bucket: ent[apad + p] (apad: byte phase of the BWT address)
-	__shared__ __attribute__((aligned(16))) uint32_t tab[TAB_N];
+	__shared__ __attribute__((aligned(16))) uint32_t tabw[TABW_N];    // two 16-bit words per dword: counts, then start | capped count; half-word F_BINS = m
 	__shared__ uint32_t wsum[F_WAVES];
-	__shared__ __attribute__((aligned(8))) uint2 rr[G_NCH + 1];
+	__shared__ __attribute__((aligned(8))) uint2 rr[V3_NCH + 1];
 	__shared__ uint16_t gfirst[GF_N];
 	__shared__ __attribute__((aligned(16))) uint4 gda[GF_N], gdb[GF_N];
-	__shared__ uint32_t s_slow;
+	__shared__ uint16_t wl[V3_WL];                                    // bins with two entries or more
+	__shared__ uint32_t tl[V3_TL];                                    // tied entries: place << 13 | index
+	__shared__ __attribute__((aligned(8))) uint2 sp[V3_SP];           // special records: {position bits 0..31, index | position bits 32.. << 16}
+	__shared__ uint32_t s_slow, s_wl, s_tl, s_sp;
+	__shared__ uint32_t lds_pad[WPC == 2 ? 6144 : 1];                 // (WPC = 2, the A/B form: enough LDS to keep a third workgroup off the CU)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
 	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
 	GLB_CHK(b < S.nbF && b0 < S.nb0 && s0 <= S.nrec && m <= S.nrec - s0);
 	if (m == 0) return;
-	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
+	if (m > (uint32_t)F_CAP || nch > (uint32_t)V3_NCH) {
 		if (tid == 0) {
 			const FinishLists L = *Lp;
 			if (m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
@@ -1467,6 +1486,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 		}
 		return;
 	}
+	if (WPC == 2 && fbits < 0) lds_pad[tid] = 0;                 // (never: keeps the padding array alive)
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
 	// ---- slots -> runs (see finish_bucket) ----
 	const uint32_t glast = (m - 1) >> 6;
@@ -1479,10 +1499,10 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 			rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
 			for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
 		}
-		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; }
+		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; s_tl = 0u; s_sp = 0u; }
 		#pragma unroll
-		for (int k = 0; k < F_BINS / F_THREADS; ++k) tab[k * F_THREADS + tid] = 0;
-		if (tid < 4) ent[tid] = 0u;                              // the places in front of the bucket's first and behind its last entry: no symbol, not special
+		for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
+		if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }      // the places in front of the bucket's first and behind its last entry: no symbol, not special
 		if (tid < 12) ent[apad + m + tid] = 0u;
 	}
 	__syncthreads();
@@ -1513,9 +1533,12 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 		const uint4 da = gda[g], db = gdb[g];
 		return (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
 	};
+	const uint64_t posmask = (1ull << O.pb) - 1;
 	const uint32_t kfull = m / F_THREADS;                        // items 0 .. kfull-1 have all their 512 slots inside the bucket
-	uint64_t r[F_PER];
+	// ---- the records, and all this thread needs of them from here on: the entry, and the bin (later: | arrival slot << 16) ----
+	uint32_t ev[F_PER], bs[F_PER];
 	{
+		uint64_t r[F_PER];
 		uint32_t adr[F_PER];
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) {
@@ -1528,107 +1551,205 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 		}
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) r[k] = S.rec[adr[k]];
+		const int lowbits = fbits - F_BINBITS;                   // <= 12
+		const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;
+		const int bsh = hks + lowbits;
+		const uint32_t lmask = (1u << lowbits) - 1u;
+		const uint32_t start_lo = (uint32_t)O.start;
+		#pragma unroll
+		for (int k = 0; k < F_PER; ++k) {
+			const uint32_t hi = (uint32_t)(r[k] >> 32), lo32 = (uint32_t)r[k], e = k * F_THREADS + tid;
+			const bool special = lo32 == start_lo || sample_hit(O.smp, lo32);
+			ev[k] = (((hi >> hks) & lmask) << E_LOW) | (e << E_IDX) | (special ? E_SPECIAL : 0u) | ((hi >> hps) & 7u);
+			bs[k] = (hi >> bsh) & (uint32_t)(F_BINS - 1);
+			if (special && ((uint32_t)k < kfull || e < m)) {     // rare: the position waits in LDS for whoever finds the entry at its final place
+				const uint32_t j = atomicAdd(&s_sp, 1u);
+				if (j < (uint32_t)V3_SP) sp[j] = make_uint2(lo32, e | ((hi & ((1u << hps) - 1u)) << 16));
+			}
+		}
 	}
-	const int lowbits = fbits - F_BINBITS;                       // <= 12
-	const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;
-	const int bsh = hks + lowbits;
-	const uint32_t lmask = (1u << lowbits) - 1u;
-	const uint64_t posmask = (1ull << O.pb) - 1;
-	// ---- count: arrival slot of every record inside its bin ----
-	uint32_t slot[F_PER];
+	// ---- count: arrival slot of every record inside its bin (16-bit counters, two per word) ----
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
-		const uint32_t bin = ((uint32_t)(r[k] >> 32) >> bsh) & (uint32_t)(F_BINS - 1);
-		if ((uint32_t)k < kfull) slot[k] = atomicAdd(&tab[bin], 1u);
-		else { slot[k] = 0; if (k * F_THREADS + tid < m) slot[k] = atomicAdd(&tab[bin], 1u); }
+		const uint32_t bin = bs[k];
+		if ((uint32_t)k < kfull || k * F_THREADS + tid < m) {
+			const uint32_t old = atomicAdd(&tabw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
+			bs[k] = bin | (((bin & 1u) ? old >> 16 : old & 0xFFFFu) << 16);
+		}
 	}
 	__syncthreads();
-	// ---- scan: thread = 16 consecutive bins; tab[bin] = start | count << 16; multi: which of them hold two entries or more ----
-	uint32_t multi = 0;
+	// ---- scan: thread = 16 consecutive bins = 8 words; half-word = start | min(count, 7) << 13; the bins with two entries or more go on the
+	// work list (their number rides in the high half of the scanned sum) ----
 	{
-		constexpr int WPT = F_BINS / F_THREADS;                  // 16
-		uint32_t w[WPT]; uint32_t sum = 0, cmax = 0;
+		constexpr int WPT = (F_BINS / 2) / F_THREADS;            // 8
+		uint32_t w[WPT]; uint32_t sum = 0, cmax = 0, multi = 0;
 		#pragma unroll
 		for (int q = 0; q < WPT / 4; ++q) {
-			const uint4 v = reinterpret_cast<const uint4 *>(tab)[tid * (WPT / 4) + q];
+			const uint4 v = reinterpret_cast<const uint4 *>(tabw)[tid * (WPT / 4) + q];
 			w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
 		}
 		#pragma unroll
-		for (int k = 0; k < WPT; ++k) { sum += w[k]; cmax = cmax > w[k] ? cmax : w[k]; multi |= (w[k] > 1u ? 1u : 0u) << k; }
-		uint32_t inc = wave_incl_sum(sum);
+		for (int k = 0; k < WPT; ++k) {
+			const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+			sum += lo + hi; cmax = cmax > lo ? cmax : lo; cmax = cmax > hi ? cmax : hi;
+			multi |= ((lo > 1u ? 1u : 0u) | (hi > 1u ? 2u : 0u)) << (2 * k);
+		}
+		const uint32_t both = sum | ((uint32_t)__popc(multi) << 16);
+		uint32_t inc = wave_incl_sum(both);
 		if (lane == 63) wsum[wave] = inc;
 		__syncthreads();
-		uint32_t run = inc - sum;
-		for (uint32_t i = 0; i < wave; ++i) run += wsum[i];
-		#pragma unroll
-		for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k]; w[k] = run | (c << 16); run += c; }
-		#pragma unroll
-		for (int q = 0; q < WPT / 4; ++q) reinterpret_cast<uint4 *>(tab)[tid * (WPT / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+		uint32_t pre = inc - both;
+		for (uint32_t i = 0; i < wave; ++i) pre += wsum[i];
+		uint32_t run = pre & 0xFFFFu, wat = pre >> 16;
+		if (tid == F_THREADS - 1) s_wl = (pre + both) >> 16;
+		while (multi) {                                          // (stores only: nothing waits)
+			const uint32_t k = (uint32_t)__ffs(multi) - 1u; multi &= multi - 1u;
+			if (wat < (uint32_t)V3_WL) wl[wat] = (uint16_t)(tid * (F_BINS / F_THREADS) + k);
+			++wat;
+		}
 		// a 16-mer repeated inside the bucket: that bin goes to the overflow list on its own
 		if (cmax > (uint32_t)LS_TIE_CAP) {
+			uint32_t st = run;
 			#pragma unroll 1
-			for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k] >> 16; if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + (w[k] & 0xFFFFu), c); }
+			for (int k = 0; k < 2 * WPT; ++k) {
+				const uint32_t c = (k & 1) ? w[k >> 1] >> 16 : w[k >> 1] & 0xFFFFu;
+				if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c);
+				st += c;
+			}
 		}
+		#pragma unroll
+		for (int k = 0; k < WPT; ++k) {
+			const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+			w[k] = (run | ((lo < 7u ? lo : 7u) << 13)) | (((run + lo) | ((hi < 7u ? hi : 7u) << 13)) << 16);
+			run += lo + hi;
+		}
+		#pragma unroll
+		for (int q = 0; q < WPT / 4; ++q) reinterpret_cast<uint4 *>(tabw)[tid * (WPT / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+		if (tid == F_THREADS - 1) tabw[F_BINS / 2] = run;        // = m: "start" of the bin behind the last one
 	}
 	__syncthreads();
+	const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(tabw);
 	// ---- entries into bin order (arrival order inside a bin) ----
-	const uint32_t start_lo = (uint32_t)O.start;
+	uint32_t tid_again = tid;
+	asm volatile("" : "+v"(tid_again));                             // (the "slot inside the bucket" masks of the count phase are computed again, not kept: they were spilled)
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
-		const uint32_t hi = (uint32_t)(r[k] >> 32), lo32 = (uint32_t)r[k], e = k * F_THREADS + tid;
-		const uint32_t tb = tab[(hi >> bsh) & (uint32_t)(F_BINS - 1)];
-		const uint32_t special = (lo32 == start_lo || sample_hit(O.smp, lo32)) ? E_SPECIAL : 0u;
-		const uint32_t x = (((hi >> hks) & lmask) << E_LOW) | (e << E_IDX) | special | ((hi >> hps) & 7u);
-		const uint32_t at = (tb & 0xFFFFu) + slot[k];
+		const uint32_t e = k * F_THREADS + tid_again, bin = bs[k] & 0xFFFFu;
+		const uint32_t t = tab16[bin];
+		const uint32_t at = (t & T_START) + (bs[k] >> 16);
 		if ((uint32_t)k < kfull || e < m) {
-			ent[apad + at] = x;
-			if ((tb >> 16) > (uint32_t)LS_TIE_CAP) sa_set(O.sa, s0 + at, r[k] & posmask);     // a hot bin (on the overflow list): the list-based rounds read positions
-		}
-	}
-	__syncthreads();
-	// ---- the bins of this thread with two entries or more: in order, in place; key ties marked for k_tie_fix ----
-	while (multi) {
-		const uint32_t kk = (uint32_t)__ffs(multi) - 1u; multi &= multi - 1u;
-		const uint32_t tw = tab[tid * (F_BINS / F_THREADS) + kk];
-		const uint32_t st = apad + (tw & 0xFFFFu), c = tw >> 16;
-		if (c > (uint32_t)LS_TIE_CAP) continue;                 // hot: left in arrival order for the list-based rounds
-		bool ties = false;
-		if (c == 2) {
-			uint32_t a = ent[st], bb = ent[st + 1];
-			if (bb < a) { const uint32_t t = a; a = bb; bb = t; ent[st] = a; ent[st + 1] = bb; }
-			ties = (a >> E_LOW) == (bb >> E_LOW);
-		} else {
-			#pragma unroll 1
-			for (uint32_t i = 1; i < c; ++i) {
-				const uint32_t x = ent[st + i]; uint32_t j = i;
-				while (j > 0) { const uint32_t y = ent[st + j - 1]; if (y <= x) break; ent[st + j] = y; --j; }
-				ent[st + j] = x;
-			}
-			#pragma unroll 1
-			for (uint32_t i = 1; i < c; ++i) ties = ties || (ent[st + i] >> E_LOW) == (ent[st + i - 1] >> E_LOW);
-		}
-		if (ties) {
-			// equal key fields: bit p of the tie bitmap = "the record at place p has the key field of the one before it"; k_tie_fix orders the run from
-			// the text and needs the positions of all its members (their records are fetched again: 0.3 % of the records); what a tied record has to
-			// say about samples or p0 is said by k_tie_fix, once its place is final
-			#pragma unroll 1
-			for (uint32_t i = 0; i < c; ++i) {
-				const uint32_t x = ent[st + i];
-				const bool tp = i > 0 && (ent[st + i - 1] >> E_LOW) == (x >> E_LOW), tn = i + 1 < c && (ent[st + i + 1] >> E_LOW) == (x >> E_LOW);
-				if (!(tp || tn)) continue;
-				const uint32_t g = s0 + (st - apad) + i;
-				sa_set(O.sa, g, S.rec[rec_adr((x >> E_IDX) & 0x1FFFu)] & posmask);
-				if (tp) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));
-				ent[st + i] = x & ~E_SPECIAL;
+			ent[apad + at] = ev[k];
+			if ((t >> 13) == 7u) {                                // maybe a hot bin (above LS_TIE_CAP entries: on the overflow list): the list-based rounds read positions
+				const uint32_t c = ((uint32_t)tab16[bin + 1] & T_START) - (t & T_START);
+				if (c > (uint32_t)LS_TIE_CAP) sa_set(O.sa, s0 + at, S.rec[rec_adr(e)] & posmask);
 			}
 		}
 	}
 	__syncthreads();
+	// ---- the listed bins: in order, in place; key ties noted ----
+	auto tie_note = [&](const uint32_t p, const uint32_t x, const bool has_pred) {       // the entry x at place p ties with a neighbour
+		const uint32_t g = s0 + p;
+		if (has_pred) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));       // bit p = "the record at place p has the key field of the one before it"
+		const uint32_t j = atomicAdd(&s_tl, 1u);
+		if (j < (uint32_t)V3_TL) tl[j] = (p << 13) | ((x >> E_IDX) & 0x1FFFu);
+		else sa_set(O.sa, g, S.rec[rec_adr((x >> E_IDX) & 0x1FFFu)] & posmask);      // (list full: the position at once, with its latency)
+	};
+	// a bin of cc entries from place st1 (entry index apad + st1) on, one entry after the other (rare: more than eight entries, or no room on the list)
+	auto fix_serial = [&](const uint32_t at0, const uint32_t cc) {
+		#pragma unroll 1
+		for (uint32_t i = 1; i < cc; ++i) {
+			const uint32_t x = ent[at0 + i]; uint32_t j = i;
+			while (j > 0) { const uint32_t y = ent[at0 + j - 1]; if (y <= x) break; ent[at0 + j] = y; --j; }
+			ent[at0 + j] = x;
+		}
+	};
+	auto ties_serial = [&](const uint32_t at0, const uint32_t cc) {
+		#pragma unroll 1
+		for (uint32_t i = 0; i < cc; ++i) {
+			const uint32_t x = ent[at0 + i];
+			const bool tp = i > 0 && (ent[at0 + i - 1] >> E_LOW) == (x >> E_LOW), tn = i + 1 < cc && (ent[at0 + i + 1] >> E_LOW) == (x >> E_LOW);
+			if (!(tp || tn)) continue;
+			ent[at0 + i] = x & ~E_SPECIAL;
+			tie_note(at0 - apad + i, x, tp);
+		}
+	};
+	const uint32_t nwl = s_wl;
+	if (nwl <= (uint32_t)V3_WL) {
+		uint32_t bin[4], st[4], c[4], e0[4], e1[4], e2[4], e3[4];
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) { const uint32_t i = q * F_THREADS + tid; bin[q] = i < nwl ? wl[i] : 0xFFFFu; }
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t t = tab16[bin[q] & (uint32_t)(F_BINS - 1)];
+			st[q] = apad + (t & T_START); c[q] = bin[q] == 0xFFFFu ? 0u : t >> 13;
+		}
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) { e0[q] = ent[st[q]]; e1[q] = ent[st[q] + 1]; e2[q] = ent[st[q] + 2]; e3[q] = ent[st[q] + 3]; }
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			if ((uint32_t)(q * F_THREADS) >= nwl) break;         // (uniform)
+			if (c[q] < 2u) continue;                               // (no bin)
+			if (c[q] <= 4u) {
+				uint32_t x0 = e0[q], x1 = e1[q], x2 = c[q] > 2u ? e2[q] : 0xFFFFFFFFu, x3 = c[q] > 3u ? e3[q] : 0xFFFFFFFFu;
+				B3M_CE(x0, x1) B3M_CE(x2, x3) B3M_CE(x0, x2) B3M_CE(x1, x3) B3M_CE(x1, x2)
+				const bool t01 = (x0 >> E_LOW) == (x1 >> E_LOW), t12 = c[q] > 2u && (x1 >> E_LOW) == (x2 >> E_LOW), t23 = c[q] > 3u && (x2 >> E_LOW) == (x3 >> E_LOW);     // (the fill values sort behind the entries)
+				if (t01 || t12 || t23) {          // what a tied record has to say about samples or p0 is said by k_tie_fix, once its place is final
+					if (t01) x0 &= ~E_SPECIAL;
+					if (t01 || t12) x1 &= ~E_SPECIAL;
+					if (t12 || t23) x2 &= ~E_SPECIAL;
+					if (t23) x3 &= ~E_SPECIAL;
+					const uint32_t p = st[q] - apad;
+					if (t01) tie_note(p, x0, false);
+					if (t01 || t12) tie_note(p + 1, x1, t01);
+					if (t12 || t23) tie_note(p + 2, x2, t12);
+					if (t23) tie_note(p + 3, x3, true);
+				}
+				ent[st[q]] = x0; ent[st[q] + 1] = x1;
+				if (c[q] > 2u) { ent[st[q] + 2] = x2; if (c[q] > 3u) ent[st[q] + 3] = x3; }
+				continue;
+			}
+			// five entries and more (0.5 % of the listed bins; the count is capped at 7 in the table: the next bin's start tells)
+			const uint32_t cc = ((uint32_t)tab16[bin[q] + 1] & T_START) - (st[q] - apad);
+			if (cc > (uint32_t)LS_TIE_CAP) continue;              // hot: left in arrival order for the list-based rounds
+			if (cc <= 8u) {
+				uint32_t x[8];
+				x[0] = e0[q]; x[1] = e1[q]; x[2] = e2[q]; x[3] = e3[q];
+				#pragma unroll
+				for (int i = 4; i < 8; ++i) x[i] = ent[st[q] + i];
+				#pragma unroll
+				for (int i = 5; i < 8; ++i) if ((uint32_t)i >= cc) x[i] = 0xFFFFFFFFu;
+				// 19 comparators (Batcher's odd-even merge sort of 8)
+				B3M_CE(x[0], x[1]) B3M_CE(x[2], x[3]) B3M_CE(x[4], x[5]) B3M_CE(x[6], x[7])
+				B3M_CE(x[0], x[2]) B3M_CE(x[1], x[3]) B3M_CE(x[4], x[6]) B3M_CE(x[5], x[7])
+				B3M_CE(x[1], x[2]) B3M_CE(x[5], x[6])
+				B3M_CE(x[0], x[4]) B3M_CE(x[1], x[5]) B3M_CE(x[2], x[6]) B3M_CE(x[3], x[7])
+				B3M_CE(x[2], x[4]) B3M_CE(x[3], x[5])
+				B3M_CE(x[1], x[2]) B3M_CE(x[3], x[4]) B3M_CE(x[5], x[6])
+				#pragma unroll
+				for (int i = 0; i < 8; ++i) if ((uint32_t)i < cc) ent[st[q] + i] = x[i];
+			} else fix_serial(st[q], cc);
+			ties_serial(st[q], cc);
+		}
+	} else {
+		// more bins with two entries or more than the list holds (a bucket of few distinct keys): every scanner, its own, one after the other
+		for (uint32_t bb = tid * (F_BINS / F_THREADS); bb < (tid + 1) * (F_BINS / F_THREADS); ++bb) {
+			const uint32_t st1 = (uint32_t)tab16[bb] & T_START, cc = ((uint32_t)tab16[bb + 1] & T_START) - st1;
+			if (cc < 2u || cc > (uint32_t)LS_TIE_CAP) continue;
+			fix_serial(apad + st1, cc);
+			ties_serial(apad + st1, cc);
+		}
+	}
+	__syncthreads();
+	// ---- the records of the tied entries: requested now, stored when the bucket has left ----
+	const uint32_t ntl = s_tl < (uint32_t)V3_TL ? s_tl : (uint32_t)V3_TL;
+	uint64_t trec = 0; uint32_t tplace = 0;
+	if (tid < ntl) { const uint32_t it = tl[tid]; tplace = it >> 13; trec = S.rec[rec_adr(it & 0x1FFFu)]; }
 	// ---- the bucket leaves: four entries = four BWT bytes = one dword (partial first / last dword bytewise) ----
 	{
 		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);      // 4-byte aligned (may point before the block's first byte: never written)
 		const uint32_t lo = apad, hi = apad + m;
 		const uint32_t ndw = (hi + 3) >> 2;
+		const uint32_t nsp = s_sp;
 		for (uint32_t j = tid; j < ndw; j += F_THREADS) {
 			const uint4 v = reinterpret_cast<const uint4 *>(ent)[j];
 			const uint32_t bytes = (v.x & 7u) | ((v.y & 7u) << 8) | ((v.z & 7u) << 16) | ((v.w & 7u) << 24);
@@ -1640,7 +1761,10 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 				#pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					if (!(vv[q] & E_SPECIAL)) continue;
-					const uint64_t pos = S.rec[rec_adr((vv[q] >> E_IDX) & 0x1FFFu)] & posmask;
+					const uint32_t idx = (vv[q] >> E_IDX) & 0x1FFFu;
+					uint64_t pos = ~0ull;
+					for (uint32_t i = 0; i < nsp && i < (uint32_t)V3_SP; ++i) { const uint2 z = sp[i]; if ((z.y & 0xFFFFu) == idx) pos = (uint64_t)z.x | ((uint64_t)(z.y >> 16) << 32); }
+					if (pos == ~0ull) pos = S.rec[rec_adr(idx)] & posmask;      // (more specials than the list holds: dense sampling)
 					const uint32_t g = s0 + (4 * j + q - apad);
 					if (pos == O.start) *O.p0 = g;
 					if (sample_hit(O.smp, (uint32_t)pos)) sample_put(O.smp, g, pos);
@@ -1648,6 +1772,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_v3(FinishSrc S, int fbits, ui
 			}
 		}
 	}
+	if (tid < ntl) sa_set(O.sa, s0 + tplace, trec & posmask);
 }
 
 // Buckets the gathering finish has listed (above its LDS capacity, or spread over more runs than it maps): their runs are
@@ -2239,9 +2364,13 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			if (bfb == bfa) continue;
 			const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
 			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
-				const int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;      // measurement switch: 0 = k_finish_fast<false> for sorts that keep no suffix array
+				// sorts that keep no suffix array take k_finish_v3 (32-bit positions; sampling off or sparse enough for its list of special records).
+				// B3M_FINISH_V3 (measurement switch): 0 = k_finish_fast<false> instead, 2 = k_finish_v3 held at two workgroups per CU
+				int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;
+				if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
-				else if (v3) hipLaunchKernelGGL(k_finish_v3, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else if (v3 == 2) hipLaunchKernelGGL(k_finish_v3<2>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else if (gather) {
 				if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
