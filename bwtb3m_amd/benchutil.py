@@ -27,9 +27,10 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
     traffic = None
     try:
         import glob
-        tj = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))[-1]))     # the latest round's PMC passes
+        files = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))      # the latest round's PMC passes
+        tj = json.load(open(files[-1])) if files else {}
         kn = KERNEL_OF.get(dname, dname)
-        if pmc_n and tj.get("workload_n") == pmc_n and kn in tj["kernels"]:
+        if pmc_n and tj.get("workload_n") == pmc_n and kn in tj.get("kernels", {}):
             traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         traffic = None

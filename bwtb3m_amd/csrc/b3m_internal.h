@@ -157,7 +157,10 @@ struct BlockSortWs {
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
 	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
 	uint8_t *sa_hi = nullptr;                    // texts of 2^32 symbols and more: bits 32.. of the suffix array entries (MSD path)
-	uint32_t *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each); t[5] = ISA of the doubling rounds
+	uint32_t *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each); t[5] = ISA of the doubling rounds.  Texts of 2^32 symbols and more:
+	                                                                           // t[0] = tie bitmap (cap bits), t[1..5] = list buffers of tie_cap+1 entries
+	uint64_t tie_cap = 0;                        // tied suffixes the list-based rounds can take
+	uint8_t *tie_hi = nullptr;                   // texts of 2^32 symbols and more: bits 32.. of the positions on the list (tie_cap+1 bytes)
 	uint32_t *scan_ws = nullptr;
 	RadixWs radix;
 	MsdWs msd;
@@ -204,12 +207,13 @@ uint64_t tie_rounds_domain(uint32_t *idx, uint64_t u, uint64_t *kx, uint64_t *ky
 void isa_from_sa_rel(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_t *d_isa, hipStream_t s);
 bool no_tree_doubling();          // B3M_NO_TREE_DOUBLING=1: key-extension rounds only (measurement switch)
 uint64_t block_overhang();        // symbols of overhang a plan leaves room for (B3M_OVERHANG, default 2^20)
+// idx_hi / tmp_hi: texts of 2^32 symbols and more (bits 32.. of the suffix array entries; a byte buffer as long as the list): key extension only
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
-                    uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0);
+                    uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0, uint8_t *idx_hi = nullptr, uint8_t *tmp_hi = nullptr);
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,
-                   const SampleOut *smp = nullptr);
+                   const SampleOut *smp = nullptr, const uint8_t *d_sa_hi = nullptr);
 // products of a sorted block
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt,
               uint32_t *d_p0 /*device scalar*/, hipStream_t s);

@@ -151,6 +151,7 @@ struct b3m_plan {
 	uint64_t tie_left = 0; uint32_t *tie_U = nullptr, *tie_gid = nullptr;   // suffix-range shard: what its local rounds left tied (b3m_plan_tie_*)
 	uint32_t *d_sa_slice = nullptr; uint64_t slice_off = 0, slice_len = 0;
 	hipStream_t copy_stream = nullptr;     // host-memory runs: slices of the BWT leave on this stream while later buckets sort
+	std::string warning;                   // what the caller should be told about this plan (a mem= target that cannot be met)
 	int packed_out = 0;                    // host-memory runs hand the BWT over 2-bit packed (b3m_plan_set_packed_output)
 	uint8_t *d_pack = nullptr;             // its device image
 	b3m_e2e_times e2e{};
@@ -342,6 +343,15 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	p->total_samples = nsamp;
 	uint64_t o_sm = take(16 * (nsamp + 1)), o_sc = take(4 * (B + 1));
 	p->ws_bytes = off;
+	if (mem && off > mem) {
+		// a memory target below what the smallest blocks need is exceeded, but never silently (the reference's mem= counts host RAM and
+		// falls back to files, /root/reference/README.md:42,46; here everything is HBM-resident: text, two BWT arrays, gt bits, the ranks of a merge)
+		char buf[320];
+		snprintf(buf, sizeof buf, "mem=%llu cannot be met: %llu leaf blocks of %llu symbols still need a workspace of %llu bytes (%.2f bytes per symbol; "
+		         "the part that does not shrink with the blocks is about 7.25 bytes per symbol); using that", (unsigned long long)mem,
+		         (unsigned long long)B, (unsigned long long)p->blocksize, (unsigned long long)off, (double)off / (double)n);
+		p->warning = buf;
+	}
 	if (off > free_b) {
 		char buf[256];
 		snprintf(buf, sizeof buf, "workspace of %.2f GB does not fit the %.2f GB of free HBM (block size %llu)", off / 1e9, free_b / 1e9,
@@ -402,6 +412,7 @@ void b3m_plan_destroy(b3m_plan *p)
 	delete p;
 }
 uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 0; }
+const char *b3m_plan_warning(const b3m_plan *p) { return p ? p->warning.c_str() : ""; }
 uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 0; }
 uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
 void *b3m_plan_text_buffer(b3m_plan *p) { return p ? (void *)p->d_text : nullptr; }

@@ -96,9 +96,12 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// blocks (the reference's scripts pass mem= for host RAM) is not applied to them
 		uint64_t mem = o->mem;
 		if (type == B3M_INPUT_BYTESTREAM && mem) { log("[V] mem= is not applied to bytestream input (sorted as one block in HBM)\n"); mem = 0; }
+		const double tp0 = now();
 		plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
 		if (!plan) throw std::runtime_error(b3m_last_error());
-		log("[V] blocks %llu workspace %.2f GB\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9);
+		if (*b3m_plan_warning(plan)) Log{log_fd}("[W] %s\n", b3m_plan_warning(plan));       // (whatever verbose= says)
+		log("[V] blocks %llu workspace %.2f GB, plan created in %.3f s (file read %.3f s)\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9,
+		    now() - tp0, tp0 - t0);
 		uint64_t tb = b3m_plan_text_bytes(plan);
 		HIPCHK(hipMalloc((void **)&d_bwt, n));
 		if (filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2) {

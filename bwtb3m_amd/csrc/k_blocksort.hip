@@ -88,11 +88,13 @@ __global__ void k_tie_compact(const uint32_t *flag_scan, const uint32_t *hid, co
 	if (!(h0 && h1)) { uint32_t p = flag_scan[s]; U2[p] = U ? U[s] : (uint32_t)s; gid2[p] = hid[s]; }
 }
 // keys of the next K symbols for the list; value = slot
-__global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, uint64_t u, uint64_t depth, uint64_t *nk, uint32_t *slot)
+// (idx_hi: bits 32.. of the positions, texts of 2^32 symbols and more; null otherwise)
+__global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, uint64_t u, uint64_t depth, uint64_t *nk, uint32_t *slot)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
-	nk[s] = key_at(T, idx[U[s]], depth);
+	const uint32_t r = U[s];
+	nk[s] = key_at(T, (uint64_t)idx[r] | (idx_hi ? (uint64_t)idx_hi[r] << 32 : 0ull), depth);
 	slot[s] = (uint32_t)s;
 }
 // prefix doubling: the key of a listed suffix is the current rank (ISA: exact for resolved suffixes,
@@ -140,32 +142,36 @@ __global__ void k_tie_gidkeys(const uint32_t *gid, const uint32_t *slot_sorted, 
 	gk[s] = gid[slot_sorted[s]];
 }
 // gather (idx, key) of the final order into temporaries (the key is recomputed from the text)
-__global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx, const uint32_t *slot_final,
-                             uint64_t u, uint64_t depth, uint32_t *tmp_idx, uint64_t *tmp_key)
+__global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, const uint32_t *slot_final,
+                             uint64_t u, uint64_t depth, uint32_t *tmp_idx, uint8_t *tmp_hi, uint64_t *tmp_key)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
-	uint32_t i = idx[U[slot_final[s]]];
+	const uint32_t r = U[slot_final[s]];
+	const uint32_t i = idx[r];
+	const uint32_t h = idx_hi ? idx_hi[r] : 0u;
 	tmp_idx[s] = i;
-	tmp_key[s] = key_at(T, i, depth);
+	if (idx_hi) tmp_hi[s] = (uint8_t)h;
+	tmp_key[s] = key_at(T, (uint64_t)i | ((uint64_t)h << 32), depth);
 }
 // write back into the tie slots (the sorted group labels equal the old ones slot by slot) and
 // mark the new group heads
-__global__ void k_tie_apply(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint64_t *tmp_key,
-                            uint64_t u, uint32_t *idx, uint32_t *hid)
+__global__ void k_tie_apply(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint8_t *tmp_hi, const uint64_t *tmp_key,
+                            uint64_t u, uint32_t *idx, uint8_t *idx_hi, uint32_t *hid)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	idx[U[s]] = tmp_idx[s];
+	if (idx_hi) idx_hi[U[s]] = tmp_hi[s];
 	bool head = (s == 0) || gid[s] != gid[s - 1] || tmp_key[s] != tmp_key[s - 1];
 	hid[s] = head ? (uint32_t)s : 0u;
 }
-__global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, uint64_t start, uint8_t *bwt, uint32_t *p0, SampleOut smp)
+__global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, const uint8_t *sa_hi, uint64_t start, uint8_t *bwt, uint32_t *p0, SampleOut smp)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	uint32_t r = U[s];
-	uint64_t i = sa[r];
+	uint64_t i = (uint64_t)sa[r] | (sa_hi ? (uint64_t)sa_hi[r] << 32 : 0ull);
 	uint64_t j = i ? i - 1 : T.n - 1;
 	bwt[r] = (uint8_t)sym_at(T, j);
 	if (i == start) *p0 = r;
@@ -293,13 +299,16 @@ void compact_decode(const uint8_t *d_words, uint64_t n, uint32_t bits, uint8_t *
 	if (n) hipLaunchKernelGGL(k_compact_decode, dim3(nblk(n)), dim3(256), 0, s, d_words, n, bits, d_out);
 }
 
+static uint64_t big_tie_cap(uint64_t cap) { return cap / 16 + (1ull << 20); }
 uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span)
 {
 	if (span < cap) span = cap;
 	uint64_t b = 0;
 	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
 	if (span >= (1ull << 32)) b += al(cap);           // bits 32.. of the suffix array entries
-	if (span >= (1ull << 32)) b += al(cap / 8 + 64);    // tie bitmap only: the list-based rounds (32-bit positions) do not run on such texts
+	// texts of 2^32 symbols and more: the tie bitmap, and list buffers for cap/16 tied suffixes (key-extension rounds with 36-bit positions;
+	// no inverse suffix array: 5 bytes per TEXT symbol would not fit beside a shard's workspace)
+	if (span >= (1ull << 32)) b += al(cap / 8 + 64) + 5 * al(4 * (big_tie_cap(cap) + 1)) + al(big_tie_cap(cap) + 1);
 	else b += 6 * al(4 * (cap + 1));                    // tie-list buffers + inverse suffix array of the doubling rounds
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
@@ -318,8 +327,13 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span
 	ws.idxB = (uint32_t *)p; p += al(4 * cap);
 	ws.sa_hi = nullptr;
 	if (span >= (1ull << 32)) { ws.sa_hi = p; p += al(cap); }
-	if (span >= (1ull << 32)) { for (int i = 0; i < 6; ++i) ws.t[i] = nullptr; ws.t[0] = (uint32_t *)p; p += al(cap / 8 + 64); }
-	else for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
+	ws.tie_cap = cap; ws.tie_hi = nullptr;
+	if (span >= (1ull << 32)) {
+		ws.t[0] = (uint32_t *)p; p += al(cap / 8 + 64);
+		ws.tie_cap = big_tie_cap(cap);
+		for (int i = 1; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (ws.tie_cap + 1)); }
+		ws.tie_hi = p; p += al(ws.tie_cap + 1);
+	} else for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
 	msd_ws_carve(ws.msd, p, cap, span); p += al(msd_ws_bytes(cap, span));
@@ -337,8 +351,10 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span
 // Returns the number of rounds run; *left = tied slots remaining.
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
-                    uint64_t max_rounds, uint32_t *isa, uint64_t h0)
+                    uint64_t max_rounds, uint32_t *isa, uint64_t h0, uint8_t *idx_hi, uint8_t *tmp_hi)
 {
+	B3M_REQUIRE(!(idx_hi && isa), "internal: prefix doubling is not available for positions above 2^32");
+	B3M_REQUIRE(!idx_hi || tmp_hi, "internal: tie rounds with 36-bit positions need a byte buffer");
 	const uint64_t K = (uint64_t)key_symbols(T.type);
 	int gbits = 1; while ((1ull << gbits) < len_for_labels + 1 && gbits < 32) ++gbits;
 	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
@@ -355,7 +371,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		if (max_rounds && rounds >= max_rounds) break;
 		++rounds;
 		if (isa) hipLaunchKernelGGL(k_tie_keys_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, u, kx, vx);
-		else hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, depth, kx, vx);
+		else hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, (const uint8_t *)idx_hi, u, depth, kx, vx);
 		uint64_t *rk; uint32_t *rv;
 		radix_sort_u64(kx, vx, ky, vy, u, isa ? gbits : key_bits(T.type), radix, s, nullptr, &rk, &rv);
 		uint64_t *gk = (rk == kx) ? ky : kx;
@@ -366,8 +382,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
 		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
 		if (isa) hipLaunchKernelGGL(k_tie_gather_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, rv2, u, tmp_idx, tmp_key);
-		else hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, rv2, u, depth, tmp_idx, tmp_key);
-		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, tmp_key, u, idx, hid);
+		else hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, (const uint8_t *)idx_hi, rv2, u, depth, tmp_idx, tmp_hi, tmp_key);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)tmp_hi, tmp_key, u, idx, idx_hi, hid);
 		inclusive_max_u32(hid, u, scan_ws, s);
 		if (isa) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);   // every key of this round has been read
 		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
@@ -514,7 +530,7 @@ uint64_t tie_rounds_domain(uint32_t *idx, uint64_t u, uint64_t *kx, uint64_t *ky
 		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
 		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
 		hipLaunchKernelGGL(k_dom_gather, dim3(nblk(u)), dim3(256), 0, s, isa, start, h, D, U, gid, idx, rv2, u, hid, tmp_idx, tmp_key);
-		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, tmp_key, u, idx, hid);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)nullptr, tmp_key, u, idx, (uint8_t *)nullptr, hid);
 		inclusive_max_u32(hid, u, scan_ws, s);
 		hipLaunchKernelGGL(k_dom_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, tmp_key, D, u, start, isa);
 		hipLaunchKernelGGL(k_dom_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, tmp_key, D, u, flag);
@@ -671,9 +687,9 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 }
 
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,
-                   const SampleOut *smp)
+                   const SampleOut *smp, const uint8_t *d_sa_hi)
 {
-	if (u) hipLaunchKernelGGL(k_emit_bwt_list, dim3(nblk(u)), dim3(256), 0, s, T, U, u, d_sa, start, d_bwt, d_p0, smp ? *smp : SampleOut());
+	if (u) hipLaunchKernelGGL(k_emit_bwt_list, dim3(nblk(u)), dim3(256), 0, s, T, U, u, d_sa, d_sa_hi, start, d_bwt, d_p0, smp ? *smp : SampleOut());
 }
 
 void emit_bwt(const TextView &T, const uint32_t *d_sa, uint64_t len, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s)

@@ -2447,7 +2447,6 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// ---- fallback: the overflow list (hot bins, oversized sub-buckets, huge buckets) goes through the list-based rounds ----
 		Scope sc(tl, KF_TIES, 0);
 		B3M_REQUIRE(nov <= ovf_cap, "too many overflow ranges for the workspace");
-		B3M_REQUIRE(!big, "repeat-rich input of 2^32 symbols and more: the list-based rounds (32-bit positions) cannot finish its overflow list yet");
 		// order the (start, size) pairs by start and turn the sizes into list offsets, all on the device
 		// (a repeat-rich genome lists millions of bins); the record buffers are free by now
 		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
@@ -2461,7 +2460,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemcpyAsync(&total32, d_off + nov, 4, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		const uint64_t total = total32;
+		// texts of 2^32 symbols and more: list buffers of tie_cap entries (the tie bitmap sits in t[0]), positions in two arrays
 		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
+		if (big) {
+			Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB;
+			B3M_REQUIRE(ws.t[5] != nullptr && ws.tie_hi != nullptr, "internal: workspace has no list buffers for positions above 2^32");
+			B3M_REQUIRE(total <= ws.tie_cap, "repeat-rich input of 2^32 symbols and more: " + std::to_string(total) + " suffixes are left to the list-based rounds, whose buffers hold " +
+			            std::to_string(ws.tie_cap) + " (a sixteenth of the sort): use more shards");
+		}
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[0], Bf[1]);
 		stage("overflow list filled");
 		B3M_HIP(hipStreamSynchronize(s));
@@ -2480,8 +2486,13 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// a block of a merge tree: the same few rounds, then prefix doubling inside the block and its overhang (tie_rounds_domain):
 		// the first time round the caller is asked to sort the block again with the overhang behind it (out.want_ext)
 		const bool tree = !whole && !defer && !no_tree_doubling();
+		// 36-bit positions: key extension until nothing is left (an inverse suffix array of 2^32 and more entries does not fit beside the sort: no doubling,
+		// O(longest repeat / 21) rounds)
+		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, sa.hi, ws.tie_hi);
+		else
 		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree) ? R0 : 0);
-		if (left && tree && out.tie_rounds >= R0) {
+		if (big) { /* finished above */ }
+		else if (left && tree && out.tie_rounds >= R0) {
 			if (allow_ext) { out.want_ext = true; goto leave_fallback; }
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			const uint64_t K = (uint64_t)key_symbols(T.type);
@@ -2491,11 +2502,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			out.tie_rounds += tie_rounds_domain(sa.lo, left, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, start, len, own ? own : len, ws.t[5], h0, s, &left, &hb);
 			if (left) { out.slow_ties = left; out.tie_rounds += tie_rounds(T, sa.lo, left, hb / K, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0); }
 		}
-		if (left && defer && out.tie_rounds >= R0) {
+		if (!big && left && defer && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1];
 		}
-		if (left && whole && out.tie_rounds >= R0) {
+		if (!big && left && whole && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
 			isa_from_sa(sa.lo, len, ws.t[5], s);
@@ -2504,7 +2515,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// BWT symbols (and p0) of the slots finished here
 		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)
 		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[5], (uint32_t *)nullptr);
-		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s, &O.smp);
+		emit_bwt_list(T, Bf[5], total, sa.lo, start, d_bwt, d_p0, s, &O.smp, sa.hi);
 		stage("fallback rounds + emit");
 		leave_fallback:;
 	}

@@ -72,6 +72,11 @@ class Plan:
         return int(lib().b3m_plan_num_blocks(self._h))
 
     @property
+    def warning(self):
+        """'' or what the caller should be told (a mem= target that cannot be met: b3m_plan_warning)"""
+        return lib().b3m_plan_warning(self._h).decode()
+
+    @property
     def workspace_bytes(self):
         return int(lib().b3m_plan_workspace_bytes(self._h))
 

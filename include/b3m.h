@@ -104,6 +104,9 @@ b3m_plan *b3m_plan_create_sharded(uint64_t n, int inputtype, int shard, int nsha
 uint64_t  b3m_plan_slice_capacity(const b3m_plan *p);
 void      b3m_plan_destroy(b3m_plan *p);
 uint64_t  b3m_plan_num_blocks(const b3m_plan *p);
+/* "" or what the caller should be told about the plan: a mem= target below the footprint of the smallest blocks is exceeded, and said
+ * so here (b3m_compute_bwt prints it as a [W] line whatever verbose= says; mem= itself: /root/reference/README.md:42) */
+const char *b3m_plan_warning(const b3m_plan *p);
 uint64_t  b3m_plan_workspace_bytes(const b3m_plan *p);
 uint64_t  b3m_plan_text_bytes(const b3m_plan *p);            /* packed input size in bytes */
 /* the plan's own resident text buffer (device memory, b3m_plan_text_bytes() bytes and padding behind them): a text loaded HERE and passed

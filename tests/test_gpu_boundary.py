@@ -286,6 +286,36 @@ def test_bench_line_contract(gpu):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # what is timed is the plan b3m_compute_bwt creates (samples at b3m_plan_sampling_rate), verified from its own samples;
+    # the BWT-only plan is reported beside it
+    sr = j["config"]["isasamplingrate"]
+    assert sr["option"] == 262144 and sr["plan"] == 1024 and sr["samples"] == (20_000_001 + 1023) // 1024
+    assert "0 symbol / 0 chain mismatches" in j["config"]["checked"]
+    assert j["config"]["bwt_only"]["equals_shipped_output"] is True and j["config"]["bwt_only"]["ms_per_step"] > 0
+
+
+def test_mem_target_that_cannot_be_met_is_said_not_hidden(gpu, oracle, tmp_path):
+    """mem= below the footprint of the smallest blocks (/root/reference/README.md:42: the reference's memory target): the plan says so
+    (b3m_plan_warning), b3m_compute_bwt prints it as a [W] line whatever verbose= says, and the result is still the BWT"""
+    from bwtb3m_amd import engine
+    torch = gpu
+    b = oracle.synth_bases(3_000_000, 5)
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    ok = engine.Plan(len(s), "pacterm", mem=1 << 30)
+    assert ok.warning == "" and ok.workspace_bytes <= 1 << 30
+    ok.close()
+    plan = engine.Plan(len(s), "pacterm", mem=8 << 20)                # 8 MB for 3 M symbols: below the 7.25 B/symbol that do not shrink
+    assert "cannot be met" in plan.warning and plan.workspace_bytes > 8 << 20 and plan.num_blocks > 1
+    out = plan.run(torch.from_numpy(buf).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.bwt(s))
+    plan.close()
+    inp = tmp_path / "in.pac"
+    inp.write_bytes(buf.tobytes())
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=1", "mem=8m", "outputfilename=" + str(tmp_path / "x.bwt"), str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"[W] mem=8388608 cannot be met" in r.stderr, r.stderr.decode()
 
 
 @pytest.mark.gpu

@@ -886,6 +886,37 @@ def test_beyond_2_32_symbols_one_gpu(gpu):
     plan.close()
 
 
+def test_repeat_rich_text_beyond_2_32_symbols(gpu):
+    """n = 2^32 + 12345 with planted repeats (a copy, a tandem array, a homopolymer run, some of them at positions above 2^32): the overflow
+    list of such a text is finished by key-extension rounds with 36-bit positions (no inverse suffix array of 2^32 entries: no prefix
+    doubling there).  Round 2 refused this input.  Verified by the LF walk over every symbol (64-bit ranks)."""
+    torch = gpu
+    from bwtb3m_amd import benchutil, engine, synth
+    nb = (1 << 32) + 12344
+    itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
+    d_text = d_text.clone()
+    hi_byte = ((1 << 32) + 4000) // 4                      # base 2^32 + 4000
+    d_text[hi_byte:hi_byte + 2000] = d_text[123_456_789:123_456_789 + 2000].clone()            # 8 kbase copy, the copy above 2^32
+    pat = torch.tensor([0x1B, 0xE4, 0x27], dtype=torch.uint8, device="cuda")
+    d_text[700_000_000:700_000_000 + 1500] = pat.repeat(500)                                  # tandem array, unit 12 bases, 6 kbase
+    d_text[hi_byte - 3000:hi_byte - 2500] = 0                                                  # 2 kbase of A just below 2^32
+    d_text[900_000_000:900_000_000 + 300] = 0xFF                                               # 1.2 kbase of T
+    plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
+    out = plan.run(d_text)
+    torch.cuda.synchronize()
+    r = plan.result()
+    assert r["tie_rounds"] > 50 and r["tie_elements"] > 1000, r
+    assert int(out[r["p0"]]) == 0
+    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    assert (m0, m1) == (0, 0)
+    ht = benchutil.text_histogram(d_text, n, itype)
+    hb = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for o in range(0, n, 1 << 28):
+        hb += torch.bincount(out[o:o + (1 << 28)].to(torch.int64), minlength=256)
+    assert hb.cpu().tolist() == ht
+    plan.close()
+
+
 def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
     """BASELINE configs[4] geometry: n = 30,000,000,001, the suffix-range shards of an 8-GPU run rehearsed one after the other on ONE GPU
     (each GPU of the node would hold the same 7.5 GB text and sort 3.75 G suffixes).  The slices must tile the rank space, every sampled
