@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--bwtonly", type=int, default=0, help="the option as given to bwtb3m")
     ap.add_argument("--no-bwt-only", dest="bwt_only", action="store_false",
                     help="skip the extra leg that times a plan without (rank,pos) samples (`config.bwt_only`)")
+    ap.add_argument("--no-genome-like", dest="genome_like", action="store_false",
+                    help="skip the extra leg on a repeat-rich text of the same size (`config.genome_like`: what a real genome costs; never the headline)")
     ap.add_argument("--no-check", dest="check", action="store_false",
                     help="skip the verification after the timed loop (default: the timed output is LF-walked on the device against the "
                          "text from the timed plan's own (rank,pos) samples, checkbwt semantics)")
@@ -123,6 +125,35 @@ def time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, steps):
     nbases = n - 1 if itype == "pacterm" else n
     return {"ms_per_step": round(dt / steps * 1e3, 3), "value": round(nbases * steps / dt / 1e9, 4), "unit": "Gbase/s", "steps": steps,
             "equals_shipped_output": same, "what": "plan without (rank,pos) samples: BWT bytes only, not what b3m_compute_bwt runs"}
+
+
+def time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate):
+    """the same size and plan, on a text with the repeat structure of a genome (synth.genome_like_device: interspersed repeats at 3-10 %
+    divergence, segmental duplications, microsatellites, a satellite array) instead of uniform bases: BASELINE.json's metric is quoted on
+    uniform text, every real .pac is on this side.  LF-verified from the plan's own samples; two timed steps."""
+    nb = n - 1 if itype == "pacterm" else n
+    t0 = time.perf_counter()
+    d_text = synth.genome_like_device(nb, 7, "cuda")
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=plan_rate)
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    plan.run(d_text, out)                                   # (the first run of a plan on repeat-rich text sorts twice: BWT only, then with the suffix array kept)
+    torch.cuda.synchronize()
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(d_text, out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r = plan.result()
+    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    assert (m0, m1) == (0, 0), "bench genome_like: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
+    fam = {k["name"]: round(k["ms"], 2) for k in plan.kernel_times() if k["ms"] > 0.05}
+    plan.close()
+    return {"ms_per_step": round(dt * 1e3, 2), "value": round(nb / dt / 1e9, 3), "unit": "Gbase/s", "steps": steps, "tie_rounds": r["tie_rounds"],
+            "tie_elements": r["tie_elements"], "families_ms": fam, "lf_verified": True, "input_gen_s": round(gen_s, 2),
+            "what": "same size, same plan, genome-like repeat-rich text (bwtb3m_amd.synth.genome_like_device): not the metric's input"}
 
 
 def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
@@ -252,6 +283,8 @@ def main():
     plan.close()
     if a.bwt_only:
         out["config"]["bwt_only"] = time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, max(1, min(a.steps, 10)))
+    if a.genome_like and itype in ("pac", "pacterm") and n >= (1 << 22):
+        out["config"]["genome_like"] = time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate)
     if not a.no_cpu_baseline:
         sample = int(min(a.cpu_sample, n))
         # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)

@@ -184,6 +184,7 @@ struct BlockSortOut {
 	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
 	bool samples_done = false;        // ws.samples was served: every sample of a suffix sorted here sits in its slot
+	bool reran_with_sa = false;       // a BWT-only sort met long repeats and started over with the suffix array kept (prefix doubling reads every rank)
 	bool want_ext = false;            // a block of a merge tree with long ties: sort it again together with an overhang (block_sort does)
 	uint64_t slow_ties = 0;           // slots that prefix doubling inside the block's domain could not finish (repeat longer than the overhang)
 	uint64_t overhang = 0;            // symbols behind the block that were sorted with it
@@ -243,7 +244,7 @@ constexpr int DICT_MAX_PARTS = 8;
 void pack2(const uint8_t *d_bwt, uint64_t m, int type, uint8_t *d_packed, hipStream_t s);
 void rank_build_from_parts(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0, uint32_t *d_blocks,
                            uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
-void dict_bytes(const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int type, uint8_t *d_out, hipStream_t s);
+void dict_bytes(const TextView &T, const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, uint64_t p0_pos, uint8_t *d_out, hipStream_t s);
 void rank_cuts(const uint32_t *d_sr, uint64_t cnt, const uint64_t *d_bounds, int nb, uint64_t *d_cuts, hipStream_t s);
 struct GapWalkArgs {
 	TextView T; RankDict rd;

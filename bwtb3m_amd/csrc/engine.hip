@@ -61,6 +61,22 @@ __global__ void k_emit_gt_ptr(const uint32_t *sa, uint64_t len, uint64_t start, 
 	uint32_t x = sa[r];
 	if (r > *p0 && x != start) atomicOr(&gt[x >> 5], 1u << (x & 31));
 }
+__global__ void k_add_u32_to_i64(const uint32_t *src, long long *dst, uint64_t count)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) dst[i] += (long long)src[i];
+}
+__global__ void k_i64_to_u32(const long long *src, uint32_t *dst, uint64_t count)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) dst[i] = (uint32_t)src[i];
+}
+__global__ void k_endbit_i64(const long long *anchor, uint64_t p0L, uint32_t *gt, uint64_t bit)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		if ((uint64_t)anchor[0] > p0L) atomicOr(&gt[bit >> 5], 1u << (bit & 31)); else atomicAnd(&gt[bit >> 5], ~(1u << (bit & 31)));
+	}
+}
 __global__ void k_clear_bits(uint32_t *dst, uint64_t b, uint64_t e)   // clears bits [b,e)
 {
 	uint64_t w = (b >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,6 +129,7 @@ struct b3m_plan {
 	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
 	int shard = 0, nshards = 1; uint64_t shard_cap = 0;   // suffix-range shard of a single-block plan
 	int keep_sa = 0;                                      // b3m_plan_set_keep_sa: the next runs keep the whole suffix array of the sort (tie export needs it)
+	int sa_hint = 0;                                      // the last run's BWT-only sort had to start over with the suffix array kept (repeat-rich text): the next ones keep it from the start
 	int seq_shards = 1;                                   // texts of 2^32 symbols and more on one GPU: the suffix-range shards of the one block, one after the other
 	std::vector<Leaf> leaves;
 	std::vector<MergeT> merges;
@@ -151,6 +168,8 @@ struct b3m_plan {
 	uint64_t tie_left = 0; uint32_t *tie_U = nullptr, *tie_gid = nullptr;   // suffix-range shard: what its local rounds left tied (b3m_plan_tie_*)
 	uint32_t *d_sa_slice = nullptr; uint64_t slice_off = 0, slice_len = 0;
 	hipStream_t copy_stream = nullptr;     // host-memory runs: slices of the BWT leave on this stream while later buckets sort
+	uint32_t *d_isa_cache = nullptr;       // suffix-range shards of a repeat-rich text: the inverse suffix array of the collective tie finish (4 n bytes, allocated at the first
+	                                       // finish and kept: no hipMalloc per step on that path either)
 	std::string warning;                   // what the caller should be told about this plan (a mem= target that cannot be met)
 	int packed_out = 0;                    // host-memory runs hand the BWT over 2-bit packed (b3m_plan_set_packed_output)
 	uint8_t *d_pack = nullptr;             // its device image
@@ -408,6 +427,7 @@ void b3m_plan_destroy(b3m_plan *p)
 	if (p->h_raw) { if (p->h_raw_pinned) (void)hipHostFree(p->h_raw); else free(p->h_raw); }
 	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
 	if (p->d_pack) (void)hipFree(p->d_pack);
+	if (p->d_isa_cache) (void)hipFree(p->d_isa_cache);
 	if (p->arena) (void)hipFree(p->arena);
 	delete p;
 }
@@ -574,7 +594,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		// (rank,pos) samples of a whole-text block (or its shards) are written by the sort itself, where each suffix is finally placed
 		// (SampleOut): no suffix array is kept for them.  Blocks of a merge tree keep theirs anyway (anchors), the LSD path always has one.
 		const bool smp_in_kernel = B == 1 && p->isarate != 0 && sample_in_kernel_ok(p->isarate, n);
-		const bool need_sa = B > 1 || p->keep_sa || (p->isarate != 0 && !smp_in_kernel);       // anchors / the tie export / samples the kernels cannot test for read the suffix array
+		const bool need_sa = B > 1 || p->keep_sa || p->sa_hint || (p->isarate != 0 && !smp_in_kernel);       // anchors / the tie export / samples the kernels cannot test for read the suffix array
 		SampleOut smp_cfg;
 		if (smp_in_kernel) smp_cfg = make_sample_out(p->d_samples + 2 * p->sample_off[k], p->isarate, (lf.a + p->isarate - 1) / p->isarate, p->sample_off[k + 1] - p->sample_off[k]);
 		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
@@ -592,6 +612,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr; p->bs.arrival = nullptr; p->bs.samples = nullptr;
 			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
+			if (so.reran_with_sa) p->sa_hint = 1;
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
 			p->d_sa_slice = so.d_sa; p->slice_off = so.slice_offset; p->slice_len = so.kept_len;
 			B3M_REQUIRE(!(so.tie_left && p->seq_shards > 1), "internal: deferred ties in a sequential shard");
@@ -869,14 +890,15 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 	B3M_REQUIRE(total <= ws.cap, "tie finish: more tied suffixes over all shards than one shard's workspace holds (low-complexity input)");
 	if (total == 0) return 0;
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
-	DevBuf isa(4 * n);
-	isa_from_sa(d_sa_global, n, isa.as<uint32_t>(), s);
+	if (!p->d_isa_cache) B3M_HIP(hipMalloc((void **)&p->d_isa_cache, 4 * n));
+	uint32_t *const d_isa = p->d_isa_cache;
+	isa_from_sa(d_sa_global, n, d_isa, s);
 	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 	hipLaunchKernelGGL(k_tie_unpairs, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, d_pairs_all, total, Bf[0], Bf[1]);
 	const uint64_t R0 = 4;
 	uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
 	uint64_t left = 0;
-	const uint64_t rounds = tie_rounds(T, d_sa_global, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, n, s, &left, 0, isa.as<uint32_t>(), h0);
+	const uint64_t rounds = tie_rounds(T, d_sa_global, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, n, s, &left, 0, d_isa, h0);
 	p->res.tie_rounds += rounds;
 	// my slice back into the workspace, the BWT symbols of the slots that were open here, p0, samples
 	const uint64_t mine = p->tie_left;
@@ -1459,6 +1481,44 @@ int b3m_dist_rank_of(b3m_dist_plan *p, const uint64_t *positions, uint64_t count
 	B3M_CATCH(1)
 }
 
+int b3m_dist_rank_of_dev(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, int64_t *d_accum, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && p->d_sa_last && (count == 0 || (positions && d_accum)), "b3m_dist_rank_of_dev: no leaf sorted yet / null argument");
+	hipStream_t s = (hipStream_t)stream;
+	const TextView T = dist_text(p);
+	for (uint64_t o = 0; o < count; o += 4096) {
+		const uint64_t c = std::min<uint64_t>(4096, count - o);
+		uint64_t *d_pos = p->d_small + 136; uint32_t *d_rk = (uint32_t *)(p->d_small + 136 + 4096);
+		B3M_HIP(hipMemcpyAsync(d_pos, positions + o, 8 * c, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemsetAsync(d_rk, 0, 4 * c, s));
+		rank_of_positions(T, p->d_sa_last, p->sa_len, d_pos, c, d_rk, s);
+		hipLaunchKernelGGL(k_add_u32_to_i64, dim3((uint32_t)((c + 255) / 256)), dim3(256), 0, s, d_rk, reinterpret_cast<long long *>(d_accum) + o, c);
+		B3M_HIP(hipStreamSynchronize(s));            // (`positions` is the caller's host memory, the staging area is reused by the next piece)
+	}
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_dist_endbit(b3m_dist_plan *p, uint32_t *d_gt_abs, uint64_t bit, const int64_t *d_anchor, uint64_t p0L, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_gt_abs && d_anchor && bit <= p->n, "b3m_dist_endbit: bad argument");
+	hipLaunchKernelGGL(k_endbit_i64, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const long long *>(d_anchor), p0L, d_gt_abs, bit);
+	return 0;
+	B3M_CATCH(1)
+}
+
+int b3m_bits_copy(const uint32_t *d_src_abs, uint32_t *d_dst_abs, uint64_t bit_begin, uint64_t bit_end, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(d_src_abs && d_dst_abs, "b3m_bits_copy: null argument");
+	copy_bits(d_src_abs, d_dst_abs, bit_begin, bit_end, (hipStream_t)stream);
+	return 0;
+	B3M_CATCH(1)
+}
+
 int b3m_dist_pack2(b3m_dist_plan *p, const uint8_t *d_bwt, uint64_t m, uint8_t *d_packed, void *stream)
 {
 	B3M_TRY
@@ -1484,11 +1544,11 @@ int b3m_dist_build_dict(b3m_dist_plan *p, const uint8_t *const *d_parts, const u
  * rank slices of the group: the gap buckets of the all-to-all).  symstart[4]: C array of L (symbols smaller than code c in L's text).
  * gt arrays as b3m_gap_chains.  One host synchronisation (the bucket sizes are split sizes of the collective). */
 int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const uint64_t *symstart, const uint32_t *d_gt_abs_in, uint32_t *d_gt_abs_out,
-                  const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                  const int64_t *d_anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
                   const uint64_t *bounds, int nbounds, uint32_t *d_sorted_out, uint64_t *cuts_out, uint64_t *count_out, void *stream)
 {
 	B3M_TRY
-	B3M_REQUIRE(p && symstart && d_gt_abs_in && d_gt_abs_out && count_out, "b3m_dist_walk: null argument");
+	B3M_REQUIRE(p && symstart && d_gt_abs_in && d_gt_abs_out && count_out && (num_chains == 0 || d_anchors), "b3m_dist_walk: null argument");
 	B3M_REQUIRE(p->dict_m == m, "b3m_dist_walk: the dictionary in the workspace is not this merge's");
 	B3M_REQUIRE(a + m + mr <= p->n && mr >= 1 && chain_len >= 1 && nbounds >= 0 && nbounds <= 64, "b3m_dist_walk: range out of bounds");
 	const uint64_t total_chains = (mr + chain_len - 1) / chain_len;
@@ -1499,9 +1559,8 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
 	const uint64_t slots = gap_walk_slots(num_chains, chain_len);
 	B3M_REQUIRE(slots <= p->max_R + p->max_R / 8 + 256 && num_chains <= p->anchors_cap, "b3m_dist_walk: chain range larger than the workspace");
 	const TextView T = dist_text(p);
-	std::vector<uint32_t> a32(num_chains);
-	for (uint64_t c = 0; c < num_chains; ++c) a32[c] = (uint32_t)anchors[c];
-	B3M_HIP(hipMemcpyAsync(p->d_anchors, a32.data(), 4 * num_chains, hipMemcpyHostToDevice, s));
+	// the anchors (ranks of the chain tops in L, summed over L's leaves and all-reduced) arrive as a device array
+	hipLaunchKernelGGL(k_i64_to_u32, dim3((uint32_t)((num_chains + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const long long *>(d_anchors), p->d_anchors, num_chains);
 	const uint32_t p032 = (uint32_t)p->dict_p0;
 	B3M_HIP(hipMemcpyAsync(p->d_p0u, &p032, 4, hipMemcpyHostToDevice, s));
 	if (nbounds) B3M_HIP(hipMemcpyAsync(p->d_small + 8, bounds, 8 * nbounds, hipMemcpyHostToDevice, s));
@@ -1530,12 +1589,13 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
 	B3M_CATCH(1)
 }
 
-/* bytes of BWT(L)[l0, l1) from the dictionary in the workspace (p0_byte: the true symbol of L's p0 entry) */
-int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t l0, uint64_t l1, int p0_byte, uint8_t *d_out, void *stream)
+/* bytes of BWT(L)[l0, l1) from the dictionary in the workspace; L = [a, a + dict_m): its p0 entry belongs to position a - 1 (circular), whose symbol
+ * the 2-bit dictionary cannot carry (the terminator): it is read from the text */
+int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t a, uint64_t l0, uint64_t l1, uint8_t *d_out, void *stream)
 {
 	B3M_TRY
-	B3M_REQUIRE(p && l0 <= l1 && l1 <= p->dict_m && (l1 == l0 || d_out), "b3m_dist_l_bytes: bad argument");
-	dict_bytes(p->d_blocks, l0, l1, p->dict_p0, p0_byte, p->type, d_out, (hipStream_t)stream);
+	B3M_REQUIRE(p && a < p->n && l0 <= l1 && l1 <= p->dict_m && (l1 == l0 || d_out), "b3m_dist_l_bytes: bad argument");
+	dict_bytes(dist_text(p), p->d_blocks, l0, l1, p->dict_p0, a ? a - 1 : p->n - 1, d_out, (hipStream_t)stream);
 	return 0;
 	B3M_CATCH(1)
 }

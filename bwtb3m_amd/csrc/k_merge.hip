@@ -117,19 +117,19 @@ __global__ __launch_bounds__(256) void k_rank_words_from_parts(PackedParts P, ui
 	wc[w] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 }
 // bytes of BWT(L)[l0, l1) back from the dictionary payload (the p0 entry gets its true byte)
-__global__ __launch_bounds__(256) void k_dict_bytes(const uint32_t *blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int add, uint8_t *out)
+__global__ __launch_bounds__(256) void k_dict_bytes(TextView T, const uint32_t *blocks, uint64_t l0, uint64_t l1, uint64_t p0, uint64_t p0_pos, int add, uint8_t *out)
 {
 	uint64_t g = l0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= l1) return;
 	const uint64_t b = g / RANK_BLK_SYMS; const uint32_t off = (uint32_t)(g - b * RANK_BLK_SYMS);
 	const uint32_t word = blocks[b * 16 + 4 + (off >> 4)];
 	uint32_t v = ((word >> (2 * (off & 15))) & 3u) + (uint32_t)add;
-	if (g == p0) v = (uint32_t)p0_byte;
+	if (g == p0) v = sym_at(T, p0_pos);                 // the entry of the node's first suffix: the symbol in front of the node, from the text
 	out[g - l0] = (uint8_t)v;
 }
-void dict_bytes(const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, int p0_byte, int type, uint8_t *d_out, hipStream_t s)
+void dict_bytes(const TextView &T, const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, uint64_t p0_pos, uint8_t *d_out, hipStream_t s)
 {
-	if (l1 > l0) hipLaunchKernelGGL(k_dict_bytes, dim3(nblk(l1 - l0)), dim3(256), 0, s, d_blocks, l0, l1, p0, p0_byte, type == B3M_INPUT_PACTERM ? 1 : 0, d_out);
+	if (l1 > l0) hipLaunchKernelGGL(k_dict_bytes, dim3(nblk(l1 - l0)), dim3(256), 0, s, T, d_blocks, l0, l1, p0, p0_pos, T.type == B3M_INPUT_PACTERM ? 1 : 0, d_out);
 }
 // cuts[j] = #{q : sr[q] < bounds[j]} over an ascending rank list
 __global__ void k_cuts(const uint32_t *sr, uint64_t cnt, const uint64_t *bounds, int nb, uint64_t *cuts)

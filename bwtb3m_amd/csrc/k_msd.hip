@@ -2519,7 +2519,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		stage("fallback rounds + emit");
 		leave_fallback:;
 	}
-	if (rerun_with_sa) { ws.d_symhist_out = nullptr; block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true, own, allow_ext); return; }   // the histogram was added by this pass already
+	if (rerun_with_sa) {
+		ws.d_symhist_out = nullptr;       // the histogram was added by this pass already
+		block_sort_msd(T, start, len_in, ws, s, tl, out, d_bwt, d_p0, shard, nshards, true, own, allow_ext);
+		out.reran_with_sa = true;         // (the plan remembers: its next runs keep the suffix array from the start)
+		return;
+	}
 	B3M_HIP(hipGetLastError());
 	out.d_sa = need_sa ? sa.lo : nullptr;      // without need_sa only the entries of tied / overflow records were written
 	out.d_sa_hi = need_sa ? sa.hi : nullptr;

@@ -143,13 +143,26 @@ class HipBackend:
         eng.check(eng.lib().b3m_dist_leaf(self._h, a, m, eng._ptr(bw), eng._ptr(gt_abs), ctypes.byref(p0), h5, eng._stream()))
         return bw, gt_abs, int(p0.value), [int(x) for x in h5]
 
-    def rank_of(self, positions):
+    def rank_of_into(self, positions, accum):
+        """accum (int64 device tensor, one entry per position) += rank of the rotation starting at each position among the suffixes of the
+        leaf sorted last: the chain anchors stay on the device (b3m_dist_rank_of_dev)"""
         eng = self.engine
         pos = np.ascontiguousarray(positions, dtype=np.uint64)
-        out = np.zeros(len(pos), dtype=np.uint64)
+        assert accum.dtype == torch.int64 and accum.is_contiguous() and accum.numel() == len(pos)
         if len(pos):
-            eng.check(eng.lib().b3m_dist_rank_of(self._h, pos.ctypes.data, len(pos), out.ctypes.data, eng._stream()))
-        return out.astype(np.int64)
+            eng.check(eng.lib().b3m_dist_rank_of_dev(self._h, pos.ctypes.data, len(pos), eng._ptr(accum), eng._stream()))
+
+    def bits_replace(self, dst, seg, seg_w0, b, e):
+        """dst bits [b,e) = bits [b,e) of `seg`, a word range that starts at word seg_w0 of the absolute-position bit array (b3m_bits_copy)"""
+        eng = self.engine
+        if e > b:
+            assert seg.is_contiguous() and dst.is_contiguous() and (b >> 5) >= seg_w0 and ((e - 1) >> 5) - seg_w0 < seg.numel()
+            eng.check(eng.lib().b3m_bits_copy(ctypes.c_void_p(seg.data_ptr() - 4 * seg_w0), eng._ptr(dst), b, e, eng._stream()))
+
+    def set_endbit(self, gt, bit, anchor, p0L):
+        """bit `bit` of gt = [anchor[0] > p0L] (anchor: device int64 tensor)"""
+        eng = self.engine
+        eng.check(eng.lib().b3m_dist_endbit(self._h, eng._ptr(gt), bit, eng._ptr(anchor), p0L, eng._stream()))
 
     def pack2(self, bwt):
         eng = self.engine
@@ -172,18 +185,19 @@ class HipBackend:
         sr = torch.empty(cap, dtype=torch.int32, device=self.device)
         gt_out = torch.zeros(self.gt_words(self.n), dtype=torch.int32, device=self.device)
         cnt = ctypes.c_uint64(0)
-        anc = np.ascontiguousarray(anchors, dtype=np.uint64)
+        assert anchors.dtype == torch.int64 and anchors.is_contiguous() and anchors.numel() == num_chains
         bd = np.ascontiguousarray(bounds, dtype=np.uint64)
         cuts = np.zeros(len(bd), dtype=np.uint64)
         ss = (ctypes.c_uint64 * 4)(*[int(x) for x in symstart])
-        eng.check(eng.lib().b3m_dist_walk(self._h, a, m, mr, ss, eng._ptr(gt_abs), eng._ptr(gt_out), anc.ctypes.data, chain_first, num_chains, chain_len,
+        eng.check(eng.lib().b3m_dist_walk(self._h, a, m, mr, ss, eng._ptr(gt_abs), eng._ptr(gt_out), eng._ptr(anchors), chain_first, num_chains, chain_len,
                                           bd.ctypes.data, len(bd), eng._ptr(sr), cuts.ctypes.data, ctypes.byref(cnt), eng._stream()))
         return sr[: cnt.value], cuts.astype(np.int64), gt_out
 
-    def l_bytes(self, l0, l1, p0_byte):
+    def l_bytes(self, a, l0, l1):
+        """BWT(L)[l0, l1) of the node L that starts at text position a, out of the dictionary (its p0 entry: the symbol in front of L, from the text)"""
         eng = self.engine
         out = torch.empty(l1 - l0, dtype=torch.uint8, device=self.device)
-        eng.check(eng.lib().b3m_dist_l_bytes(self._h, l0, l1, int(p0_byte), eng._ptr(out), eng._stream()))
+        eng.check(eng.lib().b3m_dist_l_bytes(self._h, a, l0, l1, eng._ptr(out), eng._stream()))
         return out
 
     def sort_u32(self, keys, nbits):
@@ -336,13 +350,12 @@ class DistributedBwt:
         # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks; leaf histograms for the C arrays -----
         t1 = time.perf_counter()
         tm["leaf"] += t1 - t0
+        # (the ranks never visit the host: partial ranks are added on the device, summed over the ranks by one all-reduce, and the walks read them there)
         anchors = torch.zeros(max(1, plan.total_anchors), dtype=torch.int64, device=dev)
         for mg in plan.merges_with_leaf_on_left(me):
-            r = be.rank_of(plan.anchor_positions(mg))
-            anchors[mg.anchor_off:mg.anchor_off + mg.num_chains] = torch.from_numpy(r).to(dev)
+            be.rank_of_into(plan.anchor_positions(mg), anchors[mg.anchor_off:mg.anchor_off + mg.num_chains])
         if self.world > 1:
             _all_reduce_sum(anchors)
-        h_anchors = anchors.cpu().numpy()
         self.leaf_hist = _all_gather_i64(h5, None, dev) if self.world > 1 else np.array([h5], dtype=np.int64)
         tm["anchors"] += time.perf_counter() - t1
         # ---- merge levels ----------------------------------------------------------------------------------
@@ -353,12 +366,14 @@ class DistributedBwt:
             if not mine:
                 continue
             mg = mine[0]
-            my_bwt, my_off, gt_cur, p0P = self._merge(mg, my_bwt, my_off, gt_cur, node_p0[my_node.ranks[0]], h_anchors, tm)
+            my_bwt, my_off, gt_cur, p0P = self._merge(mg, my_bwt, my_off, gt_cur, node_p0[my_node.ranks[0]], anchors, tm)
             my_node = Node(mg.L.a, mg.L.m + mg.R.m, mg.group)
             node_p0[my_node.ranks[0]] = p0P
         return my_bwt, my_off, node_p0[my_node.ranks[0]]
 
-    def _merge(self, mg, my_bwt, my_off, gt_cur, my_node_p0, h_anchors, tm):
+    def _merge(self, mg, my_bwt, my_off, gt_cur, my_node_p0, anchors, tm):
+        """one merge of the tree, this rank's part.  What the host sees of it: slice sizes and the split sizes of the two all-to-alls (and the
+        new p0 at the end); anchors, gt bits, ranks and symbols stay on the device."""
         n, be, me, dev = self.n, self.be, self.rank, self.device
         grp = self.groups[mg.idx]
         members = mg.group
@@ -368,13 +383,12 @@ class DistributedBwt:
         a, m, mr = mg.L.a, mg.L.m, mg.R.m
         rbeg, rend = a + m, a + m + mr
         t0 = time.perf_counter()
-        # 1. slice sizes, node p0 of both sides, and the true symbol of my node's p0 entry (the packed form cannot carry it)
+        # 1. slice sizes and the node p0 of both sides (the symbol of L's p0 entry, which the packed form cannot carry, is the text symbol
+        #    in front of L: the library reads it there)
         sz = my_bwt.numel()
-        p0_byte = int(my_bwt[my_node_p0 - my_off]) if my_off <= my_node_p0 < my_off + sz else -1
-        info = _all_gather_i64([sz, my_node_p0, p0_byte], grp, dev)
+        info = _all_gather_i64([sz, my_node_p0], grp, dev)
         sizes = info[:, 0]
         p0L = int(info[0, 1])
-        p0L_byte = int(info[:nL, 2].max())
         assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
         offR = np.concatenate([[0], np.cumsum(sizes[nL:])])
         # 2. BWT(L) to every member as packed slices, 2 bits per symbol (the rank dictionary is built from them where it is used)
@@ -392,8 +406,8 @@ class DistributedBwt:
         _broadcast(lseg, members[0], grp)
         rseg = gt_cur[w0:w1].clone()
         _broadcast(rseg, members[nL], grp)
-        _replace_bits_seg(gt_cur, lseg, lw0, a + 1, rbeg + 1)
-        _replace_bits_seg(gt_cur, rseg, w0, rbeg + 1, rend + 1)
+        be.bits_replace(gt_cur, lseg, lw0, a + 1, rbeg + 1)
+        be.bits_replace(gt_cur, rseg, w0, rbeg + 1, rend + 1)
         t1 = time.perf_counter()
         tm["exchange"] += t1 - t0
         # 4. dictionary, then my chain range; the ranks come back sorted and already cut at the borders of the group's rank slices
@@ -409,7 +423,7 @@ class DistributedBwt:
         flights, rc, oseg = [], None, None
         for t in range(ntile):
             ca, cz = c0 + tb[t], c0 + tb[t + 1]
-            anc = h_anchors[mg.anchor_off + ca: mg.anchor_off + cz]
+            anc = anchors[mg.anchor_off + ca: mg.anchor_off + cz]
             sr_t, cut, gt_out = be.walk(a, m, mr, symstart, gt_cur, anc, ca, cz - ca, mg.chain_len, lam)
             seg = gt_out[w0:w1]
             oseg = seg.clone() if oseg is None else oseg | seg          # new gt bits of the walked positions (disjoint between tiles and walkers)
@@ -425,8 +439,8 @@ class DistributedBwt:
         oseg = oseg.contiguous()
         _all_reduce_sum(oseg, grp)
         gt_new = gt_cur                               # L's bits (a, rbeg) stay; R's become relative to S_a
-        _replace_bits_seg(gt_new, oseg, w0, rbeg, rend)
-        _set_bit(gt_new, rend, 1 if int(h_anchors[mg.anchor_off]) > p0L else 0)
+        be.bits_replace(gt_new, oseg, w0, rbeg, rend)
+        be.set_endbit(gt_new, rend, anchors[mg.anchor_off: mg.anchor_off + 1], p0L)
         # 5. the gap buckets of my slice of the rank space [0, m], from every walker and tile
         got = torch.cat([f.result() for f in flights]) if len(flights) > 1 else flights[0].result()
         del flights
@@ -454,17 +468,20 @@ class DistributedBwt:
         l0, l1 = lam[gi], (lam[gi + 1] if gi + 1 < gs else m)
         l1 = min(l1, m)
         sr_local = (sr_slice - l0) if l0 else sr_slice
-        out = be.interleave(sr_local, be.l_bytes(l0, l1, p0L_byte), bwtR_part)
-        # new rank of L's p0 entry: p0L + #{q : sr[q] <= p0L}
-        cand = -1
-        if l0 <= p0L < l1:
-            le = int(torch.searchsorted(sr_slice, torch.tensor([p0L], dtype=torch.int32, device=dev), right=True)[0])
-            cand = p0L + int(Q[gi]) + le
-        fin = _all_gather_i64([out.numel(), cand], grp, dev)
-        p0P = int(fin[:, 1].max())
-        new_off = int(fin[:gi, 0].sum())
+        out = be.interleave(sr_local, be.l_bytes(a, l0, l1), bwtR_part)
+        p0P, new_off = self._p0_after_merge(sr_slice, p0L, l0, l1, int(Q[gi]), out.numel(), gi, grp)
         tm["interleave"] += time.perf_counter() - t3
         return out, new_off, gt_new, p0P
+
+    def _p0_after_merge(self, sr_slice, p0L, l0, l1, q0, out_len, gi, grp):
+        """new rank of L's p0 entry, p0L + #{q : sr[q] <= p0L} (known to the owner of rank p0L), and the offset of my slice of the parent:
+        the one place after a merge's interleave where a number leaves the device"""
+        cand = -1
+        if l0 <= p0L < l1:
+            le = int(torch.searchsorted(sr_slice, torch.tensor([p0L], dtype=torch.int32, device=sr_slice.device), right=True)[0])
+            cand = p0L + q0 + le
+        fin = _all_gather_i64([out_len, cand], grp, sr_slice.device)
+        return int(fin[:, 1].max()), int(fin[:gi, 0].sum())
 
 
 class PrefixShardedBwt:
@@ -481,6 +498,8 @@ class PrefixShardedBwt:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.plan = engine.Plan(n, itype, isasamplingrate=isasamplingrate, shard=self.rank, nshards=self.world)
         self.out = torch.empty(self.plan.slice_capacity, dtype=torch.uint8, device=device)
+        self.tie_finish_runs = 0           # steps that needed the collective finish of long repeats (decided once per plan: from the first such step on
+                                           # the shard keeps its suffix array, b3m_plan_set_keep_sa, and every step repeats the finish)
 
     def run(self, d_text):
         sl = self.plan.run(d_text, self.out)
@@ -504,6 +523,7 @@ class PrefixShardedBwt:
                     return allp, int(counts[:me].sum())
 
                 engine.finish_shard_ties(self.plan, sl, gather_sa, gather_pairs)
+                self.tie_finish_runs += 1
         r = self.plan.result()
         off = r["slice_offset"] if self.world > 1 else 0
         return sl, off, (r["p0"] if r["has_p0"] else None)
@@ -621,8 +641,12 @@ def bench_main(a, rank, local_rank, world):
         sys.stderr.flush()
         os._exit(3)
 
+    # the shards emit what the plan of b3m_compute_bwt emits (samples at b3m_plan_sampling_rate), as the one-GPU line does
+    from . import _lib
+    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(getattr(a, "isasamplingrate", 0), getattr(a, "bwtonly", 0)))
+
     def make(m):
-        return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev)
+        return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate)
 
     def measure(m, steps, warmup):
         wd = threading.Timer(a.blocks_timeout, _bail)
@@ -635,7 +659,8 @@ def bench_main(a, rank, local_rank, world):
             del out
             phases = {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}
             levels = len(job.plan.levels) if m == "blocks" else 0
-            return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job, "checked": checked}
+            return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job, "checked": checked,
+                    "tie_finish_runs": getattr(job, "tie_finish_runs", 0)}
         finally:
             wd.cancel()
 
@@ -658,7 +683,8 @@ def bench_main(a, rank, local_rank, world):
     if rank == 0:
         def summary(r):
             return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
-                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"]}
+                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"],
+                    "tie_finish_runs": r["tie_finish_runs"]}
         dt, steps, fam, levels = res_main["dt"], res_main["steps"], res_main["fam"], res_main["levels"]
         alg_job = nbases * (9.5 + 41.0 * levels)
         if fam:
@@ -680,7 +706,8 @@ def bench_main(a, rank, local_rank, world):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
                        "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes, "checked": res_main["checked"],
-                       "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices in HBM"},
+                       "isasamplingrate": {"plan": plan_rate, "what": "suffix-range shards emit the (rank,pos) samples of the plan b3m_compute_bwt creates (b3m_plan_sampling_rate)"},
+                       "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices (+ samples) in HBM"},
             "roofline": roof,
         }
         print(json.dumps(res), flush=True)

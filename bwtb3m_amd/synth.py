@@ -110,3 +110,53 @@ def config_input_device(name, size=None, device="cuda"):
         z = _splitmix64_torch(seed, (n + 7) // 8, 0, device)
         return itype, z.view(torch.uint8).view(-1, 8).flip(1).reshape(-1)[:n].contiguous(), n
     return itype, pac_file_bytes_torch(n, seed, device), n + (1 if itype == "pacterm" else 0)
+
+
+def genome_like_device(nb, seed=7, device="cuda"):
+    """nb bases with the repeat structure of a genome, on the device (the recipe of tools/repeat_test.py, vectorised): uniform background;
+    a 300-bp element at 10 % divergence over ~10 % of the text; a 6-kb element at 3 % over ~5 %; six 200-kb segmental duplications at
+    0.1 %; microsatellites (unit 1-6, 20-200 copies) every 100 kb; one satellite array of 171 bp x 3000 at 1 %.  Returns the .pac image
+    (uint8 tensor, padded) for inputtype pac / pacterm.  NOT the timed metric (BASELINE: uniform); reported beside it."""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    b = torch.empty(nb, dtype=torch.uint8, device=device)
+    for o in range(0, nb, 1 << 28):
+        m_ = min(1 << 28, nb - o)
+        b[o:o + m_] = torch.randint(0, 4, (m_,), device=device, dtype=torch.uint8, generator=g)
+
+    def plant(unit, copies, rate):
+        ln = unit.numel()
+        for c0 in range(0, copies, 1 << 16):
+            c = min(1 << 16, copies - c0)
+            p = torch.randint(0, nb - ln, (c,), device=device, generator=g)
+            seg = unit.repeat(c, 1)
+            mut = torch.rand((c, ln), device=device, generator=g) < rate
+            seg = torch.where(mut, (seg + torch.randint(1, 4, (c, ln), device=device, dtype=torch.uint8, generator=g)) & 3, seg)
+            b[(p[:, None] + torch.arange(ln, device=device)[None, :]).reshape(-1)] = seg.reshape(-1)
+
+    plant(torch.randint(0, 4, (300,), device=device, dtype=torch.uint8, generator=g), nb // 3000, 0.10)
+    plant(torch.randint(0, 4, (6000,), device=device, dtype=torch.uint8, generator=g), nb // 120000, 0.03)
+    if nb > 400000:
+        plant(torch.randint(0, 4, (200000,), device=device, dtype=torch.uint8, generator=g), 6, 0.001)
+    nms = nb // 100000                                           # microsatellites: unit u, c copies, as a masked (nms, 1200) block
+    if nms:
+        u = torch.randint(1, 7, (nms,), device=device, generator=g)
+        c = torch.randint(20, 200, (nms,), device=device, generator=g)
+        p = torch.randint(0, nb - 1200, (nms,), device=device, generator=g)
+        unit = torch.randint(0, 4, (nms, 6), device=device, dtype=torch.uint8, generator=g)
+        j = torch.arange(1200, device=device)[None, :]
+        val = torch.gather(unit, 1, j % u[:, None])
+        mask = j < (u * c)[:, None]
+        idx = (p[:, None] + j)[mask]
+        b[idx] = val[mask]
+    if nb > 171 * 3000:
+        sat = torch.randint(0, 4, (171,), device=device, dtype=torch.uint8, generator=g).repeat(3000)
+        mut = torch.rand(sat.numel(), device=device, generator=g) < 0.01
+        sat = torch.where(mut, (sat + torch.randint(1, 4, (sat.numel(),), device=device, dtype=torch.uint8, generator=g)) & 3, sat)
+        p = int(torch.randint(0, nb - sat.numel(), (1,), device=device, generator=g))
+        b[p:p + sat.numel()] = sat
+    pad = (-nb) % 4
+    bb = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=device)]).view(-1, 4)
+    pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
+    tail = torch.tensor([0] * (1 if nb % 4 == 0 else 0) + [nb % 4], dtype=torch.uint8, device=device)
+    return torch.cat([pac, tail, torch.zeros(64, dtype=torch.uint8, device=device)])

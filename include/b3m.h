@@ -271,12 +271,20 @@ uint64_t b3m_dist_workspace_bytes(const b3m_dist_plan *p);
 int b3m_dist_set_text(b3m_dist_plan *p, const void *d_text, void *stream);
 int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, uint64_t *hist5_out, void *stream);
 int b3m_dist_rank_of(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, uint64_t *ranks_out, void *stream);
+/* the same, the ranks ADDED to a device array (int64: the chain anchors of a merge are sums over the leaves of its left side, all-reduced
+ * between the GPUs without a detour through host memory) */
+int b3m_dist_rank_of_dev(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, int64_t *d_accum, void *stream);
 int b3m_dist_pack2(b3m_dist_plan *p, const uint8_t *d_bwt, uint64_t m, uint8_t *d_packed, void *stream);   /* 4 symbols per byte */
 int b3m_dist_build_dict(b3m_dist_plan *p, const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0L, void *stream);
 int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const uint64_t *symstart, const uint32_t *d_gt_abs_in, uint32_t *d_gt_abs_out,
-                  const uint64_t *anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
+                  const int64_t *d_anchors, uint64_t chain_first, uint64_t num_chains, uint64_t chain_len,
                   const uint64_t *bounds, int nbounds, uint32_t *d_sorted_out, uint64_t *cuts_out, uint64_t *count_out, void *stream);
-int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t l0, uint64_t l1, int p0_byte, uint8_t *d_out, void *stream);
+/* bytes of BWT(L)[l0, l1) out of the dictionary; L's p0 entry reads the symbol in front of L (position a - 1, circular), taken from the text */
+int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t a, uint64_t l0, uint64_t l1, uint8_t *d_out, void *stream);
+/* gt plumbing of a merge on the device: bit `bit` of d_gt_abs = [d_anchor[0] > p0L] (the end bit of the parent node), and
+ * bits [bit_begin, bit_end) of one absolute-position bit array copied into another (partial edge words merged under a mask) */
+int b3m_dist_endbit(b3m_dist_plan *p, uint32_t *d_gt_abs, uint64_t bit, const int64_t *d_anchor, uint64_t p0L, void *stream);
+int b3m_bits_copy(const uint32_t *d_src_abs, uint32_t *d_dst_abs, uint64_t bit_begin, uint64_t bit_end, void *stream);
 int b3m_dist_sort_u32(b3m_dist_plan *p, const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream);
 int b3m_dist_interleave(b3m_dist_plan *p, const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr, uint8_t *d_out, void *stream);
 

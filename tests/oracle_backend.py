@@ -53,8 +53,16 @@ class OracleBackend:
         h5 = np.bincount(self.sym[a:a + m], minlength=5)[:5]
         return torch.from_numpy(bw), torch.from_numpy(_bits_to_words(absb)), p0, [int(x) for x in h5]
 
-    def rank_of(self, positions):
-        return np.array([O.rank_of(self.sym, self.sa, int(x)) for x in positions], dtype=np.int64)
+    def rank_of_into(self, positions, accum):
+        accum += torch.from_numpy(np.array([O.rank_of(self.sym, self.sa, int(x)) for x in positions], dtype=np.int64))
+
+    def bits_replace(self, dst, seg, seg_w0, b, e):
+        from bwtb3m_amd.distributed import _replace_bits_seg
+        _replace_bits_seg(dst, seg, seg_w0, b, e)
+
+    def set_endbit(self, gt, bit, anchor, p0L):
+        from bwtb3m_amd.distributed import _set_bit
+        _set_bit(gt, bit, 1 if int(anchor[0]) > p0L else 0)
 
     def pack2(self, bwt):
         b = bwt.numpy().astype(np.int64)
@@ -92,18 +100,17 @@ class OracleBackend:
             c = chain_first + i
             k_hi = mr - c * chain_len
             k_lo = max(0, k_hi - chain_len)
-            rk, gtP = O.gap_range(self.sym, a, m, mr, self.bwtL, self.p0L, gtR, self.sigma, k_hi, k_lo, int(anchors[i]))
+            rk, gtP = O.gap_range(self.sym, a, m, mr, self.bwtL, self.p0L, gtR, self.sigma, k_hi, k_lo, int(anchors[i]))      # (anchors: int64 tensor)
             ranks.append(rk)
             out_bits[a + m + k_lo: a + m + k_hi] = gtP[m + k_lo: m + k_hi]
         r = np.sort(np.concatenate(ranks)) if ranks else np.zeros(0, dtype=np.int64)
         cuts = np.searchsorted(r, np.asarray(bounds, dtype=np.int64), side="left").astype(np.int64)
         return torch.from_numpy(r.astype(np.int32)), cuts, torch.from_numpy(_bits_to_words(out_bits))
 
-    def l_bytes(self, l0, l1, p0_byte):
+    def l_bytes(self, a, l0, l1):
         out = self.bwtL[l0:l1].copy()
         if l0 <= self.p0L < l1:
-            assert p0_byte >= 0
-            out[self.p0L - l0] = p0_byte
+            out[self.p0L - l0] = self.sym[(a - 1) % self.n]      # the entry of L's first suffix: the symbol in front of L
         return torch.from_numpy(out)
 
     def sort_u32(self, keys, nbits):

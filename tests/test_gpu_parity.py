@@ -300,11 +300,36 @@ def _dist_worker(rank, world, port, itype, nb, q):
         buf = O.pac_encode(b)
         sym = O.symbols_from_file_bytes(buf, itype)
         job = D.DistributedBwt(len(sym), itype, D.HipBackend(dev), dev)
-        out, off, p0 = job.run(torch.from_numpy(buf).to(dev))
+        d_text = torch.from_numpy(buf).to(dev)
+        # which functions of the driver take device data to the host while a run is on: only the transport helpers (gloo stages device
+        # tensors through host memory in this one-GPU rehearsal; RCCL does not), the split sizes of the collectives, and the new p0 after
+        # a merge's interleave -- NOT _merge itself (anchors, gt bits and the p0 symbol used to make round trips there)
+        import inspect
+        callers = set()
+
+        def spy(name):
+            orig = getattr(torch.Tensor, name)
+
+            def f(self, *a, **k):
+                if self.is_cuda:
+                    for fr in inspect.stack()[1:8]:
+                        if fr.filename.endswith("distributed.py"):
+                            callers.add(fr.function); break
+                return orig(self, *a, **k)
+            setattr(torch.Tensor, name, f)
+            return orig
+        saved = {nm: spy(nm) for nm in ("cpu", "item", "tolist", "numpy")}
+        out, off, p0 = job.run(d_text)
+        for nm, orig in saved.items():
+            setattr(torch.Tensor, nm, orig)
+        allowed = {"_all_gather_i64", "_all_to_all_v", "__init__", "result", "_broadcast", "_all_reduce_sum", "_p0_after_merge"}
         full = D.gather_result(out).cpu().numpy()
         ok = bool(np.array_equal(full, O.bwt(sym)))
         if itype == "pacterm":
             ok = ok and full[p0] == 0
+        if callers - allowed:
+            ok = False
+            print("device -> host transfers from unexpected places:", callers - allowed, flush=True)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
