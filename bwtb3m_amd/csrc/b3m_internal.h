@@ -133,7 +133,10 @@ struct MsdWs {
 	uint32_t *biglist = nullptr; uint64_t big_cap = 0;       // [0] = count, then ids of final buckets above the LDS capacity
 	uint32_t *hugelist = nullptr; uint64_t huge_cap = 0;     // [0] = count, then ids of final buckets above F_HUGE records
 	uint32_t *midlist = nullptr; uint64_t mid_cap = 0;       // [0] = count, then ids of final buckets for the 1024-thread finish: 1x..2x the LDS capacity, or listed by the gathering finishes
-	void *lists = nullptr;                                   // two FinishLists structs (device): what the finish kernels read when they must list a bucket
+	void *lists = nullptr;                                   // four FinishLists structs (device): what the finish kernels read when they must list a bucket (level 1: two, level 2: two)
+	// level 2 (buckets above twice the finish's capacity get one more 8-bit partition, in parallel tiles, through the level-1 kernels):
+	uint32_t *mid2 = nullptr, *big2 = nullptr, *huge2 = nullptr; uint64_t list2_cap = 0;      // its own bucket lists
+	uint32_t *lvl2 = nullptr; uint64_t lvl2_buckets = 0;     // starts[256 nb], ends[256 nb], bucket table[3 nb] for up to lvl2_buckets listed buckets
 	uint32_t *runpre = nullptr;                              // the same rows as start | records before the run << 14 (for the gathering finish)
 	uint32_t *runtab = nullptr; uint64_t runtab_cap = 0;     // level-1 run table: row (level-0 bucket, digit), column = chunk: start | length << 16
 	uint32_t *scan_ws = nullptr;

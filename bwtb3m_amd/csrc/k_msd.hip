@@ -57,7 +57,11 @@ constexpr int W0_MAXBITS = 12;
 constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
 // finish
 constexpr int F_CAP = 6144;                            // records of a final bucket sorted in LDS
-constexpr uint32_t F_HUGE = 1u << 20;                      // buckets above this go to the list-based rounds directly
+constexpr uint32_t F_HUGE = 1u << 20;                      // buckets above this go to the list-based rounds directly where one workgroup would have to partition them (k_bucket_finish) ...
+constexpr uint32_t F_HUGE2 = 1u << 26;                     // ... and above this where level 2 partitions them in parallel tiles
+constexpr uint32_t LVL2_MIN = 32768;                       // listed buckets above this many records take level 2 (256 sub-buckets for the gathering finish); smaller ones one workgroup
+                                                           // each (k_bucket_finish: sub-buckets for its wave sort, up to 512 records; on skewed text the heaviest sub-bucket is ~6x the
+                                                           // average).  1 Gbase at 80 % A+T: 98304 -> 97.6 ms, 49152 -> 81.3, 24576 -> 79.4; 65 % A+T: 24.0 ms with all three
 constexpr int F_AVG = 5760;                            // target average bucket size
 constexpr int F_BINBITS = 13;
 constexpr int F_BINS = 1 << F_BINBITS;                 // counting-sort bins of the finish (16-bit counters)
@@ -113,6 +117,9 @@ static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap,
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
 static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 33 + 4096; }                   // (start, size) pairs: every listed bin holds > 32 records
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
+static uint64_t msd_lvl2_buckets(uint64_t cap) { return cap / LVL2_MIN + 16; }           // listed buckets level 2 takes (each above LVL2_MIN records)
+static uint64_t msd_list2_cap(uint64_t cap) { return msd_lvl2_buckets(cap) * MSD_MAXBINS; }   // every sub-bucket of level 2 may be listed again (k_finish_fast lists sparse buckets too), each at most once
+static uint64_t msd_lvl2_words(uint64_t cap) { return msd_lvl2_buckets(cap) * (2ull * MSD_MAXBINS + 3) + 16; }
 // entries of the chunk-local level 0's run table: 2048 rows x (whole tiles of 4 chunks of 65,280 positions); 0 = no such path (small blocks, 2^32 and more)
 static uint64_t msd_local0_cap(uint64_t cap)
 {
@@ -128,6 +135,7 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	uint64_t hist = msd_hist_cap(cap, span);
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
 	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (MSD_TAB_MAX + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096
+	     + 2 * al(4 * (msd_list2_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * msd_lvl2_words(cap))
 	     + (msd_local0_cap(cap) ? 2 * al(4 * msd_local0_cap(cap)) + al(4 * (cap / L1_CHUNK + 2 * MSD_L0_MAX)) + al(32 * msd_tiles_cap(cap)) + al(4 * MSD_L0_MAX) : 0);
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
@@ -147,6 +155,11 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.runtab = (uint32_t *)p; ws.runtab_cap = msd_runtab_cap(cap); p += al(4 * ws.runtab_cap);
 	ws.runpre = (uint32_t *)p; p += al(4 * ws.runtab_cap);
 	ws.lists = p; p += 256;
+	ws.list2_cap = msd_list2_cap(cap);
+	ws.mid2 = (uint32_t *)p; p += al(4 * (ws.list2_cap + 2));
+	ws.big2 = (uint32_t *)p; p += al(4 * (ws.list2_cap + 2));
+	ws.huge2 = (uint32_t *)p; p += al(4 * (cap / F_HUGE + 18));
+	ws.lvl2 = (uint32_t *)p; ws.lvl2_buckets = msd_lvl2_buckets(cap); p += al(4 * msd_lvl2_words(cap));
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(hist));
 	// chunk-local level 0 (whole blocks below 2^32): its run table and the rows' prefixes, level 1's gather tiles
 	ws.tab0 = nullptr; ws.pre0 = nullptr; ws.tab0_cap = 0;
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 // (prefix = records of the row's earlier runs, clamped: rows of buckets above the finish's capacity are never read
 // in that form).  Then the 2^D sizes are scanned.  btab = {start[nb], tab_off[nb], nch[nb]}.
 constexpr uint32_t RUN_PRE_MAX = (1u << 18) - 1;
-__global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, uint32_t *runpre, const uint32_t *btab, uint32_t nb, int D, uint32_t len, uint32_t *lvl_start)
+__global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, uint32_t *runpre, const uint32_t *btab, uint32_t nb, int D, uint32_t len, uint32_t *lvl_start, uint32_t *lvl_end = nullptr)
 {
 	__shared__ uint32_t sz[MSD_MAXBINS];
 	__shared__ uint32_t wsum[4];
@@ -685,7 +698,8 @@ __global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, uint
 	uint32_t pre0 = 0;
 	for (uint32_t i = 0; i < wave; ++i) pre0 += wsum[i];
 	if (tid < bins) lvl_start[((uint64_t)b << D) + tid] = btab[b] + pre0 + inc - v;
-	if (b == nb - 1 && tid == 0) lvl_start[(uint64_t)nb << D] = len;
+	if (lvl_end && tid < bins) lvl_end[((uint64_t)b << D) + tid] = btab[b] + pre0 + inc;         // (level 2: the buckets of this launch are not neighbours in rank order)
+	if (b == nb - 1 && tid == 0 && !lvl_end) lvl_start[(uint64_t)nb << D] = len;
 }
 
 // totals[d] = number of records with level-0 digit d (sum of row d of the [digit][tile] counts)
@@ -899,13 +913,15 @@ constexpr int G_NCH = 512;               // runs (chunks of the level-0 bucket) 
 struct FinishSrc {
 	const uint64_t *rec;
 	const uint32_t *bstart;      // starts of the final buckets in the OUTPUT (rank) order, nbF + 1 entries
+	const uint32_t *bend;        // null: bucket b ends where b + 1 starts; else its end (level 2: the sub-buckets of listed buckets, which are not neighbours in rank order)
 	const uint32_t *runtab;      // GATHER: run table of level 1 (start | length << 16), read by the compaction kernel
 	const uint32_t *runpre;      // GATHER: the same rows as start | records before the run << 14 (k_run_totals)
 	const uint32_t *btab;        // GATHER: {start[nb0], tab_off[nb0], nch[nb0]} of the level-0 buckets
 	uint32_t nb0; int D1; uint32_t chunk;
 	uint32_t nbF, nrec;          // number of final buckets and of records (bounds of every bucket id / record range: checked in the debug build)
 };
-struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; };
+__device__ __forceinline__ uint32_t bucket_end(const FinishSrc &S, uint32_t b) { return S.bend ? S.bend[b] : S.bstart[b + 1]; }
+struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; uint32_t huge_min; };
 
 // what a gathering finish needs to know of a bucket before it starts: fetched one bucket AHEAD by k_finish_rows, so that
 // the only global-memory round trip a bucket waits for is that of its records
@@ -939,7 +955,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 		if (tid == 0) {
 			const FinishLists L = *Lp;                          // cold: the lists live in device memory, not in the kernel's registers
 			if (L.midlist && m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
-			else if (m > F_HUGE) {        // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
+			else if (m > L.huge_min) {    // one workgroup would take too long: the whole bucket goes to the overflow list (k_huge_spill)
 				uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b;
 				ovf_push(O, s0, m);
 			} else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
@@ -1158,7 +1174,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbit
 	if (!todo) {
 		const uint32_t b = b_first + blockIdx.x;
 		GLB_CHK(b < S.nbF);
-		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
 		GLB_CHK(s0 <= S.nrec && m <= S.nrec - s0);
 		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O); return;
 	}
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_lds(FinishSrc S, int fbit
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
 		const uint32_t b = todo[1 + it];
 		GLB_CHK(b < S.nbF);
-		const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+		const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
 		GLB_CHK(s0 <= S.nrec && m <= S.nrec - s0);
 		finish_bucket<WRITE_SA, THREADS, false>(b, s0, m, RB, RA, S, fbits, L, O);
 		__syncthreads();
@@ -1186,7 +1202,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_finish_rows(FinishSrc S, int fbi
 	const uint32_t b0 = b >> S.D1;
 	const RowBucket RB{S.btab[2 * S.nb0 + b0], S.btab[S.nb0 + b0], S.btab[b0]};
 	GLB_CHK(b < S.nbF && b0 < S.nb0);
-	const uint32_t s0 = S.bstart[b], s1 = S.bstart[b + 1];
+	const uint32_t s0 = S.bstart[b], s1 = bucket_end(S, b);
 	GLB_CHK(s0 <= s1 && s1 <= S.nrec);
 	if (s1 == s0) return;                                      // empty (a suffix-range shard keeps a digit range; nch may be 0)
 	const uint32_t tc = tid < RB.nch ? tid : RB.nch - 1, tn = tc + 1 < RB.nch ? tc + 1 : tc;
@@ -1225,14 +1241,14 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
-	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+	const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
 	GLB_CHK(b < S.nbF && b0 < S.nb0 && s0 <= S.nrec && m <= S.nrec - s0);
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP || nch > (uint32_t)G_NCH) {
 		if (tid == 0) {
 			const FinishLists L = *Lp;
 			if (m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
-			else if (m > F_HUGE) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
+			else if (m > L.huge_min) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
 			else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
 		}
 		return;
@@ -1474,14 +1490,14 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
-	const uint32_t s0 = S.bstart[b], m = S.bstart[b + 1] - s0;
+	const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
 	GLB_CHK(b < S.nbF && b0 < S.nb0 && s0 <= S.nrec && m <= S.nrec - s0);
 	if (m == 0) return;
 	if (m > (uint32_t)F_CAP || nch > (uint32_t)V3_NCH) {
 		if (tid == 0) {
 			const FinishLists L = *Lp;
 			if (m <= 2u * F_CAP) { uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
-			else if (m > F_HUGE) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
+			else if (m > L.huge_min) { uint32_t k = atomicAdd(&L.hugelist[0], 1u); if (k < L.huge_cap) L.hugelist[1 + k] = b; ovf_push(O, s0, m); }
 			else { uint32_t k = atomicAdd(&L.biglist[0], 1u); if (k < L.big_cap) L.biglist[1 + k] = b; }
 		}
 		return;
@@ -1832,11 +1848,22 @@ __global__ __launch_bounds__(256) void k_compact_listed(FinishSrc S, uint64_t *o
 
 // HUGE BUCKETS (low-complexity input): every workgroup copies its share of the positions into the suffix array;
 // the bucket is already on the overflow list
-__global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *hugelist, uint32_t huge_cap, SaOut sa, int pb)
+__global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const uint32_t *bstart, const uint32_t *bend, const uint32_t *hugelist, uint32_t huge_cap, SaOut sa, int pb)
 {
 	uint32_t nh = hugelist[0]; if (nh > huge_cap) nh = huge_cap;
 	for (uint32_t h = 0; h < nh; ++h) {
-		const uint32_t b = hugelist[1 + h], s0 = bstart[b], m = bstart[b + 1] - s0;
+		const uint32_t b = hugelist[1 + h], s0 = bstart[b], m = (bend ? bend[b] : bstart[b + 1]) - s0;
+		for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) sa_set(sa, (uint64_t)s0 + e, rec[s0 + e] & ((1ull << pb) - 1));
+	}
+}
+
+// listed buckets with no key bits left for another partition: the whole bucket to the overflow list, its positions to the suffix array
+__global__ __launch_bounds__(256) void k_list_to_overflow(const uint64_t *rec, const uint32_t *bstart, const uint32_t *bend, const uint32_t *list, uint32_t cap, SaOut sa, int pb, SortOut O)
+{
+	uint32_t nl = list[0]; if (nl > cap) nl = cap;
+	for (uint32_t h = 0; h < nl; ++h) {
+		const uint32_t b = list[1 + h], s0 = bstart[b], m = (bend ? bend[b] : bstart[b + 1]) - s0;
+		if (blockIdx.x == 0 && threadIdx.x == 0) ovf_push(O, s0, m);
 		for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (uint64_t)gridDim.x * 256) sa_set(sa, (uint64_t)s0 + e, rec[s0 + e] & ((1ull << pb) - 1));
 	}
 }
@@ -1845,7 +1872,7 @@ __global__ __launch_bounds__(256) void k_huge_spill(const uint64_t *rec, const u
 // 8 bits, scatters it into its own range of the other record buffer (chunks of 4096 through LDS,
 // as k_msd_pass), and its four waves then sort the 256 sub-buckets one after the other.
 template <bool WRITE_SA>
-__device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart,
+__device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *bend,
                                            int D, int shift, int sortbits, const SortOut &O)
 {
 	constexpr int CH = MSD_THREADS * MSD_ITEMS;                 // 4096
@@ -1856,7 +1883,7 @@ __device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec
 	__shared__ uint32_t wsum[8];
 	__shared__ __attribute__((aligned(16))) uint64_t big[CH];     // scatter staging, later the waves' sort buffers (32 KB)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t s0 = bstart[b], s1 = bstart[b + 1], m = s1 - s0;
+	const uint32_t s0 = bstart[b], s1 = bend ? bend[b] : bstart[b + 1], m = s1 - s0;
 	const uint32_t bins = 1u << D, dmask = bins - 1;
 	// ---- pass 1: histogram of the next digit over the bucket ----
 	cnt[tid] = 0;
@@ -1936,12 +1963,12 @@ __device__ __forceinline__ void big_bucket(const uint32_t b, const uint64_t *rec
 }
 
 template <bool WRITE_SA>
-__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *biglist, uint32_t big_cap,
+__global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *rec_in, uint64_t *rec_tmp, const uint32_t *bstart, const uint32_t *bend, const uint32_t *biglist, uint32_t big_cap,
                                                                  int D, int shift, int sortbits, SortOut O)
 {
 	uint32_t cnt = biglist[0]; cnt = cnt < big_cap ? cnt : big_cap;          // (what the list holds, not what was asked for)
 	for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {        // a fixed grid strides over the list
-		big_bucket<WRITE_SA>(biglist[1 + it], rec_in, rec_tmp, bstart, D, shift, sortbits, O);
+		big_bucket<WRITE_SA>(biglist[1 + it], rec_in, rec_tmp, bstart, bend, D, shift, sortbits, O);
 		__syncthreads();
 	}
 }
@@ -2230,7 +2257,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const uint64_t *cur = ws.keyA; uint64_t *other = ws.keyB;
 	uint32_t nbF = bins0;               // final buckets
 	const int consumed = dg.D1;         // key-field bits used by level 1
-	bool sliced = false;
+	bool sliced = false, lvl2_ran = false;
 	FinishSrc FS{};                     // where the finish finds the records of a final bucket
 	FS.bstart = M.lvl_start;
 	bool gather = false;
@@ -2340,8 +2367,10 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
 		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
-		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap},
-		                           {nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap}};
+		// (buckets up to F_HUGE2 records go through level 2 where there is one: tiles in parallel; without it one workgroup partitions a listed bucket: F_HUGE)
+		const uint32_t huge_min = (gather && !getenv("B3M_NO_LEVEL2")) ? F_HUGE2 : F_HUGE;
+		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, huge_min},
+		                           {nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, huge_min}};
 		FinishLists *dl = reinterpret_cast<FinishLists *>(M.lists);       // [0]: first launch (lists mid / big / huge), [1]: the mid launch
 		B3M_HIP(hipMemcpyAsync(dl, hl, sizeof hl, hipMemcpyHostToDevice, s));
 		B3M_HIP(hipStreamSynchronize(s));                                 // hl lives on this stack frame
@@ -2357,12 +2386,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_HIP(hipStreamSynchronize(s));
 			for (uint32_t i = 0; i <= nsl; ++i) lvl0[i] = hs[(uint64_t)bins0 * i / nsl];
 		}
+		const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
 		for (uint32_t sl = 0; sl < nsl; ++sl) {
 			const uint32_t l0a = (uint32_t)((uint64_t)bins0 * sl / nsl), l0b = (uint32_t)((uint64_t)bins0 * (sl + 1) / nsl);
 			const uint32_t bfa = nsl > 1 ? l0a << dg.D1 : 0u, bfb = nsl > 1 ? l0b << dg.D1 : nbF;
 			const uint64_t ra = nsl > 1 ? lvl0[sl] : 0, rb = nsl > 1 ? lvl0[sl + 1] : len;
 			if (bfb == bfa) continue;
-			const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
 			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
 				// sorts that keep no suffix array take k_finish_v3 (32-bit positions; sampling off or sparse enough for its list of special records).
 				// B3M_FINISH_V3 (measurement switch): 0 = k_finish_fast<false> instead, 2 = k_finish_v3 held at two workgroups per CU
@@ -2385,24 +2414,123 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			}
 		}
 		stage("first finish launch");
+		uint32_t lc1[3] = {0, 0, 0};                                      // buckets the first launch listed: mid, big, huge
 		if (gather) {
 			// what the gathering finish could not take is copied together into the buffer level 1 has read; the paths below read it there.
 			// A fixed grid strides over the lists: empty lists (uniform input) cost a launch and nothing else.
 			hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, FS, ws.keyA, M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap);
 			FS.rec = ws.keyA; cur = ws.keyA; other = ws.keyB;
 			stage("compact listed");
+			B3M_HIP(hipMemcpyAsync(&lc1[0], M.midlist, 4, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipMemcpyAsync(&lc1[1], M.biglist, 4, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipMemcpyAsync(&lc1[2], M.hugelist, 4, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
 		}
+		if (!gather || lc1[0]) {
 		if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, (uint32_t)M.mid_cap, dl + 1, O);
 		else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid), dim3(1024), 0, s, FS, fbits, 0u, (const uint32_t *)M.midlist, (uint32_t)M.mid_cap, dl + 1, O);
 		stage("mid finish");
+		}
 		// buckets above the LDS capacity (none on uniform input): one more 8-bit partition through HBM.
-		// Fixed grids stride over the lists: an empty list costs a launch and nothing else.
-		if (len > F_HUGE) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, M.lvl_start, M.hugelist, (uint32_t)M.huge_cap, sa, pb);
+		if (len > huge_min && (!gather || lc1[2])) hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, cur, (const uint32_t *)M.lvl_start, (const uint32_t *)nullptr, M.hugelist, (uint32_t)M.huge_cap, sa, pb);
+		// LEVEL 2 (skewed base composition, low-complexity text): the listed buckets above twice the finish's capacity are to level 1's kernels what
+		// the level-0 buckets were: tiles of 16 Ki records of ONE bucket sorted by their next 8 bits in LDS (k_l1_local: a stream copy from where
+		// k_compact_listed put them), a run table, and the gathering finish on 256 sub-buckets per bucket -- every tile and every sub-bucket a
+		// workgroup of its own.  (Before: one workgroup per listed bucket partitioned it alone, chunk by chunk, and sub-buckets above 512 records
+		// went to the list-based rounds: 80 % A+T cost 10x the uniform text.)  What is still too large after it takes the old paths.
+		bool lvl2_done = false; (void)lvl2_done;
+		const int no_lvl2 = getenv("B3M_NO_LEVEL2") ? atoi(getenv("B3M_NO_LEVEL2")) : 0;      // measurement switch
+		uint32_t nbig1 = lc1[1];                                          // listed buckets left to k_bucket_finish
+		if (gather && lc1[1] && !no_lvl2 && fbits > 8 && lc1[1] <= M.big_cap) {
+			std::vector<uint32_t> all(lc1[1]), ids, small, ls((size_t)nbF + 1);
+			B3M_HIP(hipMemcpyAsync(all.data(), M.biglist + 1, 4ull * lc1[1], hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipMemcpyAsync(ls.data(), M.lvl_start, 4ull * (nbF + 1), hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			const uint32_t lvl2_min = getenv("B3M_LVL2_MIN") ? (uint32_t)atoi(getenv("B3M_LVL2_MIN")) : LVL2_MIN;      // test switch: small inputs through level 2
+			for (uint32_t b : all) (ls[b + 1] - ls[b] > lvl2_min ? ids : small).push_back(b);
+			const uint32_t nb2 = (uint32_t)ids.size();
+			std::vector<MsdTile> tiles2;
+			std::vector<uint32_t> tab2(3ull * nb2);
+			uint64_t toff = 0;
+			const uint32_t TILE = (uint32_t)L1_CHUNK * L1_TCH;
+			for (uint32_t i = 0; i < nb2; ++i) {
+				const uint32_t b = ids[i], st = ls[b], sz = ls[b + 1] - st, nch = (sz + L1_CHUNK - 1) / L1_CHUNK;
+				tab2[i] = st; tab2[nb2 + i] = (uint32_t)toff; tab2[2ull * nb2 + i] = nch;
+				for (uint32_t j = 0; j * TILE < sz; ++j) {
+					MsdTile t; t.in_off = st + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
+					t.hist_base = (uint32_t)(toff + (uint64_t)j * L1_TCH); t.stride = nch;
+					tiles2.push_back(t);
+				}
+				toff += (uint64_t)MSD_MAXBINS * nch;
+			}
+			if (nb2 && nb2 <= M.lvl2_buckets && toff <= M.runtab_cap && tiles2.size() <= M.tiles_cap && toff < (1ull << 32)) {
+				// the listed buckets below LVL2_MIN stay on the list of k_bucket_finish
+				nbig1 = (uint32_t)small.size();
+				B3M_HIP(hipMemcpyAsync(M.biglist, &nbig1, 4, hipMemcpyHostToDevice, s));
+				if (nbig1) B3M_HIP(hipMemcpyAsync(M.biglist + 1, small.data(), 4ull * nbig1, hipMemcpyHostToDevice, s));
+				uint32_t *d_st2 = M.lvl2, *d_en2 = M.lvl2 + (uint64_t)nb2 * MSD_MAXBINS, *d_tab2 = M.lvl2 + 2ull * nb2 * MSD_MAXBINS;
+				const uint32_t nbF2 = nb2 * (uint32_t)MSD_MAXBINS;
+				const FinishLists hl2[2] = {{M.mid2, (uint32_t)M.list2_cap, M.big2, (uint32_t)M.list2_cap, M.huge2, (uint32_t)M.huge_cap, F_HUGE},
+				                            {nullptr, 0u, M.big2, (uint32_t)M.list2_cap, M.huge2, (uint32_t)M.huge_cap, F_HUGE}};
+				B3M_HIP(hipMemcpyAsync(dl + 2, hl2, sizeof hl2, hipMemcpyHostToDevice, s));
+				B3M_HIP(hipMemcpyAsync(M.tiles, tiles2.data(), sizeof(MsdTile) * tiles2.size(), hipMemcpyHostToDevice, s));
+				B3M_HIP(hipMemcpyAsync(d_tab2, tab2.data(), 4 * tab2.size(), hipMemcpyHostToDevice, s));
+				B3M_HIP(hipMemsetAsync(M.mid2, 0, 4, s)); B3M_HIP(hipMemsetAsync(M.big2, 0, 4, s)); B3M_HIP(hipMemsetAsync(M.huge2, 0, 4, s));
+				B3M_HIP(hipStreamSynchronize(s));                         // host vectors must outlive the copies
+				L1Args Bq{};
+				Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = MSD_MAXBITS; Bq.shift = 64 - consumed - MSD_MAXBITS;
+				hipLaunchKernelGGL((k_l1_local<L1_THREADS, L1_TCH>), dim3((uint32_t)tiles2.size()), dim3(L1_THREADS), 0, s, Bq);
+				hipLaunchKernelGGL(k_run_totals, dim3(nb2), dim3(256), 0, s, M.runtab, M.runpre, d_tab2, nb2, MSD_MAXBITS, (uint32_t)len, d_st2, d_en2);
+				stage("level 2: partition");
+				FinishSrc F2{};
+				F2.rec = ws.keyB; F2.bstart = d_st2; F2.bend = d_en2; F2.runtab = M.runtab; F2.runpre = M.runpre; F2.btab = d_tab2; F2.nb0 = nb2; F2.D1 = MSD_MAXBITS;
+				F2.chunk = (uint32_t)L1_CHUNK; F2.nbF = nbF2; F2.nrec = (uint32_t)len;
+				const int fbits2 = fbits - MSD_MAXBITS;
+				if (!no_fast && fbits2 >= F_BINBITS && fbits2 - F_BINBITS <= 12) {
+					int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;
+					if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
+					if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
+					else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
+					else hipLaunchKernelGGL((k_finish_fast<false>), dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
+				} else {
+					if (need_sa) hipLaunchKernelGGL((k_finish_rows<true, 512>), dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
+					else hipLaunchKernelGGL((k_finish_rows<false, 512>), dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
+				}
+				// what level 2 could not take either: copied together (into the buffer it has read), then the 1024-thread finish, one more
+				// partition by one workgroup per bucket, or the overflow list
+				hipLaunchKernelGGL(k_compact_listed, dim3(2048), dim3(256), 0, s, F2, ws.keyA, M.mid2, (uint32_t)M.list2_cap, M.big2, (uint32_t)M.list2_cap, M.huge2, (uint32_t)M.huge_cap);
+				F2.rec = ws.keyA;
+				const uint32_t gmid2 = (uint32_t)std::min<uint64_t>(nbF2, 1024);
+				if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid2), dim3(1024), 0, s, F2, fbits2, 0u, (const uint32_t *)M.mid2, (uint32_t)M.list2_cap, dl + 3, O);
+				else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid2), dim3(1024), 0, s, F2, fbits2, 0u, (const uint32_t *)M.mid2, (uint32_t)M.list2_cap, dl + 3, O);
+				hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, (const uint64_t *)ws.keyA, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.huge2, (uint32_t)M.huge_cap, sa, pb);
+				const uint32_t gbig2 = (uint32_t)std::min<uint64_t>(nbF2, 2048);
+				if (fbits2 > 8) {
+					if (need_sa)
+						hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - 16, fbits2 - 8, O);
+					else
+						hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - 16, fbits2 - 8, O);
+				} else {
+					hipLaunchKernelGGL(k_list_to_overflow, dim3(64), dim3(256), 0, s, (const uint64_t *)ws.keyA, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, sa, pb, O);
+				}
+				stage("level 2: finish");
+				lvl2_done = true; lvl2_ran = true;
+				if (getenv("B3M_DEBUG")) {
+					uint32_t l2[3] = {0, 0, 0};
+					B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
+					B3M_HIP(hipStreamSynchronize(s));
+					fprintf(stderr, "[b3m] level 2: %u buckets, %zu tiles, fbits %d; listed again: mid %u big %u huge %u\n", nb2, tiles2.size(), fbits2, l2[0], l2[1], l2[2]);
+				}
+			}
+		}
+		if (!gather || nbig1) {
+		// one workgroup per listed bucket: the listed buckets up to LVL2_MIN records (and all of them where there is no level 2: small blocks without a level 1)
 		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 2048);
 		if (need_sa)
-			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
+			hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, (const uint32_t *)M.lvl_start, (const uint32_t *)nullptr, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
 		else
-			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, M.lvl_start, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
+			hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig), dim3(MSD_THREADS), 0, s, cur, other, (const uint32_t *)M.lvl_start, (const uint32_t *)nullptr, M.biglist, (uint32_t)M.big_cap, 8, 64 - consumed - 8, fbits - 8, O);
+		}
 		stage("big / huge finish");
 		sliced = nsl > 1;
 	}
@@ -2440,6 +2568,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	                                 (unsigned long long)len, D0e, dg.D1, nlist[0], nlist[1], nlist[2], (unsigned long long)M.mid_cap, (unsigned long long)M.big_cap, (unsigned long long)M.huge_cap, nov);
 	// a list that ran over would have dropped buckets silently
 	B3M_REQUIRE(nlist[0] <= M.mid_cap && nlist[1] <= M.big_cap && nlist[2] <= M.huge_cap, "internal: a bucket list of the MSD finish ran over");
+	if (lvl2_ran) {
+		uint32_t l2[3] = {0, 0, 0};
+		B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		B3M_REQUIRE(l2[0] <= M.list2_cap && l2[1] <= M.list2_cap && l2[2] <= M.huge_cap, "internal: a bucket list of level 2 ran over");
+	}
 	out.msd_overflow_buckets = nov;
 	if (nov) out.late_writes = true;
 	bool rerun_with_sa = false;

@@ -19,7 +19,7 @@ def _set_env(**kv):
 
 
 def clear_switches():
-    _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None)
+    _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None)
 
 
 def case_small(rng, O, engine):
@@ -47,7 +47,8 @@ def case_small(rng, O, engine):
     if rng.integers(0, 2) and n > 20:              # blocks of a merge tree (2-bit and byte alphabets)
         bs = int(rng.integers(max(8, n // 9), n))
     d1 = int([0, 0, 0, 2, 4, 5, 6, 8][int(rng.integers(0, 8))])
-    _set_env(B3M_MSD_D1=d1 or None, B3M_L0_LOCAL=[None, None, 0][int(rng.integers(0, 3))], B3M_NO_FAST_FINISH=[None, None, 1][int(rng.integers(0, 3))])
+    _set_env(B3M_MSD_D1=d1 or None, B3M_L0_LOCAL=[None, None, 0][int(rng.integers(0, 3))], B3M_NO_FAST_FINISH=[None, None, 1][int(rng.integers(0, 3))],
+             B3M_LVL2_MIN=[None, 0, 0][int(rng.integers(0, 3))], B3M_FINISH_V3=[None, None, 0][int(rng.integers(0, 3))])     # level 2 on small inputs; k_finish_fast instead of v3
     isar = int([0, 64, 4096, 1000, 7][int(rng.integers(0, 5))])
     keep = bool(rng.integers(0, 4) == 0)
     desc = "small type=%s nb=%d kind=%d bs=%d isar=%d keep_sa=%d d1=%d" % (itype, nb, kind, bs, isar, keep, d1)
@@ -167,8 +168,9 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
     d_text = pac_image(torch, b)
     n = nb + (1 if itype == "pacterm" else 0)
     form = int(rng.integers(0, 5))
-    alt = int(rng.integers(0, 4))                     # alternative paths of the block sort on a quarter of the cases each
-    _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None)
+    alt = int(rng.integers(0, 6))                     # alternative paths of the block sort on a sixth of the cases each
+    _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None,
+             B3M_LVL2_MIN=0 if alt == 4 else None, B3M_NO_LEVEL2=1 if alt == 5 else None)
     rate = int([1 << 16, 1024, 3000][int(rng.integers(0, 3))])
     desc = "large n=%d %s comp=%d form=%d alt=%d rate=%d planted=%s" % (n, itype, comp, form, alt, rate, planted)
     ok = True

@@ -369,6 +369,7 @@ def test_msd_block_sort_paths(gpu, oracle, itype, kind, d1, monkeypatch):
     listed-bucket, hot-bin and tie paths.  (At their natural size those kernels are only reached by inputs the oracle cannot sort.)"""
     if d1:
         monkeypatch.setenv("B3M_MSD_D1", str(d1))
+        monkeypatch.setenv("B3M_LVL2_MIN", "0")      # every bucket above twice the finish's capacity through level 2 (at its natural threshold: buckets above 98,304 records)
     nb = (1 << 19) + 12345
     if kind == "uniform":
         b = oracle.synth_bases(nb, 31)

@@ -1,7 +1,10 @@
+"""Base-composition skew (uniform, human-like 59 % A+T, 65 %, 80 %) at 1 Gbase: time, listed suffixes, LF check.
+python tools/skew_test.py [n] [which: comma list of 0..3]"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from bwtb3m_amd import engine
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
+which = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3]
 def run(name, p):
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     u = torch.rand(N, device="cuda", generator=g)
@@ -23,7 +26,7 @@ def run(name, p):
     print("%-22s n=%d  %.1f ms  rounds %d listed %d  LF %d %d" % (name, n, dt * 1e3, r["tie_rounds"], r["tie_elements"], m0, m1), flush=True)
     print("   ", {k["name"]: round(k["ms"], 1) for k in plan.kernel_times() if k["ms"] > 0.3}, flush=True)
     plan.close()
-run("uniform", [0.25, 0.25, 0.25, 0.25])
-run("AT 59 % (human)", [0.295, 0.205, 0.205, 0.295])
-run("AT 65 %", [0.325, 0.175, 0.175, 0.325])
-run("AT 80 % (P. falciparum)", [0.40, 0.10, 0.10, 0.40])
+cases = [("uniform", [0.25, 0.25, 0.25, 0.25]), ("AT 59 % (human)", [0.295, 0.205, 0.205, 0.295]), ("AT 65 %", [0.325, 0.175, 0.175, 0.325]),
+         ("AT 80 % (P. falciparum)", [0.40, 0.10, 0.10, 0.40])]
+for i in which:
+    run(*cases[i])
