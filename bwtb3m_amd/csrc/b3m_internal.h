@@ -162,6 +162,9 @@ struct BlockSortWs {
 	uint8_t *sa_hi = nullptr;                    // texts of 2^32 symbols and more: bits 32.. of the suffix array entries (MSD path)
 	uint32_t *t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // tie-list buffers (cap+1 each); t[5] = ISA of the doubling rounds.  Texts of 2^32 symbols and more:
 	                                                                           // t[0] = tie bitmap (cap bits), t[1..5] = list buffers of tie_cap+1 entries
+	// LAZY tie buffers (one-block record sorts of texts below 2^32 symbols: the plans of the headline): t[1..5] (20 of the ~50 bytes per suffix of a sort's workspace)
+	// serve only the list-based rounds of repeat-rich text; they are allocated by blocksort_ensure_ties() the first time such a sort needs them and kept
+	bool lazy_ties = false; void *tie_alloc = nullptr;
 	uint64_t tie_cap = 0;                        // tied suffixes the list-based rounds can take
 	uint8_t *tie_hi = nullptr;                   // texts of 2^32 symbols and more: bits 32.. of the positions on the list (tie_cap+1 bytes)
 	uint32_t *scan_ws = nullptr;
@@ -174,8 +177,10 @@ struct BlockSortWs {
 	const SampleOut *samples = nullptr; // optional (whole-text blocks / their shards, MSD path): (rank,pos) samples are emitted by the sort itself (out.samples_done)
 };
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
-uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0);
-void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span = 0);
+uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0, bool lazy_ties = false);
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span = 0, bool lazy_ties = false);
+void blocksort_ensure_ties(BlockSortWs &ws);       // no-op unless the tie buffers are lazy and not there yet
+void blocksort_release(BlockSortWs &ws);           // frees what blocksort_ensure_ties allocated
 struct BlockSortOut {
 	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions
 	uint8_t *d_sa_hi = nullptr;       // their bits 32.. (texts of 2^32 symbols and more), else null

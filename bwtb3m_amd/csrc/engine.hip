@@ -334,7 +334,10 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	const uint64_t ovh = (B > 1 && !sharded_sort) ? std::min(block_overhang(), p->blocksize / 8) : 0;
 	const uint64_t sort_cap = sharded_sort ? p->shard_cap : p->blocksize + ovh;
 	const uint64_t sort_span = std::max(p->blocksize, sort_cap);
-	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, sort_span));
+	// one block (or a suffix-range shard of one) below 2^32 symbols: the tie-list buffers of the sort are allocated when a repeat-rich text first
+	// needs them (20 of ~50 bytes per suffix: the arena of C3 is 90 GB instead of 150)
+	const bool lazy_ties = B == 1 && n < (1ull << 32) && inputtype != B3M_INPUT_BYTESTREAM;      // (byte alphabets sort by key/index pairs and list their ties always)
+	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, sort_span, lazy_ties));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
 	uint64_t nbk = rank_blocks(maxL);
@@ -381,7 +384,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
 	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
-	blocksort_ws_carve(p->bs, A + o_bs, sort_cap, sort_span);
+	blocksort_ws_carve(p->bs, A + o_bs, sort_cap, sort_span, lazy_ties);
 	if (B > 1) {
 		p->d_rank_blocks = (uint32_t *)(A + o_rb); p->d_rank_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
 		p->d_ranks[0] = (uint32_t *)(A + o_r0); p->d_ranks[1] = (uint32_t *)(A + o_r1);
@@ -428,6 +431,7 @@ void b3m_plan_destroy(b3m_plan *p)
 	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
 	if (p->d_pack) (void)hipFree(p->d_pack);
 	if (p->d_isa_cache) (void)hipFree(p->d_isa_cache);
+	blocksort_release(p->bs);
 	if (p->arena) (void)hipFree(p->arena);
 	delete p;
 }
@@ -889,6 +893,7 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 	BlockSortWs &ws = p->bs;
 	B3M_REQUIRE(total <= ws.cap, "tie finish: more tied suffixes over all shards than one shard's workspace holds (low-complexity input)");
 	if (total == 0) return 0;
+	blocksort_ensure_ties(ws);
 	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
 	if (!p->d_isa_cache) B3M_HIP(hipMalloc((void **)&p->d_isa_cache, 4 * n));
 	uint32_t *const d_isa = p->d_isa_cache;

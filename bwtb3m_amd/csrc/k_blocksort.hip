@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void k_histogram(TextView T, uint64_t start, u
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t nblk(uint64_t n, uint32_t t = 256) { return (uint32_t)((n + t - 1) / t); }
 static inline uint64_t al(uint64_t x) { return (x + 255) & ~255ull; }
+static inline bool msd_applicable_len(uint64_t cap) { return cap >= (1ull << 18); }      // (MSD_MIN_LEN of k_msd.hip: smaller sorts take the key/index path, which lists ties always)
 
 // compactstream (row a3/f4, role of CompactInputTypes::linear_wrapper): symbol i = `bits` bits at bit offset i*bits of the
 // big-endian word stream, most significant bit first -> one byte per symbol (alphabets above 4 symbols take the byte paths)
@@ -300,25 +301,29 @@ void compact_decode(const uint8_t *d_words, uint64_t n, uint32_t bits, uint8_t *
 }
 
 static uint64_t big_tie_cap(uint64_t cap) { return cap / 16 + (1ull << 20); }
-uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span)
+uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span, bool lazy_ties)
 {
 	if (span < cap) span = cap;
+	if (span >= (1ull << 32) || !msd_applicable_len(cap)) lazy_ties = false;
 	uint64_t b = 0;
 	b += 2 * al(8 * cap) + 2 * al(4 * cap);           // key/record and idx ping-pong
 	if (span >= (1ull << 32)) b += al(cap);           // bits 32.. of the suffix array entries
 	// texts of 2^32 symbols and more: the tie bitmap, and list buffers for cap/16 tied suffixes (key-extension rounds with 36-bit positions;
 	// no inverse suffix array: 5 bytes per TEXT symbol would not fit beside a shard's workspace)
 	if (span >= (1ull << 32)) b += al(cap / 8 + 64) + 5 * al(4 * (big_tie_cap(cap) + 1)) + al(big_tie_cap(cap) + 1);
-	else b += 6 * al(4 * (cap + 1));                    // tie-list buffers + inverse suffix array of the doubling rounds
+	else b += (lazy_ties ? 1 : 6) * al(4 * (cap + 1));  // tie-list buffers + inverse suffix array of the doubling rounds (lazy: the tie bitmap's buffer only)
 	b += al(4 * scan_ws_elems(cap + 1));
 	b += al(radix_ws_bytes(cap));
 	b += al(msd_ws_bytes(cap, span));
 	b += 4096;
 	return b;
 }
-void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span)
+void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span, bool lazy_ties)
 {
 	if (span < cap) span = cap;
+	if (span >= (1ull << 32) || !msd_applicable_len(cap)) lazy_ties = false;
+	blocksort_release(ws);
+	ws.lazy_ties = lazy_ties;
 	uint8_t *p = (uint8_t *)base;
 	ws.cap = cap;
 	ws.keyA = (uint64_t *)p; p += al(8 * cap);
@@ -333,11 +338,28 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span
 		ws.tie_cap = big_tie_cap(cap);
 		for (int i = 1; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (ws.tie_cap + 1)); }
 		ws.tie_hi = p; p += al(ws.tie_cap + 1);
-	} else for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
+	} else if (lazy_ties) { for (int i = 1; i < 6; ++i) ws.t[i] = nullptr; ws.t[0] = (uint32_t *)p; p += al(4 * (cap + 1)); }
+	else for (int i = 0; i < 6; ++i) { ws.t[i] = (uint32_t *)p; p += al(4 * (cap + 1)); }
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(cap + 1));
 	radix_ws_carve(ws.radix, p, cap); p += al(radix_ws_bytes(cap));
 	msd_ws_carve(ws.msd, p, cap, span); p += al(msd_ws_bytes(cap, span));
 	ws.d_scalars = (uint32_t *)p;
+}
+
+void blocksort_ensure_ties(BlockSortWs &ws)
+{
+	if (!ws.lazy_ties || ws.t[1]) return;
+	const uint64_t one = al(4 * (ws.cap + 1));
+	if (hipMalloc(&ws.tie_alloc, 5 * one) != hipSuccess) {
+		(void)hipGetLastError();
+		ws.tie_alloc = nullptr;
+		throw Error("repeat-rich input: no HBM left for the buffers of the list-based rounds (" + std::to_string(5 * one / 1000000) + " MB beside the plan's workspace): use blocks (blocksize= / mem=)");
+	}
+	for (int i = 1; i < 6; ++i) ws.t[i] = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ws.tie_alloc) + (uint64_t)(i - 1) * one);
+}
+void blocksort_release(BlockSortWs &ws)
+{
+	if (ws.tie_alloc) { (void)hipFree(ws.tie_alloc); ws.tie_alloc = nullptr; for (int i = 1; i < 6; ++i) ws.t[i] = nullptr; }
 }
 
 // Rounds on the list (U, gid) of u tied slots.  idx = the suffix array being built.  Buffers: kx/ky
@@ -655,10 +677,12 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 	const bool tree = nshards <= 1 && !(start == 0 && len == T.n) && T.n < (1ull << 32);
 	const uint64_t H = tree ? std::min(std::min<uint64_t>(ws.cap - len, T.n - (start + len)), block_overhang()) : 0;
 	const bool msd = msd_applicable(T, len);
+	if (!msd) blocksort_ensure_ties(ws);               // (the key/index path lists its ties in them from the start)
 	if (!msd && ws.arrival) for (int i = 0; i < ws.arrival->n; ++i) B3M_HIP(hipStreamWaitEvent(s, ws.arrival->ev[i], 0));      // only the MSD path starts behind a text that is still arriving
 	if (msd) block_sort_msd(T, start, len, ws, s, tl, out, d_bwt, d_p0, shard, nshards, need_sa, 0, H > 0);
 	else block_sort_lsd(T, start, len, ws, s, tl, out, 0, H > 0);
 	if (out.want_ext) {
+		blocksort_ensure_ties(ws);
 		// long ties: the block and its overhang as one block (suffix array kept, BWT into scratch), then the overhang is filtered out
 		const uint64_t first_rounds = out.tie_rounds, first_elems = out.tie_elements;
 		uint64_t *hist_keep = ws.d_symhist_out; ws.d_symhist_out = nullptr;      // the histogram of the block was added by the first pass (MSD) or is the caller's business

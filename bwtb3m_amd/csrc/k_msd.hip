@@ -2594,6 +2594,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemcpyAsync(&total32, d_off + nov, 4, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		const uint64_t total = total32;
+		blocksort_ensure_ties(ws);                             // (lazy in one-block plans: uniform text never comes here)
 		// texts of 2^32 symbols and more: list buffers of tie_cap entries (the tie bitmap sits in t[0]), positions in two arrays
 		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 		if (big) {
