@@ -1589,6 +1589,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	for (int k = 0; k < F_PER; ++k) {
 		const uint32_t bin = bs[k];
 		if ((uint32_t)k < kfull || k * F_THREADS + tid < m) {
+			LDS_CHK(bin >> 1, TABW_N);
 			const uint32_t old = atomicAdd(&tabw[bin >> 1], (bin & 1u) ? 0x10000u : 1u);
 			bs[k] = bin | (((bin & 1u) ? old >> 16 : old & 0xFFFFu) << 16);
 		}
@@ -1620,6 +1621,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 		if (tid == F_THREADS - 1) s_wl = (pre + both) >> 16;
 		while (multi) {                                          // (stores only: nothing waits)
 			const uint32_t k = (uint32_t)__ffs(multi) - 1u; multi &= multi - 1u;
+			LDS_CHK(tid * (F_BINS / F_THREADS) + k, F_BINS);
 			if (wat < (uint32_t)V3_WL) wl[wat] = (uint16_t)(tid * (F_BINS / F_THREADS) + k);
 			++wat;
 		}
@@ -1654,6 +1656,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 		const uint32_t t = tab16[bin];
 		const uint32_t at = (t & T_START) + (bs[k] >> 16);
 		if ((uint32_t)k < kfull || e < m) {
+			LDS_CHK(apad + at, ENT_N); LDS_CHK(at, m);
 			ent[apad + at] = ev[k];
 			if ((t >> 13) == 7u) {                                // maybe a hot bin (above LS_TIE_CAP entries: on the overflow list): the list-based rounds read positions
 				const uint32_t c = ((uint32_t)tab16[bin + 1] & T_START) - (t & T_START);
@@ -1700,11 +1703,12 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 			st[q] = apad + (t & T_START); c[q] = bin[q] == 0xFFFFu ? 0u : t >> 13;
 		}
 		#pragma unroll
-		for (int q = 0; q < 4; ++q) { e0[q] = ent[st[q]]; e1[q] = ent[st[q] + 1]; e2[q] = ent[st[q] + 2]; e3[q] = ent[st[q] + 3]; }
+		for (int q = 0; q < 4; ++q) { LDS_CHK(st[q] + 3, ENT_N); e0[q] = ent[st[q]]; e1[q] = ent[st[q] + 1]; e2[q] = ent[st[q] + 2]; e3[q] = ent[st[q] + 3]; }
 		#pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			if ((uint32_t)(q * F_THREADS) >= nwl) break;         // (uniform)
 			if (c[q] < 2u) continue;                               // (no bin)
+			LDS_CHK(st[q] - apad + c[q], m + 1);
 			if (c[q] <= 4u) {
 				uint32_t x0 = e0[q], x1 = e1[q], x2 = c[q] > 2u ? e2[q] : 0xFFFFFFFFu, x3 = c[q] > 3u ? e3[q] : 0xFFFFFFFFu;
 				B3M_CE(x0, x1) B3M_CE(x2, x3) B3M_CE(x0, x2) B3M_CE(x1, x3) B3M_CE(x1, x2)
@@ -1727,6 +1731,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 			// five entries and more (0.5 % of the listed bins; the count is capped at 7 in the table: the next bin's start tells)
 			const uint32_t cc = ((uint32_t)tab16[bin[q] + 1] & T_START) - (st[q] - apad);
 			if (cc > (uint32_t)LS_TIE_CAP) continue;              // hot: left in arrival order for the list-based rounds
+			LDS_CHK(st[q] - apad + cc, m + 1);
 			if (cc <= 8u) {
 				uint32_t x[8];
 				x[0] = e0[q]; x[1] = e1[q]; x[2] = e2[q]; x[3] = e3[q];

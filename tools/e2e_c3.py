@@ -16,7 +16,7 @@ ref = plan.run(d_text); torch.cuda.synchronize()
 href = hashlib.sha256(ref.cpu().numpy().tobytes()).hexdigest()
 p0 = plan.result()["p0"]
 plan.close(); del ref, d_text; torch.cuda.empty_cache()
-for bwtonly in (1, 0):
+for bwtonly in (1, 0, 0):          # (the second bwtonly=0 run is the warm one: files in the page cache, driver initialised)
     out = os.path.join(tmp, "c3_%d.bwt" % bwtonly)
     t0 = time.time()
     r = subprocess.run(["/root/repo/bin/bwtb3m", "inputtype=pacterm", "bwtonly=%d" % bwtonly, "numthreads=16", "verbose=1", "outputfilename=" + out, pac],
