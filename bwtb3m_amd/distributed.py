@@ -612,8 +612,9 @@ def _check_slices(out, off, p0, d_text, n, itype, dev):
 
 def bench_main(a, rank, local_rank, world):
     """N>1 leg of bench.py: one process per GPU (torchrun), RCCL process group.  Headline = the mode asked for (default:
-    suffix-range shards); the other mode runs too (one step) and both are in the ONE JSON line (`config.modes`).  Any failure
-    or a hung collective ends the process with a non-zero status -- no line is printed for a run that did not finish."""
+    suffix-range shards); the other mode runs too (one step) and both are in the ONE JSON line (`config.modes`).  A failure or a
+    hung collective of the HEADLINE mode ends the process with a non-zero status and no line; one of the other mode is named in
+    `config.modes[<mode>].error` and the headline line stands."""
     import sys
     import threading
     from . import benchutil, synth
@@ -625,6 +626,10 @@ def bench_main(a, rank, local_rank, world):
     # B3M_BENCH_BACKEND=gloo: rehearsal of the N>1 flow with several ranks on ONE GPU (RCCL needs a GPU
     # per rank); collectives are then staged through host memory
     backend = os.environ.get("B3M_BENCH_BACKEND", "nccl")
+    # a peer that has left must show as a collective that does not complete (this module's own watchdog deals with that), not as an abort
+    # of this process from the process group's error-handling thread
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    inject = os.environ.get("B3M_BENCH_INJECT", "")          # "<mode>:<rank>": that rank raises when it starts that mode (tests of the failure paths)
     if backend == "nccl":
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -648,11 +653,13 @@ def bench_main(a, rank, local_rank, world):
     def make(m):
         return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate)
 
-    def measure(m, steps, warmup):
-        wd = threading.Timer(a.blocks_timeout, _bail)
+    def measure(m, steps, warmup, bail=None):
+        wd = threading.Timer(a.blocks_timeout, bail or _bail)
         wd.daemon = True
         wd.start()
         try:
+            if inject == "%s:%d" % (m, rank):
+                raise RuntimeError("injected failure (B3M_BENCH_INJECT=%s)" % inject)
             job = make(m)
             dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times()) if m != "blocks" else None)
             checked = _check_slices(out, off, p0, d_text, n, itype, dev) if getattr(a, "check", True) else None
@@ -664,24 +671,23 @@ def bench_main(a, rank, local_rank, world):
         finally:
             wd.cancel()
 
+    other = "blocks" if mode != "blocks" else "prefix"
     try:
         if a.verify:
             raise SystemExit("bench.py --verify with --gpus > 1: use tests/ (the oracle is test infrastructure, not part of the package)")
         res_main = measure(mode, a.steps, a.warmup)
-        other = "blocks" if mode != "blocks" else "prefix"
-        res_other = None
-        if getattr(a, "also_blocks", True) and n < (1 << 32):
-            res_main.pop("job", None)
-            torch.cuda.empty_cache()
-            res_other = measure(other, 1, 1)
-            res_other.pop("job", None)
+        res_main.pop("job", None)
     except BaseException as ex:   # noqa: BLE001
         # peers may be stuck in a collective this rank has left: no barrier, no teardown -- fail at once
         sys.stderr.write("[bench] rank %d failed: %r\n" % (rank, ex))
         sys.stderr.flush()
         os._exit(2)
-    if rank == 0:
+
+    def report(res_other):
+        """rank 0's ONE JSON line; res_other: the other mode's measurement, None (not run) or {"error": ...}"""
         def summary(r):
+            if "error" in r:
+                return r
             return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
                     "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"],
                     "tie_finish_runs": r["tie_finish_runs"]}
@@ -711,5 +717,29 @@ def bench_main(a, rank, local_rank, world):
             "roofline": roof,
         }
         print(json.dumps(res), flush=True)
+
+    # the other mode (one step) rides in the same line.  It must not be able to take the headline with it: if it fails or a collective of it never
+    # completes (it has never run on this many real GPUs before the driver's own run), rank 0 still prints the line, with the failure named in
+    # `config.modes`, and every rank leaves at once with status 0 (peers may be stuck in a collective: no barrier, no teardown)
+    res_other = None
+    if getattr(a, "also_blocks", True) and n < (1 << 32):
+        def _bail_other():
+            sys.stderr.write("[bench] rank %d: mode %s: watchdog fired after %d s; the headline line stands\n" % (rank, other, a.blocks_timeout))
+            sys.stderr.flush()
+            if rank == 0:
+                report({"error": "a collective of this mode did not complete within %d s" % a.blocks_timeout})
+            os._exit(0)
+        try:
+            torch.cuda.empty_cache()
+            res_other = measure(other, 1, 1, bail=_bail_other)
+            res_other.pop("job", None)
+        except BaseException as ex:   # noqa: BLE001
+            sys.stderr.write("[bench] rank %d: mode %s failed: %r; the headline line stands\n" % (rank, other, ex))
+            sys.stderr.flush()
+            if rank == 0:
+                report({"error": repr(ex)[:300]})
+            os._exit(0)
+    if rank == 0:
+        report(res_other)
     dist.barrier()
     dist.destroy_process_group()

@@ -1054,6 +1054,17 @@ def test_bench_two_ranks_on_one_gpu_reports_both_modes_and_fails_loudly(gpu, tmp
     cmd_bad = cmd[:-4] + ["--config", "c1", "--mode", "blocks"]
     r = subprocess.run(cmd_bad, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+    # a rank that fails in the OTHER mode (the one step that rides along) must not cost the headline: the line stands and names the failure ...
+    for who in ("1", "0"):
+        r = subprocess.run(cmd + ["--blocks-timeout", "25"], env=dict(env, B3M_BENCH_INJECT="blocks:" + who), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["value"] > 0 and j["config"]["mode"] == "prefix" and "error" in j["config"]["modes"]["blocks"] and "ms_per_step" in j["config"]["modes"]["prefix"]
+    # ... while one that fails in the headline mode ends the run non-zero without a line
+    r = subprocess.run(cmd, env=dict(env, B3M_BENCH_INJECT="prefix:1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
 
 
 @pytest.mark.parametrize("bits,n", [(2, 1), (2, 1000), (2, 300000), (3, 777), (3, 100000), (1, 5000), (4, 65536), (8, 4097)])
