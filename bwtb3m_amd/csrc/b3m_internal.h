@@ -219,8 +219,11 @@ uint64_t block_overhang();        // symbols of overhang a plan leaves room for 
 // idx_hi / tmp_hi: texts of 2^32 symbols and more (bits 32.. of the suffix array entries; a byte buffer as long as the list): key extension only
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
-                    uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0, uint8_t *idx_hi = nullptr, uint8_t *tmp_hi = nullptr);
+                    uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0, uint8_t *idx_hi = nullptr, uint8_t *tmp_hi = nullptr,
+                    uint64_t sym_off = 0, bool isa_sparse = false);      // isa_sparse: entries may be unset (isa_sparse_from_slots); sym_off: symbols every group of the list shares in front of depth0's key (the record sort's reading: key_at_off)
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
+// the inverse suffix array with entries for the listed slots only (their suffix -> the slot), every other one unset: tie_rounds(..., isa_sparse = true)
+void isa_sparse_from_slots(const uint32_t *d_sa, uint64_t len, const uint32_t *d_slots, uint64_t total, uint32_t *d_isa, hipStream_t s);
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,
                    const SampleOut *smp = nullptr, const uint8_t *d_sa_hi = nullptr);
 // products of a sorted block

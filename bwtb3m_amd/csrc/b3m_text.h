@@ -74,6 +74,41 @@ __device__ inline uint64_t key_at(const TextView &T, uint64_t i, uint64_t depth)
 	return k;
 }
 
+// Key of the tie rounds (k_blocksort.hip): the K symbols [off, off + K) of the rotation starting at i, for a list whose groups agree on their
+// first `off` symbols IN THE READING OF THE RECORD SORT (k_msd.hip: the terminator and what lies behind it read as base 0).  pacterm: a suffix whose
+// terminator lies in front of the window is smaller than every member of its group that is longer (what it agreed with was padding) and
+// shorter ones come first, so its key is its length (below 64); every other key is key_at's plus 64.  A group never holds two suffixes with the
+// terminator in the same place, so such members leave the list in the round that sees them.
+__device__ inline uint64_t key_at_off(const TextView &T, uint64_t i, uint64_t off)
+{
+	if (T.type == B3M_INPUT_PACTERM) {
+		constexpr int K = KSYM_PACTERM;
+		const uint64_t pos = i + off;
+		if (pos + K <= T.nbases) return (((window32(T, pos) >> (64 - 2 * K)) << TAGBITS_PACTERM) | TAG_NORMAL) + 64u;
+		if (pos > T.nbases) { const uint64_t t = T.nbases - i; return t < 63u ? t : 63u; }
+		uint64_t k = 0; uint32_t t = 0;
+		for (; t < (uint32_t)K; ++t) {
+			uint64_t p = pos + t;
+			if (p == T.nbases) break;
+			k = (k << 2) | base_at(T, p);
+		}
+		k <<= 2 * (K - t);
+		return ((k << TAGBITS_PACTERM) | t) + 64u;
+	}
+	const int K = T.type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_BYTES;
+	uint64_t pos = (i + off) % T.n;
+	if (T.type == B3M_INPUT_PAC) {
+		if (pos + KSYM_PAC <= T.n) return window32(T, pos);
+		uint64_t k = 0;
+		for (int t = 0; t < K; ++t) { k = (k << 2) | base_at(T, pos); if (++pos == T.n) pos = 0; }
+		return k;
+	}
+	uint64_t k = 0;
+	for (int t = 0; t < K; ++t) { k = (k << 8) | T.b[pos]; if (++pos == T.n) pos = 0; }
+	return k;
+}
+inline int key_off_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM + 1 : 64; }
+
 // compare rotations S_x and S_y (x != y): -1, 0 (equal over >= n symbols), +1
 __device__ inline int compare_rotations(const TextView &T, uint64_t x, uint64_t y)
 {

@@ -89,12 +89,13 @@ __global__ void k_tie_compact(const uint32_t *flag_scan, const uint32_t *hid, co
 }
 // keys of the next K symbols for the list; value = slot
 // (idx_hi: bits 32.. of the positions, texts of 2^32 symbols and more; null otherwise)
-__global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, uint64_t u, uint64_t depth, uint64_t *nk, uint32_t *slot)
+// (off: the symbols in front of the key, see key_at_off)
+__global__ void k_tie_keys(TextView T, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, uint64_t u, uint64_t off, uint64_t *nk, uint32_t *slot)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	const uint32_t r = U[s];
-	nk[s] = key_at(T, (uint64_t)idx[r] | (idx_hi ? (uint64_t)idx_hi[r] << 32 : 0ull), depth);
+	nk[s] = key_at_off(T, (uint64_t)idx[r] | (idx_hi ? (uint64_t)idx_hi[r] << 32 : 0ull), off);
 	slot[s] = (uint32_t)s;
 }
 // prefix doubling: the key of a listed suffix is the current rank (ISA: exact for resolved suffixes,
@@ -122,6 +123,46 @@ __global__ void k_isa_init(const uint32_t *sa, uint64_t len, uint32_t *isa)
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r < len) isa[sa[r]] = (uint32_t)r;
 }
+// ---- the inverse suffix array, written where it is read ----
+// Doubling reads the rank of suffix i+h for the LISTED suffixes i only; filling all n entries is n random 4-byte writes (137 ms at 3 Gbase, a
+// third of a repeat-rich genome's whole sort).  Sparse form: every entry starts UNSET, the suffixes that were ever listed get theirs (exact for
+// those the key rounds finished, the group's first slot for the rest: k_isa_slots, k_isa_list), and a round first collects the targets that are
+// still UNSET -- suffixes the record sort placed for good, near the end of a repeat mostly -- and finds their ranks by binary search in the
+// suffix array (k_isa_need, k_isa_search).  Slots of groups still tied hold their members in any order: a suffix that is not in the group compares
+// the same way with all of them, so the search steps over them correctly.  Too many such targets (n/64): the whole array is filled after all.
+constexpr uint32_t ISA_UNSET = 0xFFFFFFFFu;
+__global__ void k_isa_slots(const uint32_t *U0, uint64_t total, const uint32_t *sa, uint32_t *isa)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < total) { const uint32_t r = U0[s]; isa[sa[r]] = r; }
+}
+__global__ void k_isa_need(const uint32_t *isa, uint64_t n, uint64_t h, const uint32_t *U, const uint32_t *idx, uint64_t u, uint32_t *Q, uint32_t *cnt)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t q = 0; bool need = false;
+	if (s < u) { q = (uint64_t)idx[U[s]] + h; if (q >= n) q -= n; need = isa[q] == ISA_UNSET; }
+	const uint64_t mask = __ballot(need);
+	if (!mask) return;
+	const uint32_t lane = lane_id(), first = (uint32_t)__ffsll((long long)mask) - 1u;
+	uint32_t base = 0;
+	if (lane == first) base = atomicAdd(cnt, (uint32_t)__popcll(mask));
+	base = __shfl(base, (int)first, 64);
+	if (need) Q[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)q;
+}
+__global__ void k_isa_search(TextView T, const uint32_t *sa, uint64_t n, const uint32_t *Q, uint32_t nq, uint32_t *isa)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nq) return;
+	const uint32_t q = Q[t];
+	uint64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		const uint32_t p = sa[mid];
+		if (p == q) { lo = mid; break; }
+		if (compare_rotations(T, p, q) < 0) lo = mid + 1; else hi = mid;
+	}
+	isa[q] = (uint32_t)lo;
+}
 // hid[s] = s where the label changes (heads of the listed groups), else 0
 __global__ void k_heads_from_gid(const uint32_t *gid, uint64_t u, uint32_t *hid)
 {
@@ -143,7 +184,7 @@ __global__ void k_tie_gidkeys(const uint32_t *gid, const uint32_t *slot_sorted, 
 }
 // gather (idx, key) of the final order into temporaries (the key is recomputed from the text)
 __global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, const uint32_t *slot_final,
-                             uint64_t u, uint64_t depth, uint32_t *tmp_idx, uint8_t *tmp_hi, uint64_t *tmp_key)
+                             uint64_t u, uint64_t off, uint32_t *tmp_idx, uint8_t *tmp_hi, uint64_t *tmp_key)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
@@ -152,19 +193,20 @@ __global__ void k_tie_gather(TextView T, const uint32_t *U, const uint32_t *idx,
 	const uint32_t h = idx_hi ? idx_hi[r] : 0u;
 	tmp_idx[s] = i;
 	if (idx_hi) tmp_hi[s] = (uint8_t)h;
-	tmp_key[s] = key_at(T, (uint64_t)i | ((uint64_t)h << 32), depth);
+	tmp_key[s] = key_at_off(T, (uint64_t)i | ((uint64_t)h << 32), off);
 }
 // write back into the tie slots (the sorted group labels equal the old ones slot by slot) and
-// mark the new group heads
+// mark the new group heads.  (lpos: the list handed in is a sub-list -- whole groups, in order -- of the list hid belongs to: lpos[s] = index there)
 __global__ void k_tie_apply(const uint32_t *U, const uint32_t *gid, const uint32_t *tmp_idx, const uint8_t *tmp_hi, const uint64_t *tmp_key,
-                            uint64_t u, uint32_t *idx, uint8_t *idx_hi, uint32_t *hid)
+                            uint64_t u, uint32_t *idx, uint8_t *idx_hi, uint32_t *hid, const uint32_t *lpos)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	idx[U[s]] = tmp_idx[s];
 	if (idx_hi) idx_hi[U[s]] = tmp_hi[s];
 	bool head = (s == 0) || gid[s] != gid[s - 1] || tmp_key[s] != tmp_key[s - 1];
-	hid[s] = head ? (uint32_t)s : 0u;
+	const uint32_t at = lpos ? lpos[s] : (uint32_t)s;
+	hid[at] = head ? at : 0u;
 }
 __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const uint32_t *sa, const uint8_t *sa_hi, uint64_t start, uint8_t *bwt, uint32_t *p0, SampleOut smp)
 {
@@ -176,6 +218,160 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 	bwt[r] = (uint8_t)sym_at(T, j);
 	if (i == start) *p0 = r;
 	if (sample_hit(smp, (uint32_t)i)) sample_put(smp, r, i);      // the listed slots are final here: their samples could not be written earlier
+}
+
+// ------------------------------------------------------------------------------------------------
+// A round inside LDS.  Two radix sorts of the whole list per round (by key, then stably by group) cost ten to twelve passes
+// over it, whatever the groups look like; once the groups are small -- after the first round or two of a repeat-rich genome they
+// are -- a workgroup can take a TILE of the list (whole groups, at most TT_CAP slots), fetch the keys, order every group in LDS
+// and write the suffixes back: one pass.  Tile c = the groups whose head lies in the list slots [c * TT_STRIDE, (c+1) * TT_STRIDE);
+// a group above TT_GROUP members belongs to no tile and goes through the radix sorts as a sub-list of its own
+// (k_tie_large_*).  Groups of up to TT_COUNT members are ordered by counting (each member counts the smaller ones), larger
+// ones by a bitonic network over the tile, keyed (group, key).
+// ------------------------------------------------------------------------------------------------
+constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 256;
+static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
+
+// flag[s] = 1 if the group of slot s has more than TT_GROUP members (hid[s] = list index of the group's head); flag[u] = 0
+__device__ __forceinline__ bool tie_large(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint64_t s)
+{
+	const uint64_t far = (uint64_t)hid[s] + TT_GROUP;
+	return far < u && gid[far] == gid[s];
+}
+__global__ void k_tie_large_flags(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint32_t *flag)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > u) return;
+	flag[s] = (s < u && tie_large(hid, gid, u, s)) ? 1u : 0u;
+}
+__global__ void k_tie_large_compact(const uint32_t *flag_scan, const uint32_t *hid, const uint32_t *gid, const uint32_t *U, uint64_t u,
+                                    uint32_t *U2, uint32_t *gid2, uint32_t *lpos)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	if (tie_large(hid, gid, u, s)) { const uint32_t p = flag_scan[s]; U2[p] = U[s]; gid2[p] = gid[s]; lpos[p] = (uint32_t)s; }
+}
+
+template <bool ISA>
+__global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint32_t *U, const uint32_t *gid, uint64_t u, uint32_t *idx,
+                                                         const uint32_t *isa, uint64_t off, uint32_t *hid)
+{
+	__shared__ uint64_t sk[TT_CAP];                  // keys
+	__shared__ uint32_t sv[TT_CAP];                  // suffixes
+	__shared__ uint16_t sg[TT_CAP];                  // group of the slot, counted inside the tile from 1 (0xFFFF: padding)
+	__shared__ uint16_t gs[TT_CAP + 2];              // first slot of group g; gs[groups + 1] = m
+	__shared__ uint32_t wtot[TT_THREADS / 64];
+	__shared__ uint32_t red[4];
+	const uint32_t tid = threadIdx.x;
+	const uint64_t c0 = (uint64_t)blockIdx.x * TT_STRIDE, c1 = c0 + TT_STRIDE < u ? c0 + TT_STRIDE : u;
+	if (tid == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0u; red[2] = 0xFFFFFFFFu; red[3] = 0u; }
+	__syncthreads();
+	for (uint64_t s = c0 + tid; s < c1; s += TT_THREADS)
+		if (s == 0 || gid[s] != gid[s - 1]) { atomicMin(&red[0], (uint32_t)s); atomicMax(&red[1], (uint32_t)s); }
+	__syncthreads();
+	const uint32_t a = red[0], hl = red[1];
+	if (a == 0xFFFFFFFFu) return;                    // no group starts here (the inside of a large one)
+	// the end of the last group: the first head behind the stride, looked for as far as a group of TT_GROUP reaches
+	const uint64_t lim = (uint64_t)hl + TT_GROUP + 1 < u ? (uint64_t)hl + TT_GROUP + 1 : u;
+	for (uint64_t s = c1 + tid; s < lim; s += TT_THREADS) if (gid[s] != gid[s - 1]) atomicMin(&red[2], (uint32_t)s);
+	__syncthreads();
+	uint64_t e;
+	if (red[2] != 0xFFFFFFFFu) e = red[2];
+	else e = (u - hl <= (uint64_t)TT_GROUP) ? u : hl;       // runs to the end of the list, or is a large group: not this tile's
+	const uint32_t m = (uint32_t)(e - a);
+	if (m == 0) return;
+	uint32_t P = 64; while (P < m) P <<= 1;
+	// ---- fetch: suffix, key, head mark ----
+	uint32_t hsum = 0;
+	#pragma unroll
+	for (int k = 0; k < TT_PER; ++k) {
+		const uint32_t p = tid * TT_PER + k;          // consecutive slots per thread: the head marks are summed in place
+		uint32_t head = 0;
+		if (p < m) {
+			const uint64_t s = (uint64_t)a + p;
+			const uint32_t i = idx[U[s]];
+			uint64_t key;
+			if (ISA) { uint64_t q = (uint64_t)i + off; if (q >= T.n) q -= T.n; key = isa[q]; }
+			else key = key_at_off(T, i, off);
+			head = (p == 0 || gid[s] != gid[s - 1]) ? 1u : 0u;
+			sk[p] = key; sv[p] = i;
+			if (head) hsum += 1;
+			sg[p] = (uint16_t)(hsum | (head << 15));   // partial count inside the thread (< 16), head mark in bit 15
+		} else if (p < P) { sk[p] = ~0ull; sv[p] = 0u; sg[p] = 0xFFFFu; }
+	}
+	// heads in front of this thread's slots: scan of the 512 counts (inside the waves, then the eight wave totals)
+	uint32_t before;
+	{
+		const uint32_t inc = wave_incl_sum(hsum);
+		if ((tid & 63u) == 63u) wtot[tid >> 6] = inc;
+		__syncthreads();
+		before = inc - hsum;
+		for (uint32_t w = 0; w < (tid >> 6); ++w) before += wtot[w];
+	}
+	#pragma unroll
+	for (int k = 0; k < TT_PER; ++k) {
+		const uint32_t p = tid * TT_PER + k;
+		if (p < m) {
+			const uint32_t w = sg[p], g = before + (w & 0x7FFFu);
+			sg[p] = (uint16_t)g;
+			if (w & 0x8000u) gs[g] = (uint16_t)p;
+			if (p == m - 1) gs[g + 1] = (uint16_t)m;
+		}
+	}
+	__syncthreads();
+	// largest group of the tile
+	#pragma unroll
+	for (int k = 0; k < TT_PER; ++k) {
+		const uint32_t p = tid * TT_PER + k;
+		if (p < m && (p == 0 || sg[p] != sg[p - 1])) { const uint32_t g = sg[p]; atomicMax(&red[3], (uint32_t)gs[g + 1] - (uint32_t)gs[g]); }
+	}
+	__syncthreads();
+	const uint32_t gmax = red[3];
+	if (gmax <= (uint32_t)TT_COUNT) {
+		// ---- every member counts the members of its group in front of it in (key, slot) order ----
+		uint64_t mk[TT_PER]; uint32_t mv[TT_PER]; uint32_t dst[TT_PER];
+		#pragma unroll
+		for (int k = 0; k < TT_PER; ++k) {
+			const uint32_t p = tid + k * TT_THREADS;
+			dst[k] = 0xFFFFFFFFu;
+			if (p < m) {
+				const uint32_t g = sg[p], b = gs[g], en = gs[g + 1];
+				const uint64_t my = sk[p];
+				uint32_t less = 0;
+				for (uint32_t j = b; j < en; ++j) { const uint64_t kj = sk[j]; less += (kj < my || (kj == my && j < p)) ? 1u : 0u; }
+				mk[k] = my; mv[k] = sv[p]; dst[k] = b + less;
+			}
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int k = 0; k < TT_PER; ++k) if (dst[k] != 0xFFFFFFFFu) { sk[dst[k]] = mk[k]; sv[dst[k]] = mv[k]; }
+		__syncthreads();
+	} else {
+		// ---- bitonic network over the tile, keyed (group, key) ----
+		for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+			for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+				for (uint32_t t = tid; t < (P >> 1); t += TT_THREADS) {
+					const uint32_t i1 = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), i2 = i1 | j;
+					const bool up = (i1 & kk) == 0u;
+					const uint32_t g1 = sg[i1], g2 = sg[i2];
+					const uint64_t k1 = sk[i1], k2 = sk[i2];
+					const bool gt = g1 > g2 || (g1 == g2 && k1 > k2);
+					if (gt == up) {
+						sg[i1] = (uint16_t)g2; sg[i2] = (uint16_t)g1; sk[i1] = k2; sk[i2] = k1;
+						const uint32_t v1 = sv[i1]; sv[i1] = sv[i2]; sv[i2] = v1;
+					}
+				}
+				__syncthreads();
+			}
+		}
+	}
+	// ---- back into the slots; heads of the groups as they are now ----
+	for (uint32_t p = tid; p < m; p += TT_THREADS) {
+		const uint64_t s = (uint64_t)a + p;
+		idx[U[s]] = sv[p];
+		const bool head = p == 0 || sg[p] != sg[p - 1] || sk[p] != sk[p - 1];
+		hid[s] = head ? (uint32_t)s : 0u;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,9 +567,31 @@ void blocksort_release(BlockSortWs &ws)
 //                   isa must be initialised: whole-text blocks only): round r sorts by the rank of
 //                   the suffix h0*2^r further on and refreshes the ranks of the listed suffixes.
 // Returns the number of rounds run; *left = tied slots remaining.
+// one round by radix sorts on the list (Ux, gidx) of cnt slots: by key, then stably by group label; the suffixes go back into their group's slots and
+// the new heads into hid (at lpos[.] when the list is a sub-list of the one hid belongs to)
+static void tie_round_lsd(const TextView &T, uint32_t *idx, uint8_t *idx_hi, uint8_t *tmp_hi, const uint32_t *Ux, const uint32_t *gidx, uint64_t cnt,
+                          uint64_t *kx, uint64_t *ky, uint32_t *vx, uint32_t *vy, uint32_t *hid, const uint32_t *lpos,
+                          const uint32_t *isa, uint64_t h, uint64_t off, int gbits, RadixWs &radix, hipStream_t s)
+{
+	if (isa) hipLaunchKernelGGL(k_tie_keys_isa, dim3(nblk(cnt)), dim3(256), 0, s, isa, T.n, h, Ux, idx, cnt, kx, vx);
+	else hipLaunchKernelGGL(k_tie_keys, dim3(nblk(cnt)), dim3(256), 0, s, T, Ux, idx, (const uint8_t *)idx_hi, cnt, off, kx, vx);
+	uint64_t *rk; uint32_t *rv;
+	radix_sort_u64(kx, vx, ky, vy, cnt, isa ? gbits : key_off_bits(T.type), radix, s, nullptr, &rk, &rv);
+	uint64_t *gk = (rk == kx) ? ky : kx;
+	uint32_t *vidle = (rv == vx) ? vy : vx;
+	hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(cnt)), dim3(256), 0, s, gidx, rv, cnt, gk);
+	uint64_t *rk2; uint32_t *rv2;
+	radix_sort_u64(gk, rv, rk, vidle, cnt, gbits, radix, s, nullptr, &rk2, &rv2);
+	uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
+	uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
+	if (isa) hipLaunchKernelGGL(k_tie_gather_isa, dim3(nblk(cnt)), dim3(256), 0, s, isa, T.n, h, Ux, idx, rv2, cnt, tmp_idx, tmp_key);
+	else hipLaunchKernelGGL(k_tie_gather, dim3(nblk(cnt)), dim3(256), 0, s, T, Ux, idx, (const uint8_t *)idx_hi, rv2, cnt, off, tmp_idx, tmp_hi, tmp_key);
+	hipLaunchKernelGGL(k_tie_apply, dim3(nblk(cnt)), dim3(256), 0, s, Ux, gidx, tmp_idx, (const uint8_t *)tmp_hi, tmp_key, cnt, idx, idx_hi, hid, lpos);
+}
+
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
-                    uint64_t max_rounds, uint32_t *isa, uint64_t h0, uint8_t *idx_hi, uint8_t *tmp_hi)
+                    uint64_t max_rounds, uint32_t *isa, uint64_t h0, uint8_t *idx_hi, uint8_t *tmp_hi, uint64_t sym_off, bool isa_sparse)
 {
 	B3M_REQUIRE(!(idx_hi && isa), "internal: prefix doubling is not available for positions above 2^32");
 	B3M_REQUIRE(!idx_hi || tmp_hi, "internal: tie rounds with 36-bit positions need a byte buffer");
@@ -388,24 +606,70 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		inclusive_max_u32(hid, u, scan_ws, s);
 		hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);
 	}
+	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	// tiles (k_tie_tile): 32-bit positions; B3M_NO_TIE_TILES=1 keeps every round on the radix sorts
+	const bool tiles_ok = !idx_hi && !(getenv("B3M_NO_TIE_TILES") && atoi(getenv("B3M_NO_TIE_TILES")));
+	bool any_large = true;                             // (groups only shrink: once none is large, none will be)
 	for (uint64_t depth = depth0; u > 0; ++depth) {
-		if (isa ? h >= T.n : depth * K >= T.n) break;   // compared >= n symbols: equal rotations
+		const uint64_t off = sym_off + depth * K;       // symbols in front of this round's key
+		if (isa ? h >= T.n : off >= T.n) break;         // compared >= n symbols: equal rotations
 		if (max_rounds && rounds >= max_rounds) break;
 		++rounds;
-		if (isa) hipLaunchKernelGGL(k_tie_keys_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, u, kx, vx);
-		else hipLaunchKernelGGL(k_tie_keys, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, (const uint8_t *)idx_hi, u, depth, kx, vx);
-		uint64_t *rk; uint32_t *rv;
-		radix_sort_u64(kx, vx, ky, vy, u, isa ? gbits : key_bits(T.type), radix, s, nullptr, &rk, &rv);
-		uint64_t *gk = (rk == kx) ? ky : kx;
-		uint32_t *vidle = (rv == vx) ? vy : vx;
-		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, gid, rv, u, gk);
-		uint64_t *rk2; uint32_t *rv2;
-		radix_sort_u64(gk, rv, rk, vidle, u, gbits, radix, s, nullptr, &rk2, &rv2);
-		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
-		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
-		if (isa) hipLaunchKernelGGL(k_tie_gather_isa, dim3(nblk(u)), dim3(256), 0, s, isa, T.n, h, U, idx, rv2, u, tmp_idx, tmp_key);
-		else hipLaunchKernelGGL(k_tie_gather, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, (const uint8_t *)idx_hi, rv2, u, depth, tmp_idx, tmp_hi, tmp_key);
-		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)tmp_hi, tmp_key, u, idx, idx_hi, hid);
+		if (dbg >= 3) {      // census of the tie groups entering this round: elements in groups of size < 2^k
+			std::vector<uint32_t> g(u);
+			B3M_HIP(hipMemcpyAsync(g.data(), gid, 4ull * u, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
+			uint64_t by[34] = {0}, ng = 0, big = 0;
+			for (uint64_t a = 0; a < u;) { uint64_t b = a + 1; while (b < u && g[b] == g[a]) ++b; int k = 0; while ((1ull << k) < b - a + 1) ++k; by[k] += b - a; ++ng; if (b - a > big) big = b - a; a = b; }
+			fprintf(stderr, "[b3m] tie round %llu (%s, depth %llu): %llu listed in %llu groups, largest %llu; elements by group size <2^k:", (unsigned long long)rounds, isa ? "doubling" : "keys",
+			        (unsigned long long)(isa ? h : off), (unsigned long long)u, (unsigned long long)ng, (unsigned long long)big);
+			for (int k = 0; k < 34; ++k) if (by[k]) fprintf(stderr, " %d:%llu", k, (unsigned long long)by[k]);
+			fprintf(stderr, "\n");
+		}
+		if (isa && isa_sparse) {
+			// targets without a rank yet (see k_isa_slots): listed in kx, found in the suffix array
+			uint32_t *Q = reinterpret_cast<uint32_t *>(kx), *qcnt = flag, nq = 0;
+			B3M_HIP(hipMemsetAsync(qcnt, 0, 4, s));
+			hipLaunchKernelGGL(k_isa_need, dim3(nblk(u)), dim3(256), 0, s, (const uint32_t *)isa, T.n, h, U, idx, u, Q, qcnt);
+			B3M_HIP(hipMemcpyAsync(&nq, qcnt, 4, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			if (dbg >= 3) fprintf(stderr, "[b3m]   doubling by %llu: %u of %llu targets have no rank yet\n", (unsigned long long)h, nq, (unsigned long long)u);
+			if (nq > T.n / 64) {
+				isa_from_sa(idx, len_for_labels, isa, s);
+				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+				inclusive_max_u32(hid, u, scan_ws, s);
+				hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);
+				isa_sparse = false;
+			} else if (nq) hipLaunchKernelGGL(k_isa_search, dim3(nblk(nq)), dim3(256), 0, s, T, (const uint32_t *)idx, T.n, (const uint32_t *)Q, nq, isa);
+		}
+		// ---- which slots belong to groups too large for a tile ----
+		uint64_t nL = u;
+		if (tiles_ok) {
+			nL = 0;
+			if (any_large) {
+				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+				inclusive_max_u32(hid, u, scan_ws, s);
+				hipLaunchKernelGGL(k_tie_large_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, gid, u, flag);
+				exclusive_sum_u32(flag, u + 1, scan_ws, s);
+				uint32_t h_nl = 0;
+				B3M_HIP(hipMemcpyAsync(&h_nl, flag + u, 4, hipMemcpyDeviceToHost, s));
+				B3M_HIP(hipStreamSynchronize(s));
+				nL = h_nl;
+				if (nL == 0) any_large = false;
+			}
+			if (nL > u / 2) nL = u;                      // mostly large groups: the radix sorts take the whole list
+		}
+		if (nL == u) tie_round_lsd(T, idx, idx_hi, tmp_hi, U, gid, u, kx, ky, vx, vy, hid, nullptr, isa, h, off, gbits, radix, s);
+		else {
+			// the sub-list of the large groups (nL <= u/2 slots) and its sort buffers share the round's buffers: kx/ky hold u keys each
+			const uint64_t hu = (u + 1) / 2;
+			uint32_t *U_L = reinterpret_cast<uint32_t *>(kx + hu), *gid_L = U_L + nL, *lpos = reinterpret_cast<uint32_t *>(ky + hu);
+			if (nL) hipLaunchKernelGGL(k_tie_large_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, gid, U, u, U_L, gid_L, lpos);
+			const uint32_t ntile = (uint32_t)((u + TT_STRIDE - 1) / TT_STRIDE);
+			if (isa) hipLaunchKernelGGL(k_tie_tile<true>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid);
+			else hipLaunchKernelGGL(k_tie_tile<false>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid);
+			if (nL) tie_round_lsd(T, idx, nullptr, nullptr, U_L, gid_L, nL, kx, ky, vx, vy, hid, lpos, isa, h, off, gbits, radix, s);
+			if (dbg >= 3) fprintf(stderr, "[b3m]   tiles: %u, %llu slots of large groups through the radix sorts\n", ntile, (unsigned long long)nL);
+		}
 		inclusive_max_u32(hid, u, scan_ws, s);
 		if (isa) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);   // every key of this round has been read
 		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
@@ -552,7 +816,7 @@ uint64_t tie_rounds_domain(uint32_t *idx, uint64_t u, uint64_t *kx, uint64_t *ky
 		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
 		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
 		hipLaunchKernelGGL(k_dom_gather, dim3(nblk(u)), dim3(256), 0, s, isa, start, h, D, U, gid, idx, rv2, u, hid, tmp_idx, tmp_key);
-		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)nullptr, tmp_key, u, idx, (uint8_t *)nullptr, hid);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)nullptr, tmp_key, u, idx, (uint8_t *)nullptr, hid, (const uint32_t *)nullptr);
 		inclusive_max_u32(hid, u, scan_ws, s);
 		hipLaunchKernelGGL(k_dom_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, tmp_key, D, u, start, isa);
 		hipLaunchKernelGGL(k_dom_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, tmp_key, D, u, flag);
@@ -587,6 +851,11 @@ void isa_from_sa_rel(const uint32_t *d_sa, uint64_t len, uint64_t start, uint32_
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s)
 {
 	if (len) hipLaunchKernelGGL(k_isa_init, dim3(nblk(len)), dim3(256), 0, s, d_sa, len, d_isa);
+}
+void isa_sparse_from_slots(const uint32_t *d_sa, uint64_t len, const uint32_t *d_slots, uint64_t total, uint32_t *d_isa, hipStream_t s)
+{
+	B3M_HIP(hipMemsetAsync(d_isa, 0xFF, 4ull * len, s));
+	if (total) hipLaunchKernelGGL(k_isa_slots, dim3(nblk(total)), dim3(256), 0, s, d_slots, total, d_sa, d_isa);
 }
 
 bool no_tree_doubling() { const char *e = getenv("B3M_NO_TREE_DOUBLING"); return e && atoi(e) != 0; }

@@ -771,10 +771,13 @@ __device__ __forceinline__ void wave_sync()
 struct SortOut { SaOut sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; int pb; SampleOut smp; };
 
 // a sub-bucket the in-kernel sort cannot finish: (start, size) goes to the overflow list (lane 0 only)
-__device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m)
+// (word 1 of the table: set once a range was pushed whose records are only known to share their BUCKET; ranges that are one bin of a finish
+// share the bin's bits as well, and the rounds on the list start behind what every range shares)
+__device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m, bool one_bin = false)
 {
 	uint32_t k = atomicAdd(&O.overflow[0], 1u);
 	if (k < O.overflow_cap) { O.overflow[2 + 2 * k] = b0; O.overflow[3 + 2 * k] = m; }   // 8-byte aligned pairs: u64 = size << 32 | start
+	if (!one_bin) atomicOr(&O.overflow[1], 1u);
 }
 
 // one wave sorts the m <= LS_CAP records it holds in r (lane l: records l, l+64, ...), destined
@@ -1083,7 +1086,7 @@ __device__ __forceinline__ void finish_bucket(const uint32_t b, const uint32_t s
 		#pragma unroll 1
 		for (uint32_t bb = tid * (F_BINS / F_THREADS); bb < (tid + 1) * (F_BINS / F_THREADS); ++bb) {
 			const uint32_t st = cs[bb], c = (uint32_t)cs[bb + 1] - st;
-			if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c);
+			if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c, true);
 		}
 	}
 	uint32_t stv[F_PER], env[F_PER];                          // start and end of the record's bin (spare bin: m, 0)
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 		// here (a bucket handed to the slower path lists its bins there: pushed from both places, the list would hold the slots twice)
 		if (cmax > (uint32_t)LS_TIE_CAP) {
 			#pragma unroll 1
-			for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k] >> 16; if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + (w[k] & 0xFFFFu), c); }
+			for (int k = 0; k < WPT; ++k) { const uint32_t c = w[k] >> 16; if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + (w[k] & 0xFFFFu), c, true); }
 		}
 	}
 	// ---- entries into bin order ----
@@ -1631,7 +1634,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 			#pragma unroll 1
 			for (int k = 0; k < 2 * WPT; ++k) {
 				const uint32_t c = (k & 1) ? w[k >> 1] >> 16 : w[k >> 1] & 0xFFFFu;
-				if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c);
+				if (c > (uint32_t)LS_TIE_CAP) ovf_push(O, s0 + st, c, true);
 				st += c;
 			}
 		}
@@ -2366,7 +2369,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	{
 		Scope sc(tl, KF_LDS_SORT, (need_sa ? 13 : 9) * len);
-		B3M_HIP(hipMemsetAsync(M.overflow, 0, 4, s));
+		B3M_HIP(hipMemsetAsync(M.overflow, 0, 8, s));
 		B3M_HIP(hipMemsetAsync(M.biglist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(M.hugelist, 0, 4, s));
 		B3M_HIP(hipMemsetAsync(d_tiebits, 0, 4 * ((len + 31) / 32 + 1), s));
@@ -2563,12 +2566,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0, O.smp);
 	}
 	stage("tie fix");
-	uint32_t nov = 0, nlist[3] = {0, 0, 0};
-	B3M_HIP(hipMemcpyAsync(&nov, M.overflow, 4, hipMemcpyDeviceToHost, s));
+	uint32_t novw[2] = {0, 0}, nlist[3] = {0, 0, 0};
+	B3M_HIP(hipMemcpyAsync(novw, M.overflow, 8, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipMemcpyAsync(&nlist[0], M.midlist, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipMemcpyAsync(&nlist[1], M.biglist, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipMemcpyAsync(&nlist[2], M.hugelist, 4, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
+	const uint32_t nov = novw[0];
+	// what every range of the overflow list shares: the bits of its bucket, and those of its bin when every range is one bin of a finish (a repeated
+	// 16-mer at the usual geometry).  The rounds on the list start behind it (in the record sort's reading of the text: key_at_off)
+	const uint64_t ovf_syms = (uint64_t)(D0e + consumed + ((novw[1] & 1u) ? 0 : std::min(fbits, F_BINBITS))) / 2;
 	if (getenv("B3M_DEBUG")) fprintf(stderr, "[b3m] block_sort_msd len %llu D0 %d D1 %d: listed mid %u big %u huge %u (caps %llu %llu %llu), overflow ranges %u\n",
 	                                 (unsigned long long)len, D0e, dg.D1, nlist[0], nlist[1], nlist[2], (unsigned long long)M.mid_cap, (unsigned long long)M.big_cap, (unsigned long long)M.huge_cap, nov);
 	// a list that ran over would have dropped buckets silently
@@ -2623,14 +2630,15 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// (b3m_plan_tie_export / b3m_plan_tie_finish): O(log longest repeat) rounds there too
 		const bool defer = nshards > 1 && start == 0 && len_in == T.n;
 		const uint64_t R0 = 4;
+		const uint64_t off0 = getenv("B3M_TIE_FROM_0") ? 0 : ovf_syms;      // (switch: the rounds start at symbol 0, as they did before)
 		// a block of a merge tree: the same few rounds, then prefix doubling inside the block and its overhang (tie_rounds_domain):
 		// the first time round the caller is asked to sort the block again with the overhang behind it (out.want_ext)
 		const bool tree = !whole && !defer && !no_tree_doubling();
 		// 36-bit positions: key extension until nothing is left (an inverse suffix array of 2^32 and more entries does not fit beside the sort: no doubling,
 		// O(longest repeat / 21) rounds)
-		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, sa.hi, ws.tie_hi);
+		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, sa.hi, ws.tie_hi, off0);
 		else
-		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree) ? R0 : 0);
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0);
 		if (big) { /* finished above */ }
 		else if (left && tree && out.tie_rounds >= R0) {
 			if (allow_ext) { out.want_ext = true; goto leave_fallback; }
@@ -2649,8 +2657,13 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (!big && left && whole && out.tie_rounds >= R0) {
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
-			isa_from_sa(sa.lo, len, ws.t[5], s);
-			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0);
+			// ranks for the suffixes that were ever listed; the few others doubling asks for are searched (B3M_ISA_FULL=1: all n entries, as before)
+			const bool sparse = !(getenv("B3M_ISA_FULL") && atoi(getenv("B3M_ISA_FULL")));
+			if (sparse) {
+				hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[4], (uint32_t *)nullptr);
+				isa_sparse_from_slots(sa.lo, len, Bf[4], total, ws.t[5], s);
+			} else isa_from_sa(sa.lo, len, ws.t[5], s);
+			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0, nullptr, nullptr, 0, sparse);
 		}
 		// BWT symbols (and p0) of the slots finished here
 		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)

@@ -398,6 +398,51 @@ def test_msd_block_sort_paths(gpu, oracle, itype, kind, d1, monkeypatch):
         plan.close()
 
 
+def _repeat_family_bases(oracle, nb, seed, tail):
+    """random bases with what sends suffixes to the list-based rounds in groups of every size: a 120-base element in 3000 copies at 8 % divergence,
+    a 1500-base element in 40 copies at 2 %, 300 poly-A runs of 18..80, one exact 30,000-base copy; the last `tail` bases are A"""
+    rng = np.random.default_rng(seed)
+    b = oracle.synth_bases(nb, seed).copy()
+    for unit, copies, rate in ((120, 3000, 0.08), (1500, 40, 0.02)):
+        el = rng.integers(0, 4, unit, dtype=np.uint8)
+        for p in rng.integers(0, nb - unit, copies):
+            c = el.copy()
+            mut = rng.random(unit) < rate
+            c[mut] = (c[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+            b[p:p + unit] = c
+    for p in rng.integers(0, nb - 100, 300):
+        b[p:p + int(rng.integers(18, 81))] = 0
+    b[nb // 2: nb // 2 + 30000] = b[1000:31000]
+    if tail:
+        b[-tail:] = 0
+    return b
+
+
+@pytest.mark.parametrize("itype", ["pacterm", "pac"])
+@pytest.mark.parametrize("tail", [0, 7, 16, 21, 37])
+def test_list_rounds_in_tiles_and_behind_the_shared_symbols(gpu, oracle, itype, tail, monkeypatch):
+    """the rounds on the overflow list: they start behind the symbols every listed range shares (in the record sort's reading: the terminator
+    and what follows read as A, so a suffix that ends inside those symbols -- the poly-A tails here -- is placed by its length), small groups are
+    ordered in LDS tiles, large ones by the radix sorts.  Equal to the oracle with the tiles, without them, and from symbol 0."""
+    nb = (1 << 19) + 777
+    buf = _pac(oracle, _repeat_family_bases(oracle, nb, 500 + tail, tail))
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    for env in ({}, {"B3M_NO_TIE_TILES": "1"}, {"B3M_TIE_FROM_0": "1"}):
+        for k in ("B3M_NO_TIE_TILES", "B3M_TIE_FROM_0"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for isarate, keep in ((0, False), (64, True)):
+            out, res, plan = _plan_bwt(gpu, buf, itype, isarate=isarate, keep_sa=keep)
+            assert np.array_equal(out, ref), (env, isarate)
+            assert res["tie_elements"] > 50000 and res["tie_rounds"] >= 3, res
+            if isarate:
+                _check_samples(plan, sa, len(s), isarate)
+            plan.close()
+
+
 @pytest.mark.parametrize("itype,isarate", [("pacterm", 0), ("pacterm", 4096), ("pac", 0), ("bytestream", 0)])
 def test_deep_repeats_use_prefix_doubling(gpu, oracle, itype, isarate):
     # a block that is the whole text finishes long repeats by prefix doubling: the number of rounds
