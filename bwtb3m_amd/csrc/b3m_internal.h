@@ -136,7 +136,7 @@ struct MsdWs {
 	void *lists = nullptr;                                   // four FinishLists structs (device): what the finish kernels read when they must list a bucket (level 1: two, level 2: two)
 	// level 2 (buckets above twice the finish's capacity get one more 8-bit partition, in parallel tiles, through the level-1 kernels):
 	uint32_t *mid2 = nullptr, *big2 = nullptr, *huge2 = nullptr; uint64_t list2_cap = 0;      // its own bucket lists
-	uint32_t *lvl2 = nullptr; uint64_t lvl2_buckets = 0;     // starts[256 nb], ends[256 nb], bucket table[3 nb] for up to lvl2_buckets listed buckets
+	uint32_t *lvl2 = nullptr; uint64_t lvl2_buckets = 0, lvl2_words = 0;     // starts[256 nb], ends[256 nb], bucket table[3 nb] for up to lvl2_buckets listed buckets
 	uint32_t *runpre = nullptr;                              // the same rows as start | records before the run << 14 (for the gathering finish)
 	uint32_t *runtab = nullptr; uint64_t runtab_cap = 0;     // level-1 run table: row (level-0 bucket, digit), column = chunk: start | length << 16
 	uint32_t *scan_ws = nullptr;

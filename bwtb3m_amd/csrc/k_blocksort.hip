@@ -633,7 +633,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			B3M_HIP(hipMemcpyAsync(&nq, qcnt, 4, hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipStreamSynchronize(s));
 			if (dbg >= 3) fprintf(stderr, "[b3m]   doubling by %llu: %u of %llu targets have no rank yet\n", (unsigned long long)h, nq, (unsigned long long)u);
-			if (nq > T.n / 64) {
+			const uint64_t nq_max = getenv("B3M_ISA_SEARCH_MAX") ? strtoull(getenv("B3M_ISA_SEARCH_MAX"), nullptr, 10) : T.n / 64;      // (switch: 0 = fill the array as soon as one target is unset)
+			if (nq > nq_max) {
 				isa_from_sa(idx, len_for_labels, isa, s);
 				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
 				inclusive_max_u32(hid, u, scan_ws, s);

@@ -57,6 +57,7 @@ constexpr int W0_MAXBITS = 12;
 constexpr int W0_MAXBINS = 1 << W0_MAXBITS;
 // finish
 constexpr int F_CAP = 6144;                            // records of a final bucket sorted in LDS
+constexpr uint32_t LVL2_AVG = 3072;                    // level 2: records a sub-bucket is to average (the digit width is chosen per bucket)
 constexpr uint32_t F_HUGE = 1u << 20;                      // buckets above this go to the list-based rounds directly where one workgroup would have to partition them (k_bucket_finish) ...
 constexpr uint32_t F_HUGE2 = 1u << 26;                     // ... and above this where level 2 partitions them in parallel tiles
 constexpr uint32_t LVL2_MIN = 32768;                       // listed buckets above this many records take level 2 (256 sub-buckets for the gathering finish); smaller ones one workgroup
@@ -117,9 +118,11 @@ static uint64_t msd_hist_cap(uint64_t cap, uint64_t span) { return std::max(cap,
 static uint64_t msd_tiles_cap(uint64_t cap) { return cap / MSD_SUPER + MSD_L0_MAX + 2; }
 static uint64_t msd_ovf_cap(uint64_t cap) { return cap / 33 + 4096; }                   // (start, size) pairs: every listed bin holds > 32 records
 static uint64_t msd_big_cap(uint64_t cap) { return cap / F_CAP + 16; }
-static uint64_t msd_lvl2_buckets(uint64_t cap) { return cap / LVL2_MIN + 16; }           // listed buckets level 2 takes (each above LVL2_MIN records)
-static uint64_t msd_list2_cap(uint64_t cap) { return msd_lvl2_buckets(cap) * MSD_MAXBINS; }   // every sub-bucket of level 2 may be listed again (k_finish_fast lists sparse buckets too), each at most once
-static uint64_t msd_lvl2_words(uint64_t cap) { return msd_lvl2_buckets(cap) * (2ull * MSD_MAXBINS + 3) + 16; }
+static uint64_t msd_lvl2_buckets(uint64_t cap) { return cap / (2 * F_CAP) + 16; }       // listed buckets level 2 takes at once (each above twice the finish's capacity)
+// sub-buckets of one class of level 2: a bucket of sz records makes 2^d2 < 2 sz / LVL2_AVG of them (2 for d2 = 1); every one may be listed again
+// (k_finish_fast lists sparse buckets too), each at most once
+static uint64_t msd_list2_cap(uint64_t cap) { return 2 * cap / LVL2_AVG + 2 * msd_lvl2_buckets(cap) + 256; }
+static uint64_t msd_lvl2_words(uint64_t cap) { return 2 * msd_list2_cap(cap) + 3 * msd_lvl2_buckets(cap) + 16; }   // starts, ends, bucket table
 // entries of the chunk-local level 0's run table: 2048 rows x (whole tiles of 4 chunks of 65,280 positions); 0 = no such path (small blocks, 2^32 and more)
 static uint64_t msd_local0_cap(uint64_t cap)
 {
@@ -159,7 +162,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.mid2 = (uint32_t *)p; p += al(4 * (ws.list2_cap + 2));
 	ws.big2 = (uint32_t *)p; p += al(4 * (ws.list2_cap + 2));
 	ws.huge2 = (uint32_t *)p; p += al(4 * (cap / F_HUGE + 18));
-	ws.lvl2 = (uint32_t *)p; ws.lvl2_buckets = msd_lvl2_buckets(cap); p += al(4 * msd_lvl2_words(cap));
+	ws.lvl2 = (uint32_t *)p; ws.lvl2_buckets = msd_lvl2_buckets(cap); ws.lvl2_words = msd_lvl2_words(cap); p += al(4 * msd_lvl2_words(cap));
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(hist));
 	// chunk-local level 0 (whole blocks below 2^32): its run table and the rows' prefixes, level 1's gather tiles
 	ws.tab0 = nullptr; ws.pre0 = nullptr; ws.tab0_cap = 0;
@@ -1467,6 +1470,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 constexpr int V3_NCH = 256;              // runs a bucket may be spread over (more: listed)
 constexpr int V3_WL = 1536;              // work list: bins with two entries or more (uniform input: 1280 +- 33 of a full bucket's 8192)
 constexpr int V3_TL = 256;               // tied entries whose records are fetched again
+constexpr int V3_BL = 128;               // bins of 9 .. LS_TIE_CAP entries: ordered by half a wave each (skewed text; a uniform bucket has none)
 constexpr int V3_SP = 64;                // positions of special records
 constexpr uint64_t V3_MIN_RATE = 256;    // sampling rates below this take k_finish_fast (F_CAP / rate specials per bucket must fit V3_SP)
 
@@ -1479,6 +1483,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	constexpr int ENT_N = F_CAP + 16, TABW_N = F_BINS / 2 + 4, GF_N = F_CAP / 64 + 2;
 	constexpr int E_IDX = 4, E_LOW = 17;                              // entry = low key bits << 17 | index << 4 | special << 3 | predecessor symbol
 	constexpr uint32_t E_SPECIAL = 8u, T_START = 0x1FFFu;             // table half-word after the scan: start (13 bits) | min(count, 7) << 13
+	constexpr uint32_t E_PEND = 1u << 31;                             // (set once the entry is in place) a tied record whose position is still to be fetched: no room on the tie list
 	__shared__ __attribute__((aligned(16))) uint32_t ent[ENT_N];      // entry of the record at place p of the bucket: ent[apad + p] (apad: byte phase of the BWT address)
 	__shared__ __attribute__((aligned(16))) uint32_t tabw[TABW_N];    // two 16-bit words per dword: counts, then start | capped count; half-word F_BINS = m
 	__shared__ uint32_t wsum[F_WAVES];
@@ -1488,7 +1493,8 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	__shared__ uint16_t wl[V3_WL];                                    // bins with two entries or more
 	__shared__ uint32_t tl[V3_TL];                                    // tied entries: place << 13 | index
 	__shared__ __attribute__((aligned(8))) uint2 sp[V3_SP];           // special records: {position bits 0..31, index | position bits 32.. << 16}
-	__shared__ uint32_t s_slow, s_wl, s_tl, s_sp;
+	__shared__ uint16_t bl[V3_BL];                                    // bins above eight entries
+	__shared__ uint32_t s_slow, s_wl, s_tl, s_sp, s_bl;
 	__shared__ uint32_t lds_pad[WPC == 2 ? 6144 : 1];                 // (WPC = 2, the A/B form: enough LDS to keep a third workgroup off the CU)
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
 	const uint32_t b0 = b >> S.D1;
@@ -1518,7 +1524,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 			rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
 			for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
 		}
-		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; s_tl = 0u; s_sp = 0u; }
+		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; s_tl = 0u; s_sp = 0u; s_bl = 0u; }
 		#pragma unroll
 		for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
 		if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }      // the places in front of the bucket's first and behind its last entry: no symbol, not special
@@ -1669,13 +1675,16 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	}
 	__syncthreads();
 	// ---- the listed bins: in order, in place; key ties noted ----
-	auto tie_note = [&](const uint32_t p, const uint32_t x, const bool has_pred) {       // the entry x at place p ties with a neighbour
+	// the entry x at place p ties with a neighbour; returns what to OR into the entry (no room on the list: its position is fetched when the bucket leaves,
+	// by whoever writes its byte -- a bucket of an A+T-rich prefix ties a third of its records, and fetching them here, one after the other, cost 100 us per bucket)
+	auto tie_note = [&](const uint32_t p, const uint32_t x, const bool has_pred) -> uint32_t {
 		const uint32_t g = s0 + p;
 		if (has_pred) atomicOr(&O.tiebits[g >> 5], 1u << (g & 31));       // bit p = "the record at place p has the key field of the one before it"
 		const uint32_t j = atomicAdd(&s_tl, 1u);
-		if (j < (uint32_t)V3_TL) tl[j] = (p << 13) | ((x >> E_IDX) & 0x1FFFu);
-		else sa_set(O.sa, g, S.rec[rec_adr((x >> E_IDX) & 0x1FFFu)] & posmask);      // (list full: the position at once, with its latency)
+		if (j < (uint32_t)V3_TL) { tl[j] = (p << 13) | ((x >> E_IDX) & 0x1FFFu); return 0u; }
+		return E_PEND;
 	};
+	auto ekey = [&](const uint32_t x) -> uint32_t { return (x & ~E_PEND) >> E_LOW; };
 	// a bin of cc entries from place st1 (entry index apad + st1) on, one entry after the other (rare: more than eight entries, or no room on the list)
 	auto fix_serial = [&](const uint32_t at0, const uint32_t cc) {
 		#pragma unroll 1
@@ -1689,10 +1698,9 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 		#pragma unroll 1
 		for (uint32_t i = 0; i < cc; ++i) {
 			const uint32_t x = ent[at0 + i];
-			const bool tp = i > 0 && (ent[at0 + i - 1] >> E_LOW) == (x >> E_LOW), tn = i + 1 < cc && (ent[at0 + i + 1] >> E_LOW) == (x >> E_LOW);
+			const bool tp = i > 0 && ekey(ent[at0 + i - 1]) == ekey(x), tn = i + 1 < cc && ekey(ent[at0 + i + 1]) == ekey(x);
 			if (!(tp || tn)) continue;
-			ent[at0 + i] = x & ~E_SPECIAL;
-			tie_note(at0 - apad + i, x, tp);
+			ent[at0 + i] = (x & ~E_SPECIAL) | tie_note(at0 - apad + i, x, tp);
 		}
 	};
 	const uint32_t nwl = s_wl;
@@ -1722,10 +1730,10 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 					if (t12 || t23) x2 &= ~E_SPECIAL;
 					if (t23) x3 &= ~E_SPECIAL;
 					const uint32_t p = st[q] - apad;
-					if (t01) tie_note(p, x0, false);
-					if (t01 || t12) tie_note(p + 1, x1, t01);
-					if (t12 || t23) tie_note(p + 2, x2, t12);
-					if (t23) tie_note(p + 3, x3, true);
+					if (t01) x0 |= tie_note(p, x0, false);
+					if (t01 || t12) x1 |= tie_note(p + 1, x1, t01);
+					if (t12 || t23) x2 |= tie_note(p + 2, x2, t12);
+					if (t23) x3 |= tie_note(p + 3, x3, true);
 				}
 				ent[st[q]] = x0; ent[st[q] + 1] = x1;
 				if (c[q] > 2u) { ent[st[q] + 2] = x2; if (c[q] > 3u) ent[st[q] + 3] = x3; }
@@ -1751,7 +1759,12 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 				B3M_CE(x[1], x[2]) B3M_CE(x[3], x[4]) B3M_CE(x[5], x[6])
 				#pragma unroll
 				for (int i = 0; i < 8; ++i) if ((uint32_t)i < cc) ent[st[q] + i] = x[i];
-			} else fix_serial(st[q], cc);
+			} else {
+				// nine entries and more: to the half-waves below
+				const uint32_t j = atomicAdd(&s_bl, 1u);
+				if (j < (uint32_t)V3_BL) { bl[j] = (uint16_t)bin[q]; continue; }
+				fix_serial(st[q], cc);
+			}
 			ties_serial(st[q], cc);
 		}
 	} else {
@@ -1764,6 +1777,29 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 		}
 	}
 	__syncthreads();
+	// ---- bins of nine entries and more: half a wave each, every lane counts the entries smaller than its own (entries are distinct: the index is in them) ----
+	{
+		const uint32_t nbl = s_bl < (uint32_t)V3_BL ? s_bl : (uint32_t)V3_BL;      // (the same for every thread: the barrier inside is taken by all or none)
+		if (nbl) {
+			const uint32_t l = tid & 31u;
+			for (uint32_t i = tid >> 5; i < ((nbl + 1u) & ~1u); i += F_THREADS / 32) {        // (both halves of a wave make the same number of trips)
+				uint32_t at0 = 0, cc = 0;
+				if (i < nbl) { const uint32_t bn = bl[i], st1 = (uint32_t)tab16[bn] & T_START; at0 = apad + st1; cc = ((uint32_t)tab16[bn + 1] & T_START) - st1; }
+				const uint32_t x = l < cc ? ent[at0 + l] : 0xFFFFFFFFu;
+				uint32_t less = 0;
+				for (uint32_t j = 0; j < (uint32_t)LS_TIE_CAP; ++j) if (j < cc) less += ent[at0 + j] < x ? 1u : 0u;
+				wave_sync();
+				if (l < cc) ent[at0 + less] = x;
+				wave_sync();
+				if (l < cc) {
+					const uint32_t y = ent[at0 + l];
+					const bool tp = l > 0 && ekey(ent[at0 + l - 1]) == ekey(y), tn = l + 1 < cc && ekey(ent[at0 + l + 1]) == ekey(y);
+					if (tp || tn) ent[at0 + l] = (y & ~E_SPECIAL) | tie_note(at0 - apad + l, y, tp);
+				}
+			}
+			__syncthreads();
+		}
+	}
 	// ---- the records of the tied entries: requested now, stored when the bucket has left ----
 	const uint32_t ntl = s_tl < (uint32_t)V3_TL ? s_tl : (uint32_t)V3_TL;
 	uint64_t trec = 0; uint32_t tplace = 0;
@@ -1779,6 +1815,15 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 			const uint32_t bytes = (v.x & 7u) | ((v.y & 7u) << 8) | ((v.z & 7u) << 16) | ((v.w & 7u) << 24);
 			if (4 * j >= lo && 4 * j + 4 <= hi) reinterpret_cast<uint32_t *>(gb)[j] = bytes;
 			else { for (uint32_t q = 4 * j; q < 4 * j + 4; ++q) if (q >= lo && q < hi) gb[q] = (uint8_t)(bytes >> (8 * (q & 3u))); }
+			if ((v.x | v.y | v.z | v.w) & E_PEND) {
+				// tied records the list had no room for: their positions now (up to four loads in flight)
+				const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+				uint64_t rc[4];
+				#pragma unroll
+				for (int q = 0; q < 4; ++q) rc[q] = (vv[q] & E_PEND) ? S.rec[rec_adr((vv[q] >> E_IDX) & 0x1FFFu)] : 0ull;
+				#pragma unroll
+				for (int q = 0; q < 4; ++q) if (vv[q] & E_PEND) sa_set(O.sa, (uint64_t)s0 + (4 * j + q - apad), rc[q] & posmask);
+			}
 			if ((v.x | v.y | v.z | v.w) & E_SPECIAL) {
 				// a (rank,pos) sample or the block's first suffix, alone in its key: its place is final (entries outside the bucket are zero)
 				const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
@@ -2455,45 +2500,68 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_HIP(hipMemcpyAsync(ls.data(), M.lvl_start, 4ull * (nbF + 1), hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipStreamSynchronize(s));
 			const uint32_t lvl2_min = getenv("B3M_LVL2_MIN") ? (uint32_t)atoi(getenv("B3M_LVL2_MIN")) : LVL2_MIN;      // test switch: small inputs through level 2
-			for (uint32_t b : all) (ls[b + 1] - ls[b] > lvl2_min ? ids : small).push_back(b);
-			const uint32_t nb2 = (uint32_t)ids.size();
-			std::vector<MsdTile> tiles2;
-			std::vector<uint32_t> tab2(3ull * nb2);
-			uint64_t toff = 0;
-			const uint32_t TILE = (uint32_t)L1_CHUNK * L1_TCH;
-			for (uint32_t i = 0; i < nb2; ++i) {
-				const uint32_t b = ids[i], st = ls[b], sz = ls[b + 1] - st, nch = (sz + L1_CHUNK - 1) / L1_CHUNK;
-				tab2[i] = st; tab2[nb2 + i] = (uint32_t)toff; tab2[2ull * nb2 + i] = nch;
-				for (uint32_t j = 0; j * TILE < sz; ++j) {
-					MsdTile t; t.in_off = st + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
-					t.hist_base = (uint32_t)(toff + (uint64_t)j * L1_TCH); t.stride = nch;
-					tiles2.push_back(t);
-				}
-				toff += (uint64_t)MSD_MAXBINS * nch;
+			// a bucket's fan-out is chosen from its own size: the sub-buckets are to average LVL2_AVG records (half a finish workgroup's capacity: on
+			// skewed text the heaviest is a few times the average), so a class of buckets per digit width D2 = 1 .. 8, one after the other.  (With 8 bits
+			// for all of them a 65 K bucket made 256 sub-buckets of 256 records: 1.3 M workgroups, 24 ms of the 80 a Gbase at 80 % A+T took.)
+			const uint32_t lvl2_avg = getenv("B3M_LVL2_AVG") ? std::min<uint32_t>(LVL2_AVG, (uint32_t)atoi(getenv("B3M_LVL2_AVG"))) : LVL2_AVG;      // (measurement switch: smaller only, the tables are sized for LVL2_AVG)
+			std::vector<uint32_t> cls[MSD_MAXBITS + 1];
+			const int d2_max = std::min(MSD_MAXBITS, fbits - 1);
+			for (uint32_t b : all) {
+				const uint32_t sz = ls[b + 1] - ls[b];
+				if (sz <= lvl2_min) { small.push_back(b); continue; }
+				int d2 = 1; while (d2 < d2_max && (sz >> d2) > lvl2_avg) ++d2;
+				cls[d2].push_back(b);
 			}
-			if (nb2 && nb2 <= M.lvl2_buckets && toff <= M.runtab_cap && tiles2.size() <= M.tiles_cap && toff < (1ull << 32)) {
-				// the listed buckets below LVL2_MIN stay on the list of k_bucket_finish
+			const uint32_t TILE = (uint32_t)L1_CHUNK * L1_TCH;
+			// classes the tables have no room for stay with k_bucket_finish
+			struct Cls { int d2; std::vector<MsdTile> tiles; std::vector<uint32_t> tab; uint64_t toff; uint32_t nb; };
+			std::vector<Cls> run;
+			for (int d2 = 1; d2 <= MSD_MAXBITS; ++d2) {
+				const uint32_t nb2 = (uint32_t)cls[d2].size();
+				if (!nb2) continue;
+				Cls c; c.d2 = d2; c.nb = nb2; c.tab.resize(3ull * nb2); c.toff = 0;
+				for (uint32_t i = 0; i < nb2; ++i) {
+					const uint32_t b = cls[d2][i], st = ls[b], sz = ls[b + 1] - st, nch = (sz + L1_CHUNK - 1) / L1_CHUNK;
+					c.tab[i] = st; c.tab[nb2 + i] = (uint32_t)c.toff; c.tab[2ull * nb2 + i] = nch;
+					for (uint32_t j = 0; j * TILE < sz; ++j) {
+						MsdTile t; t.in_off = st + j * TILE; t.count = std::min<uint32_t>(TILE, sz - j * TILE);
+						t.hist_base = (uint32_t)(c.toff + (uint64_t)j * L1_TCH); t.stride = nch;
+						c.tiles.push_back(t);
+					}
+					c.toff += ((uint64_t)1 << d2) * nch;
+				}
+				const uint64_t nsub = (uint64_t)nb2 << d2;
+				if (nb2 <= M.lvl2_buckets && 2 * nsub + 3ull * nb2 + 16 <= M.lvl2_words && nsub <= M.list2_cap && c.toff <= M.runtab_cap && c.tiles.size() <= M.tiles_cap && c.toff < (1ull << 32))
+					run.push_back(std::move(c));
+				else small.insert(small.end(), cls[d2].begin(), cls[d2].end());
+			}
+			if (!run.empty()) {
+				// the listed buckets level 2 does not take stay on the list of k_bucket_finish
 				nbig1 = (uint32_t)small.size();
 				B3M_HIP(hipMemcpyAsync(M.biglist, &nbig1, 4, hipMemcpyHostToDevice, s));
 				if (nbig1) B3M_HIP(hipMemcpyAsync(M.biglist + 1, small.data(), 4ull * nbig1, hipMemcpyHostToDevice, s));
-				uint32_t *d_st2 = M.lvl2, *d_en2 = M.lvl2 + (uint64_t)nb2 * MSD_MAXBINS, *d_tab2 = M.lvl2 + 2ull * nb2 * MSD_MAXBINS;
-				const uint32_t nbF2 = nb2 * (uint32_t)MSD_MAXBINS;
+				B3M_HIP(hipStreamSynchronize(s));
+			}
+			for (Cls &c : run) {
+				const int d2 = c.d2;
+				const uint32_t nb2 = c.nb, nbF2 = nb2 << d2;
+				uint32_t *d_st2 = M.lvl2, *d_en2 = M.lvl2 + nbF2, *d_tab2 = M.lvl2 + 2ull * nbF2;
 				const FinishLists hl2[2] = {{M.mid2, (uint32_t)M.list2_cap, M.big2, (uint32_t)M.list2_cap, M.huge2, (uint32_t)M.huge_cap, F_HUGE},
 				                            {nullptr, 0u, M.big2, (uint32_t)M.list2_cap, M.huge2, (uint32_t)M.huge_cap, F_HUGE}};
 				B3M_HIP(hipMemcpyAsync(dl + 2, hl2, sizeof hl2, hipMemcpyHostToDevice, s));
-				B3M_HIP(hipMemcpyAsync(M.tiles, tiles2.data(), sizeof(MsdTile) * tiles2.size(), hipMemcpyHostToDevice, s));
-				B3M_HIP(hipMemcpyAsync(d_tab2, tab2.data(), 4 * tab2.size(), hipMemcpyHostToDevice, s));
+				B3M_HIP(hipMemcpyAsync(M.tiles, c.tiles.data(), sizeof(MsdTile) * c.tiles.size(), hipMemcpyHostToDevice, s));
+				B3M_HIP(hipMemcpyAsync(d_tab2, c.tab.data(), 4 * c.tab.size(), hipMemcpyHostToDevice, s));
 				B3M_HIP(hipMemsetAsync(M.mid2, 0, 4, s)); B3M_HIP(hipMemsetAsync(M.big2, 0, 4, s)); B3M_HIP(hipMemsetAsync(M.huge2, 0, 4, s));
 				B3M_HIP(hipStreamSynchronize(s));                         // host vectors must outlive the copies
 				L1Args Bq{};
-				Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = MSD_MAXBITS; Bq.shift = 64 - consumed - MSD_MAXBITS;
-				hipLaunchKernelGGL((k_l1_local<L1_THREADS, L1_TCH>), dim3((uint32_t)tiles2.size()), dim3(L1_THREADS), 0, s, Bq);
-				hipLaunchKernelGGL(k_run_totals, dim3(nb2), dim3(256), 0, s, M.runtab, M.runpre, d_tab2, nb2, MSD_MAXBITS, (uint32_t)len, d_st2, d_en2);
+				Bq.rec_in = ws.keyA; Bq.rec_out = ws.keyB; Bq.tiles = M.tiles; Bq.runtab = M.runtab; Bq.D = d2; Bq.shift = 64 - consumed - d2;
+				hipLaunchKernelGGL((k_l1_local<L1_THREADS, L1_TCH>), dim3((uint32_t)c.tiles.size()), dim3(L1_THREADS), 0, s, Bq);
+				hipLaunchKernelGGL(k_run_totals, dim3(nb2), dim3(256), 0, s, M.runtab, M.runpre, d_tab2, nb2, d2, (uint32_t)len, d_st2, d_en2);
 				stage("level 2: partition");
 				FinishSrc F2{};
-				F2.rec = ws.keyB; F2.bstart = d_st2; F2.bend = d_en2; F2.runtab = M.runtab; F2.runpre = M.runpre; F2.btab = d_tab2; F2.nb0 = nb2; F2.D1 = MSD_MAXBITS;
+				F2.rec = ws.keyB; F2.bstart = d_st2; F2.bend = d_en2; F2.runtab = M.runtab; F2.runpre = M.runpre; F2.btab = d_tab2; F2.nb0 = nb2; F2.D1 = d2;
 				F2.chunk = (uint32_t)L1_CHUNK; F2.nbF = nbF2; F2.nrec = (uint32_t)len;
-				const int fbits2 = fbits - MSD_MAXBITS;
+				const int fbits2 = fbits - d2;
 				if (!no_fast && fbits2 >= F_BINBITS && fbits2 - F_BINBITS <= 12) {
 					int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;
 					if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
@@ -2515,20 +2583,21 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				const uint32_t gbig2 = (uint32_t)std::min<uint64_t>(nbF2, 2048);
 				if (fbits2 > 8) {
 					if (need_sa)
-						hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - 16, fbits2 - 8, O);
+						hipLaunchKernelGGL(k_bucket_finish<true>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - d2 - 8, fbits2 - 8, O);
 					else
-						hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - 16, fbits2 - 8, O);
+						hipLaunchKernelGGL(k_bucket_finish<false>, dim3(gbig2), dim3(MSD_THREADS), 0, s, (const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, 8, 64 - consumed - d2 - 8, fbits2 - 8, O);
 				} else {
 					hipLaunchKernelGGL(k_list_to_overflow, dim3(64), dim3(256), 0, s, (const uint64_t *)ws.keyA, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, sa, pb, O);
 				}
 				stage("level 2: finish");
-				lvl2_done = true; lvl2_ran = true;
-				if (getenv("B3M_DEBUG")) {
-					uint32_t l2[3] = {0, 0, 0};
-					B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
-					B3M_HIP(hipStreamSynchronize(s));
-					fprintf(stderr, "[b3m] level 2: %u buckets, %zu tiles, fbits %d; listed again: mid %u big %u huge %u\n", nb2, tiles2.size(), fbits2, l2[0], l2[1], l2[2]);
-				}
+				lvl2_ran = true;
+				// a list that ran over would have dropped sub-buckets silently
+				uint32_t l2[3] = {0, 0, 0};
+				B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
+				B3M_HIP(hipStreamSynchronize(s));
+				B3M_REQUIRE(l2[0] <= M.list2_cap && l2[1] <= M.list2_cap && l2[2] <= M.huge_cap, "internal: a bucket list of level 2 ran over");
+				if (getenv("B3M_DEBUG"))
+					fprintf(stderr, "[b3m] level 2: %u buckets by %d bits, %zu tiles, fbits %d; listed again: mid %u big %u huge %u\n", nb2, d2, c.tiles.size(), fbits2, l2[0], l2[1], l2[2]);
 			}
 		}
 		if (!gather || nbig1) {
@@ -2562,6 +2631,10 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_HIP(hipMemsetAsync(gcnt, 0, 4, s));
 			hipLaunchKernelGGL(k_tie_collect, dim3(nblk((len + 31) / 32, 256 * TIE_WPT)), dim3(256), 0, s, ws.t[0], len, glist, gcap, gcnt);
 			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0, O.smp);
+			if (getenv("B3M_DEBUG")) {
+				uint32_t ng = 0; B3M_HIP(hipMemcpyAsync(&ng, gcnt, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
+				fprintf(stderr, "[b3m] tie fix: %u groups of records with equal key fields\n", ng);
+			}
 		} else
 			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0, O.smp);
 	}
@@ -2580,12 +2653,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	                                 (unsigned long long)len, D0e, dg.D1, nlist[0], nlist[1], nlist[2], (unsigned long long)M.mid_cap, (unsigned long long)M.big_cap, (unsigned long long)M.huge_cap, nov);
 	// a list that ran over would have dropped buckets silently
 	B3M_REQUIRE(nlist[0] <= M.mid_cap && nlist[1] <= M.big_cap && nlist[2] <= M.huge_cap, "internal: a bucket list of the MSD finish ran over");
-	if (lvl2_ran) {
-		uint32_t l2[3] = {0, 0, 0};
-		B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
-		B3M_HIP(hipStreamSynchronize(s));
-		B3M_REQUIRE(l2[0] <= M.list2_cap && l2[1] <= M.list2_cap && l2[2] <= M.huge_cap, "internal: a bucket list of level 2 ran over");
-	}
+	(void)lvl2_ran;
 	out.msd_overflow_buckets = nov;
 	if (nov) out.late_writes = true;
 	bool rerun_with_sa = false;

@@ -19,7 +19,15 @@ def _set_env(**kv):
 
 
 def clear_switches():
-    _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None)
+    _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None,
+             B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None)
+
+
+def _tie_switches(rng):
+    """the list-based rounds' alternatives: radix sorts only / from symbol 0 with the whole inverse suffix array (the forms before the LDS tiles)"""
+    t = int(rng.integers(0, 5))
+    _set_env(B3M_NO_TIE_TILES=1 if t == 2 else None, B3M_TIE_FROM_0=1 if t == 3 else None, B3M_ISA_FULL=1 if t == 3 else None, B3M_ISA_SEARCH_MAX=0 if t == 4 else None)
+    return t
 
 
 def case_small(rng, O, engine):
@@ -51,7 +59,8 @@ def case_small(rng, O, engine):
              B3M_LVL2_MIN=[None, 0, 0][int(rng.integers(0, 3))], B3M_FINISH_V3=[None, None, 0][int(rng.integers(0, 3))])     # level 2 on small inputs; k_finish_fast instead of v3
     isar = int([0, 64, 4096, 1000, 7][int(rng.integers(0, 5))])
     keep = bool(rng.integers(0, 4) == 0)
-    desc = "small type=%s nb=%d kind=%d bs=%d isar=%d keep_sa=%d d1=%d" % (itype, nb, kind, bs, isar, keep, d1)
+    tie = _tie_switches(rng)
+    desc = "small type=%s nb=%d kind=%d bs=%d isar=%d keep_sa=%d d1=%d tie=%d" % (itype, nb, kind, bs, isar, keep, d1, tie)
     try:
         out, res, plan = engine.bwt_device(buf, itype, blocksize=bs, isasamplingrate=isar, keep_sa=keep)
         ok = bool(np.array_equal(out, O.bwt(s)))
@@ -172,7 +181,8 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
     _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None,
              B3M_LVL2_MIN=0 if alt == 4 else None, B3M_NO_LEVEL2=1 if alt == 5 else None)
     rate = int([1 << 16, 1024, 3000][int(rng.integers(0, 3))])
-    desc = "large n=%d %s comp=%d form=%d alt=%d rate=%d planted=%s" % (n, itype, comp, form, alt, rate, planted)
+    tie = _tie_switches(rng)
+    desc = "large n=%d %s comp=%d form=%d alt=%d rate=%d tie=%d planted=%s" % (n, itype, comp, form, alt, rate, tie, planted)
     ok = True
     try:
         plan = engine.Plan(n, itype, isasamplingrate=rate)

@@ -429,8 +429,8 @@ def test_list_rounds_in_tiles_and_behind_the_shared_symbols(gpu, oracle, itype, 
     s = oracle.symbols_from_file_bytes(buf, itype)
     ref = oracle.bwt(s)
     sa = oracle.sa_circular(s)
-    for env in ({}, {"B3M_NO_TIE_TILES": "1"}, {"B3M_TIE_FROM_0": "1"}):
-        for k in ("B3M_NO_TIE_TILES", "B3M_TIE_FROM_0"):
+    for env in ({}, {"B3M_NO_TIE_TILES": "1"}, {"B3M_TIE_FROM_0": "1"}, {"B3M_ISA_SEARCH_MAX": "0"}, {"B3M_ISA_FULL": "1"}):
+        for k in ("B3M_NO_TIE_TILES", "B3M_TIE_FROM_0", "B3M_ISA_SEARCH_MAX", "B3M_ISA_FULL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
