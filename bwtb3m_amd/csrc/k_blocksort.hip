@@ -229,13 +229,14 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 // (k_tie_large_*).  Groups of up to TT_COUNT members are ordered by counting (each member counts the smaller ones), larger
 // ones by a bitonic network over the tile, keyed (group, key).
 // ------------------------------------------------------------------------------------------------
-constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 256;
+constexpr int MP_GROUP = 512, MP_ROW = 9;               // pieces above MP_GROUP slots are split further; table row = piece start >> MP_ROW
+constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
 static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
 
 // flag[s] = 1 if the group of slot s has more than TT_GROUP members (hid[s] = list index of the group's head); flag[u] = 0
-__device__ __forceinline__ bool tie_large(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint64_t s)
+__device__ __forceinline__ bool tie_large(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint64_t s, uint32_t group = TT_GROUP)
 {
-	const uint64_t far = (uint64_t)hid[s] + TT_GROUP;
+	const uint64_t far = (uint64_t)hid[s] + group;
 	return far < u && gid[far] == gid[s];
 }
 __global__ void k_tie_large_flags(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint32_t *flag)
@@ -252,10 +253,24 @@ __global__ void k_tie_large_compact(const uint32_t *flag_scan, const uint32_t *h
 	if (tie_large(hid, gid, u, s)) { const uint32_t p = flag_scan[s]; U2[p] = U[s]; gid2[p] = gid[s]; lpos[p] = (uint32_t)s; }
 }
 
-template <bool ISA>
-__global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint32_t *U, const uint32_t *gid, uint64_t u, uint32_t *idx,
-                                                         const uint32_t *isa, uint64_t off, uint32_t *hid)
+// MODE 0: keys from the text; 1: ranks (isa); 2: keys and suffixes are given per slot (kin, vin: what the splits of the large groups left, k_msd_*)
+// and a group also starts where the splits marked a boundary (pb[s] & MSD_BND)
+constexpr uint32_t MSD_BND = 0x80000000u, MSD_LOC = 0x40000000u, MSD_PID = 0x3FFFFFFFu;      // (MSD_LOC: the slot's pair lives in the second of the two buffers)
+template <int MODE>
+__device__ __forceinline__ bool tile_head(const uint32_t *gid, const uint32_t *pb, uint64_t s)
 {
+	return s == 0 || gid[s] != gid[s - 1] || (MODE == 2 && (pb[s] & MSD_BND));
+}
+template <int MODE>
+__global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint32_t *U, const uint32_t *gid, uint64_t u, uint32_t *idx,
+                                                         const uint32_t *isa, uint64_t off, uint32_t *hid,
+                                                         const uint64_t *kin, const uint32_t *vin, const uint32_t *pb,
+                                                         const uint64_t *kin1, const uint32_t *vin1, int kshift)
+{
+	// kshift = 12 where the key leaves room (pacterm: 48 bits, ranks: 32): the slot inside the tile rides in the low bits, every key of the tile is
+	// distinct and one 64-bit compare per pair orders them (0: 64-bit keys, ties are broken by the slot in a second compare)
+	constexpr bool ISA = MODE == 1;
+	constexpr uint32_t GROUP = MODE == 2 ? MP_GROUP : TT_GROUP;       // (MODE 2: a group above MP_GROUP is a piece of one key, k_msd_leftover's)
 	__shared__ uint64_t sk[TT_CAP];                  // keys
 	__shared__ uint32_t sv[TT_CAP];                  // suffixes
 	__shared__ uint16_t sg[TT_CAP];                  // group of the slot, counted inside the tile from 1 (0xFFFF: padding)
@@ -267,17 +282,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 	if (tid == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0u; red[2] = 0xFFFFFFFFu; red[3] = 0u; }
 	__syncthreads();
 	for (uint64_t s = c0 + tid; s < c1; s += TT_THREADS)
-		if (s == 0 || gid[s] != gid[s - 1]) { atomicMin(&red[0], (uint32_t)s); atomicMax(&red[1], (uint32_t)s); }
+		if (tile_head<MODE>(gid, pb, s)) { atomicMin(&red[0], (uint32_t)s); atomicMax(&red[1], (uint32_t)s); }
 	__syncthreads();
 	const uint32_t a = red[0], hl = red[1];
 	if (a == 0xFFFFFFFFu) return;                    // no group starts here (the inside of a large one)
 	// the end of the last group: the first head behind the stride, looked for as far as a group of TT_GROUP reaches
-	const uint64_t lim = (uint64_t)hl + TT_GROUP + 1 < u ? (uint64_t)hl + TT_GROUP + 1 : u;
-	for (uint64_t s = c1 + tid; s < lim; s += TT_THREADS) if (gid[s] != gid[s - 1]) atomicMin(&red[2], (uint32_t)s);
+	const uint64_t lim = (uint64_t)hl + GROUP + 1 < u ? (uint64_t)hl + GROUP + 1 : u;
+	for (uint64_t s = c1 + tid; s < lim; s += TT_THREADS) if (tile_head<MODE>(gid, pb, s)) atomicMin(&red[2], (uint32_t)s);
 	__syncthreads();
 	uint64_t e;
 	if (red[2] != 0xFFFFFFFFu) e = red[2];
-	else e = (u - hl <= (uint64_t)TT_GROUP) ? u : hl;       // runs to the end of the list, or is a large group: not this tile's
+	else e = (u - hl <= (uint64_t)GROUP) ? u : hl;          // runs to the end of the list, or is a large group: not this tile's
 	const uint32_t m = (uint32_t)(e - a);
 	if (m == 0) return;
 	uint32_t P = 64; while (P < m) P <<= 1;
@@ -289,12 +304,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 		uint32_t head = 0;
 		if (p < m) {
 			const uint64_t s = (uint64_t)a + p;
-			const uint32_t i = idx[U[s]];
+			const bool loc1 = MODE == 2 && (pb[s] & MSD_LOC);
+			const uint32_t i = MODE == 2 ? (loc1 ? vin1[s] : vin[s]) : idx[U[s]];
 			uint64_t key;
-			if (ISA) { uint64_t q = (uint64_t)i + off; if (q >= T.n) q -= T.n; key = isa[q]; }
+			if (MODE == 2) key = loc1 ? kin1[s] : kin[s];
+			else if (ISA) { uint64_t q = (uint64_t)i + off; if (q >= T.n) q -= T.n; key = isa[q]; }
 			else key = key_at_off(T, i, off);
-			head = (p == 0 || gid[s] != gid[s - 1]) ? 1u : 0u;
-			sk[p] = key; sv[p] = i;
+			head = (p == 0 || tile_head<MODE>(gid, pb, s)) ? 1u : 0u;
+			sk[p] = (key << kshift) | (kshift ? (uint64_t)p : 0ull); sv[p] = i;
 			if (head) hsum += 1;
 			sg[p] = (uint16_t)(hsum | (head << 15));   // partial count inside the thread (< 16), head mark in bit 15
 		} else if (p < P) { sk[p] = ~0ull; sv[p] = 0u; sg[p] = 0xFFFFu; }
@@ -338,7 +355,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 				const uint32_t g = sg[p], b = gs[g], en = gs[g + 1];
 				const uint64_t my = sk[p];
 				uint32_t less = 0;
-				for (uint32_t j = b; j < en; ++j) { const uint64_t kj = sk[j]; less += (kj < my || (kj == my && j < p)) ? 1u : 0u; }
+				if (kshift) { for (uint32_t j = b; j < en; ++j) less += sk[j] < my ? 1u : 0u; }
+				else for (uint32_t j = b; j < en; ++j) { const uint64_t kj = sk[j]; less += (kj < my || (kj == my && j < p)) ? 1u : 0u; }
 				mk[k] = my; mv[k] = sv[p]; dst[k] = b + less;
 			}
 		}
@@ -369,9 +387,175 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 	for (uint32_t p = tid; p < m; p += TT_THREADS) {
 		const uint64_t s = (uint64_t)a + p;
 		idx[U[s]] = sv[p];
-		const bool head = p == 0 || sg[p] != sg[p - 1] || sk[p] != sk[p - 1];
+		const bool head = p == 0 || sg[p] != sg[p - 1] || (sk[p] >> kshift) != (sk[p - 1] >> kshift);
 		hid[s] = head ? (uint32_t)s : 0u;
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large groups inside a round: MSD splits on the round's own key.  Two radix sorts of a sub-list cost ten passes whatever its groups look
+// like; a group of a repeat family is mostly its consensus, so splitting it by the key's leading byte, then the pieces still above
+// MP_GROUP by the next byte, ... touches 1 + 0.66 + 0.43 + ... of it, and whatever falls to MP_GROUP or below is finished by the tiles ON THE
+// SAME KEY (so the whole list still advances by one key per round).  A piece that is still large after the key's last byte holds one
+// key: it stays a group.
+//   K/V, K2/V2: key and suffix of every list slot, in the first pair of buffers or -- MSD_LOC, after an odd number of splits -- in the second;
+//   pid[s] = (start slot of the large piece s is in) + 1, or 0, and MSD_BND where a piece starts; tab[row * 256 + d], row = piece start >> 11
+//   (pieces are longer than 512 slots: a row has one piece): counts, then places.
+// A chunk of 1024 slots meets at most three pieces (one that began in front of it, two that begin inside): three LDS histograms.
+// ------------------------------------------------------------------------------------------------
+constexpr int MP_CHUNK = 1024, MP_THREADS = 256, MP_PER = MP_CHUNK / MP_THREADS;
+static_assert(MP_CHUNK <= 2 * MP_GROUP && (1 << MP_ROW) <= MP_GROUP, "at most two pieces begin inside a chunk, one piece per table row");
+static_assert(MP_GROUP <= TT_COUNT, "what the splits leave is ordered by counting");
+
+template <bool ISA>
+__global__ void k_tie_keyvals(TextView T, const uint32_t *U, const uint32_t *idx, uint64_t u, const uint32_t *isa, uint64_t off, uint64_t *K, uint32_t *V)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t i = idx[U[s]];
+	uint64_t key;
+	if (ISA) { uint64_t q = (uint64_t)i + off; if (q >= T.n) q -= T.n; key = isa[q]; }
+	else key = key_at_off(T, i, off);
+	K[s] = key; V[s] = i;
+}
+// pid of the large groups (hid[s] = list index of the group's head); *nlarge += their slots
+// (one atomic per workgroup on the counter: one per wave of a 360 M list took 9 ms); act[chunk] = the chunk has slots of pieces: the splits skip the others
+__device__ __forceinline__ void msd_block_count(uint32_t mine, uint32_t *total, uint8_t *act)
+{
+	__shared__ uint32_t acc;
+	if (threadIdx.x == 0) acc = 0u;
+	__syncthreads();
+	const uint32_t w = wave_incl_sum(mine);
+	if (lane_id() == 63u && w) atomicAdd(&acc, w);
+	__syncthreads();
+	if (threadIdx.x == 0) { act[blockIdx.x] = acc ? 1 : 0; if (acc) atomicAdd(total + (blockIdx.x & 63u), acc); }      // (64 counters, summed by the host)
+}
+__global__ __launch_bounds__(MP_THREADS) void k_msd_init(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint32_t *pid, uint32_t *nlarge, uint8_t *act)
+{
+	uint32_t mine = 0;
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) {
+		const uint64_t s = (uint64_t)blockIdx.x * MP_CHUNK + threadIdx.x + (uint64_t)k * MP_THREADS;
+		if (s >= u) continue;
+		const bool large = tie_large(hid, gid, u, s, MP_GROUP);
+		pid[s] = large ? hid[s] + 1u : 0u;
+		mine += large ? 1u : 0u;
+	}
+	msd_block_count(mine, nlarge, act);
+}
+// the chunk's pieces: ps[0] = start of the one that began in front of the chunk, ps[1] / ps[2] = the first / last start inside
+__device__ __forceinline__ void msd_chunk_pieces(const uint32_t (&q)[MP_PER], uint64_t c0, uint32_t *ps)
+{
+	if (threadIdx.x == 0) { ps[0] = 0u; ps[1] = 0xFFFFFFFFu; ps[2] = 0u; }
+	__syncthreads();
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) if (q[k]) {
+		const uint32_t st = q[k] - 1u;
+		if ((uint64_t)st < c0) ps[0] = st; else { atomicMin(&ps[1], st); atomicMax(&ps[2], st); }
+	}
+	__syncthreads();
+}
+__device__ __forceinline__ uint32_t msd_local_piece(uint32_t st, uint64_t c0, const uint32_t *ps) { return (uint64_t)st < c0 ? 0u : (st == ps[1] ? 1u : 2u); }
+
+__global__ __launch_bounds__(MP_THREADS) void k_msd_count(const uint64_t *K, const uint32_t *pid, uint64_t u, int shift, uint32_t *tab, const uint8_t *act)
+{
+	__shared__ uint32_t h[3 * 256];
+	__shared__ uint32_t ps[3];
+	if (!act[blockIdx.x]) return;
+	const uint32_t tid = threadIdx.x;
+	const uint64_t c0 = (uint64_t)blockIdx.x * MP_CHUNK;
+	uint32_t q[MP_PER];
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) { const uint64_t s = c0 + tid + (uint64_t)k * MP_THREADS; q[k] = s < u ? pid[s] & MSD_PID : 0u; }
+	for (uint32_t t = tid; t < 768u; t += MP_THREADS) h[t] = 0u;
+	msd_chunk_pieces(q, c0, ps);
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) if (q[k]) {
+		const uint64_t s = c0 + tid + (uint64_t)k * MP_THREADS;
+		atomicAdd(&h[msd_local_piece(q[k] - 1u, c0, ps) * 256u + (uint32_t)((K[s] >> shift) & 255u)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t t = tid; t < 768u; t += MP_THREADS) if (h[t]) atomicAdd(&tab[(uint64_t)(ps[t >> 8] >> MP_ROW) * 256u + (t & 255u)], h[t]);
+}
+// counts -> places inside the piece (exclusive); one wave per table row, four bytes per lane (a row belongs to the piece that starts in its
+// 512 slots: the rows of two chunks are those of chunk 2r and 2r + 1)
+__global__ __launch_bounds__(256) void k_msd_scan(uint32_t *tab, uint64_t rows, const uint8_t *act, uint64_t nchunk)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= rows) return;
+	const uint64_t c = r >> 1;                                    // (MP_CHUNK = 2 << MP_ROW)
+	if (c < nchunk && !act[c]) return;
+	uint4 *row = reinterpret_cast<uint4 *>(tab + r * 256u) + lane_id();
+	const uint4 v = *row;
+	const uint32_t t = v.x + v.y + v.z + v.w, inc = wave_incl_sum(t);
+	uint4 o; o.x = inc - t; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+	*row = o;
+}
+static_assert(MP_CHUNK == (2 << MP_ROW), "k_msd_scan: two table rows per chunk");
+// the pairs to their byte's place inside the piece (any order inside it), from one pair of buffers to the other; slots outside the pieces stay where they are
+__global__ __launch_bounds__(MP_THREADS) void k_msd_scatter(const uint64_t *K, const uint32_t *V, const uint32_t *pid, uint64_t u, int shift, uint32_t *tab,
+                                                            uint64_t *K2, uint32_t *V2, const uint8_t *act)
+{
+	__shared__ uint32_t h[3 * 256], hb[3 * 256];
+	__shared__ uint32_t ps[3];
+	if (!act[blockIdx.x]) return;
+	const uint32_t tid = threadIdx.x;
+	const uint64_t c0 = (uint64_t)blockIdx.x * MP_CHUNK;
+	uint32_t q[MP_PER], v[MP_PER]; uint64_t key[MP_PER];
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) {
+		const uint64_t s = c0 + tid + (uint64_t)k * MP_THREADS;
+		q[k] = 0u; key[k] = 0; v[k] = 0;
+		if (s < u) { q[k] = pid[s] & MSD_PID; if (q[k]) { key[k] = K[s]; v[k] = V[s]; } }
+	}
+	for (uint32_t t = tid; t < 768u; t += MP_THREADS) h[t] = 0u;
+	msd_chunk_pieces(q, c0, ps);
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) if (q[k]) atomicAdd(&h[msd_local_piece(q[k] - 1u, c0, ps) * 256u + (uint32_t)((key[k] >> shift) & 255u)], 1u);
+	__syncthreads();
+	for (uint32_t t = tid; t < 768u; t += MP_THREADS) {
+		const uint32_t c = h[t];
+		hb[t] = c ? atomicAdd(&tab[(uint64_t)(ps[t >> 8] >> MP_ROW) * 256u + (t & 255u)], c) : 0u;
+		h[t] = 0u;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) {
+		const uint64_t s = c0 + tid + (uint64_t)k * MP_THREADS;
+		if (s >= u || !q[k]) continue;
+		const uint32_t st = q[k] - 1u, t = msd_local_piece(st, c0, ps) * 256u + (uint32_t)((key[k] >> shift) & 255u);
+		const uint64_t dest = (uint64_t)st + hb[t] + atomicAdd(&h[t], 1u);
+		K2[dest] = key[k]; V2[dest] = v[k];
+	}
+}
+// after the scatter the table holds the END of every byte's range (= the start of the next byte's): the new pieces are the ranges above TT_GROUP
+// (K: where this split wrote; loc: MSD_LOC if that is the second pair of buffers)
+__global__ __launch_bounds__(MP_THREADS) void k_msd_repid(const uint64_t *K, uint32_t *pid, uint64_t u, int shift, const uint32_t *tab, uint32_t loc, uint32_t *nleft, uint8_t *act)
+{
+	if (!act[blockIdx.x]) return;
+	uint32_t mine = 0;
+	#pragma unroll
+	for (int k = 0; k < MP_PER; ++k) {
+		const uint64_t s = (uint64_t)blockIdx.x * MP_CHUNK + threadIdx.x + (uint64_t)k * MP_THREADS;
+		if (s >= u) continue;
+		const uint32_t p = pid[s], q = p & MSD_PID;
+		if (!q) continue;
+		const uint32_t st = q - 1u, d = (uint32_t)((K[s] >> shift) & 255u);
+		const uint32_t *row = tab + (uint64_t)(st >> MP_ROW) * 256u;
+		const uint32_t e = row[d], b = d ? row[d - 1] : 0u;
+		const bool large = e - b > (uint32_t)MP_GROUP;
+		pid[s] = (large ? st + b + 1u : 0u) | (p & MSD_BND) | (s == (uint64_t)st + b ? MSD_BND : 0u) | loc;
+		mine += large ? 1u : 0u;
+	}
+	msd_block_count(mine, nleft, act);
+}
+// pieces still large after the key's last byte hold one key each: they stay groups
+__global__ void k_msd_leftover(const uint32_t *U, const uint32_t *gid, const uint32_t *pid, const uint32_t *V, const uint32_t *V1, uint64_t u, uint32_t *idx, uint32_t *hid)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u || !(pid[s] & MSD_PID)) return;
+	idx[U[s]] = (pid[s] & MSD_LOC) ? V1[s] : V[s];
+	hid[s] = tile_head<2>(gid, pid, s) ? (uint32_t)s : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,6 +793,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
 	// tiles (k_tie_tile): 32-bit positions; B3M_NO_TIE_TILES=1 keeps every round on the radix sorts
 	const bool tiles_ok = !idx_hi && !(getenv("B3M_NO_TIE_TILES") && atoi(getenv("B3M_NO_TIE_TILES")));
+	// large groups split inside the round (k_msd_*); B3M_NO_TIE_MSD=1: through the radix sorts as a sub-list
+	const bool msd_on = !(getenv("B3M_NO_TIE_MSD") && atoi(getenv("B3M_NO_TIE_MSD")));
 	bool any_large = true;                             // (groups only shrink: once none is large, none will be)
 	for (uint64_t depth = depth0; u > 0; ++depth) {
 		const uint64_t off = sym_off + depth * K;       // symbols in front of this round's key
@@ -642,6 +828,53 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 				isa_sparse = false;
 			} else if (nq) hipLaunchKernelGGL(k_isa_search, dim3(nblk(nq)), dim3(256), 0, s, T, (const uint32_t *)idx, T.n, (const uint32_t *)Q, nq, isa);
 		}
+		const uint32_t ntile = (uint32_t)((u + TT_STRIDE - 1) / TT_STRIDE);
+		const int kshift = (isa || key_off_bits(T.type) <= 52) ? 12 : 0;      // (k_tie_tile: the slot in the key's low bits)
+		if (tiles_ok && msd_on && u >= 8192 && u < (1ull << 30)) {
+			// ---- tiles; large groups are split by the key's bytes first ----
+			uint32_t *pid = flag, *tab = hid;               // (hid is written last, by the tiles; flag is free until the round's compaction)
+			uint32_t *cnt = radix.tile_hist;                 // 64 words (the radix sorts' tile histograms: 256 words per 4096 keys, idle in such a round)
+			const uint64_t rows = (u >> MP_ROW) + 2;
+			const uint32_t nchunk = (uint32_t)((u + MP_CHUNK - 1) / MP_CHUNK);
+			uint8_t *act = reinterpret_cast<uint8_t *>(radix.tile_hist + 64);   // a byte per chunk
+			uint32_t h_n = 0, h_c[64];
+			auto read_count = [&]() { B3M_HIP(hipMemcpyAsync(h_c, cnt, 256, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s)); uint64_t t = 0; for (int i = 0; i < 64; ++i) t += h_c[i]; return (uint32_t)std::min<uint64_t>(t, 0xFFFFFFFFull); };
+			if (any_large) {
+				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+				inclusive_max_u32(hid, u, scan_ws, s);
+				B3M_HIP(hipMemsetAsync(cnt, 0, 256, s));
+				hipLaunchKernelGGL(k_msd_init, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint32_t *)hid, (const uint32_t *)gid, u, pid, cnt, act);
+				h_n = read_count();
+				if (h_n == 0) any_large = false;
+			}
+			if (h_n == 0) {
+				if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
+				else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
+			} else {
+				if (isa) hipLaunchKernelGGL(k_tie_keyvals<true>, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, (const uint32_t *)isa, h, kx, vx);
+				else hipLaunchKernelGGL(k_tie_keyvals<false>, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, (const uint32_t *)nullptr, off, kx, vx);
+				int cur = 0;                                  // the pieces' pairs are in (kx, vx) / (ky, vy)
+				const int kb = isa ? 32 : (key_off_bits(T.type) + 7) / 8 * 8;
+				uint32_t passes = 0;
+				for (int shift = kb - 8; shift >= 0 && h_n; shift -= 8) {
+					B3M_HIP(hipMemsetAsync(tab, 0, 4ull * rows * 256, s));
+					uint64_t *K0 = cur ? ky : kx, *K1 = cur ? kx : ky; uint32_t *V0 = cur ? vy : vx, *V1 = cur ? vx : vy;
+					hipLaunchKernelGGL(k_msd_count, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K0, (const uint32_t *)pid, u, shift, tab, (const uint8_t *)act);
+					hipLaunchKernelGGL(k_msd_scan, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, s, tab, rows, (const uint8_t *)act, (uint64_t)nchunk);
+					hipLaunchKernelGGL(k_msd_scatter, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K0, (const uint32_t *)V0, (const uint32_t *)pid, u, shift, tab, K1, V1, (const uint8_t *)act);
+					cur ^= 1;
+					B3M_HIP(hipMemsetAsync(cnt, 0, 256, s));
+					hipLaunchKernelGGL(k_msd_repid, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K1, pid, u, shift, (const uint32_t *)tab, cur ? MSD_LOC : 0u, cnt, act);
+					h_n = read_count();
+					++passes;
+				}
+				if (dbg >= 3) fprintf(stderr, "[b3m]   large groups: %u split passes, %u slots in pieces of one key\n", passes, h_n);
+				// (the table in hid is dead: the tiles and the pieces of one key write the heads there)
+				hipLaunchKernelGGL(k_tie_tile<2>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)kx, (const uint32_t *)vx, (const uint32_t *)pid,
+				                   (const uint64_t *)ky, (const uint32_t *)vy, kshift);
+				if (h_n) hipLaunchKernelGGL(k_msd_leftover, dim3(nblk(u)), dim3(256), 0, s, (const uint32_t *)U, (const uint32_t *)gid, (const uint32_t *)pid, (const uint32_t *)vx, (const uint32_t *)vy, u, idx, hid);
+			}
+		} else {
 		// ---- which slots belong to groups too large for a tile ----
 		uint64_t nL = u;
 		if (tiles_ok) {
@@ -665,11 +898,11 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			const uint64_t hu = (u + 1) / 2;
 			uint32_t *U_L = reinterpret_cast<uint32_t *>(kx + hu), *gid_L = U_L + nL, *lpos = reinterpret_cast<uint32_t *>(ky + hu);
 			if (nL) hipLaunchKernelGGL(k_tie_large_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, gid, U, u, U_L, gid_L, lpos);
-			const uint32_t ntile = (uint32_t)((u + TT_STRIDE - 1) / TT_STRIDE);
-			if (isa) hipLaunchKernelGGL(k_tie_tile<true>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid);
-			else hipLaunchKernelGGL(k_tie_tile<false>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid);
+			if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
+			else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
 			if (nL) tie_round_lsd(T, idx, nullptr, nullptr, U_L, gid_L, nL, kx, ky, vx, vy, hid, lpos, isa, h, off, gbits, radix, s);
 			if (dbg >= 3) fprintf(stderr, "[b3m]   tiles: %u, %llu slots of large groups through the radix sorts\n", ntile, (unsigned long long)nL);
+		}
 		}
 		inclusive_max_u32(hid, u, scan_ws, s);
 		if (isa) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);   // every key of this round has been read

@@ -20,13 +20,14 @@ def _set_env(**kv):
 
 def clear_switches():
     _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None,
-             B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None)
+             B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None, B3M_NO_TIE_MSD=None)
 
 
 def _tie_switches(rng):
     """the list-based rounds' alternatives: radix sorts only / from symbol 0 with the whole inverse suffix array (the forms before the LDS tiles)"""
-    t = int(rng.integers(0, 5))
-    _set_env(B3M_NO_TIE_TILES=1 if t == 2 else None, B3M_TIE_FROM_0=1 if t == 3 else None, B3M_ISA_FULL=1 if t == 3 else None, B3M_ISA_SEARCH_MAX=0 if t == 4 else None)
+    t = int(rng.integers(0, 6))
+    _set_env(B3M_NO_TIE_TILES=1 if t == 2 else None, B3M_TIE_FROM_0=1 if t == 3 else None, B3M_ISA_FULL=1 if t == 3 else None, B3M_ISA_SEARCH_MAX=0 if t == 4 else None,
+             B3M_NO_TIE_MSD=1 if t == 5 else None)
     return t
 
 

@@ -423,14 +423,15 @@ def _repeat_family_bases(oracle, nb, seed, tail):
 def test_list_rounds_in_tiles_and_behind_the_shared_symbols(gpu, oracle, itype, tail, monkeypatch):
     """the rounds on the overflow list: they start behind the symbols every listed range shares (in the record sort's reading: the terminator
     and what follows read as A, so a suffix that ends inside those symbols -- the poly-A tails here -- is placed by its length), small groups are
-    ordered in LDS tiles, large ones by the radix sorts.  Equal to the oracle with the tiles, without them, and from symbol 0."""
+    ordered in LDS tiles, large ones split by the bytes of the round's key first (or sorted by the radix sorts as a sub-list).  Equal to the oracle in
+    every form, and from symbol 0."""
     nb = (1 << 19) + 777
     buf = _pac(oracle, _repeat_family_bases(oracle, nb, 500 + tail, tail))
     s = oracle.symbols_from_file_bytes(buf, itype)
     ref = oracle.bwt(s)
     sa = oracle.sa_circular(s)
-    for env in ({}, {"B3M_NO_TIE_TILES": "1"}, {"B3M_TIE_FROM_0": "1"}, {"B3M_ISA_SEARCH_MAX": "0"}, {"B3M_ISA_FULL": "1"}):
-        for k in ("B3M_NO_TIE_TILES", "B3M_TIE_FROM_0", "B3M_ISA_SEARCH_MAX", "B3M_ISA_FULL"):
+    for env in ({}, {"B3M_NO_TIE_MSD": "1"}, {"B3M_NO_TIE_TILES": "1"}, {"B3M_TIE_FROM_0": "1"}, {"B3M_ISA_SEARCH_MAX": "0"}, {"B3M_ISA_FULL": "1"}):
+        for k in ("B3M_NO_TIE_MSD", "B3M_NO_TIE_TILES", "B3M_TIE_FROM_0", "B3M_ISA_SEARCH_MAX", "B3M_ISA_FULL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
