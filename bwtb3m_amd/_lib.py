@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("B3M_LIB") or os.path.join(_HERE, "libb3m.so")
 
 INPUT_TYPES = {"bytestream": 0, "compactstream": 1, "pac": 2, "pacterm": 3, "lz4": 4, "utf-8": 5}
+SYMBOLS32 = 6      # B3M_INPUT_SYMBOLS32: plans only (n uint32 symbols below 2^21), not a file type of the reference
 
 
 class LibraryMissing(RuntimeError):
@@ -100,6 +101,7 @@ SYMBOLS = [
     ("b3m_dist_workspace_bytes", _u64, [_p]),
     ("b3m_dist_set_text", _i, [_p, _p, _p]),
     ("b3m_dist_leaf", _i, [_p, _u64, _u64, _p, _p, ctypes.POINTER(_u64), _p, _p]),
+    ("b3m_dist_leaf_hist", _i, [_p, _p]),
     ("b3m_dist_rank_of", _i, [_p, _p, _u64, _p, _p]),
     ("b3m_dist_rank_of_dev", _i, [_p, _p, _u64, _p, _p]),
     ("b3m_dist_endbit", _i, [_p, _p, _u64, _p, _u64, _p]),

@@ -27,7 +27,7 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 // Packed input exactly as in the file, copied into a buffer padded with >= 16 zero bytes so
 // that 3-word look-ahead reads never leave the allocation.
 struct TextView {
-	const uint8_t *b;   // bytes
+	const uint8_t *b;   // bytes (symbols32: n uint32 words)
 	uint64_t n;         // number of symbols (pacterm: bases + 1)
 	uint64_t nbases;    // pac/pacterm: number of 2-bit bases; bytestream: n
 	int type;           // B3M_INPUT_*
@@ -40,14 +40,16 @@ struct TextView {
 constexpr int KSYM_BYTES = 8;
 constexpr int KSYM_PAC = 32;
 constexpr int KSYM_PACTERM = 21;
+constexpr int KSYM_WIDE = 3, WIDE_BITS = 21;      // symbols32: three 21-bit symbols per key (63 bits)
 constexpr int TAGBITS_PACTERM = 5;
 constexpr uint32_t TAG_NORMAL = 31;
 
-inline int key_symbols(int type) { return type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_PACTERM; }
-inline int key_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM : 64; }
+inline int key_symbols(int type) { return type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : type == B3M_INPUT_PAC ? KSYM_PAC : type == B3M_INPUT_SYMBOLS32 ? KSYM_WIDE : KSYM_PACTERM; }
+inline int key_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM : type == B3M_INPUT_SYMBOLS32 ? KSYM_WIDE * WIDE_BITS : 64; }
 inline uint64_t packed_text_bytes(uint64_t n, int type)
 {
 	if (type == B3M_INPUT_BYTESTREAM) return n;
+	if (type == B3M_INPUT_SYMBOLS32) return 4 * n;
 	uint64_t l = (type == B3M_INPUT_PACTERM) ? n - 1 : n;
 	return l / 4 + 2;                    // BWA .pac file size
 }
@@ -274,7 +276,8 @@ uint64_t byte_rank_rows(uint64_t m);
 uint64_t byte_rank_tiles(uint64_t m);
 void byte_rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, uint32_t *d_occ, uint32_t *d_th, hipStream_t s);
 void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_bwtL, const uint32_t *d_p0, const uint32_t *d_C, uint64_t a, uint64_t m, uint64_t mr,
-                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s);
+                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s,
+                    uint64_t chain_first = 0);      // chain_first: global index of this launch's first chain (multi-GPU: each rank walks a chain range)
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
 // d_blocks: rank dictionary of the whole BWT (rank_build64), p0 = rank of the terminator entry (~0: none), C = symbol starts
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);

@@ -16,6 +16,7 @@ __device__ __forceinline__ uint32_t base_at(const TextView &T, uint64_t i)
 __device__ __forceinline__ uint32_t sym_at(const TextView &T, uint64_t i)
 {
 	if (T.type == B3M_INPUT_BYTESTREAM) return T.b[i];
+	if (T.type == B3M_INPUT_SYMBOLS32) return reinterpret_cast<const uint32_t *>(T.b)[i];
 	if (T.type == B3M_INPUT_PAC) return base_at(T, i);
 	return (i == T.n - 1) ? 0u : base_at(T, i) + 1u;   // pacterm
 }
@@ -63,6 +64,12 @@ __device__ inline uint64_t key_at(const TextView &T, uint64_t i, uint64_t depth)
 		for (int t = 0; t < KSYM_PAC; ++t) { k = (k << 2) | base_at(T, pos); if (++pos == T.n) pos = 0; }
 		return k;
 	}
+	if (T.type == B3M_INPUT_SYMBOLS32) {      // three 21-bit symbols, circular
+		const uint32_t *w = reinterpret_cast<const uint32_t *>(T.b);
+		uint64_t pos = (i + depth * KSYM_WIDE) % T.n, k = 0;
+		for (int t = 0; t < KSYM_WIDE; ++t) { k = (k << WIDE_BITS) | w[pos]; if (++pos == T.n) pos = 0; }
+		return k;
+	}
 	// bytestream: 8 bytes, circular
 	uint64_t pos = (i + depth * KSYM_BYTES) % T.n;
 	uint64_t k = 0;
@@ -95,8 +102,14 @@ __device__ inline uint64_t key_at_off(const TextView &T, uint64_t i, uint64_t of
 		k <<= 2 * (K - t);
 		return ((k << TAGBITS_PACTERM) | t) + 64u;
 	}
-	const int K = T.type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_BYTES;
 	uint64_t pos = (i + off) % T.n;
+	if (T.type == B3M_INPUT_SYMBOLS32) {
+		const uint32_t *w = reinterpret_cast<const uint32_t *>(T.b);
+		uint64_t k = 0;
+		for (int t = 0; t < KSYM_WIDE; ++t) { k = (k << WIDE_BITS) | w[pos]; if (++pos == T.n) pos = 0; }
+		return k;
+	}
+	const int K = T.type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_BYTES;
 	if (T.type == B3M_INPUT_PAC) {
 		if (pos + KSYM_PAC <= T.n) return window32(T, pos);
 		uint64_t k = 0;
@@ -107,12 +120,12 @@ __device__ inline uint64_t key_at_off(const TextView &T, uint64_t i, uint64_t of
 	for (int t = 0; t < K; ++t) { k = (k << 8) | T.b[pos]; if (++pos == T.n) pos = 0; }
 	return k;
 }
-inline int key_off_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM + 1 : 64; }
+inline int key_off_bits(int type) { return type == B3M_INPUT_PACTERM ? 2 * KSYM_PACTERM + TAGBITS_PACTERM + 1 : type == B3M_INPUT_SYMBOLS32 ? KSYM_WIDE * WIDE_BITS : 64; }
 
 // compare rotations S_x and S_y (x != y): -1, 0 (equal over >= n symbols), +1
 __device__ inline int compare_rotations(const TextView &T, uint64_t x, uint64_t y)
 {
-	int K = T.type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : T.type == B3M_INPUT_PAC ? KSYM_PAC : KSYM_PACTERM;
+	int K = T.type == B3M_INPUT_BYTESTREAM ? KSYM_BYTES : T.type == B3M_INPUT_PAC ? KSYM_PAC : T.type == B3M_INPUT_SYMBOLS32 ? KSYM_WIDE : KSYM_PACTERM;
 	for (uint64_t d = 0; d * K < T.n; ++d) {
 		uint64_t kx = key_at(T, x, d), ky = key_at(T, y, d);
 		if (kx != ky) return kx < ky ? -1 : 1;

@@ -251,7 +251,7 @@ extern "C" {
 int b3m_version(void) { return B3M_VERSION; }
 const char *b3m_last_error(void) { return g_err.c_str(); }
 
-static const char *type_names[6] = {"bytestream", "compactstream", "pac", "pacterm", "lz4", "utf-8"};
+static const char *type_names[7] = {"bytestream", "compactstream", "pac", "pacterm", "lz4", "utf-8", "symbols32"};
 int b3m_parse_input_type(const char *name)
 {
 	if (name) for (int i = 0; i < 6; ++i) if (!strcmp(name, type_names[i])) return i;
@@ -260,7 +260,7 @@ int b3m_parse_input_type(const char *name)
 	set_error("libmaus2::suffixsort::bwtb3m::BwtMergeSort::computeBwt: unknown/unsupported input type");
 	return -1;
 }
-const char *b3m_input_type_name(int t) { return (t >= 0 && t < 6) ? type_names[t] : "unknown"; }
+const char *b3m_input_type_name(int t) { return (t >= 0 && t < 7) ? type_names[t] : "unknown"; }      // (symbols32 has a name but is no file type: not parsed)
 
 #define B3M_TRY try {
 #define B3M_CATCH(ret)                                                          \
@@ -273,9 +273,13 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 {
 	b3m_plan *p = nullptr;
 	B3M_TRY
-	B3M_REQUIRE(inputtype == B3M_INPUT_BYTESTREAM || inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM,
+	B3M_REQUIRE(inputtype == B3M_INPUT_BYTESTREAM || inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM || inputtype == B3M_INPUT_SYMBOLS32,
 	            std::string("input type ") + b3m_input_type_name(inputtype) + " is not supported by the GPU engine yet");
 	B3M_REQUIRE(n >= 1, "empty input");
+	// symbols32 (utf-8 texts of more than 256 distinct code points): one block through the key/index sort, uint32 symbols in and out
+	B3M_REQUIRE(inputtype != B3M_INPUT_SYMBOLS32 || (n < (1ull << 32) && nshards == 1 && (blocksize == 0 || blocksize >= n)),
+	            "symbols32 texts are sorted as one block of fewer than 2^32 symbols (no blocksize=, no shards)");
+	if (inputtype == B3M_INPUT_SYMBOLS32) blocksize = n;
 	B3M_REQUIRE(inputtype != B3M_INPUT_PACTERM || n >= 1, "pacterm needs n >= 1");
 	B3M_REQUIRE(n < (1ull << 36), "n >= 2^36 symbols is not supported");
 	B3M_REQUIRE(n < (1ull << 32) || ((inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM) && blocksize == 0),
@@ -336,7 +340,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	const uint64_t sort_span = std::max(p->blocksize, sort_cap);
 	// one block (or a suffix-range shard of one) below 2^32 symbols: the tie-list buffers of the sort are allocated when a repeat-rich text first
 	// needs them (20 of ~50 bytes per suffix: the arena of C3 is 90 GB instead of 150)
-	const bool lazy_ties = B == 1 && n < (1ull << 32) && inputtype != B3M_INPUT_BYTESTREAM;      // (byte alphabets sort by key/index pairs and list their ties always)
+	const bool lazy_ties = B == 1 && n < (1ull << 32) && inputtype != B3M_INPUT_BYTESTREAM && inputtype != B3M_INPUT_SYMBOLS32;      // (byte alphabets sort by key/index pairs and list their ties always)
 	uint64_t o_bs = take(blocksort_ws_bytes(sort_cap, sort_span, lazy_ties));
 	uint64_t maxL = 0, maxTot = 0;
 	for (auto &M : p->merges) { maxL = std::max(maxL, M.L.m); maxTot = std::max(maxTot, M.L.m + M.R.m); }
@@ -533,6 +537,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	double wall0 = 0;
 	if (host) {
 		B3M_REQUIRE(p->nshards == 1, "host-memory runs need an unsharded plan");
+		B3M_REQUIRE(p->type != B3M_INPUT_SYMBOLS32, "host-memory runs: symbols32 texts are device-resident only");
 		if (!p->copy_stream) B3M_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
 		d_bwt_out = p->d_bwt[0];                    // one block: the leaf sort writes here; several: the last level is copied here
 		sink.d_bwt = d_bwt_out;
@@ -626,7 +631,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			p->res.tie_slow += so.slow_ties;
 			Scope sc(tl, KF_EMIT, 6 * lf.m);
 			hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0tmp + k, p->d_p0pairs + 2 * k, lf.a, so.slice_offset);
-			if (!so.symhist_done && (sh == 0 || p->seq_shards == 1)) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
+			if (!so.symhist_done && (sh == 0 || p->seq_shards == 1) && p->type != B3M_INPUT_SYMBOLS32) histogram_symbols(T, lf.a, lf.m, p->d_hist + 256 * k, s);
 			if (p->isarate && !so.samples_done) {
 				B3M_REQUIRE(so.d_sa != nullptr || so.kept_len == 0, "internal: samples asked for, but the sort kept no suffix array");
 				emit_samples(so.d_sa, so.d_sa_hi, so.kept_len, p->isarate, so.slice_offset, p->d_samples + 2 * p->sample_off[k], (lf.a + p->isarate - 1) / p->isarate,
@@ -1300,8 +1305,8 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	const std::vector<uint64_t> &anc = p->h_samples;
 	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
 	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
-	if (p->type == B3M_INPUT_BYTESTREAM) {
-		// byte alphabet: the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
+	if (p->type == B3M_INPUT_BYTESTREAM || p->type == B3M_INPUT_SYMBOLS32) {
+		// byte alphabet (and wide symbols): the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
 		B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
 		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
 		RadixWs rw; radix_ws_carve(rw, rws.p, n);
@@ -1362,6 +1367,8 @@ struct b3m_dist_plan {
 	uint32_t *d_r0 = nullptr, *d_r1 = nullptr; RadixWs radix;       // rank lists (walk output, received buckets)
 	uint32_t *d_tile_q = nullptr;
 	uint32_t *d_anchors = nullptr; uint64_t anchors_cap = 0;
+	uint8_t *d_lcopy = nullptr; uint32_t *d_C = nullptr, *d_th = nullptr;   // byte alphabets: aligned copy of BWT(L), the 256 symbol starts of L's text, the build's tile counts (d_blocks = count rows)
+	uint64_t leaf_hist[256] = {0};                                 // symbol counts of the last leaf's text
 	uint64_t *d_small = nullptr;                                   // [0..1] p0 pair, [2] end rank (u32), [3] end position, [8..8+64) bounds, [72..72+64) cuts, [136..] query positions / ranks
 	uint32_t *d_p0u = nullptr;
 };
@@ -1372,8 +1379,9 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	b3m_dist_plan *p = nullptr;
 	B3M_TRY
 	require_device();
-	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "the multi-GPU block merge needs a 2-bit alphabet (pac/pacterm)");
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM || inputtype == B3M_INPUT_BYTESTREAM, "the multi-GPU block merge takes pac, pacterm and bytestream texts");
 	B3M_REQUIRE(n >= 1 && n < (1ull << 32), "n out of range for the block-merge mode (use suffix-range shards above 2^32)");
+	const bool bytes = inputtype == B3M_INPUT_BYTESTREAM;
 	B3M_REQUIRE(max_leaf >= 1 && max_leaf <= n && max_L <= n && max_R <= n, "dist plan: sizes out of range");
 	p = new b3m_dist_plan();
 	p->n = n; p->type = inputtype; p->max_leaf = max_leaf; p->max_L = max_L; p->max_R = max_R;
@@ -1383,7 +1391,10 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	const uint64_t nbk = rank_blocks(max_L ? max_L : 1);
 	const uint64_t chains_max = max_R / 32 + 2;
 	const uint64_t leaf_cap = max_leaf + (max_leaf < n ? std::min(block_overhang(), max_leaf / 8) : 0);      // room for an overhang (tie_rounds_domain)
-	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(leaf_cap)), o_rb = take(64 * nbk), o_rs = take(64 * nbk + 64),
+	// byte alphabets: count rows (1 KB per 64 symbols of L), an aligned copy of BWT(L) + the 256 symbol starts + the build's tile counts (as the one-GPU plan)
+	const uint64_t mL = max_L ? max_L : 1;
+	uint64_t o_text = take(p->text_cap), o_bs = take(blocksort_ws_bytes(leaf_cap)), o_rb = take(bytes ? 1024 * byte_rank_rows(mL) : 64 * nbk),
+	         o_rs = take(bytes ? al256(mL) + 256 + 1024 + 1024 * byte_rank_tiles(mL) + 1024 : 64 * nbk + 64),
 	         o_sw = take(4 * scan_ws_elems(nbk) + 64), o_r0 = take(4 * (max_R + max_R / 8 + 256)), o_r1 = take(4 * (max_R + max_R / 8 + 256)), o_rx = take(radix_ws_bytes(max_R + max_R / 8 + 256)),
 	         o_tq = take(4 * (interleave_tiles(max_L + max_R + 1) + 2)), o_an = take(4 * chains_max), o_sm = take(8 * DIST_SMALL), o_p0 = take(64);
 	p->ws_bytes = off;
@@ -1395,6 +1406,7 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 	p->d_text = A + o_text;
 	blocksort_ws_carve(p->bs, A + o_bs, leaf_cap);
 	p->d_blocks = (uint32_t *)(A + o_rb); p->d_scratch = (uint32_t *)(A + o_rs); p->d_scan_ws = (uint32_t *)(A + o_sw);
+	if (bytes) { p->d_lcopy = A + o_rs; p->d_C = (uint32_t *)(p->d_lcopy + al256(mL) + 256); p->d_th = p->d_C + 256; }
 	p->d_r0 = (uint32_t *)(A + o_r0); p->d_r1 = (uint32_t *)(A + o_r1);
 	radix_ws_carve(p->radix, A + o_rx, max_R + max_R / 8 + 256);
 	p->d_tile_q = (uint32_t *)(A + o_tq);
@@ -1447,12 +1459,13 @@ int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, 
 	if (!so.symhist_done) histogram_symbols(T, a, m, d_hist, s);
 	p->d_sa_last = so.d_sa; p->sa_len = m;
 	hipLaunchKernelGGL(k_p0_to_pair, dim3(1), dim3(64), 0, s, p->d_p0u, d_pair, a, (uint64_t)0);
-	emit_gt_from_text(T, a, m, d_gt_abs, s);
+	if (p->type == B3M_INPUT_BYTESTREAM) hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, s, so.d_sa, m, a, p->d_p0u, d_gt_abs);
+	else emit_gt_from_text(T, a, m, d_gt_abs, s);
 	const uint64_t endpos = a + m;
 	B3M_HIP(hipMemcpyAsync(d_ep, &endpos, 8, hipMemcpyHostToDevice, s));
 	rank_of_positions(T, so.d_sa, m, d_ep, 1, d_er, s);
 	hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, d_er, d_pair, d_gt_abs, a + m);
-	uint64_t pr[2] = {0, 0}, hh[256];
+	uint64_t pr[2] = {0, 0}, *hh = p->leaf_hist;
 	B3M_HIP(hipMemcpyAsync(pr, d_pair, 16, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipMemcpyAsync(hh, d_hist, 8 * 256, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
@@ -1461,6 +1474,14 @@ int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, 
 	if (hist5_out) for (int c = 0; c < 5; ++c) hist5_out[c] = hh[c];
 	return 0;
 	B3M_CATCH(1)
+}
+
+/* the 256 symbol counts of the text of the leaf sorted last (byte alphabets: the C arrays of the merges; hist5_out of b3m_dist_leaf holds the first five) */
+int b3m_dist_leaf_hist(const b3m_dist_plan *p, uint64_t *hist256_out)
+{
+	if (!p || !hist256_out) { set_error("null argument"); return 1; }
+	memcpy(hist256_out, p->leaf_hist, 8 * 256);
+	return 0;
 }
 
 /* ranks of the rotations starting at positions[] (host) among the suffixes of the last leaf sorted here: the chain anchors (z-ranks) */
@@ -1528,6 +1549,7 @@ int b3m_dist_pack2(b3m_dist_plan *p, const uint8_t *d_bwt, uint64_t m, uint8_t *
 {
 	B3M_TRY
 	B3M_REQUIRE(p && (m == 0 || (d_bwt && d_packed)), "b3m_dist_pack2: null argument");
+	if (p->type == B3M_INPUT_BYTESTREAM) { if (m) B3M_HIP(hipMemcpyAsync(d_packed, d_bwt, m, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return 0; }      // byte alphabets travel as they are
 	pack2(d_bwt, m, p->type, d_packed, (hipStream_t)stream);
 	return 0;
 	B3M_CATCH(1)
@@ -1538,6 +1560,19 @@ int b3m_dist_build_dict(b3m_dist_plan *p, const uint8_t *const *d_parts, const u
 {
 	B3M_TRY
 	B3M_REQUIRE(p && d_parts && part_syms && m >= 1 && m <= p->max_L, "b3m_dist_build_dict: bad argument");
+	if (p->type == B3M_INPUT_BYTESTREAM) {
+		// byte alphabet: the slices side by side as the aligned copy of BWT(L), then the count rows every 64 symbols
+		hipStream_t s = (hipStream_t)stream;
+		uint64_t at = 0;
+		for (int i = 0; i < nparts; ++i) { if (part_syms[i]) B3M_HIP(hipMemcpyAsync(p->d_lcopy + at, d_parts[i], part_syms[i], hipMemcpyDeviceToDevice, s)); at += part_syms[i]; }
+		B3M_REQUIRE(at == m, "b3m_dist_build_dict: the slices do not add up to |L|");
+		B3M_HIP(hipMemsetAsync(p->d_lcopy + m, 0, al256(m) + 256 - m, s));
+		const uint32_t p032 = (uint32_t)p0L;
+		B3M_HIP(hipMemcpyAsync(p->d_p0u, &p032, 4, hipMemcpyHostToDevice, s));
+		byte_rank_build(p->d_lcopy, m, p->d_p0u, p->d_blocks, p->d_th, s);
+		p->dict_m = m; p->dict_p0 = p0L;
+		return 0;
+	}
 	rank_build_from_parts(d_parts, part_syms, nparts, m, p0L, p->d_blocks, p->d_scratch, p->d_scan_ws, (hipStream_t)stream);
 	p->dict_m = m; p->dict_p0 = p0L;
 	return 0;
@@ -1569,6 +1604,13 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
 	const uint32_t p032 = (uint32_t)p->dict_p0;
 	B3M_HIP(hipMemcpyAsync(p->d_p0u, &p032, 4, hipMemcpyHostToDevice, s));
 	if (nbounds) B3M_HIP(hipMemcpyAsync(p->d_small + 8, bounds, 8 * nbounds, hipMemcpyHostToDevice, s));
+	if (p->type == B3M_INPUT_BYTESTREAM) {
+		uint32_t hC[256];
+		for (int c = 0; c < 256; ++c) hC[c] = (uint32_t)symstart[c];
+		B3M_HIP(hipMemcpyAsync(p->d_C, hC, 1024, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipStreamSynchronize(s));                  // hC is on this stack frame
+		gap_walk_bytes(T, p->d_blocks, p->d_lcopy, p->d_p0u, p->d_C, a, m, mr, d_gt_abs_in, d_gt_abs_out, p->d_anchors, num_chains, chain_len, p->d_r0, s, chain_first);
+	} else {
 	RankDict rd{};
 	rd.blocks = p->d_blocks; rd.m = m; rd.p0ptr = p->d_p0u;
 	for (int c = 0; c < 4; ++c) rd.C[c] = (uint32_t)symstart[c];
@@ -1576,6 +1618,7 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
 	G.T = T; G.rd = rd; G.a = a; G.m = m; G.mr = mr; G.gt_cur = d_gt_abs_in; G.gt_next = d_gt_abs_out;
 	G.anchors = p->d_anchors; G.num_chains = num_chains; G.chain_len = chain_len; G.chain_first = chain_first; G.ranks_out = p->d_r0;
 	gap_walk(G, s);
+	}
 	uint32_t *sr = nullptr;
 	int nbits = 1; while ((1ull << nbits) <= m + 1 && nbits < 32) ++nbits;
 	radix_sort_u32(p->d_r0, p->d_r1, slots, nbits, p->radix, s, nullptr, &sr, true);
@@ -1600,6 +1643,7 @@ int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t a, uint64_t l0, uint64_t l1, uin
 {
 	B3M_TRY
 	B3M_REQUIRE(p && a < p->n && l0 <= l1 && l1 <= p->dict_m && (l1 == l0 || d_out), "b3m_dist_l_bytes: bad argument");
+	if (p->type == B3M_INPUT_BYTESTREAM) { if (l1 > l0) B3M_HIP(hipMemcpyAsync(d_out, p->d_lcopy + l0, l1 - l0, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return 0; }
 	dict_bytes(dist_text(p), p->d_blocks, l0, l1, p->dict_p0, a ? a - 1 : p->n - 1, d_out, (hipStream_t)stream);
 	return 0;
 	B3M_CATCH(1)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <unistd.h>
 
@@ -57,6 +58,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// compactstream (row f4): 2-bit files are a .pac payload behind a 32-byte header; other widths are decoded to bytes on the device
 		uint32_t cbits = 0; uint64_t coff = 0; const int filetype = type;
 		int64_t symmap_store[256]; const int64_t *symmap = nullptr;
+		std::vector<int64_t> wide_map;                        // utf-8 above 256 distinct code points: rank -> code point (the text goes as symbols32)
 		if (type == B3M_INPUT_COMPACTSTREAM) {
 			if (b3m_compact_info(file.data(), file.size(), &cbits, &n, &coff)) throw std::runtime_error(b3m_last_error());
 			file.erase(file.begin(), file.begin() + (long)coff);
@@ -71,14 +73,24 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			std::vector<int32_t> rank(0x110000, -1);
 			uint32_t k = 0;
 			for (uint32_t c = 0; c < 0x110000; ++c) if (seen[c]) { if (k < 256) symmap_store[k] = (int64_t)c; rank[c] = (int32_t)k++; }
-			if (k > 256) throw std::runtime_error("inputtype=utf-8: the text has " + std::to_string(k) + " distinct code points; this engine ranks them into a byte alphabet and supports at most 256");
+			n = cps.size();
+			if (k > 256) {
+				// more than a byte alphabet holds: the ranks go as 32-bit symbols (one block, key/index sort over three 21-bit symbols per key)
+				if (n >= (1ull << 32)) throw std::runtime_error("inputtype=utf-8: texts of more than 256 distinct code points must stay below 2^32 code points");
+				wide_map.resize(k);
+				for (uint32_t c = 0; c < 0x110000; ++c) if (rank[c] >= 0) wide_map[(size_t)rank[c]] = (int64_t)c;
+				file.assign(4 * cps.size() + 16, 0);
+				uint32_t *w = reinterpret_cast<uint32_t *>(file.data());
+				for (size_t i = 0; i < cps.size(); ++i) w[i] = (uint32_t)rank[cps[i]];
+				type = B3M_INPUT_SYMBOLS32;
+			} else {
 			for (uint32_t j = k; j < 256; ++j) symmap_store[j] = (int64_t)0x110000 + j;      // (unused ranks: never written)
 			file.resize(cps.size());
 			for (size_t i = 0; i < cps.size(); ++i) file[i] = (uint8_t)rank[cps[i]];
-			n = cps.size();
 			symmap = symmap_store;
 			type = B3M_INPUT_BYTESTREAM;
 			file.resize(file.size() + 16, 0);
+			}
 		} else if (type == B3M_INPUT_BYTESTREAM) n = file.size();
 		else {
 			if (file.size() < 2 || file.back() > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
@@ -95,7 +107,8 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// byte alphabets are sorted as ONE block (no byte-alphabet merge): a memory target that would force several
 		// blocks (the reference's scripts pass mem= for host RAM) is not applied to them
 		uint64_t mem = o->mem;
-		if (type == B3M_INPUT_BYTESTREAM && mem) { log("[V] mem= is not applied to bytestream input (sorted as one block in HBM)\n"); mem = 0; }
+		const bool wide = type == B3M_INPUT_SYMBOLS32;
+		if ((type == B3M_INPUT_BYTESTREAM || wide) && mem) { log("[V] mem= is not applied to bytestream input (sorted as one block in HBM)\n"); mem = 0; }
 		const double tp0 = now();
 		plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
 		if (!plan) throw std::runtime_error(b3m_last_error());
@@ -103,7 +116,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		log("[V] blocks %llu workspace %.2f GB, plan created in %.3f s (file read %.3f s)\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9,
 		    now() - tp0, tp0 - t0);
 		uint64_t tb = b3m_plan_text_bytes(plan);
-		HIPCHK(hipMalloc((void **)&d_bwt, n));
+		HIPCHK(hipMalloc((void **)&d_bwt, wide ? 4 * n : n));
 		if (filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2) {
 			void *d_words = nullptr;
 			HIPCHK(hipMalloc(&d_words, file.size()));
@@ -126,14 +139,24 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// X.bwt: written from the BWT in HBM (runs, frequencies and code streams on the device); the host encoder takes what that
 		// one does not (2^32 symbols and more) and B3M_HOST_RL=1 asks for it (both write the same bytes)
 		const unsigned enc_threads = o->numthreads ? o->numthreads : 1;
+		if (wide) {
+			std::vector<uint32_t> bw(n);
+			HIPCHK(hipMemcpy(bw.data(), d_bwt, 4 * n, hipMemcpyDeviceToHost));
+			b3m::rl_encode_file_wide(outfn, bw.data(), n, 64 * 1024, wide_map.data());
+			std::map<int64_t, uint64_t> hm;
+			for (uint64_t i = 0; i < n; ++i) hm[wide_map[bw[i]]]++;
+			b3m::write_hist_map(prefix + ".hist", hm);
+		} else
 		if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, d_bwt, n, 64 * 1024, enc_threads, symmap, nullptr)) {
 			std::vector<uint8_t> bwt(n);
 			HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
 			b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, enc_threads, symmap);
 		}
-		uint64_t hist[256];
-		b3m_plan_histogram(plan, hist);
-		b3m::write_hist(prefix + ".hist", hist, symmap);
+		if (!wide) {
+			uint64_t hist[256];
+			b3m_plan_histogram(plan, hist);
+			b3m::write_hist(prefix + ".hist", hist, symmap);
+		}
 		std::vector<uint64_t> pairs(2 * res.num_samples);
 		if (res.num_samples) b3m_plan_samples(plan, pairs.data(), res.num_samples);
 		b3m::write_meta(prefix + ".meta", {n, res.num_blocks, res.levels, res.p0, isarate});

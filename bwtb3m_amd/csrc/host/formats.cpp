@@ -297,6 +297,43 @@ void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, u
 	if (fclose(f)) throw std::runtime_error("error closing " + fn);
 }
 
+// the same container for symbols of any width (utf-8 texts of more than 256 distinct code points): ranks[i] names the symbol symmap[ranks[i]];
+// the code tables are built per block from maps instead of the flat byte counters (one thread: such texts are small)
+void rl_encode_file_wide(const std::string &fn, const uint32_t *ranks, uint64_t n, uint64_t runs_per_block, const int64_t *symmap)
+{
+	if (!runs_per_block) runs_per_block = 64 * 1024;
+	std::vector<uint8_t> blocks; std::vector<RLIndexEntry> index;
+	std::vector<RLRun> runs; runs.reserve((size_t)runs_per_block);
+	auto flush = [&]() {
+		if (runs.empty()) return;
+		std::map<int64_t, uint64_t> sh, ch; uint64_t syms = 0;
+		for (auto &r : runs) { sh[r.sym]++; ch[(int64_t)std::min<uint64_t>(r.len, RL_ESCAPE)]++; syms += r.len; }
+		Canon sc = Canon::from_freq(sh), cc = Canon::from_freq(ch);
+		std::vector<uint8_t> out;
+		BitWriter w(out);
+		w.elias(runs.size());
+		w.put(ch.count((int64_t)RL_ESCAPE) ? 1 : 0, 1);
+		sc.serialise(w); cc.serialise(w);
+		w.align();
+		for (auto &r : runs) sc.put(w, r.sym);
+		w.align();
+		for (auto &r : runs) { if (r.len >= RL_ESCAPE) { cc.put(w, (int64_t)RL_ESCAPE); w.elias(r.len); } else cc.put(w, (int64_t)r.len); }
+		w.align();
+		index.push_back({8 + blocks.size(), runs.size(), syms});
+		blocks.insert(blocks.end(), out.begin(), out.end());
+		runs.clear();
+	};
+	for (uint64_t i = 0; i < n;) {
+		uint64_t j = i + 1;
+		while (j < n && ranks[j] == ranks[i]) ++j;
+		runs.push_back({symmap ? symmap[ranks[i]] : (int64_t)ranks[i], j - i});
+		if (runs.size() == runs_per_block) flush();
+		i = j;
+	}
+	flush();
+	rl_write_container(fn, n, blocks.data(), blocks.size(), index);
+}
+
 static std::vector<RLIndexEntry> rl_index_of(const std::vector<uint8_t> &d, const std::string &fn)
 {
 	if (d.size() < 24) throw std::runtime_error(fn + " is not an RL .bwt file (too short)");
@@ -493,6 +530,13 @@ void write_hist(const std::string &fn, const uint64_t hist256[256], const int64_
 	for (int i = 0; i < 256; ++i) cnt += hist256[i] != 0;
 	put_be64(o, cnt);
 	for (int i = 0; i < 256; ++i) if (hist256[i]) { put_be64(o, (uint64_t)(symmap ? symmap[i] : i)); put_be64(o, hist256[i]); }
+	write_file(fn, o.data(), o.size());
+}
+void write_hist_map(const std::string &fn, const std::map<int64_t, uint64_t> &hist)
+{
+	std::vector<uint8_t> o;
+	put_be64(o, hist.size());
+	for (auto &kv : hist) { put_be64(o, (uint64_t)kv.first); put_be64(o, kv.second); }
 	write_file(fn, o.data(), o.size());
 }
 std::vector<uint32_t> utf8_decode(const std::vector<uint8_t> &f)

@@ -24,6 +24,8 @@ bool file_exists(const std::string &fn);
 struct RLRun { int64_t sym; uint64_t len; };
 // symmap (may be null): the symbol value written for byte b is symmap[b] (monotone; utf-8 input: code points ranked into a byte alphabet)
 void rl_encode_file(const std::string &fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap = nullptr);
+// symbols of any width: ranks[i] < k names symmap[ranks[i]] (symmap null: the rank itself); same container, tables from maps
+void rl_encode_file_wide(const std::string &fn, const uint32_t *ranks, uint64_t n, uint64_t runs_per_block, const int64_t *symmap);
 // decodeRun() stream: calls sink(sym,len) per run; returns n
 uint64_t rl_decode_file(const std::string &fn, void (*sink)(void *, int64_t, uint64_t), void *ctx);
 uint64_t rl_length(const std::string &fn);
@@ -55,6 +57,7 @@ struct RLSparseRank {
 // X.hist: NumberMapSerialisation::serialiseMap<int64,uint64> (reader at
 // /root/reference/src/bwtdecodeblock.cpp:150-173): u64 BE count, then (i64 BE key, u64 BE value)
 void write_hist(const std::string &fn, const uint64_t hist256[256], const int64_t *symmap = nullptr);
+void write_hist_map(const std::string &fn, const std::map<int64_t, uint64_t> &hist);
 std::map<int64_t, uint64_t> read_hist(const std::string &fn);
 // X.preisa: raw host-endian u64 pairs (rank,pos) (/root/reference/src/hwtPreIsaToIsa.cpp:64-77)
 void write_preisa(const std::string &fn, const uint64_t *pairs, uint64_t count);

@@ -215,7 +215,8 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 	uint32_t r = U[s];
 	uint64_t i = (uint64_t)sa[r] | (sa_hi ? (uint64_t)sa_hi[r] << 32 : 0ull);
 	uint64_t j = i ? i - 1 : T.n - 1;
-	bwt[r] = (uint8_t)sym_at(T, j);
+	if (T.type == B3M_INPUT_SYMBOLS32) reinterpret_cast<uint32_t *>(bwt)[r] = sym_at(T, j);      // (wide symbols: the BWT array holds uint32)
+	else bwt[r] = (uint8_t)sym_at(T, j);
 	if (i == start) *p0 = r;
 	if (sample_hit(smp, (uint32_t)i)) sample_put(smp, r, i);      // the listed slots are final here: their samples could not be written earlier
 }
@@ -567,7 +568,7 @@ __global__ void k_emit_bwt(TextView T, const uint32_t *sa, uint64_t len, uint64_
 	if (r >= len) return;
 	uint64_t i = sa[r];
 	uint64_t j = i ? i - 1 : T.n - 1;
-	if (bwt) bwt[r] = (uint8_t)sym_at(T, j);
+	if (bwt) { if (T.type == B3M_INPUT_SYMBOLS32) reinterpret_cast<uint32_t *>(bwt)[r] = sym_at(T, j); else bwt[r] = (uint8_t)sym_at(T, j); }
 	if (i == start) *p0 = (uint32_t)r;
 }
 // gt bit of absolute position x: [S_x > S_start], for the block's own positions (x != start)
@@ -1100,7 +1101,7 @@ void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs
 	// K1 keys
 	{
 		Scope sc(tl, KF_KEYS, len / 4 + 12 * len);
-		if (T.type == B3M_INPUT_BYTESTREAM)
+		if (T.type == B3M_INPUT_BYTESTREAM || T.type == B3M_INPUT_SYMBOLS32)
 			hipLaunchKernelGGL(k_keys_generic, dim3(nblk(len)), dim3(256), 0, s, T, start, len, ws.keyA, ws.idxA);
 		else {
 			uint64_t words = ((start + len + 15) >> 4) - (start >> 4);
@@ -1310,6 +1311,7 @@ __global__ __launch_bounds__(256) void k_histogram_packed(TextView T, uint64_t s
 void histogram_symbols(const TextView &T, uint64_t start, uint64_t len, uint64_t *d_hist256, hipStream_t s)
 {
 	if (!len) return;
+	B3M_REQUIRE(T.type != B3M_INPUT_SYMBOLS32, "internal: no 256-bin histogram of a symbols32 text");
 	if (T.type != B3M_INPUT_BYTESTREAM && len >= 4096) {
 		uint32_t grid = nblk(len / 16, 256 * 8); if (grid > 2048) grid = 2048; if (grid == 0) grid = 1;
 		hipLaunchKernelGGL(k_histogram_packed, dim3(grid), dim3(256), 0, s, T, start, len, (unsigned long long *)d_hist256);

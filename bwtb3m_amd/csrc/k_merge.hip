@@ -498,10 +498,10 @@ __global__ __launch_bounds__(256) void k_gap_walk_bytes(ByteWalkArgs A)
 	for (; t < A.chain_len; ++t) A.ranks_out[t * A.num_chains + c] = 0xFFFFFFFFu;
 }
 void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_bwtL, const uint32_t *d_p0, const uint32_t *d_C, uint64_t a, uint64_t m, uint64_t mr,
-                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s)
+                    const uint32_t *gt_cur, uint32_t *gt_next, const uint32_t *d_anchors, uint64_t num_chains, uint64_t chain_len, uint32_t *ranks_out, hipStream_t s, uint64_t chain_first)
 {
 	if (!num_chains) return;
-	ByteWalkArgs A{T, d_occ, d_bwtL, d_p0, d_C, a, m, mr, gt_cur, gt_next, d_anchors, num_chains, chain_len, 0, ranks_out};
+	ByteWalkArgs A{T, d_occ, d_bwtL, d_p0, d_C, a, m, mr, gt_cur, gt_next, d_anchors, num_chains, chain_len, chain_first, ranks_out};
 	const uint64_t used = num_chains * chain_len, all = gap_walk_slots(num_chains, chain_len);
 	if (all > used) fill_u32(ranks_out + used, 0xFFFFFFFFu, all - used, s);
 	hipLaunchKernelGGL(k_gap_walk_bytes, dim3(nblk(num_chains, 256)), dim3(256), 0, s, A);
@@ -575,10 +575,10 @@ void lf_walk(const TextView &T, const uint32_t *d_blocks, uint64_t p0, const uin
 // Byte alphabets (byte LF walk): no rank dictionary -- the whole LF array is built by ONE
 // stable counting sort of the BWT by symbol (lf[i] = slot of i in that order, /root/reference/src/bwtdecodeblock.cpp:280-284)
 // and the chains walk it directly.
-__global__ void k_bwt_keys(const uint8_t *bwt, uint64_t n, uint64_t *keys, uint32_t *vals)
+__global__ void k_bwt_keys(const uint8_t *bwt, uint64_t n, uint64_t *keys, uint32_t *vals, int wide)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) { keys[i] = bwt[i]; vals[i] = (uint32_t)i; }
+	if (i < n) { keys[i] = wide ? reinterpret_cast<const uint32_t *>(bwt)[i] : bwt[i]; vals[i] = (uint32_t)i; }
 }
 __global__ void k_lf_from_sorted(const uint32_t *sorted_idx, uint64_t n, uint32_t *lf)
 {
@@ -601,7 +601,8 @@ __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 	uint32_t bad = 0;
 	while (p > pend) {
 		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
-		bad += A.bwt[r] != T.b[p - 1];                  // the symbol preceding the rotation at p
+		const uint32_t have = T.type == B3M_INPUT_SYMBOLS32 ? reinterpret_cast<const uint32_t *>(A.bwt)[r] : A.bwt[r];
+		bad += have != sym_at(T, p - 1);                // the symbol preceding the rotation at p
 		r = A.lf[r]; --p;
 	}
 	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
@@ -612,9 +613,10 @@ void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, ui
                    RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
 {
 	const uint64_t n = T.n;
-	hipLaunchKernelGGL(k_bwt_keys, dim3(nblk(n)), dim3(256), 0, s, d_bwt, n, d_keys, d_vals);
+	const int wide = T.type == B3M_INPUT_SYMBOLS32;      // (d_bwt: n uint32 symbols below 2^21)
+	hipLaunchKernelGGL(k_bwt_keys, dim3(nblk(n)), dim3(256), 0, s, d_bwt, n, d_keys, d_vals, wide);
 	uint64_t *rk; uint32_t *rv;
-	radix_sort_u64(d_keys, d_vals, d_keys2, d_vals2, n, 8, rw, s, nullptr, &rk, &rv);
+	radix_sort_u64(d_keys, d_vals, d_keys2, d_vals2, n, wide ? WIDE_BITS : 8, rw, s, nullptr, &rk, &rv);
 	hipLaunchKernelGGL(k_lf_from_sorted, dim3(nblk(n)), dim3(256), 0, s, rv, n, d_lf);
 	LfWalkBytesArgs A{T, d_bwt, d_lf, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk_bytes, dim3(nblk(nanchors)), dim3(256), 0, s, A);

@@ -98,9 +98,10 @@ class Plan:
         return torch.as_tensor(_View(), device="cuda")
 
     def run(self, d_text, d_out=None):
-        """one pass of the hot path.  Sharded plans return the view of their slice (see result())."""
+        """one pass of the hot path.  Sharded plans return the view of their slice (see result()).  symbols32 plans: text and result are
+        uint8 views of n uint32 words (4n bytes each)."""
         assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.numel() >= self.text_bytes
-        cap = self.slice_capacity
+        cap = self.slice_capacity * (4 if self.type == _lib.SYMBOLS32 else 1)
         if d_out is None:
             d_out = torch.empty(cap, dtype=torch.uint8, device=d_text.device)
         assert d_out.is_cuda and d_out.numel() >= cap
@@ -255,6 +256,23 @@ def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0, keep_sa=Fa
         out = plan.run(d)
         torch.cuda.synchronize()
         return out.cpu().numpy(), plan.result(), plan
+    except Exception:
+        plan.close()
+        raise
+
+
+def bwt_symbols32(symbols, isasamplingrate=0):
+    """texts over alphabets wider than a byte (B3M_INPUT_SYMBOLS32: what inputtype=utf-8 ranks a text of more than 256 distinct code points
+    into): symbols = integers below 2^21 -> (bwt as uint32 numpy array, result dict, plan, the BWT's device tensor as uint8 view)"""
+    sym = np.ascontiguousarray(symbols, dtype=np.uint32)
+    if len(sym) and int(sym.max()) >= 1 << 21:
+        raise _lib.B3MError("symbols32: symbols must be below 2^21")
+    plan = Plan(len(sym), _lib.SYMBOLS32, isasamplingrate=isasamplingrate)
+    try:
+        d = torch.from_numpy(sym.view(np.uint8).copy()).cuda()
+        out = plan.run(d)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32).copy(), plan.result(), plan, out
     except Exception:
         plan.close()
         raise

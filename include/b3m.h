@@ -42,7 +42,10 @@ enum {
 	B3M_INPUT_PAC = 2,
 	B3M_INPUT_PACTERM = 3,
 	B3M_INPUT_LZ4 = 4,           /* parsed, not yet constructed */
-	B3M_INPUT_UTF8 = 5           /* b3m_compute_bwt: texts of at most 256 distinct code points (ranked into a byte alphabet); plans take the ranked bytes as bytestream */
+	B3M_INPUT_UTF8 = 5,          /* b3m_compute_bwt: the code points that occur are ranked; up to 256 of them: plans take the ranks as bytestream, more: as symbols32 */
+	B3M_INPUT_SYMBOLS32 = 6      /* plans only (no file type of the reference): n uint32 symbols below 2^21, circular, no terminator; what a utf-8 text of more than
+	                                256 distinct code points is ranked into (/root/reference/src/bwtb3mdecoderl.cpp:47-57 writes the code points back).  One block,
+	                                n < 2^32; b3m_plan_run reads 4n bytes and writes n uint32 symbols (4n bytes) to d_bwt_out */
 };
 
 int         b3m_version(void);
@@ -115,7 +118,7 @@ void     *b3m_plan_text_buffer(b3m_plan *p);
 
 /* d_text: packed input exactly as in the file (bytestream: n bytes; pac/pacterm: BWA .pac
  * payload, base i in byte i>>2 at bit ((~i)&3)<<1), b3m_plan_text_bytes() readable bytes.
- * d_bwt_out: n bytes, one symbol per byte, in rank order. */
+ * d_bwt_out: n bytes, one symbol per byte, in rank order (symbols32: n uint32, text and result). */
 int b3m_plan_run(b3m_plan *p, const void *d_text, uint8_t *d_bwt_out, void *stream);
 
 /* The same pass from HOST memory to HOST memory: what SURVEY.md 8(d) calls end to end (input in the page cache -> BWT symbols in
@@ -263,13 +266,16 @@ int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64
 /* One process per GPU.  The collectives between these calls -- broadcast of the packed BWT(L) slices, RCCL all-to-all(v) of the gap buckets
  * (rank lists cut at the borders of the group's rank slices) and of the BWT(R) ranges -- are issued by the host side
  * (bwtb3m_amd/distributed.py over torch.distributed); the reference has no counterpart (single process, OpenMP: SURVEY.md 5).
- * max_leaf / max_L / max_R: largest leaf this rank sorts, largest left / right side of a merge it takes part in. */
+ * max_leaf / max_L / max_R: largest leaf this rank sorts, largest left / right side of a merge it takes part in.
+ * pac, pacterm (2-bit rank lines; BWT(L) travels 4 symbols per byte) and bytestream (count rows every 64 symbols; BWT(L) travels as it is:
+ * b3m_dist_pack2 copies, b3m_dist_walk takes 256 symbol starts instead of 4, b3m_dist_leaf_hist has the leaf's 256 symbol counts). */
 typedef struct b3m_dist_plan b3m_dist_plan;
 b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uint64_t max_L, uint64_t max_R);
 void     b3m_dist_destroy(b3m_dist_plan *p);
 uint64_t b3m_dist_workspace_bytes(const b3m_dist_plan *p);
 int b3m_dist_set_text(b3m_dist_plan *p, const void *d_text, void *stream);
 int b3m_dist_leaf(b3m_dist_plan *p, uint64_t a, uint64_t m, uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, uint64_t *hist5_out, void *stream);
+int b3m_dist_leaf_hist(const b3m_dist_plan *p, uint64_t *hist256_out);
 int b3m_dist_rank_of(b3m_dist_plan *p, const uint64_t *positions, uint64_t count, uint64_t *ranks_out, void *stream);
 /* the same, the ranks ADDED to a device array (int64: the chain anchors of a merge are sums over the leaves of its left side, all-reduced
  * between the GPUs without a detour through host memory) */

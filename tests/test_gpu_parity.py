@@ -1315,8 +1315,8 @@ def test_host_to_host_runs_and_the_packed_hand_over(gpu, oracle, case):
 def test_cli_utf8(gpu, oracle, tmp_path):
     """row f4, inputtype=utf-8: the text is the file's sequence of code points (here Latin, Greek, Cyrillic, CJK and an emoji: one to four
     bytes each); the .bwt names the code points, `bwtb3mdecoderl inputtype=utf-8` writes them as UTF-8 (/root/reference/src/bwtb3mdecoderl.cpp:47-57),
-    X.hist is keyed by code point (reader /root/reference/src/bwtdecodeblock.cpp:150-173).  More than 256 distinct code points and invalid
-    UTF-8 are refused with a message."""
+    X.hist is keyed by code point (reader /root/reference/src/bwtdecodeblock.cpp:150-173).  Up to 256 distinct code points are ranked into a byte
+    alphabet, more into 32-bit symbols (second half of the test); invalid UTF-8 is refused with a message."""
     import ctypes, os, subprocess
     from bwtb3m_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1348,14 +1348,86 @@ def test_cli_utf8(gpu, oracle, tmp_path):
         sa = np.frombuffer((tmp_path / "out.sa").read_bytes(), dtype=np.uint64)
         full = oracle.sa_circular(np.unique(cps, return_inverse=True)[1].astype(np.uint8))
         assert int(sa[0]) == 16 and np.array_equal(sa[2:].astype(np.int64), full[::16])
+    # more than 256 distinct code points: the ranks no longer fit a byte alphabet and go as 32-bit symbols (B3M_INPUT_SYMBOLS32: one block,
+    # three 21-bit symbols per sort key); same files, same decoder.  CJK + Hangul + astral-plane text with repeats and a long run.
+    pool = [chr(0x4E00 + 7 * i) for i in range(900)] + [chr(0xAC00 + 3 * i) for i in range(400)] + [chr(0x1F300 + i) for i in range(60)] + list("abc ,.\n")
+    pick = rng.integers(0, len(pool), 30000)
+    wide = "".join(pool[i] for i in pick)
+    wide = wide[:12000] + wide[2000:7000] + "\u4e00" * 700 + wide[12000:] + wide[100:2100]
     big = tmp_path / "big.txt"
-    big.write_bytes("".join(chr(0x4E00 + i) for i in range(300)).encode("utf-8"))
-    r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % (tmp_path / "b.bwt"), str(big)], capture_output=True)
-    assert r.returncode != 0 and b"300 distinct code points" in r.stderr
+    big.write_bytes(wide.encode("utf-8"))
+    wcps = np.array([ord(c) for c in wide], dtype=np.int64)
+    assert len(set(wide)) > 1000
+    wref = oracle.bwt_wide(wcps)
+    for extra in (["bwtonly=1"], ["bwtonly=0", "isasamplingrate=512", "sasamplingrate=32"]):
+        outfn = tmp_path / "b.bwt"
+        r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % outfn] + extra + [str(big)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        n = ctypes.c_uint64(0)
+        got = np.zeros(len(wcps), dtype=np.int64)
+        assert _lib.lib().b3m_rl_read_symbols(str(outfn).encode(), got.ctypes.data, len(got), ctypes.byref(n)) == 0 and n.value == len(wcps)
+        assert np.array_equal(got, wref)
+        d = subprocess.run([os.path.join(root, "bin", "bwtb3mdecoderl"), "inputtype=utf-8", str(outfn)], capture_output=True)
+        assert d.returncode == 0 and d.stdout.decode("utf-8") == "".join(chr(int(c)) for c in wref)
+        hist = np.frombuffer((tmp_path / "b.hist").read_bytes(), dtype=">u8")
+        cnt = dict(zip(*np.unique(wcps, return_counts=True)))
+        assert int(hist[0]) == len(cnt) and {int(k): int(v) for k, v in zip(hist[1::2], hist[2::2])} == {int(k): int(v) for k, v in cnt.items()}
+    # the sampled suffix array and its inverse of the bwtonly=0 run, against a plain sort of the rotations' ranks
+    rk = np.unique(wcps, return_inverse=True)[1].astype(np.int64)
+    r2 = rk.copy(); h = 1
+    while True:                                                     # prefix doubling, as in oracle.bwt_wide
+        order = np.lexsort((r2[(np.arange(len(r2)) + h) % len(r2)], r2))
+        a, b = r2[order], r2[(order + h) % len(r2)]
+        nr = np.empty_like(r2); nr[order] = np.concatenate([[0], np.cumsum((a[1:] != a[:-1]) | (b[1:] != b[:-1]))]); r2 = nr; h *= 2
+        if r2.max() == len(r2) - 1 or h >= len(r2):
+            break
+    full = np.argsort(r2, kind="stable")
+    sa = np.frombuffer((tmp_path / "b.sa").read_bytes(), dtype=np.uint64)
+    assert int(sa[0]) == 32 and np.array_equal(sa[2:].astype(np.int64), full[::32])
+    isa = np.frombuffer((tmp_path / "b.isa").read_bytes(), dtype=np.uint64)
+    assert int(isa[0]) == 512 and np.array_equal(isa[2:].astype(np.int64), r2[::512])
     bad = tmp_path / "bad.txt"
     bad.write_bytes(b"abc\xc3\x28def")
     r = subprocess.run([os.path.join(root, "bin", "bwtb3m"), "inputtype=utf-8", "outputfilename=%s" % (tmp_path / "c.bwt"), str(bad)], capture_output=True)
     assert r.returncode != 0 and b"invalid byte sequence at offset 3" in r.stderr
+
+
+def test_symbols32_plans_against_the_oracle(gpu, oracle):
+    """B3M_INPUT_SYMBOLS32 at plan level (row f4: alphabets wider than a byte, what utf-8 texts of more than 256 distinct code points become):
+    the BWT of the circular text of 21-bit symbols against the oracle's bwt_wide, (rank,pos) samples against a plain rotation sort, the LF walk
+    over the result.  Cases: tiny texts, full-width symbols, period-p texts (equal rotations), long repeats (prefix doubling), two symbols that
+    differ only above bit 16."""
+    from bwtb3m_amd import engine, _lib
+    rng = np.random.default_rng(321)
+    cases = [np.array([5]), np.array([9, 9]), np.array([3, 1, 2]), np.array([(1 << 21) - 1, 0, (1 << 21) - 1, 1]),
+             rng.integers(0, 1 << 21, 5000), rng.integers(0, 700, 70000), np.tile(rng.integers(0, 40000, 37), 300),
+             rng.integers(0, 3, 20000) * 65536 + 1, np.full(3000, 1234)]
+    base = rng.integers(0, 5000, 30000)
+    cases.append(np.concatenate([base, base[4000:24000], rng.integers(0, 5000, 500), base[:9000]]))      # 20,000- and 9,000-symbol repeats
+    for sym in cases:
+        sym = np.asarray(sym, dtype=np.int64)
+        n = len(sym)
+        rate = 64 if n >= 64 else 1
+        got, res, plan, d_out = engine.bwt_symbols32(sym, isasamplingrate=rate)
+        try:
+            assert np.array_equal(got.astype(np.int64), oracle.bwt_wide(sym)), (n, int(sym.max()))
+            rot_equal = n > 1 and any(n % p == 0 and np.array_equal(sym, np.roll(sym, p)) for p in range(1, min(n, 400)))
+            if not rot_equal:
+                # ranks of the sampled positions: the number of rotations smaller than theirs
+                smp = plan.samples()
+                assert len(smp) == (n + rate - 1) // rate and np.array_equal(smp[:, 1].astype(np.int64), np.arange(0, n, rate))
+                if n <= 6000:
+                    order = sorted(range(n), key=lambda i: list(sym[i:]) + list(sym[:i]))
+                    rank = np.empty(n, dtype=np.int64); rank[order] = np.arange(n)
+                    assert np.array_equal(smp[:, 0].astype(np.int64), rank[::rate])
+                mm0, mm1, sa = plan.lf_walk(d_out, sarate=16)
+                assert (mm0, mm1) == (0, 0)
+                if n <= 6000:
+                    assert np.array_equal(sa.astype(np.int64), np.array(order)[::16])
+        finally:
+            plan.close()
+    with pytest.raises(_lib.B3MError):
+        engine.Plan(1000, _lib.SYMBOLS32, blocksize=100)        # one block only
 
 
 def test_repeat_rich_100mbase_one_block_lf_verified(gpu):
