@@ -147,6 +147,7 @@ struct MsdWs {
 	uint32_t *tile_fr = nullptr; uint64_t tile_fr_cap = 0;
 	void *gtiles = nullptr; uint64_t gtiles_cap = 0;
 	uint32_t *tfirst = nullptr;
+	uint32_t *cbase0 = nullptr; uint64_t cbase0_cap = 0;    // one-pass shards: where the records of level-0 chunk c start (+ two scalars behind the columns)
 };
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span);
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);

@@ -130,6 +130,12 @@ static uint64_t msd_local0_cap(uint64_t cap)
 	const uint64_t tile = (uint64_t)W0A_CHUNK * W0A_TCH;
 	return (uint64_t)W0A_BINS * (((cap + 16 + tile - 1) / tile) * W0A_TCH);
 }
+// columns of the level-0 run table over a text range of `span` positions (a one-pass shard's chunks cover the whole block, not its own cap)
+static uint64_t msd_cols0(uint64_t span)
+{
+	const uint64_t tile = (uint64_t)W0A_CHUNK * W0A_TCH;
+	return ((span + 16 + tile - 1) / tile) * W0A_TCH;
+}
 static uint64_t msd_runtab_cap(uint64_t cap) { return (cap / L1_CHUNK + MSD_L0_MAX) * (uint64_t)MSD_MAXBINS; }   // one column per chunk, 2^D1 rows per level-0 bucket
 
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
@@ -139,7 +145,8 @@ uint64_t msd_ws_bytes(uint64_t cap, uint64_t span)
 	return al(4 * hist) + al(sizeof(MsdTile) * msd_tiles_cap(cap)) + al(8 * MSD_L0_MAX) + al(4 * 3 * MSD_L0_MAX) + al(4 * MSD_TAB_MAX)
 	     + al(4 * (2 * msd_ovf_cap(cap) + 4)) + al(4 * (msd_big_cap(cap) + 2)) + al(4 * (MSD_TAB_MAX + 2)) + al(4 * (cap / F_HUGE + 18)) + 2 * al(4 * msd_runtab_cap(cap)) + 256 + al(4 * scan_ws_elems(hist)) + 4096
 	     + 2 * al(4 * (msd_list2_cap(cap) + 2)) + al(4 * (cap / F_HUGE + 18)) + al(4 * msd_lvl2_words(cap))
-	     + (msd_local0_cap(cap) ? 2 * al(4 * msd_local0_cap(cap)) + al(4 * (cap / L1_CHUNK + 2 * MSD_L0_MAX)) + al(32 * msd_tiles_cap(cap)) + al(4 * MSD_L0_MAX) : 0);
+	     + (msd_local0_cap(cap) ? 2 * al(4 * msd_local0_cap(cap)) + al(4 * (cap / L1_CHUNK + 2 * MSD_L0_MAX)) + al(32 * msd_tiles_cap(cap)) + al(4 * MSD_L0_MAX)
+	                              + al(4 * (msd_cols0(std::max(cap, span)) + 32)) : 0);
 }
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 {
@@ -165,7 +172,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	ws.lvl2 = (uint32_t *)p; ws.lvl2_buckets = msd_lvl2_buckets(cap); ws.lvl2_words = msd_lvl2_words(cap); p += al(4 * msd_lvl2_words(cap));
 	ws.scan_ws = (uint32_t *)p; p += al(4 * scan_ws_elems(hist));
 	// chunk-local level 0 (whole blocks below 2^32): its run table and the rows' prefixes, level 1's gather tiles
-	ws.tab0 = nullptr; ws.pre0 = nullptr; ws.tab0_cap = 0;
+	ws.tab0 = nullptr; ws.pre0 = nullptr; ws.tab0_cap = 0; ws.cbase0 = nullptr; ws.cbase0_cap = 0;
 	if (msd_local0_cap(cap)) {
 		ws.tab0_cap = msd_local0_cap(cap);
 		ws.tab0 = (uint32_t *)p; p += al(4 * ws.tab0_cap);
@@ -173,6 +180,7 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 		ws.tile_fr_cap = cap / L1_CHUNK + 2 * MSD_L0_MAX; ws.tile_fr = (uint32_t *)p; p += al(4 * ws.tile_fr_cap);
 		ws.gtiles_cap = msd_tiles_cap(cap); ws.gtiles = p; p += al(32 * ws.gtiles_cap);
 		ws.tfirst = (uint32_t *)p; p += al(4 * MSD_L0_MAX);
+		ws.cbase0_cap = msd_cols0(std::max(cap, span)); ws.cbase0 = (uint32_t *)p; p += al(4 * (ws.cbase0_cap + 32));     // + 32: the reservation counter, the overflow flag, the "below" count and five symbol counts behind the columns
 	}
 }
 
@@ -221,6 +229,12 @@ struct L0Args {
 	uint32_t *runtab0;           // LOCAL: row (digit) x column (chunk): start inside the chunk | length << 16
 	uint32_t nchunks0;           // LOCAL: columns
 	uint32_t tile_base;          // LOCAL: first tile of this launch (the text may arrive in pieces: one launch per piece)
+	uint32_t tile_stride;        // COUNT_ONLY: workgroup i counts tile i * tile_stride into column i (0 = 1; a sample of the tiles: shard borders)
+	// SHARD (chunk-local level 0 of a suffix-range shard: ONE pass over the text): a chunk keeps the positions of the shard's digits only and
+	// reserves room for them at the end of what the chunks before it (in time) took; where, says cbase[column]
+	uint32_t *cbase; uint32_t *alloc; uint32_t cap;
+	unsigned long long *below;   // += positions of the block with a digit below keep_lo: the global rank of the shard's first suffix
+	unsigned long long *symhist; // SHARD, may be null: += the block's symbol histogram (256 entries; every position is looked at anyway)
 };
 
 // window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
@@ -238,9 +252,12 @@ __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t 
 // LOCAL (whole-text blocks, no shard): the chunk's records go out in digit order to the chunk's OWN index range of the record buffer,
 // a stream of whole lines instead of 2048 scattered 32-record runs, and where digit d sits inside chunk c is one entry of a run table
 // (row d, column c); no counting pass and no [digit][tile] offsets are needed.  Level 1 gathers a bucket from its row's runs.
-template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false>
+// (SHARD with a third of the index array and two workgroups per CU -- what paces this pass is the chain of latencies per chunk, not the atomics
+// of the few positions kept -- needs 64 registers per thread: 161 spilled, the pass went from 3.0 to 7.5 ms at N = 8.  One workgroup per CU it is.)
+template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false, bool SHARD = false>
 __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 {
+	static_assert(!SHARD || (LOCAL && !COUNT_ONLY), "a one-pass shard is a chunk-local level 0");
 	constexpr int WORDS = CHUNK / 16;
 	static_assert(CHUNK % 16 == 0 && CHUNK <= 65536, "chunk-local positions are 16-bit");
 	__shared__ uint32_t cur[MAXBINS];                            // count, then exclusive start, then end of every digit run
@@ -248,11 +265,15 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : CHUNK];            // chunk-local positions in digit order
 	__shared__ uint32_t stext[WORDS + 4];                        // [0] = the word before the chunk
 	__shared__ uint32_t wsum[W0_THREADS / 64];
+	__shared__ uint32_t s_base;
+	uint32_t n_below = 0;                                        // SHARD: this thread's positions with a digit below the shard's
+	uint32_t n_s1 = 0, n_s2 = 0, n_s3 = 0, n_all = 0, n_term = 0; // SHARD: this thread's positions by leading base 1, 2, 3, all of them, the terminator
 	const uint32_t tid = threadIdx.x;
 	const int bins = (int)(A.keep_hi - A.keep_lo);           // bin = digit - keep_lo; digits outside [keep_lo, keep_hi) are not this sort's (suffix-range shard)
 	const uint32_t klo = A.keep_lo, nbin = (uint32_t)bins;
 	const int dsh = 64 - A.D, dsh32 = 32 - A.D;
-	const uint32_t tile = (LOCAL ? A.tile_base : 0u) + blockIdx.x, ntiles = gridDim.x;
+	const uint32_t tcol = blockIdx.x, ntiles = gridDim.x;      // column of the [bin][tile] matrix this workgroup owns
+	const uint32_t tile = (LOCAL ? A.tile_base : 0u) + ((COUNT_ONLY && A.tile_stride > 1u) ? tcol * A.tile_stride : tcol);
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
 	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
@@ -264,6 +285,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			// a chunk outside the block: its column of the run table is empty (written here: the table is not cleared beforehand)
 			const uint32_t col = tile * TCH + c;
 			for (int b = tid; b < bins; b += W0_THREADS) A.runtab0[(uint64_t)b * A.nchunks0 + col] = 0u;
+			if (SHARD && tid == 0) A.cbase[col] = 0u;
 			continue;
 		}
 		if (cpos >= end) break;
@@ -280,9 +302,10 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		// a suffix-range shard keeps 1/N of the positions: the count remembers WHICH (16 bits per word of 16 positions, in registers: the
 		// same thread takes the same words in the place phase) so that the place phase only visits those
 		constexpr int NJ = (WORDS + W0_THREADS - 1) / W0_THREADS;
-		uint32_t km[(COUNT_ONLY || LOCAL) ? 1 : (NJ + 1) / 2];
-		const bool sparse = !COUNT_ONLY && !LOCAL && 2u * nbin <= (1u << A.D);
-		if (!COUNT_ONLY && !LOCAL) { for (int j = 0; j < (NJ + 1) / 2; ++j) km[j] = 0u; }
+		constexpr bool KM = !COUNT_ONLY && (!LOCAL || SHARD);
+		uint32_t km[KM ? (NJ + 1) / 2 : 1];
+		const bool sparse = KM && 2u * nbin <= (1u << A.D);
+		if (KM) { for (int j = 0; j < (NJ + 1) / 2; ++j) km[j] = 0u; }
 		if (fast) {
 			#pragma unroll
 			for (int j = 0; j < NJ; ++j) {
@@ -291,12 +314,18 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				// the digit needs <= 12 bits of the window: 32-bit funnel shifts of two words do
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				uint32_t mk = 0;
+				if (SHARD) {          // the 16 positions of this word start with its 16 bases
+					const uint32_t lo = w0 & 0x55555555u, hi = (w0 >> 1) & 0x55555555u;
+					n_s1 += __popc(lo & ~hi); n_s2 += __popc(hi & ~lo); n_s3 += __popc(lo & hi); n_all += 16u;
+				}
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					const uint32_t bin = ((s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32) - klo;
+					const uint32_t dg0 = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
+					const uint32_t bin = dg0 - klo;
+					if (SHARD) n_below += dg0 < klo ? 1u : 0u;
 					if (bin < nbin) { atomicAdd(&cur[bin], 1u); mk |= 1u << s; }
 				}
-				if (!COUNT_ONLY && !LOCAL) km[j >> 1] |= mk << (16 * (j & 1));
+				if (KM) km[j >> 1] |= mk << (16 * (j & 1));
 			}
 		} else {
 			#pragma nounroll
@@ -304,6 +333,12 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
+					if (SHARD) {
+						n_below += (uint32_t)(x >> dsh) < klo ? 1u : 0u;
+						const uint64_t ap = cpos + li;
+						if (A.T.type == B3M_INPUT_PACTERM && ap == A.T.n - 1) n_term += 1u;
+						else { const uint32_t bs = base_at(A.T, ap); n_s1 += bs == 1u; n_s2 += bs == 2u; n_s3 += bs == 3u; n_all += 1u; }
+					}
 					if (bin < nbin) atomicAdd(&cur[bin], 1u);
 				}
 			}
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			for (int j = 0; j < NJ; ++j) {
 				const uint32_t w = j * W0_THREADS + tid;
 				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
-				uint32_t mk = (km[(COUNT_ONLY || LOCAL) ? 0 : (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+				uint32_t mk = (km[KM ? (j >> 1) : 0] >> (16 * (j & 1))) & 0xFFFFu;
 				if (mk == 0) continue;
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				while (mk) {
@@ -367,6 +402,12 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		__syncthreads();
 		// ---- generate the records in digit order: cur[d] is now the END of run d ----
 		const uint32_t nvalid = cur[bins - 1];
+		if (SHARD) {
+			// the chunk's records go behind what earlier chunks reserved (any order: level 1 finds them through the run table and cbase)
+			if (tid == 0) { const uint32_t bs = nvalid ? atomicAdd(A.alloc, nvalid) : 0u; s_base = bs; A.cbase[tile * TCH + c] = bs; }
+			__syncthreads();
+		}
+		const uint32_t obase = SHARD ? s_base : 0u;
 		for (uint32_t q = tid; q < nvalid; q += W0_THREADS) {
 			const uint32_t li = sidx[q];
 			uint32_t dgt; uint64_t r;
@@ -384,6 +425,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 				l0_slow(A.T, cpos + li, A.start, end, &x, &pr);
 				r = make_rec(x, A.D, pr, cpos + li, &dgt, A.pb);
 			}
+			if (SHARD) { if ((uint64_t)obase + q < (uint64_t)A.cap) __builtin_nontemporal_store(r, &A.rec_out[(uint64_t)obase + q]); continue; }      // (past the workspace: the host sees alloc > cap and takes the two-pass path)
 			if (LOCAL) { __builtin_nontemporal_store(r, &A.rec_out[(cpos - A.P0) + q]); continue; }
 			const uint32_t bin = dgt - klo;
 			const uint32_t rs = bin ? cur[bin - 1] : 0u;          // start of run bin
@@ -401,7 +443,37 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	}
 	if (COUNT_ONLY) {
 		__syncthreads();
-		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tile + (uint64_t)b * ntiles] = cur[b];
+		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tcol + (uint64_t)b * ntiles] = cur[b];
+	}
+	if (SHARD) {
+		#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			n_below += __shfl_xor(n_below, o, 64);
+			n_s1 += __shfl_xor(n_s1, o, 64); n_s2 += __shfl_xor(n_s2, o, 64); n_s3 += __shfl_xor(n_s3, o, 64); n_all += __shfl_xor(n_all, o, 64); n_term += __shfl_xor(n_term, o, 64);
+		}
+		// one atomic per workgroup and counter (one per wave was 16 x 11,500 workgroups on six addresses: the pass took 7 ms instead of 3)
+		__syncthreads();
+		uint32_t *red = cur;                                     // (dead: the last chunk's run table has been written)
+		if ((tid & 63u) == 0u) { uint32_t *r = red + 8u * (tid >> 6); r[0] = n_below; r[1] = n_s1; r[2] = n_s2; r[3] = n_s3; r[4] = n_all; r[5] = n_term; }
+		__syncthreads();
+		if (tid < 6u) {
+			unsigned long long v = 0;
+			for (uint32_t w = 0; w < (uint32_t)(W0_THREADS / 64); ++w) v += red[8u * w + tid];
+			red[256 + tid * 2] = (uint32_t)v; red[257 + tid * 2] = (uint32_t)(v >> 32);
+		}
+		__syncthreads();
+		if (tid == 0) {
+			auto tot = [&](int i) { return (unsigned long long)red[256 + 2 * i] | ((unsigned long long)red[257 + 2 * i] << 32); };
+			if (tot(0)) atomicAdd(A.below, tot(0));
+			if (A.symhist && tot(4) + tot(5)) {
+				const uint32_t off = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
+				atomicAdd(&A.symhist[off], tot(4) - tot(1) - tot(2) - tot(3));
+				if (tot(1)) atomicAdd(&A.symhist[off + 1], tot(1));
+				if (tot(2)) atomicAdd(&A.symhist[off + 2], tot(2));
+				if (tot(3)) atomicAdd(&A.symhist[off + 3], tot(3));
+				if (tot(5)) atomicAdd(&A.symhist[0], tot(5));
+			}
+		}
 	}
 }
 
@@ -544,6 +616,7 @@ struct L1GArgs {
 	uint32_t *runtab;            // this level's run table (as k_l1_local)
 	const uint32_t *tab0, *pre0, *tile_fr; uint32_t nchunks0; uint32_t chunk0;      // level 0's table, row prefixes, first runs; index stride of a level-0 chunk
 	int D, shift;
+	const uint32_t *cbase;       // null, or (one-pass shard) where the records of level-0 chunk c start: cbase[c] instead of c * chunk0
 };
 constexpr int L1G_RUNS = 1536;       // runs of one chunk kept in LDS (uniform input: ~512); more: every lane searches the row in HBM
 
@@ -585,7 +658,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 				const uint32_t slot = S0 + e;
 				uint32_t lo = fr, hi = fre + 1;                       // largest i in [fr, fre] with prow[i] <= slot
 				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prow[mid] <= slot) lo = mid; else hi = mid; }
-				rec[s] = A.rec_in[(uint64_t)lo * A.chunk0 + (row0[lo] & 0xFFFFu) + (slot - prow[lo])];
+				rec[s] = A.rec_in[(A.cbase ? (uint64_t)A.cbase[lo] : (uint64_t)lo * A.chunk0) + (row0[lo] & 0xFFFFu) + (slot - prow[lo])];
 			}
 			return;
 		}
@@ -594,7 +667,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 			const uint32_t e = row0[fr + j], pre = prow[fr + j], len = e >> 16;
 			const uint32_t lo = pre > S0 ? pre - S0 : 0u, skip = S0 > pre ? S0 - pre : 0u;
 			uint32_t hi = pre + len > S0 ? pre + len - S0 : 0u; hi = hi < nv ? hi : nv;
-			rr[j] = make_uint2(lo < nv ? lo : nv, (fr + j) * A.chunk0 + (e & 0xFFFFu) + skip);
+			rr[j] = make_uint2(lo < nv ? lo : nv, (A.cbase ? A.cbase[fr + j] : (fr + j) * A.chunk0) + (e & 0xFFFFu) + skip);
 			for (uint32_t g = (lo + 63) >> 6; (g << 6) < hi; ++g) gfirst[g] = (uint16_t)j;
 		}
 		if (tid == 0) { rr[nr] = make_uint2(nv, 0u); rr[nr + 1] = make_uint2(nv, 0u); gfirst[glast + 1] = (uint16_t)(nr - 1); }
@@ -705,6 +778,7 @@ __global__ __launch_bounds__(256) void k_run_totals(const uint32_t *runtab, uint
 	if (b == nb - 1 && tid == 0 && !lvl_end) lvl_start[(uint64_t)nb << D] = len;
 }
 
+__global__ void k_add5_u64(const unsigned long long *src, unsigned long long *dst) { if (threadIdx.x < 5) dst[threadIdx.x] += src[threadIdx.x]; }
 // totals[d] = number of records with level-0 digit d (sum of row d of the [digit][tile] counts)
 __global__ __launch_bounds__(256) void k_row_totals(const uint32_t *hist, uint32_t ntiles, unsigned long long *totals)
 {
@@ -2193,13 +2267,85 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// chunk's own index range, level 1 gathers (k_l0_pass<.., LOCAL>, k_l1_gather).  B3M_L0_LOCAL=0: the scattering form.
 	const int l0_local_on = getenv("B3M_L0_LOCAL") ? atoi(getenv("B3M_L0_LOCAL")) : 1;
 	const uint32_t nchunks0 = (uint32_t)((span + W0A_CHUNK - 1) / W0A_CHUNK);
-	const bool local0 = l0_local_on && nshards <= 1 && geoA && dg.D1 > 0 && !big && span <= ws.cap && M.tab0 != nullptr
-	                    && (uint64_t)bins0 * ((uint64_t)ntA * W0A_TCH) <= M.tab0_cap && span < (1ull << 32);
+	bool local0 = l0_local_on && nshards <= 1 && geoA && dg.D1 > 0 && !big && span <= ws.cap && M.tab0 != nullptr
+	              && (uint64_t)bins0 * ((uint64_t)ntA * W0A_TCH) <= M.tab0_cap && span < (1ull << 32);
 	const uint32_t ncol0 = ntA * (uint32_t)W0A_TCH;             // columns of the level-0 run table (whole tiles)
 	(void)nchunks0;
 	unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(M.sub_start);   // free until level 0 is done
 	if (!local0 && ws.arrival) for (int i = 0; i < ws.arrival->n; ++i) B3M_HIP(hipStreamWaitEvent(s, ws.arrival->ev[i], 0));
-	if (local0) {
+	// ---- a suffix-range shard in ONE pass over the text (B3M_SHARD_ONEPASS=0: the counting pass + the scattering pass) ----
+	// The shard's borders need digit totals of the whole text before a record can be kept or dropped -- but only to balance the shards, and
+	// every rank must arrive at the SAME borders without talking: a count over every 16th tile does both (the same sample on every rank;
+	// the shards then differ by the sampling error, ~0.1 %).  What must be exact is counted by the pass itself: the shard's size (what its chunks
+	// reserved) and the global rank of its first suffix (the positions with a smaller digit, A.below).  The pass is the chunk-local level 0
+	// restricted to the shard's digits: a chunk sorts the 1/N of its positions it keeps and puts them behind what earlier chunks reserved
+	// (cbase[column]); level 1 gathers through the run table as for a whole block.
+	bool shard1 = false, borders_fixed = false; uint32_t fixed_lo = 0, fixed_hi = 0;
+	{
+		const int onepass_on = getenv("B3M_SHARD_ONEPASS") ? atoi(getenv("B3M_SHARD_ONEPASS")) : 1;
+		int tfin = 0; while ((len_in >> tfin) > (uint64_t)F_AVG) ++tfin;
+		if (nshards > 1 && onepass_on && l0_local_on && geoA && dg.D1 > 0 && !big && M.tab0 != nullptr && M.cbase0 != nullptr && span < (1ull << 32)
+		    && ncol0 <= M.cbase0_cap && !allow_ext && own == 0 && tfin - dg.D0 - dg.D1 <= 0) {
+			const uint32_t stride = ntA >= 64 ? 16u : 1u, ns = (ntA + stride - 1) / stride;
+			{
+				Scope sc(tl, KF_MSD_HIST, span / 4 / stride);
+				A.tile_stride = stride;
+				hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ns), dim3(W0_THREADS), 0, s, A);
+				A.tile_stride = 0;
+				hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ns, d_tot);
+			}
+			std::vector<unsigned long long> tot(bins0);
+			B3M_HIP(hipMemcpyAsync(tot.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			std::vector<uint64_t> cum(bins0 + 1, 0);
+			for (uint32_t d = 0; d < bins0; ++d) cum[d + 1] = cum[d] + tot[d];
+			auto bound = [&](int k) -> uint32_t {
+				if (k <= 0) return 0; if (k >= nshards) return bins0;
+				const uint64_t target = (uint64_t)((unsigned __int128)cum[bins0] * (unsigned)k / (unsigned)nshards);
+				uint32_t d = 0; while (d < bins0 && cum[d] < target) ++d;
+				return d;
+			};
+			const uint32_t lo = bound(shard), hi = bound(shard + 1);
+			// (whether THIS shard then takes the one pass or, for want of room, the two: its borders are these -- the other shards' are)
+			borders_fixed = true; fixed_lo = lo; fixed_hi = hi;
+			const double est = cum[bins0] ? (double)(cum[hi] - cum[lo]) / (double)cum[bins0] * (double)len_in : 0.0;
+			const uint64_t capr = std::min<uint64_t>(ws.cap, 0xFFFFFFFFull);
+			const unsigned two_mask = getenv("B3M_SHARD_TWO_PASS") ? (unsigned)strtoul(getenv("B3M_SHARD_TWO_PASS"), nullptr, 0) : 0u;      // test switch: these shards (bit k = shard k) take the two passes, the others one
+			if (hi > lo && (uint64_t)(hi - lo) * ncol0 <= M.tab0_cap && est <= 0.97 * (double)capr && !((two_mask >> (shard & 31)) & 1u)) {
+				uint32_t *d_alloc = M.cbase0 + M.cbase0_cap;
+				unsigned long long *d_below = reinterpret_cast<unsigned long long *>(d_alloc + 2);
+				B3M_HIP(hipMemsetAsync(d_alloc, 0, 32 + 64, s));
+				L0Args B = A;
+				B.keep_lo = lo; B.keep_hi = hi; B.runtab0 = M.tab0; B.nchunks0 = ncol0; B.tile_base = 0;
+				B.cbase = M.cbase0; B.alloc = d_alloc; B.below = d_below; B.cap = (uint32_t)capr;
+				// the block's symbol histogram rides along (no second pass over the text for it); a fallback to the two passes must not count twice
+				const bool want_hist = ws.d_symhist_out != nullptr;
+				unsigned long long *d_h5 = reinterpret_cast<unsigned long long *>(d_alloc + 8);      // five counters behind the scalars, added to the caller's array on success
+				B.symhist = want_hist ? d_h5 : nullptr;
+				{
+					Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * (uint64_t)est);
+					hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, true>), dim3(ntA), dim3(W0_THREADS), 0, s, B);
+				}
+				uint32_t h_sc[4] = {0, 0, 0, 0};
+				B3M_HIP(hipMemcpyAsync(h_sc, d_alloc, 16, hipMemcpyDeviceToHost, s));
+				B3M_HIP(hipStreamSynchronize(s));
+				stage("level 0 (one-pass shard)");
+				if ((uint64_t)h_sc[0] <= capr) {
+					shard1 = true; local0 = true;
+					if (want_hist) { hipLaunchKernelGGL(k_add5_u64, dim3(1), dim3(64), 0, s, d_h5, reinterpret_cast<unsigned long long *>(ws.d_symhist_out)); out.symhist_done = true; }
+					bins0 = hi - lo; len = h_sc[0];
+					out.slice_offset = (uint64_t)h_sc[2] | ((uint64_t)h_sc[3] << 32);
+					A.keep_lo = lo; A.keep_hi = hi;
+					Scope sc(tl, KF_SCAN, 4ull * bins0 * ncol0);
+					if (bins0) hipLaunchKernelGGL(k_rows0_totals, dim3(bins0), dim3(256), 0, s, M.tab0, ncol0, d_tot);
+				}
+				// (more than the workspace holds, against the estimate: nothing is lost, the two passes below start over and say what is too large)
+			}
+		}
+	}
+	if (shard1) {
+		// (the pass has counted the block's symbols itself)
+	} else if (local0) {
 		{
 			Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
 			A.runtab0 = M.tab0; A.nchunks0 = ncol0;                  // (every column is written by its chunk, empty ones too)
@@ -2231,16 +2377,16 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
-	bool totals_ready = local0;             // d_tot holds this pass's digit totals (NOT out.symhist_done: a pass that starts over with the suffix array kept inherits that flag, while d_tot has been overwritten since)
-	if (ws.d_symhist_out && dg.D0 >= 2) {
+	bool totals_ready = local0 && !shard1;  // d_tot holds this pass's digit totals (NOT out.symhist_done: a pass that starts over with the suffix array kept inherits that flag, while d_tot has been overwritten since)
+	if (ws.d_symhist_out && dg.D0 >= 2 && !shard1) {
 		if (!local0) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
 		totals_ready = true;
 		hipLaunchKernelGGL(k_symhist_from_totals, dim3(1), dim3(256), 0, s, d_tot, bins0, dg.D0, T.type == B3M_INPUT_PACTERM ? 1 : 0,
 		                   (T.type == B3M_INPUT_PACTERM && start + len_in == T.n) ? 1 : 0, reinterpret_cast<unsigned long long *>(ws.d_symhist_out));
 		out.symhist_done = true;
 	}
-	out.slice_offset = 0;
-	if (nshards > 1) {
+	if (!shard1) out.slice_offset = 0;
+	if (nshards > 1 && !shard1) {
 		// suffix-range shard: this rank keeps the level-0 digits [lo, hi) holding the ranks
 		// [shard*n/N, (shard+1)*n/N) as evenly as whole digits allow.  The totals come from the
 		// text alone, so every rank derives the same boundaries without talking to anyone.
@@ -2257,6 +2403,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			return d;
 		};
 		uint32_t lo = bound(shard), hi = bound(shard + 1);
+		if (borders_fixed) { lo = fixed_lo; hi = fixed_hi; }      // the borders every shard of this text uses (from the sampled count above); sizes and offsets below are exact
 		out.slice_offset = cum[lo];
 		len = cum[hi] - cum[lo];
 		if (!(len <= ws.cap && len < (1ull << 32))) {
@@ -2376,6 +2523,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			L1GArgs Gq{};
 			Gq.rec_in = ws.keyA; Gq.rec_out = ws.keyB; Gq.tiles = reinterpret_cast<const L1GTile *>(M.gtiles); Gq.runtab = M.runtab;
 			Gq.tab0 = M.tab0; Gq.pre0 = M.pre0; Gq.tile_fr = M.tile_fr; Gq.nchunks0 = ncol0; Gq.chunk0 = (uint32_t)W0A_CHUNK; Gq.D = dg.D1; Gq.shift = 64 - dg.D1;
+			Gq.cbase = shard1 ? M.cbase0 : nullptr;
 			ntB = (uint32_t)gtiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
 			hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);

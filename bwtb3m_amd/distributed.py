@@ -134,14 +134,22 @@ class HipBackend:
         eng.check(eng.lib().b3m_dist_set_text(self._h, eng._ptr(d_text), eng._stream()))
 
     def leaf(self, a, m):
-        """-> (bwt, gt_abs words with this leaf's bits, p0, symbol counts 0..4 of the leaf's text)"""
+        """-> (bwt, gt_abs words with this leaf's bits, p0, symbol counts of the leaf's text: 0..4 for 2-bit alphabets, 0..255 for bytes)"""
         eng = self.engine
         bw = torch.empty(m, dtype=torch.uint8, device=self.device)
         gt_abs = torch.zeros(self.gt_words(self.n), dtype=torch.int32, device=self.device)
         p0 = ctypes.c_uint64(0)
         h5 = (ctypes.c_uint64 * 5)()
         eng.check(eng.lib().b3m_dist_leaf(self._h, a, m, eng._ptr(bw), eng._ptr(gt_abs), ctypes.byref(p0), h5, eng._stream()))
+        if self.type == eng.INPUT_TYPES["bytestream"]:
+            h256 = (ctypes.c_uint64 * 256)()
+            eng.check(eng.lib().b3m_dist_leaf_hist(self._h, h256))
+            return bw, gt_abs, int(p0.value), [int(x) for x in h256]
         return bw, gt_abs, int(p0.value), [int(x) for x in h5]
+
+    def packed_len(self, count):
+        """bytes of the transport form of `count` BWT symbols (pack2): 4 per byte for 2-bit alphabets, as they are for bytes"""
+        return count if self.type == self.engine.INPUT_TYPES["bytestream"] else (count + 3) // 4
 
     def rank_of_into(self, positions, accum):
         """accum (int64 device tensor, one entry per position) += rank of the rotation starting at each position among the suffixes of the
@@ -167,7 +175,7 @@ class HipBackend:
     def pack2(self, bwt):
         eng = self.engine
         m = bwt.numel()
-        pk = torch.empty((m + 3) // 4, dtype=torch.uint8, device=self.device)
+        pk = torch.empty(self.packed_len(m), dtype=torch.uint8, device=self.device)
         eng.check(eng.lib().b3m_dist_pack2(self._h, eng._ptr(bwt), m, eng._ptr(pk), eng._stream()))
         return pk
 
@@ -188,7 +196,7 @@ class HipBackend:
         assert anchors.dtype == torch.int64 and anchors.is_contiguous() and anchors.numel() == num_chains
         bd = np.ascontiguousarray(bounds, dtype=np.uint64)
         cuts = np.zeros(len(bd), dtype=np.uint64)
-        ss = (ctypes.c_uint64 * 4)(*[int(x) for x in symstart])
+        ss = (ctypes.c_uint64 * len(symstart))(*[int(x) for x in symstart])      # 4 symbol starts (2-bit alphabets) or 256 (bytes)
         eng.check(eng.lib().b3m_dist_walk(self._h, a, m, mr, ss, eng._ptr(gt_abs), eng._ptr(gt_out), eng._ptr(anchors), chain_first, num_chains, chain_len,
                                           bd.ctypes.data, len(bd), eng._ptr(sr), cuts.ctypes.data, ctypes.byref(cnt), eng._stream()))
         return sr[: cnt.value], cuts.astype(np.int64), gt_out
@@ -334,6 +342,8 @@ class DistributedBwt:
     def _symstart(self, ranks):
         """C array of a node's text: symbols smaller than code c (pacterm: code c = symbol c + 1, the terminator is smaller than every base)"""
         h = self.leaf_hist[ranks].sum(axis=0)
+        if self.itype == "bytestream":
+            return [int(x) for x in np.concatenate([[0], np.cumsum(h[:255])])]
         if self.itype == "pacterm":
             return [int(h[0] + h[1:1 + c].sum()) for c in range(4)]
         return [int(h[:c].sum()) for c in range(4)]
@@ -391,11 +401,11 @@ class DistributedBwt:
         p0L = int(info[0, 1])
         assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
         offR = np.concatenate([[0], np.cumsum(sizes[nL:])])
-        # 2. BWT(L) to every member as packed slices, 2 bits per symbol (the rank dictionary is built from them where it is used)
+        # 2. BWT(L) to every member as packed slices, 2 bits per symbol (bytes: as they are); the rank dictionary is built from them where it is used
         parts = []
         for j in range(nL):
             cj = int(sizes[j])
-            part = be.pack2(my_bwt) if gi == j else torch.empty((cj + 3) // 4, dtype=torch.uint8, device=dev)
+            part = be.pack2(my_bwt) if gi == j else torch.empty(be.packed_len(cj), dtype=torch.uint8, device=dev)
             _broadcast(part, members[j], grp)
             parts.append((part, cj))
         # 3. gt bits: L's positions (a, rbeg) are valid on L's members, R's (rbeg, rend] on R's.

@@ -50,7 +50,7 @@ class OracleBackend:
         self.sa = sa
         absb = np.zeros(self.gt_words(n) * 32, dtype=np.uint8)
         absb[a + 1: a + m + 1] = gt[1:]
-        h5 = np.bincount(self.sym[a:a + m], minlength=5)[:5]
+        h5 = np.bincount(self.sym[a:a + m], minlength=256) if self.itype == "bytestream" else np.bincount(self.sym[a:a + m], minlength=5)[:5]
         return torch.from_numpy(bw), torch.from_numpy(_bits_to_words(absb)), p0, [int(x) for x in h5]
 
     def rank_of_into(self, positions, accum):
@@ -64,7 +64,12 @@ class OracleBackend:
         from bwtb3m_amd.distributed import _set_bit
         _set_bit(gt, bit, 1 if int(anchor[0]) > p0L else 0)
 
+    def packed_len(self, count):
+        return count if self.itype == "bytestream" else (count + 3) // 4
+
     def pack2(self, bwt):
+        if self.itype == "bytestream":
+            return bwt.clone()
         b = bwt.numpy().astype(np.int64)
         codes = (b - self.sub) & 3
         pad = np.zeros((len(codes) + 3) // 4 * 4, dtype=np.int64)
@@ -76,6 +81,9 @@ class OracleBackend:
         assert m <= self.limits[1]
         out = []
         for t, cnt in parts:
+            if self.itype == "bytestream":
+                out.append(t.numpy()[:cnt].copy())
+                continue
             v = t.numpy().astype(np.int64)
             codes = np.stack([(v >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[:cnt]
             out.append((codes + self.sub).astype(np.uint8))
@@ -87,7 +95,9 @@ class OracleBackend:
         n = self.n
         # the C array handed in must be the one of L's text
         hist = np.bincount(self.sym[a:a + m], minlength=5)
-        if self.itype == "pacterm":
+        if self.itype == "bytestream":
+            assert list(symstart) == [int(x) for x in np.concatenate([[0], np.cumsum(np.bincount(self.sym[a:a + m], minlength=256)[:255])])]
+        elif self.itype == "pacterm":
             assert list(symstart) == [int(hist[0] + hist[1:1 + c].sum()) for c in range(4)]
         else:
             assert list(symstart) == [int(hist[:c].sum()) for c in range(4)]

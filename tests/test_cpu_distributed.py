@@ -33,7 +33,13 @@ def _worker(rank, world, port, itype, nb, seed, repeat, q):
         from oracle_backend import OracleBackend
         from bwtb3m_amd import distributed as D
         b = O.synth_repeat_bases(nb, seed) if repeat else O.synth_bases(nb, seed)
-        buf = O.pac_encode(b)
+        if itype == "bytestream":
+            # a byte text with structure: bases mapped to letters, a 400-symbol repeat, a few rare symbols (0 and 255 among them)
+            buf = np.frombuffer(b"ACGT", dtype=np.uint8)[b].copy()
+            buf[nb // 2: nb // 2 + 400] = buf[100:500]
+            buf[::97] = 255; buf[5::211] = 0; buf[7::53] = 10
+        else:
+            buf = O.pac_encode(b)
         sym = O.symbols_from_file_bytes(buf, itype)
         n = len(sym)
         job = D.DistributedBwt(n, itype, OracleBackend(sym, itype), torch.device("cpu"))
@@ -52,7 +58,7 @@ def _worker(rank, world, port, itype, nb, seed, repeat, q):
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
-@pytest.mark.parametrize("itype,nb,repeat", [("pacterm", 5000, False), ("pac", 4097, False), ("pacterm", 6000, True)])
+@pytest.mark.parametrize("itype,nb,repeat", [("pacterm", 5000, False), ("pac", 4097, False), ("pacterm", 6000, True), ("bytestream", 4001, False)])
 def test_distributed_driver_gloo(world, itype, nb, repeat):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -297,7 +297,13 @@ def _dist_worker(rank, world, port, itype, nb, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(0)
         b = O.synth_bases(nb, 99)
-        buf = O.pac_encode(b)
+        if itype == "bytestream":
+            # byte alphabets across ranks (count rows instead of 2-bit rank lines): text of four frequent letters, rare symbols 0 / 10 / 255, a repeat
+            buf = np.frombuffer(b"ACGT", dtype=np.uint8)[b].copy()
+            buf[nb // 2: nb // 2 + 3000] = buf[1000:4000]
+            buf[::97] = 255; buf[5::211] = 0; buf[7::53] = 10
+        else:
+            buf = O.pac_encode(b)
         sym = O.symbols_from_file_bytes(buf, itype)
         job = D.DistributedBwt(len(sym), itype, D.HipBackend(dev), dev)
         d_text = torch.from_numpy(buf).to(dev)
@@ -335,7 +341,7 @@ def _dist_worker(rank, world, port, itype, nb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,itype,nb", [(2, "pacterm", 300000), (4, "pac", 262144), (3, "pacterm", 100001)])
+@pytest.mark.parametrize("world,itype,nb", [(2, "pacterm", 300000), (4, "pac", 262144), (3, "pacterm", 100001), (2, "bytestream", 200001), (3, "bytestream", 70000)])
 def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
     import socket
     import torch.multiprocessing as mp
@@ -516,6 +522,39 @@ def test_msd_leaves_then_merges(gpu, oracle, itype):
     smp = plan.samples()
     assert np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
     plan.close()
+
+
+def test_shards_one_pass_and_two_pass_agree_on_their_borders(gpu, oracle, monkeypatch):
+    """A suffix-range shard takes ONE pass over the text (chunk-local level 0 restricted to its digits, borders from a sampled count) and
+    falls back to the counting + scattering passes when its workspace is short; a fallback on one rank must not move the borders the other
+    ranks use.  Shards 0 and 2 of 4 are forced onto the two passes (B3M_SHARD_TWO_PASS), 1 and 3 take one: the slices must tile the oracle's BWT;
+    then all one-pass and all two-pass (B3M_SHARD_ONEPASS=0), with samples and the symbol histogram the pass counts on the way."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    nb = (1 << 20) + 777
+    b = oracle.synth_bases(nb, 77).copy()
+    b[300000:420000] = b[100000:220000]            # a 120-kb repeat
+    buf = oracle.pac_encode(b)
+    for itype in ("pacterm", "pac"):
+        s = oracle.symbols_from_file_bytes(buf, itype)
+        ref = oracle.bwt(s)
+        n = len(s)
+        d_text = torch.from_numpy(np.asarray(buf)).cuda()
+        for env in ({"B3M_SHARD_TWO_PASS": "5"}, {}, {"B3M_SHARD_ONEPASS": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            plans, slices = _run_all_shards(torch, engine, d_text, n, itype, 4, 4096)
+            for k in env:
+                monkeypatch.delenv(k)
+            got = np.concatenate([sl.cpu().numpy() for sl in slices])
+            assert len(got) == n and np.array_equal(got, ref), (itype, env)
+            off = 0
+            for plan, sl in zip(plans, slices):
+                r = plan.result()
+                assert r["slice_offset"] == off
+                off += sl.numel()
+                assert np.array_equal(plan.histogram().astype(np.int64), np.bincount(s, minlength=256)), (itype, env)
+                plan.close()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1096,10 +1135,12 @@ def test_bench_two_ranks_on_one_gpu_reports_both_modes_and_fails_loudly(gpu, tmp
     for m in ("prefix", "blocks"):       # both modes check what they timed: slices tile the rank space, histograms add up, BWT[p0] = terminator
         assert "tile [0, n)" in j["config"]["modes"][m]["checked"] and "terminator" in j["config"]["modes"][m]["checked"]
     assert j["config"]["checked"] == j["config"]["modes"]["prefix"]["checked"]
-    # block mode on a byte alphabet is refused by the library: the run must fail, not report
-    cmd_bad = cmd[:-4] + ["--config", "c1", "--mode", "blocks"]
-    r = subprocess.run(cmd_bad, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+    # block mode on a byte alphabet (C1, bytestream): the same exchange path over count rows instead of 2-bit rank lines
+    cmd_c1 = cmd[:-4] + ["--config", "c1", "--mode", "blocks", "--no-also-blocks"]
+    r = subprocess.run(cmd_c1, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j1 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["config"]["mode"] == "blocks" and j1["config"]["modes"]["blocks"]["merge_levels"] == 1 and "tile [0, n)" in j1["config"]["checked"]
     # a rank that fails in the OTHER mode (the one step that rides along) must not cost the headline: the line stands and names the failure ...
     for who in ("1", "0"):
         r = subprocess.run(cmd + ["--blocks-timeout", "25"], env=dict(env, B3M_BENCH_INJECT="blocks:" + who), capture_output=True, text=True, timeout=600, cwd=root)

@@ -2,7 +2,7 @@ import sys, time, torch
 sys.path.insert(0, "/root/repo")
 from bwtb3m_amd import engine, synth
 itype, d_text, n = synth.config_input_device("c3", device="cuda")
-for ns in (1, 2, 4, 8):
+for ns in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (1, 2, 4, 8)):
     worst = 0
     for k in sorted({0, ns // 2, ns - 1}):
         plan = engine.Plan(n, itype, shard=k, nshards=ns)
