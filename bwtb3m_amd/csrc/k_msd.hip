@@ -184,6 +184,15 @@ void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span)
 	}
 }
 
+// XCD-aware workgroup order (8 XCDs, each with its own L2; workgroup i lands on XCD i % 8): workgroup i takes item (i % 8) * (n / 8) + i / 8
+// (bijective for any n), so that the workgroups resident on one XCD at a time hold NEIGHBOURING items.  Neighbouring final buckets (and
+// neighbouring level-0 buckets over the same chunks) read neighbouring runs: the 128-byte line at a run's unaligned edge belongs to both, and
+// is then fetched into that XCD's L2 once instead of by two XCDs.
+__device__ __forceinline__ uint32_t xcd_order(uint32_t i, uint32_t n)
+{
+	const uint32_t q = n >> 3, r = n & 7u, x = i & 7u;
+	return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (i >> 3);
+}
 // 64 bits = the 32 bases from `pos` on, with the bucketing convention for the end of the text:
 // pacterm: the terminator and everything behind it read as 0; pac: circular.
 __device__ inline uint64_t window_tail(const TextView &T, uint64_t pos)
@@ -617,6 +626,7 @@ struct L1GArgs {
 	const uint32_t *tab0, *pre0, *tile_fr; uint32_t nchunks0; uint32_t chunk0;      // level 0's table, row prefixes, first runs; index stride of a level-0 chunk
 	int D, shift;
 	const uint32_t *cbase;       // null, or (one-pass shard) where the records of level-0 chunk c start: cbase[c] instead of c * chunk0
+	uint32_t xcd;                // 1: the tiles are listed tile-major (tile j of every bucket, then j + 1) and taken in xcd_order
 };
 constexpr int L1G_RUNS = 1536;       // runs of one chunk kept in LDS (uniform input: ~512); more: every lane searches the row in HBM
 
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 	static_assert(THREADS >= MSD_MAXBINS && NG <= THREADS, "one bin / one group per thread");
 	const uint32_t tid = threadIdx.x, wave = tid >> 6;
 	const int bins = 1 << A.D;
-	const L1GTile tile = A.tiles[blockIdx.x];
+	const L1GTile tile = A.tiles[A.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x];
 	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;       // <= TCH
 	const uint32_t *row0 = A.tab0 + (uint64_t)tile.d * A.nchunks0, *prow = A.pre0 + (uint64_t)tile.d * A.nchunks0;
 	uint64_t rec[MSD_ITEMS];
@@ -999,6 +1009,7 @@ struct FinishSrc {
 	const uint32_t *btab;        // GATHER: {start[nb0], tab_off[nb0], nch[nb0]} of the level-0 buckets
 	uint32_t nb0; int D1; uint32_t chunk;
 	uint32_t nbF, nrec;          // number of final buckets and of records (bounds of every bucket id / record range: checked in the debug build)
+	uint32_t xcd;                // 1: workgroups take the buckets of a launch in xcd_order
 };
 __device__ __forceinline__ uint32_t bucket_end(const FinishSrc &S, uint32_t b) { return S.bend ? S.bend[b] : S.bstart[b + 1]; }
 struct FinishLists { uint32_t *midlist; uint32_t mid_cap; uint32_t *biglist; uint32_t big_cap; uint32_t *hugelist; uint32_t huge_cap; uint32_t huge_min; };
@@ -1318,7 +1329,7 @@ __global__ __launch_bounds__(512, 4) void k_finish_fast(FinishSrc S, int fbits, 
 	__shared__ uint16_t gfirst[GF_N];
 	__shared__ __attribute__((aligned(16))) uint4 gda[GF_N], gdb[GF_N];      // {o1, o2, o3, A} and {B - o1, C - o2, D - o3, -}
 	__shared__ uint32_t s_slow;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + (S.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x);
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
 	const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
@@ -1570,7 +1581,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	__shared__ uint16_t bl[V3_BL];                                    // bins above eight entries
 	__shared__ uint32_t s_slow, s_wl, s_tl, s_sp, s_bl;
 	__shared__ uint32_t lds_pad[WPC == 2 ? 6144 : 1];                 // (WPC = 2, the A/B form: enough LDS to keep a third workgroup off the CU)
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + blockIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + (S.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x);
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
 	const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
@@ -2458,8 +2469,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	uint32_t nbF = bins0;               // final buckets
 	const int consumed = dg.D1;         // key-field bits used by level 1
 	bool sliced = false, lvl2_ran = false;
+	const int xcd_on = getenv("B3M_XCD_ORDER") ? atoi(getenv("B3M_XCD_ORDER")) : 1;       // measurement switch: 0 = workgroups take their items in launch order
 	FinishSrc FS{};                     // where the finish finds the records of a final bucket
-	FS.bstart = M.lvl_start;
+	FS.bstart = M.lvl_start; FS.xcd = xcd_on ? 1u : 0u;
 	bool gather = false;
 	if (dg.D1 == 0) {
 		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.lvl_start);
@@ -2523,7 +2535,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			L1GArgs Gq{};
 			Gq.rec_in = ws.keyA; Gq.rec_out = ws.keyB; Gq.tiles = reinterpret_cast<const L1GTile *>(M.gtiles); Gq.runtab = M.runtab;
 			Gq.tab0 = M.tab0; Gq.pre0 = M.pre0; Gq.tile_fr = M.tile_fr; Gq.nchunks0 = ncol0; Gq.chunk0 = (uint32_t)W0A_CHUNK; Gq.D = dg.D1; Gq.shift = 64 - dg.D1;
-			Gq.cbase = shard1 ? M.cbase0 : nullptr;
+			Gq.cbase = shard1 ? M.cbase0 : nullptr; Gq.xcd = xcd_on ? 1u : 0u;
 			ntB = (uint32_t)gtiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
 			hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
