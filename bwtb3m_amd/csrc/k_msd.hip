@@ -46,7 +46,9 @@ constexpr int MSD_SUPER = 16 * MSD_CHUNK;              // 65536 records per work
 constexpr int L1_THREADS = 1024;                      // level 1: 16 records per thread, chunks of 16 Ki records sorted in LDS (128 KB)
 constexpr int L1_CHUNK = L1_THREADS * MSD_ITEMS;
 constexpr int L1_TCH = 4;                              // chunks per workgroup (its columns of the run table leave as 16-byte pieces)
-constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass (9 bits measured: level 1 +2.3 ms, level 0 at 10 bits -1.6 ms)
+constexpr int MSD_MAXBITS = 8;                         // fan-out of a record pass (9 bits measured in round 1: level 1 +2.3 ms, level 0 at 10 bits -1.6 ms; again in round 3 with the
+                                                       // gathering kernels and the XCD-aware finish, 10 + 9 against 11 + 8 bits at C3: level 0 -0.27, level 1 -0.40, finish +0.63, ties +0.64 ms
+                                                       // (a record then knows 39 bits of its rotation, not 40): +0.55 ms in all)
 constexpr int MSD_MAXBINS = 1 << MSD_MAXBITS;
 constexpr uint64_t MSD_MIN_LEN = 1ull << 18;
 // level 0
