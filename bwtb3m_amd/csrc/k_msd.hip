@@ -263,19 +263,23 @@ __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t 
 // LOCAL (whole-text blocks, no shard): the chunk's records go out in digit order to the chunk's OWN index range of the record buffer,
 // a stream of whole lines instead of 2048 scattered 32-record runs, and where digit d sits inside chunk c is one entry of a run table
 // (row d, column c); no counting pass and no [digit][tile] offsets are needed.  Level 1 gathers a bucket from its row's runs.
-// (SHARD with a third of the index array and two workgroups per CU -- what paces this pass is the chain of latencies per chunk, not the atomics
-// of the few positions kept -- needs 64 registers per thread: 161 spilled, the pass went from 3.0 to 7.5 ms at N = 8.  One workgroup per CU it is.)
-template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false, bool SHARD = false>
-__global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
+// SHARD = 1: the one-pass level 0 of a suffix-range shard (L0Args).  SHARD = 2: the same with 512 threads and an index array of W0S_SIDX entries
+// (three or more shards: a chunk keeps a third of its positions at most; one that keeps more raises a flag and the host takes SHARD = 1), so that TWO
+// workgroups share a CU: what paces this pass is the chain of latencies per chunk (text load, barriers, the reservation, the stores), not the
+// atomics of the few positions kept.  (Two workgroups of 1024 threads need 64 registers per thread: 161 spilled, the pass went from 3.0 to 7.5 ms.)
+constexpr int W0S_SIDX = 24576, W0S_THREADS = 512;
+template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false, int SHARD = 0>
+__global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ? 4 : 1) void k_l0_pass(L0Args A)
 {
 	static_assert(!SHARD || (LOCAL && !COUNT_ONLY), "a one-pass shard is a chunk-local level 0");
+	constexpr int TH = SHARD == 2 ? W0S_THREADS : W0_THREADS;
 	constexpr int WORDS = CHUNK / 16;
 	static_assert(CHUNK % 16 == 0 && CHUNK <= 65536, "chunk-local positions are 16-bit");
 	__shared__ uint32_t cur[MAXBINS];                            // count, then exclusive start, then end of every digit run
 	__shared__ uint32_t gbase[(COUNT_ONLY || LOCAL) ? 1 : MAXBINS];
-	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : CHUNK];            // chunk-local positions in digit order
+	__shared__ uint16_t sidx[COUNT_ONLY ? 1 : SHARD == 2 ? W0S_SIDX : CHUNK];     // chunk-local positions in digit order
 	__shared__ uint32_t stext[WORDS + 4];                        // [0] = the word before the chunk
-	__shared__ uint32_t wsum[W0_THREADS / 64];
+	__shared__ uint32_t wsum[TH / 64];
 	__shared__ uint32_t s_base;
 	uint32_t n_below = 0;                                        // SHARD: this thread's positions with a digit below the shard's
 	uint32_t n_s1 = 0, n_s2 = 0, n_s3 = 0, n_all = 0, n_term = 0; // SHARD: this thread's positions by leading base 1, 2, 3, all of them, the terminator
@@ -287,15 +291,15 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 	const uint32_t tile = (LOCAL ? A.tile_base : 0u) + ((COUNT_ONLY && A.tile_stride > 1u) ? tcol * A.tile_stride : tcol);
 	const uint64_t end = A.start + A.len;
 	const uint32_t padd = A.T.type == B3M_INPUT_PACTERM ? 1u : 0u;
-	if (COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
-	else if (!LOCAL) { for (int b = tid; b < bins; b += W0_THREADS) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
+	if (COUNT_ONLY) { for (int b = tid; b < bins; b += TH) cur[b] = 0; }
+	else if (!LOCAL) { for (int b = tid; b < bins; b += TH) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
 	__syncthreads();
 	for (int c = 0; c < TCH; ++c) {
 		const uint64_t cpos = A.P0 + (uint64_t)tile * (TCH * CHUNK) + (uint64_t)c * CHUNK;
 		if (LOCAL && (cpos >= end || cpos + CHUNK <= A.start)) {
 			// a chunk outside the block: its column of the run table is empty (written here: the table is not cleared beforehand)
 			const uint32_t col = tile * TCH + c;
-			for (int b = tid; b < bins; b += W0_THREADS) A.runtab0[(uint64_t)b * A.nchunks0 + col] = 0u;
+			for (int b = tid; b < bins; b += TH) A.runtab0[(uint64_t)b * A.nchunks0 + col] = 0u;
 			if (SHARD && tid == 0) A.cbase[col] = 0u;
 			continue;
 		}
@@ -305,14 +309,14 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		const bool fast = cpos >= A.start && cpos >= 16 && cpos + CHUNK <= end && cpos + CHUNK + 48 <= A.T.nbases;
 		if (fast) {
 			const uint8_t *p = A.T.b + (((cpos >> 4) - 1) << 2);
-			for (int j = tid; j < WORDS + 4; j += W0_THREADS) stext[j] = be32(p + 4 * j);
+			for (int j = tid; j < WORDS + 4; j += TH) stext[j] = be32(p + 4 * j);
 		}
-		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += W0_THREADS) cur[b] = 0; }
+		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += TH) cur[b] = 0; }
 		__syncthreads();
 		// ---- count ----
 		// a suffix-range shard keeps 1/N of the positions: the count remembers WHICH (16 bits per word of 16 positions, in registers: the
 		// same thread takes the same words in the place phase) so that the place phase only visits those
-		constexpr int NJ = (WORDS + W0_THREADS - 1) / W0_THREADS;
+		constexpr int NJ = (WORDS + TH - 1) / TH;
 		constexpr bool KM = !COUNT_ONLY && (!LOCAL || SHARD);
 		uint32_t km[KM ? (NJ + 1) / 2 : 1];
 		const bool sparse = KM && 2u * nbin <= (1u << A.D);
@@ -320,8 +324,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		if (fast) {
 			#pragma unroll
 			for (int j = 0; j < NJ; ++j) {
-				const uint32_t w = j * W0_THREADS + tid;
-				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
+				const uint32_t w = j * TH + tid;
+				if (WORDS % TH != 0 && w >= (uint32_t)WORDS) break;
 				// the digit needs <= 12 bits of the window: 32-bit funnel shifts of two words do
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				uint32_t mk = 0;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			}
 		} else {
 			#pragma nounroll
-			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
+			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += TH) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		__syncthreads();
 		// ---- exclusive scan of the counts, in place ----
 		{
-			constexpr int per = MAXBINS / W0_THREADS;           // consecutive bins per thread
+			constexpr int per = MAXBINS / TH;           // consecutive bins per thread
 			uint32_t loc[per]; uint32_t sum = 0;
 			#pragma unroll
 			for (int k = 0; k < per; ++k) { int b = tid * per + k; loc[k] = b < bins ? cur[b] : 0; sum += loc[k]; }
@@ -369,6 +373,19 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			uint32_t pre = 0;
 			for (uint32_t i = 0; i < w; ++i) pre += wsum[i];
 			uint32_t run = pre + inc - sum;
+			if (SHARD == 2) {
+				// more positions kept than the index array holds (the shard's digits are much denser here than on average): nothing of this
+				// chunk is placed, the flag tells the host to take the form with the whole index array
+				uint32_t all = 0;
+				for (uint32_t i = 0; i < (uint32_t)(TH / 64); ++i) all += wsum[i];
+				if (all > (uint32_t)W0S_SIDX) {
+					const uint32_t col = tile * TCH + c;
+					if (tid == 0) { atomicOr(A.alloc + 1, 1u); A.cbase[col] = 0u; }
+					for (int b = tid; b < bins; b += TH) A.runtab0[(uint64_t)b * A.nchunks0 + col] = 0u;
+					__syncthreads();
+					continue;
+				}
+			}
 			#pragma unroll
 			for (int k = 0; k < per; ++k) { int b = tid * per + k; if (b < bins) cur[b] = run; run += loc[k]; }
 		}
@@ -377,8 +394,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		if (fast && sparse) {
 			#pragma unroll
 			for (int j = 0; j < NJ; ++j) {
-				const uint32_t w = j * W0_THREADS + tid;
-				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
+				const uint32_t w = j * TH + tid;
+				if (WORDS % TH != 0 && w >= (uint32_t)WORDS) break;
 				uint32_t mk = (km[KM ? (j >> 1) : 0] >> (16 * (j & 1))) & 0xFFFFu;
 				if (mk == 0) continue;
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
@@ -391,8 +408,8 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		} else if (fast) {
 			#pragma unroll
 			for (int j = 0; j < NJ; ++j) {
-				const uint32_t w = j * W0_THREADS + tid;
-				if (WORDS % W0_THREADS != 0 && w >= (uint32_t)WORDS) break;
+				const uint32_t w = j * TH + tid;
+				if (WORDS % TH != 0 && w >= (uint32_t)WORDS) break;
 				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			}
 		} else {
 			#pragma nounroll
-			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += W0_THREADS) {
+			for (uint32_t li = tid; li < (uint32_t)CHUNK; li += TH) {
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 			__syncthreads();
 		}
 		const uint32_t obase = SHARD ? s_base : 0u;
-		for (uint32_t q = tid; q < nvalid; q += W0_THREADS) {
+		for (uint32_t q = tid; q < nvalid; q += TH) {
 			const uint32_t li = sidx[q];
 			uint32_t dgt; uint64_t r;
 			if (fast) {
@@ -444,17 +461,17 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		}
 		if (LOCAL) {
 			const uint32_t col = tile * TCH + c;
-			for (int b = tid; b < bins; b += W0_THREADS) { const uint32_t st0 = b ? cur[b - 1] : 0u; A.runtab0[(uint64_t)b * A.nchunks0 + col] = st0 | ((cur[b] - st0) << 16); }
+			for (int b = tid; b < bins; b += TH) { const uint32_t st0 = b ? cur[b - 1] : 0u; A.runtab0[(uint64_t)b * A.nchunks0 + col] = st0 | ((cur[b] - st0) << 16); }
 			__syncthreads();
 			continue;
 		}
 		__syncthreads();
-		for (int b = tid; b < bins; b += W0_THREADS) gbase[b] += cur[b] - (b ? cur[b - 1] : 0u);
+		for (int b = tid; b < bins; b += TH) gbase[b] += cur[b] - (b ? cur[b - 1] : 0u);
 		__syncthreads();
 	}
 	if (COUNT_ONLY) {
 		__syncthreads();
-		for (int b = tid; b < bins; b += W0_THREADS) A.hist[tcol + (uint64_t)b * ntiles] = cur[b];
+		for (int b = tid; b < bins; b += TH) A.hist[tcol + (uint64_t)b * ntiles] = cur[b];
 	}
 	if (SHARD) {
 		#pragma unroll
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(W0_THREADS) void k_l0_pass(L0Args A)
 		__syncthreads();
 		if (tid < 6u) {
 			unsigned long long v = 0;
-			for (uint32_t w = 0; w < (uint32_t)(W0_THREADS / 64); ++w) v += red[8u * w + tid];
+			for (uint32_t w = 0; w < (uint32_t)(TH / 64); ++w) v += red[8u * w + tid];
 			red[256 + tid * 2] = (uint32_t)v; red[257 + tid * 2] = (uint32_t)(v >> 32);
 		}
 		__syncthreads();
@@ -2335,13 +2352,19 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				const bool want_hist = ws.d_symhist_out != nullptr;
 				unsigned long long *d_h5 = reinterpret_cast<unsigned long long *>(d_alloc + 8);      // five counters behind the scalars, added to the caller's array on success
 				B.symhist = want_hist ? d_h5 : nullptr;
-				{
-					Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * (uint64_t)est);
-					hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, true>), dim3(ntA), dim3(W0_THREADS), 0, s, B);
-				}
+				// three shards and more: 512-thread workgroups with a third of the index array, two to a CU (B3M_SHARD_WG2=0: always the 1024-thread form);
+				// a chunk that keeps more than that array holds raises the flag and the pass is repeated in the other form
+				const int wg2_on = getenv("B3M_SHARD_WG2") ? atoi(getenv("B3M_SHARD_WG2")) : 1;
 				uint32_t h_sc[4] = {0, 0, 0, 0};
-				B3M_HIP(hipMemcpyAsync(h_sc, d_alloc, 16, hipMemcpyDeviceToHost, s));
-				B3M_HIP(hipStreamSynchronize(s));
+				for (int form = (wg2_on && est <= 0.30 * (double)len_in) ? 2 : 1; form >= 1; --form) {
+					if (form == 1 && h_sc[1]) B3M_HIP(hipMemsetAsync(d_alloc, 0, 32 + 64, s));      // (the flagged attempt's counts start over)
+					Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * (uint64_t)est);
+					if (form == 2) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 2>), dim3(ntA), dim3(W0S_THREADS), 0, s, B);
+					else hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 1>), dim3(ntA), dim3(W0_THREADS), 0, s, B);
+					B3M_HIP(hipMemcpyAsync(h_sc, d_alloc, 16, hipMemcpyDeviceToHost, s));
+					B3M_HIP(hipStreamSynchronize(s));
+					if (!h_sc[1]) break;
+				}
 				stage("level 0 (one-pass shard)");
 				if ((uint64_t)h_sc[0] <= capr) {
 					shard1 = true; local0 = true;

@@ -4,7 +4,7 @@ set -e
 TAG=${TAG:-r03}
 export TMPDIR=/tmp
 R=$PWD
-ARGS="--no-cpu-baseline --no-check --e2e-steps 0 --no-bwt-only"
+ARGS="--no-cpu-baseline --no-check --e2e-steps 0 --no-bwt-only --no-genome-like"
 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o stats -- python3 bench.py --steps 10 --warmup 3 $ARGS > gpurun_out/${TAG}_stats.log 2>&1
 echo stats done
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_fetch -o pmc -- python3 bench.py --steps 1 --warmup 0 $ARGS > gpurun_out/${TAG}_pmc_fetch.log 2>&1
