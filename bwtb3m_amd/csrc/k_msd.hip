@@ -2364,6 +2364,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 					B3M_HIP(hipMemcpyAsync(h_sc, d_alloc, 16, hipMemcpyDeviceToHost, s));
 					B3M_HIP(hipStreamSynchronize(s));
 					if (!h_sc[1]) break;
+					if (dbg_stages >= 1) fprintf(stderr, "[b3m] one-pass shard %d of %d: a chunk keeps more positions than the 512-thread form's index array holds: the pass again with 1024 threads\n", shard, nshards);
 				}
 				stage("level 0 (one-pass shard)");
 				if ((uint64_t)h_sc[0] <= capr) {

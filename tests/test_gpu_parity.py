@@ -531,9 +531,11 @@ def test_shards_one_pass_and_two_pass_agree_on_their_borders(gpu, oracle, monkey
     then all one-pass and all two-pass (B3M_SHARD_ONEPASS=0), with samples and the symbol histogram the pass counts on the way."""
     torch = gpu
     from bwtb3m_amd import engine
+    monkeypatch.setenv("B3M_MSD_D1", "4")          # a level 1 whatever the size: the one-pass shard is the chunk-local level 0 of the large geometries (at its natural size: texts above 24 Mbase)
     nb = (1 << 20) + 777
     b = oracle.synth_bases(nb, 77).copy()
     b[300000:420000] = b[100000:220000]            # a 120-kb repeat
+    b[600000:700000] = 0                           # 100 kb of A: one chunk keeps far more positions of shard 0 than the 512-thread form's index array holds (the pass is repeated with 1024 threads)
     buf = oracle.pac_encode(b)
     for itype in ("pacterm", "pac"):
         s = oracle.symbols_from_file_bytes(buf, itype)
