@@ -20,7 +20,8 @@ def _set_env(**kv):
 
 def clear_switches():
     _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None,
-             B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None, B3M_NO_TIE_MSD=None)
+             B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None, B3M_NO_TIE_MSD=None,
+             B3M_SHARD_ONEPASS=None, B3M_SHARD_TWO_PASS=None, B3M_SHARD_WG2=None, B3M_XCD_ORDER=None)
 
 
 def _tie_switches(rng):
@@ -113,7 +114,11 @@ def case_shards(rng, O, engine, torch):
     geo = int(rng.integers(0, 4))
     isar = int([0, 256, 1000][int(rng.integers(0, 3))])
     _set_env(B3M_MSD_D0=[None, None, "2", "3"][geo], B3M_MSD_D1=[None, "4", "3", "4"][geo])
-    desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d" % (itype, nb, kind, ns, geo, isar)
+    # the one pass of a shard (geo 1: a level 1 and no finer level 0), its forms, and a mix of one-pass and two-pass shards (their borders must agree)
+    alt = int(rng.integers(0, 5))
+    _set_env(B3M_SHARD_ONEPASS=0 if alt == 1 else None, B3M_SHARD_TWO_PASS=int(rng.integers(1, 255)) if alt == 2 else None, B3M_SHARD_WG2=0 if alt == 3 else None,
+             B3M_XCD_ORDER=0 if alt == 4 else None)
+    desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d alt=%d" % (itype, nb, kind, ns, geo, isar, alt)
     try:
         d_text = torch.from_numpy(np.asarray(buf)).cuda()
         plans, slices, _ = run_shards(torch, engine, d_text, n, itype, ns, isar)
