@@ -228,7 +228,7 @@ def main():
         blocksize = (n + a.blocks - 1) // a.blocks
     # the timed plan is the one b3m_compute_bwt creates for these options (same rule, b3m_plan_sampling_rate): BWT + (rank,pos) samples
     from bwtb3m_amd import _lib
-    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(a.isasamplingrate, a.bwtonly))
+    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(a.isasamplingrate, a.bwtonly, n))
     plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=plan_rate)
     d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
     d_text_gen = d_text

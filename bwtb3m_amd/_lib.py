@@ -60,7 +60,7 @@ SYMBOLS = [
     ("b3m_input_type_name", _cp, [_i]),
     ("b3m_options_init", None, [ctypes.POINTER(Options)]),
     ("b3m_compute_bwt", _i, [ctypes.POINTER(Options), _i]),
-    ("b3m_plan_sampling_rate", _u64, [_u64, _i]),
+    ("b3m_plan_sampling_rate", _u64, [_u64, _i, _u64]),
     ("b3m_plan_create", _p, [_u64, _i, _u64, _u64, _u64]),
     ("b3m_plan_create_sharded", _p, [_u64, _i, _i, _i, _u64, _u64]),
     ("b3m_plan_slice_capacity", _u64, [_p]),

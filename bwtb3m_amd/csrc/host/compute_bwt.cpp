@@ -32,10 +32,15 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 }
 
-extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly)
+extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly, uint64_t n)
 {
 	const uint64_t isarate = isasamplingrate ? isasamplingrate : (bwtonly ? 64 : 262144);
-	if (!bwtonly && isarate > 1024 && isarate % 1024 == 0) return 1024;
+	if (bwtonly) return isarate;
+	// bwtonly=0: the samples are also the anchors of the LF walks that make .sa / .isa, one chain per sample.  The walks are fastest from ~10^5 chains on
+	// (C3, tools/rate_sweep.py: 137 / 127 / 123 / 478 ms at rates 1024 / 4096 / 16384 / 262144), the sort pays for every sample (finish 12.4 / 11.4 / 11.2 / 11.1 ms
+	// and 16 bytes to pinned host memory each): the sparsest of 16384, 4096, 1024 that divides the rate and still leaves 2^17 chains; short texts: 1024
+	for (uint64_t r : {16384ull, 4096ull, 1024ull})
+		if (isarate > r && isarate % r == 0 && (r == 1024 || n / r >= (1ull << 17))) return r;
 	return isarate;
 }
 
@@ -103,7 +108,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		uint64_t sarate = o->sasamplingrate ? o->sasamplingrate : 32;
 		const bool want_sa = !o->bwtonly;                     // sampled SA/ISA stage (byte alphabets walk the LF array)
 		// anchors of the LF walks: a divisor of the output rate, dense enough to fill the GPU
-		const uint64_t anchor_rate = b3m_plan_sampling_rate(o->isasamplingrate, (int)o->bwtonly);
+		const uint64_t anchor_rate = b3m_plan_sampling_rate(o->isasamplingrate, (int)o->bwtonly, n);
 		// byte alphabets are sorted as ONE block (no byte-alphabet merge): a memory target that would force several
 		// blocks (the reference's scripts pass mem= for host RAM) is not applied to them
 		uint64_t mem = o->mem;

@@ -658,7 +658,7 @@ def bench_main(a, rank, local_rank, world):
 
     # the shards emit what the plan of b3m_compute_bwt emits (samples at b3m_plan_sampling_rate), as the one-GPU line does
     from . import _lib
-    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(getattr(a, "isasamplingrate", 0), getattr(a, "bwtonly", 0)))
+    plan_rate = int(_lib.lib().b3m_plan_sampling_rate(getattr(a, "isasamplingrate", 0), getattr(a, "bwtonly", 0), n))
 
     def make(m):
         return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate)

@@ -83,10 +83,11 @@ void b3m_options_init(b3m_options *o);                       /* getDefault*() va
 /* file -> X.bwt (+ X.hist, X.meta, X.preisa | X.sa/X.isa), log lines to log_fd (2 = stderr) */
 int  b3m_compute_bwt(const b3m_options *o, int log_fd);
 /* the (rank,pos) sampling rate of the plan b3m_compute_bwt creates for these options (0 = the mode's default: 262144, or 64 with
- * bwtonly=1, /root/reference/src/bwtb3m.cpp:46, ChangeLog:281).  bwtonly=0 samples at 1024 when that divides the rate: the samples
- * are also the anchors of the LF walks that make .sa/.isa (/root/reference/src/hwtPreIsaToIsa.cpp:107-172) and must fill the GPU.
- * bench.py times a plan created with exactly this rate. */
-uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly);
+ * bwtonly=1, /root/reference/src/bwtb3m.cpp:46, ChangeLog:281) and a text of n symbols.  bwtonly=0 samples more densely than the .isa
+ * file needs: the samples are also the anchors of the LF walks that make .sa/.isa (/root/reference/src/hwtPreIsaToIsa.cpp:107-172), one
+ * chain per sample, and must fill the GPU: the sparsest of 16384 / 4096 / 1024 that divides the rate and leaves 2^17 chains (short
+ * texts: 1024).  bench.py times a plan created with exactly this rate. */
+uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly, uint64_t n);
 
 /* ---- device-resident construction (what bench.py times) ----------------------------------- */
 

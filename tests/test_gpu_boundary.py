@@ -289,7 +289,11 @@ def test_bench_line_contract(gpu):
     # what is timed is the plan b3m_compute_bwt creates (samples at b3m_plan_sampling_rate), verified from its own samples;
     # the BWT-only plan is reported beside it
     sr = j["config"]["isasamplingrate"]
-    assert sr["option"] == 262144 and sr["plan"] == 1024 and sr["samples"] == (20_000_001 + 1023) // 1024
+    assert sr["option"] == 262144 and sr["plan"] == 1024 and sr["samples"] == (20_000_001 + 1023) // 1024      # (a text this short: 1024; C3: 16384)
+    from bwtb3m_amd import _lib
+    rate = _lib.lib().b3m_plan_sampling_rate
+    assert [int(rate(0, 0, n)) for n in (20_000_001, 600_000_000, 3_000_000_001)] == [1024, 4096, 16384] and int(rate(0, 1, 3_000_000_001)) == 64
+    assert int(rate(1000, 0, 3_000_000_001)) == 1000 and int(rate(8192, 0, 3_000_000_001)) == 4096
     assert "0 symbol / 0 chain mismatches" in j["config"]["checked"]
     assert j["config"]["bwt_only"]["equals_shipped_output"] is True and j["config"]["bwt_only"]["ms_per_step"] > 0
 

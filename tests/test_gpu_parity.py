@@ -796,9 +796,9 @@ def test_mid_sizes_verified_by_the_lf_walk(gpu, nb):
     plan.close()
 
 
-def _shipped_rate():
+def _shipped_rate(n=3_000_000_001):
     from bwtb3m_amd import _lib
-    return int(_lib.lib().b3m_plan_sampling_rate(0, 0))          # the plan b3m_compute_bwt creates by default (isasamplingrate=262144, bwtonly=0)
+    return int(_lib.lib().b3m_plan_sampling_rate(0, 0, n))       # the plan b3m_compute_bwt creates by default (isasamplingrate=262144, bwtonly=0) for a text of n symbols
 
 
 def _c3_one_block(torch, engine, synth):
