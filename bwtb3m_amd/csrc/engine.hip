@@ -909,6 +909,8 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 	uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
 	uint64_t left = 0;
 	const uint64_t rounds = tie_rounds(T, d_sa_global, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, n, s, &left, 0, d_isa, h0);
+	// (left > 0 here means rotations that are EQUAL over all n symbols -- a circular pac text with a period: the doubling rounds only stop early when h >= n --
+	// and any order of equal rotations gives the same BWT; a list above the workspace was refused above)
 	p->res.tie_rounds += rounds;
 	// my slice back into the workspace, the BWT symbols of the slots that were open here, p0, samples
 	const uint64_t mine = p->tie_left;
