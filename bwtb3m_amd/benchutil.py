@@ -6,8 +6,8 @@ import os
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
-KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true>",
-             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048>", "bucket_finish": "b3m::k_finish_v3<3>", "ties": "b3m::k_tie_fix",
+KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true, 0>",
+             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3>", "ties": "b3m::k_tie_fix",
              "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk"}
 
 
@@ -17,10 +17,15 @@ def add_kernel_times(fam, kernel_times):
         f["ms"] += k["ms"]; f["launches"] += k["launches"]; f["alg_bytes"] += k["alg_bytes"]
 
 
-def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
+def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1, shards=1):
     """fam: accumulated over `steps` runs on this rank; dt: wall seconds of those steps; pmc_n: symbol
-    count for which the committed PMC traffic may be quoted (0 = none)."""
+    count for which the committed PMC traffic may be quoted (0 = none); shards: suffix-range shards of the run (their level 0 is the
+    one-pass instantiation of k_l0_pass: 512-thread workgroups from three shards on)."""
     dname, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    if shards > 1 and dname == "msd_scatter_text":
+        KERNEL_OF_ = dict(KERNEL_OF, msd_scatter_text="b3m::k_l0_pass<false, 65280, 4, 2048, true, %d>" % (2 if shards >= 3 else 1))
+    else:
+        KERNEL_OF_ = KERNEL_OF
     achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     # HBM traffic of the dominant kernel from the committed PMC pass (separate rocprofv3 --pmc runs,
     # gfx950 FETCH_SIZE correction applied: see the file); only valid for the workload it was taken on
@@ -29,14 +34,14 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1):
         import glob
         files = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))      # the latest round's PMC passes
         tj = json.load(open(files[-1])) if files else {}
-        kn = KERNEL_OF.get(dname, dname)
+        kn = KERNEL_OF_.get(dname, dname)
         if pmc_n and tj.get("workload_n") == pmc_n and kn in tj.get("kernels", {}):
             traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         traffic = None
     alg_job = nbases * (9.5 + 41.0 * levels)      # alg_bytes(n,B)
     return {
-        "bound": "hbm", "kernel": KERNEL_OF.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": KERNEL_OF_.get(dname, dname), "family": dname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 4), "launches_per_step": d["launches"] // max(1, steps),
         "alg_bytes_per_launch": d["alg_bytes"] // max(1, d["launches"]),

@@ -705,7 +705,7 @@ def bench_main(a, rank, local_rank, world):
         alg_job = nbases * (9.5 + 41.0 * levels)
         if fam:
             # dominant kernel of rank 0's shard (every rank runs the same kernels on its own suffix range)
-            roof = benchutil.dominant_roofline(fam, steps, dt, nbases, levels, 0, root, peak_gpus=world)
+            roof = benchutil.dominant_roofline(fam, steps, dt, nbases, levels, 0, root, peak_gpus=world, shards=world if mode == "prefix" else 1)
             roof["rank"] = 0
         else:
             roof = {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / steps) / 1e9, 1),
