@@ -213,10 +213,15 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
             h_text = torch.zeros(plan.text_bytes, dtype=torch.uint8).pin_memory(); h_text.copy_(d_text[:plan.text_bytes].cpu())
             h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
             plan.run_host(h_text, h_out)
-            ok &= bool(torch.equal(h_out, one.cpu()))
+            d1 = (h_out != one.cpu()).nonzero().flatten()
+            ok &= d1.numel() == 0
             h_pk = torch.empty((n + 3) // 4, dtype=torch.uint8).pin_memory()
             plan.run_host(h_text, h_pk, packed=True)
-            ok &= bool(torch.equal(h_pk, engine.Plan.pack_pac(one, itype == "pacterm").cpu())); desc += " host runs"
+            d2 = (h_pk != engine.Plan.pack_pac(one, itype == "pacterm").cpu()).nonzero().flatten()
+            ok &= d2.numel() == 0; desc += " host runs"
+            if d1.numel() or d2.numel():
+                desc += " [byte hand-over: %d bytes differ, first %s last %s; packed: %d bytes differ, first %s last %s; p0 %d]" % (
+                    d1.numel(), d1[:3].tolist(), d1[-3:].tolist(), d2.numel(), d2[:3].tolist(), d2[-3:].tolist(), plan.result()["p0"])
             plan.close()
         elif form == 2:
             ns = int(rng.integers(2, 17))
