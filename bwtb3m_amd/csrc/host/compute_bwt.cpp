@@ -139,7 +139,9 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (b3m_plan_run(plan, d_text, d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
 		double t2 = now();
 		b3m_result res; b3m_plan_result(plan, &res);
-		log("[V] constructed BWT in %.3f s (sort %.1f ms, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, res.ms_sort, res.ms_gap,
+		// (this process launches every kernel for the first time: `sort` includes the loading of their code objects, 3-14 ms at 3 Gbase; with
+		// HIP_ENABLE_DEFERRED_LOADING=0 the figure is bench.py's ms_per_step and the 2.4 s of loading move in front of the plan: tools/cli_sort_time.py)
+		log("[V] constructed BWT in %.3f s (sort %.1f ms incl. first-launch code loading, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, res.ms_sort, res.ms_gap,
 		    res.ms_interleave, n / (t2 - t1) / 1e9);
 		// X.bwt: written from the BWT in HBM (runs, frequencies and code streams on the device); the host encoder takes what that
 		// one does not (2^32 symbols and more) and B3M_HOST_RL=1 asks for it (both write the same bytes)
