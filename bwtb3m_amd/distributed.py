@@ -506,16 +506,38 @@ class PrefixShardedBwt:
         from . import engine
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.n, self.itype, self.device = n, itype, device
         self.plan = engine.Plan(n, itype, isasamplingrate=isasamplingrate, shard=self.rank, nshards=self.world)
         self.out = torch.empty(self.plan.slice_capacity, dtype=torch.uint8, device=device)
         self.tie_finish_runs = 0           # steps that needed the collective finish of long repeats (decided once per plan: from the first such step on
                                            # the shard keeps its suffix array, b3m_plan_set_keep_sa, and every step repeats the finish)
+        self.fallback = None               # the block-merge driver, once some shard has refused its range (skewed text): see run()
 
     def run(self, d_text):
-        sl = self.plan.run(d_text, self.out)
+        """One step.  A shard whose range does not fit its workspace -- one level-0 digit of a skewed text heavier than a shard's share plus slack --
+        refuses; all ranks then agree (one small all-gather, which every step makes anyway) to construct this text by block merging instead
+        (DistributedBwt, the mode with the all-to-all of gap buckets), this step and every later one."""
+        from . import _lib
+        if self.fallback is not None:
+            return self.fallback.run(d_text)
+        refused = 0
+        try:
+            sl = self.plan.run(d_text, self.out)
+        except _lib.B3MError as ex:
+            if self.world == 1 or "suffix-range shard larger than the workspace" not in str(ex) or self.n >= (1 << 32):
+                raise
+            refused, sl = 1, self.out[:0]
         if self.world > 1:
-            # long repeats (row a6): what the local rounds left tied on any shard is finished by prefix doubling over all shards' suffix arrays
-            pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
+            # one small all-gather per step: who refused, and (long repeats, row a6) what the local rounds left tied on any shard
+            pend = _all_gather_i64([0 if refused else self.plan.tie_pending(), sl.numel(), refused], None, self.out.device)
+            if int(pend[:, 2].sum()) > 0:
+                self.refusal = "suffix-range shards refused by rank(s) %s: block merging instead" % [int(i) for i in np.nonzero(pend[:, 2])[0]]
+                self.plan.close()
+                del self.out, sl
+                torch.cuda.empty_cache()
+                self.fallback = DistributedBwt(self.n, self.itype, HipBackend(self.device), self.device)
+                return self.fallback.run(d_text)
+            # ties: finished by prefix doubling over all shards' suffix arrays
             if int(pend[:, 0].sum()) > 0:
                 from . import engine
                 if not self.plan.has_sa():                       # a BWT-only run kept no suffix array: once more, with it
@@ -671,13 +693,15 @@ def bench_main(a, rank, local_rank, world):
             if inject == "%s:%d" % (m, rank):
                 raise RuntimeError("injected failure (B3M_BENCH_INJECT=%s)" % inject)
             job = make(m)
-            dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times()) if m != "blocks" else None)
+            dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times() if getattr(j, "fallback", None) is None else []) if m != "blocks" else None)
             checked = _check_slices(out, off, p0, d_text, n, itype, dev) if getattr(a, "check", True) else None
             del out
             phases = {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}
             levels = len(job.plan.levels) if m == "blocks" else 0
+            if getattr(job, "fallback", None) is not None:      # a shard refused its range (skewed text): the steps ran as block merges
+                fam, levels, phases = {}, len(job.fallback.plan.levels), {k: round(v, 4) for k, v in job.fallback.timing.items()}
             return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job, "checked": checked,
-                    "tie_finish_runs": getattr(job, "tie_finish_runs", 0)}
+                    "tie_finish_runs": getattr(job, "tie_finish_runs", 0), "refusal": getattr(job, "refusal", None)}
         finally:
             wd.cancel()
 
@@ -698,9 +722,12 @@ def bench_main(a, rank, local_rank, world):
         def summary(r):
             if "error" in r:
                 return r
-            return {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
-                    "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"],
-                    "tie_finish_runs": r["tie_finish_runs"]}
+            out = {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
+                   "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"],
+                   "tie_finish_runs": r["tie_finish_runs"]}
+            if r.get("refusal"):
+                out["fell_back"] = r["refusal"]
+            return out
         dt, steps, fam, levels = res_main["dt"], res_main["steps"], res_main["fam"], res_main["levels"]
         alg_job = nbases * (9.5 + 41.0 * levels)
         if fam:

@@ -680,6 +680,67 @@ def test_prefix_sharded_driver_two_ranks(gpu, nb):
     assert all(ok for _, ok, _ in res) and sum(1 for _, _, h in res if h) == 1, res
 
 
+def _skew_worker(rank, world, port, nb, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bwtb3m_amd import distributed as D, engine
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        # 85 % A: the level-0 digit AAAAA.A holds 0.85^5.5 = 41 % of the suffixes, more than a shard of four's share plus slack
+        g = torch.Generator(device="cuda"); g.manual_seed(4711)
+        u = torch.rand(nb, device="cuda", generator=g)
+        b = (u >= 0.85).to(torch.uint8) + (u >= 0.90).to(torch.uint8) + (u >= 0.95).to(torch.uint8)
+        bb = b.view(-1, 4)
+        pac = ((bb[:, 0] << 6) | (bb[:, 1] << 4) | (bb[:, 2] << 2) | bb[:, 3]).to(torch.uint8)
+        d_text = torch.cat([pac, torch.zeros(66, dtype=torch.uint8, device="cuda")])       # l % 4 == 0: the last file byte is 0
+        n = nb + 1
+        job = D.PrefixShardedBwt(n, "pacterm", dev)
+        out, off, p0 = job.run(d_text)
+        fell = job.fallback is not None
+        out2, off2, p02 = job.run(d_text)                 # later steps go straight to the block merge
+        ok = fell and off == off2 and bool(torch.equal(out, out2))
+        full = D.gather_result(out)
+        ok = ok and full.numel() == n
+        if rank == 0:
+            # the whole BWT against one block on this GPU, LF-verified
+            plan = engine.Plan(n, "pacterm", isasamplingrate=1 << 14)
+            one = plan.run(d_text)
+            ok = ok and plan.lf_walk(one, sarate=0)[:2] == (0, 0) and bool(torch.equal(one, full)) and int(one[p0]) == 0
+            plan.close()
+        q.put((rank, bool(ok), getattr(job, "refusal", "")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_skewed_text_falls_back_from_shards_to_block_merging(gpu):
+    """N>1 default mode on a text whose base composition puts more suffixes into ONE level-0 digit than a shard may hold: the shard refuses
+    (that is the documented limit of suffix-range shards), all ranks agree in the step's one small all-gather, and the text is constructed by
+    block merging -- this step and the following ones -- instead of ending the run.  Four ranks on this GPU, 80 Mbase at 85 % A."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_skew_worker, args=(r, 4, port, 80_000_000, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:
+        assert not p.is_alive() and p.exitcode == 0
+    res = [q.get() for _ in range(4)]
+    assert all(ok for _, ok, _ in res), res
+    assert all("refused by rank(s)" in why for _, _, why in res), res
+
+
 # ---------------------------------------------------------------------------------------------
 # large size (too big for the CPU oracle in a test): size-independent properties.  Three different
 # algorithmic routes -- one block; 5 leaf blocks + 3 levels of gap merges; 4 suffix-range shards --
