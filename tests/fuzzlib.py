@@ -21,7 +21,7 @@ def _set_env(**kv):
 def clear_switches():
     _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None,
              B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None, B3M_NO_TIE_MSD=None,
-             B3M_SHARD_ONEPASS=None, B3M_SHARD_TWO_PASS=None, B3M_SHARD_WG2=None, B3M_XCD_ORDER=None)
+             B3M_SHARD_ONEPASS=None, B3M_SHARD_TWO_PASS=None, B3M_SHARD_WG2=None, B3M_XCD_ORDER=None, B3M_L1_ORDER=None)
 
 
 def _tie_switches(rng):
@@ -183,9 +183,9 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
     d_text = pac_image(torch, b)
     n = nb + (1 if itype == "pacterm" else 0)
     form = int(rng.integers(0, 5))
-    alt = int(rng.integers(0, 6))                     # alternative paths of the block sort on a sixth of the cases each
+    alt = int(rng.integers(0, 8))                     # alternative paths of the block sort on an eighth of the cases each
     _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None,
-             B3M_LVL2_MIN=0 if alt == 4 else None, B3M_NO_LEVEL2=1 if alt == 5 else None)
+             B3M_LVL2_MIN=0 if alt == 4 else None, B3M_NO_LEVEL2=1 if alt == 5 else None, B3M_L1_ORDER=1 if alt == 6 else None, B3M_XCD_ORDER=0 if alt == 7 else None)
     rate = int([1 << 16, 1024, 3000][int(rng.integers(0, 3))])
     tie = _tie_switches(rng)
     desc = "large n=%d %s comp=%d form=%d alt=%d rate=%d tie=%d planted=%s" % (n, itype, comp, form, alt, rate, tie, planted)
