@@ -294,6 +294,11 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 	if (COUNT_ONLY) { for (int b = tid; b < bins; b += TH) cur[b] = 0; }
 	else if (!LOCAL) { for (int b = tid; b < bins; b += TH) gbase[b] = A.hist[tile + (uint64_t)b * ntiles]; }
 	__syncthreads();
+	// LOCAL: the text words of the NEXT chunk are requested while this chunk's records are generated and stored (a few registers per thread; the
+	// load's latency used to open every chunk's chain with nothing else in flight: one workgroup per CU)
+	constexpr bool PF = LOCAL && SHARD != 2;                      // (the 512-thread form would hold eight words per thread: spills)
+	constexpr int PFN = PF ? (WORDS + 4 + TH - 1) / TH : 1;
+	uint32_t pf[PFN]; int pf_c = -1;                              // pf_c: the chunk whose words pf[] holds (-1: none)
 	for (int c = 0; c < TCH; ++c) {
 		const uint64_t cpos = A.P0 + (uint64_t)tile * (TCH * CHUNK) + (uint64_t)c * CHUNK;
 		if (LOCAL && (cpos >= end || cpos + CHUNK <= A.start)) {
@@ -308,8 +313,13 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 		// the whole chunk inside the block, every window inside the text, a word in front of it
 		const bool fast = cpos >= A.start && cpos >= 16 && cpos + CHUNK <= end && cpos + CHUNK + 48 <= A.T.nbases;
 		if (fast) {
-			const uint8_t *p = A.T.b + (((cpos >> 4) - 1) << 2);
-			for (int j = tid; j < WORDS + 4; j += TH) stext[j] = be32(p + 4 * j);
+			if (PF && pf_c == c) {
+				#pragma unroll
+				for (int j = 0; j < PFN; ++j) { const int w = j * TH + (int)tid; if (w < WORDS + 4) stext[w] = __builtin_bswap32(pf[j]); }
+			} else {
+				const uint8_t *p = A.T.b + (((cpos >> 4) - 1) << 2);
+				for (int j = tid; j < WORDS + 4; j += TH) stext[j] = be32(p + 4 * j);
+			}
 		}
 		if (!COUNT_ONLY) { for (int b = tid; b < bins; b += TH) cur[b] = 0; }
 		__syncthreads();
@@ -436,6 +446,15 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 			__syncthreads();
 		}
 		const uint32_t obase = SHARD ? s_base : 0u;
+		if (PF && c + 1 < TCH) {
+			const uint64_t npos = cpos + CHUNK;
+			if (npos >= A.start && npos >= 16 && npos + CHUNK <= end && npos + CHUNK + 48 <= A.T.nbases) {       // (the next chunk will be `fast`)
+				const uint32_t *p = reinterpret_cast<const uint32_t *>(A.T.b + (((npos >> 4) - 1) << 2));
+				#pragma unroll
+				for (int j = 0; j < PFN; ++j) { const int w = j * TH + (int)tid; pf[j] = w < WORDS + 4 ? p[w] : 0u; }
+				pf_c = c + 1;
+			}
+		}
 		for (uint32_t q = tid; q < nvalid; q += TH) {
 			const uint32_t li = sidx[q];
 			uint32_t dgt; uint64_t r;
