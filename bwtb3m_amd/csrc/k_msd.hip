@@ -461,7 +461,14 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 			if (fast) {
 				// 32-bit funnel shifts only: xh:xl = the 64-bit window at base li, key field = its 29 bits after the digit
 				const uint32_t w = li >> 4, sh = 2u * (li & 15u);
-				const uint32_t wp = stext[w], w0 = stext[w + 1], w1 = stext[w + 2], w2 = stext[w + 3];
+				// (the 40 bits a record takes from its window lie in w0 and w1 unless it starts in the last three bases of its word; the predecessor base lies
+				// in the word in front only for the first base of a word: the two rare words are read by the lanes that need them -- these reads are random
+				// and bank conflicts are what the generate phase waits for)
+				const uint32_t w0 = stext[w + 1], w1 = stext[w + 2];
+				uint32_t w2 = 0u, wp = 0u;
+				if (sh + (uint32_t)A.D + (uint32_t)rec_key_bits(A.pb) > 64u) w2 = stext[w + 3];
+				if (sh == 0u) wp = stext[w];
+				asm volatile("" : "+v"(w2), "+v"(wp));                   // (keeps the two reads under their conditions: they are safe to speculate and would be hoisted)
 				const uint32_t xh = __funnelshift_l(w1, w0, sh), xl = __funnelshift_l(w2, w1, sh);
 				const uint32_t pr = (__funnelshift_l(w0, wp, sh) & 3u) + padd;
 				dgt = xh >> dsh32;
