@@ -961,6 +961,7 @@ int b3m_plan_samples(const b3m_plan *p, uint64_t *pairs_out, uint64_t cap)
 int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256)
 {
 	if (!p || !hist256) { set_error("null argument"); return 1; }
+	if (p->type == B3M_INPUT_SYMBOLS32) { set_error("b3m_plan_histogram: a symbols32 text has no 256-entry histogram (count the symbols the caller ranked)"); return 1; }
 	memcpy(hist256, p->h_hist.data(), 8 * 256);
 	return 0;
 }

@@ -1538,6 +1538,10 @@ def test_symbols32_plans_against_the_oracle(gpu, oracle):
             plan.close()
     with pytest.raises(_lib.B3MError):
         engine.Plan(1000, _lib.SYMBOLS32, blocksize=100)        # one block only
+    plan = engine.Plan(1000, _lib.SYMBOLS32)
+    with pytest.raises(_lib.B3MError):
+        plan.histogram()                                        # no 256-entry histogram of wide symbols: said, not zeros
+    plan.close()
 
 
 def test_repeat_rich_100mbase_one_block_lf_verified(gpu):
