@@ -81,6 +81,12 @@ def test_distributed_driver_gloo(world, itype, nb, repeat):
     assert sum(sz for _, _, sz in res) == n
 
 
+def test_distributed_driver_gloo_eight_ranks():
+    """the world size of the reference's configs[3] (8 GPUs): three merge levels, groups of 2, 4 and 8 ranks, one leaf per rank"""
+    test_distributed_driver_gloo(8, "pacterm", 6001, False)
+    test_distributed_driver_gloo(8, "bytestream", 5003, False)
+
+
 def test_tree_plan_shapes():
     sys.path.insert(0, ROOT)
     from bwtb3m_amd.distributed import TreePlan, split_even, chains_for

@@ -341,7 +341,8 @@ def _dist_worker(rank, world, port, itype, nb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,itype,nb", [(2, "pacterm", 300000), (4, "pac", 262144), (3, "pacterm", 100001), (2, "bytestream", 200001), (3, "bytestream", 70000)])
+@pytest.mark.parametrize("world,itype,nb", [(2, "pacterm", 300000), (4, "pac", 262144), (3, "pacterm", 100001), (2, "bytestream", 200001), (3, "bytestream", 70000),
+                                            (5, "pacterm", 500001)])      # five ranks: three merge levels with a carried node (with this process the six the box allows on one GPU)
 def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
     import socket
     import torch.multiprocessing as mp
