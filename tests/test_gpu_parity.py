@@ -681,6 +681,59 @@ def test_prefix_sharded_driver_two_ranks(gpu, nb):
     assert all(ok for _, ok, _ in res) and sum(1 for _, _, h in res if h) == 1, res
 
 
+def _prefix_large_worker(rank, world, port, nb, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bwtb3m_amd import distributed as D, engine, synth
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        itype, d_text, n = synth.config_input_device("c3", size=nb, device=dev)
+        job = D.PrefixShardedBwt(n, itype, dev, isasamplingrate=4096)
+        out, off, p0 = job.run(d_text)
+        out2, off2, _ = job.run(d_text)
+        ok = job.fallback is None and off == off2 and bool(torch.equal(out, out2))
+        nsmp = job.plan.result()["num_samples"]
+        cnt = D._all_gather_i64([nsmp], None, dev)
+        ok = ok and int(cnt[:, 0].sum()) == (n + 4095) // 4096          # every sampled position gets its rank from exactly one shard
+        full = D.gather_result(out)
+        if rank == 0:
+            plan = engine.Plan(n, itype, isasamplingrate=4096)
+            one = plan.run(d_text)
+            ok = ok and plan.lf_walk(one, sarate=0)[:2] == (0, 0) and bool(torch.equal(one, full))
+            plan.close()
+        q.put((rank, bool(ok), p0 is not None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefix_sharded_driver_four_ranks_one_pass(gpu):
+    """the default N>1 mode as the scaling bench runs it -- one process per shard, every shard ONE pass over the text (40 Mbase: a level 1, 512-thread
+    form of the pass from three shards on) -- with four ranks on this GPU: the gathered slices equal the one-block BWT (LF-verified), two steps agree,
+    the shards' samples cover every sampled position once"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prefix_large_worker, args=(r, 4, port, 40_000_000, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:
+        assert not p.is_alive() and p.exitcode == 0
+    res = [q.get() for _ in range(4)]
+    assert all(ok for _, ok, _ in res) and sum(1 for _, _, h in res if h) == 1, res
+
+
 def _skew_worker(rank, world, port, nb, q):
     import os
     import sys
