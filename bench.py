@@ -196,8 +196,35 @@ def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
     return res
 
 
+def launch_ranks(a):
+    """`python3 bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): this process starts the N ranks itself --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`,
+    the form the driver uses -- BEFORE anything here has touched a GPU (it never does: no HIP call, no torch.cuda.is_available()), lets
+    rank 0's ONE JSON line through on the inherited stdout and returns the ranks' status.  One rank per GPU over RCCL; with
+    B3M_BENCH_BACKEND=gloo the ranks share the GPUs that exist (rehearsal on a one-GPU box, collectives staged through host memory)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    if os.environ.get("B3M_BENCH_BACKEND", "nccl") == "nccl" and a.gpus > max(1, ndev):
+        sys.stderr.write("bench.py: --gpus %d but this machine shows %d GPU(s); RCCL needs one GPU per rank "
+                         "(B3M_BENCH_BACKEND=gloo rehearses the N>1 flow with the ranks sharing a GPU)\n" % (a.gpus, ndev))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import numpy as np
     import torch
     from bwtb3m_amd import benchutil, engine, synth

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("b3m_dist_build_dict", _i, [_p, _p, _p, _i, _u64, _u64, _p]),
     ("b3m_dist_walk", _i, [_p, _u64, _u64, _u64, _p, _p, _p, _p, _u64, _u64, _u64, _p, _i, _p, _p, ctypes.POINTER(_u64), _p]),
     ("b3m_dist_l_bytes", _i, [_p, _u64, _u64, _u64, _p, _p]),
+    ("b3m_dist_r_bytes", _i, [_p, _p, _p, _i, _u64, _u64, _p, _p]),
     ("b3m_dist_sort_u32", _i, [_p, _p, _u64, _i, _p, _p]),
     ("b3m_dist_interleave", _i, [_p, _p, _p, _u64, _p, _u64, _p, _p]),
     ("b3m_rl_write", _i, [_cp, _p, _u64, _u64]),

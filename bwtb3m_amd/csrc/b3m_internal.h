@@ -258,6 +258,7 @@ constexpr int DICT_MAX_PARTS = 8;
 void pack2(const uint8_t *d_bwt, uint64_t m, int type, uint8_t *d_packed, hipStream_t s);
 void rank_build_from_parts(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t m, uint64_t p0, uint32_t *d_blocks,
                            uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
+void parts_bytes(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t q0, uint64_t q1, int type, uint8_t *d_out, hipStream_t s);
 void dict_bytes(const TextView &T, const uint32_t *d_blocks, uint64_t l0, uint64_t l1, uint64_t p0, uint64_t p0_pos, uint8_t *d_out, hipStream_t s);
 void rank_cuts(const uint32_t *d_sr, uint64_t cnt, const uint64_t *d_bounds, int nb, uint64_t *d_cuts, hipStream_t s);
 struct GapWalkArgs {

@@ -1652,6 +1652,27 @@ int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t a, uint64_t l0, uint64_t l1, uin
 	B3M_CATCH(1)
 }
 
+/* bytes [q0, q1) of BWT(R) out of R's packed slices (the same all-gather that brought L's): an owner's range of the right side */
+int b3m_dist_r_bytes(b3m_dist_plan *p, const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t q0, uint64_t q1, uint8_t *d_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_parts && part_syms && nparts >= 1 && q0 <= q1 && (q1 == q0 || d_out), "b3m_dist_r_bytes: bad argument");
+	hipStream_t s = (hipStream_t)stream;
+	if (p->type == B3M_INPUT_BYTESTREAM) {
+		uint64_t at = 0;
+		for (int i = 0; i < nparts; ++i) {
+			const uint64_t b = std::max(q0, at), e = std::min(q1, at + part_syms[i]);
+			if (e > b) B3M_HIP(hipMemcpyAsync(d_out + (b - q0), d_parts[i] + (b - at), e - b, hipMemcpyDeviceToDevice, s));
+			at += part_syms[i];
+		}
+		B3M_REQUIRE(q1 <= at, "b3m_dist_r_bytes: range outside the slices");
+		return 0;
+	}
+	parts_bytes(d_parts, part_syms, nparts, q0, q1, p->type, d_out, s);
+	return 0;
+	B3M_CATCH(1)
+}
+
 /* ascending sort of the rank buckets this rank received (all keys < 2^nbits), in the workspace */
 int b3m_dist_sort_u32(b3m_dist_plan *p, const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream)
 {

@@ -131,6 +131,25 @@ void dict_bytes(const TextView &T, const uint32_t *d_blocks, uint64_t l0, uint64
 {
 	if (l1 > l0) hipLaunchKernelGGL(k_dict_bytes, dim3(nblk(l1 - l0)), dim3(256), 0, s, T, d_blocks, l0, l1, p0, p0_pos, T.type == B3M_INPUT_PACTERM ? 1 : 0, d_out);
 }
+// bytes [q0, q1) of a block BWT that arrived as packed slices laid end to end (multi-GPU merges: an owner's range of BWT(R) out of the ONE all-gather
+// that carried both sides' slices; R never holds the terminator and its p0 entry is a real symbol of the text, so the codes are the whole truth)
+__global__ __launch_bounds__(256) void k_parts_bytes(PackedParts P, uint64_t q0, uint64_t q1, int add, uint8_t *out)
+{
+	const uint64_t g = q0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= q1) return;
+	int j = 0;
+	while (j + 1 < P.n && P.off[j + 1] <= g) ++j;
+	const uint64_t l = g - P.off[j];
+	out[g - q0] = (uint8_t)((((uint32_t)P.p[j][l >> 2] >> (2 * (l & 3))) & 3u) + (uint32_t)add);
+}
+void parts_bytes(const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t q0, uint64_t q1, int type, uint8_t *d_out, hipStream_t s)
+{
+	B3M_REQUIRE(nparts >= 1 && nparts <= DICT_MAX_PARTS, "too many packed slices");
+	PackedParts P{}; P.n = nparts; P.off[0] = 0;
+	for (int i = 0; i < nparts; ++i) { P.p[i] = d_parts[i]; P.off[i + 1] = P.off[i] + part_syms[i]; }
+	B3M_REQUIRE(q0 <= q1 && q1 <= P.off[nparts], "range outside the packed slices");
+	if (q1 > q0) hipLaunchKernelGGL(k_parts_bytes, dim3(nblk(q1 - q0)), dim3(256), 0, s, P, q0, q1, type == B3M_INPUT_PACTERM ? 1 : 0, d_out);
+}
 // cuts[j] = #{q : sr[q] < bounds[j]} over an ascending rank list
 __global__ void k_cuts(const uint32_t *sr, uint64_t cnt, const uint64_t *bounds, int nb, uint64_t *cuts)
 {

@@ -208,6 +208,17 @@ class HipBackend:
         eng.check(eng.lib().b3m_dist_l_bytes(self._h, a, l0, l1, eng._ptr(out), eng._stream()))
         return out
 
+    def r_bytes(self, parts, q0, q1):
+        """BWT(R)[q0, q1) out of R's packed slices (the merge's one all-gather brought them with L's)"""
+        eng = self.engine
+        out = torch.empty(q1 - q0, dtype=torch.uint8, device=self.device)
+        if q1 > q0:
+            k = len(parts)
+            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t, _ in parts])
+            syms = (ctypes.c_uint64 * k)(*[int(c) for _, c in parts])
+            eng.check(eng.lib().b3m_dist_r_bytes(self._h, ptrs, syms, k, q0, q1, eng._ptr(out), eng._stream()))
+        return out
+
     def sort_u32(self, keys, nbits):
         eng = self.engine
         out = torch.empty_like(keys)
@@ -242,15 +253,23 @@ def _all_gather_i64(vals, group, device):
     return torch.stack(out).cpu().numpy()
 
 
-def _all_to_all_v(send, send_counts, recv_counts, group):
-    """variable all-to-all of a 1-D tensor; counts are python ints per group member"""
-    dev = send.device
-    st = _staged(send)
-    src = send.cpu() if st else send
-    recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=src.device)
-    dist.all_to_all_single(recv, src.contiguous(), output_split_sizes=[int(x) for x in recv_counts],
-                           input_split_sizes=[int(x) for x in send_counts], group=group)
-    return recv.to(dev) if st else recv
+def _all_gather_padded(mine, chunk, group):
+    """ONE all-gather of every member's 1-D uint8 tensor, each padded to `chunk` bytes: -> (members, chunk) tensor on mine's device"""
+    gs = dist.get_world_size(group)
+    pad = torch.empty(chunk, dtype=mine.dtype, device=mine.device)
+    pad[: mine.numel()] = mine
+    if _staged(pad):
+        h = pad.cpu()
+        parts = [torch.empty_like(h) for _ in range(gs)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(mine.device)
+    out = torch.empty(gs * chunk, dtype=mine.dtype, device=mine.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.view(gs, chunk).unbind(0))
+        dist.all_gather(parts, pad, group=group)
+    else:
+        dist.all_gather_into_tensor(out, pad, group=group)
+    return out.view(gs, chunk)
 
 
 class _PendingA2A:
@@ -328,7 +347,7 @@ class DistributedBwt:
     created once (new_group is collective over ALL ranks); the backend's workspace is allocated once, in __init__."""
 
     def __init__(self, n, itype, backend, device):
-        self.n, self.itype, self.be, self.device = n, itype, backend, device
+        self.n, self.itype, self.be, self.device = n, itype, backend, torch.device(device)
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
         self.plan = TreePlan(n, self.world)
@@ -338,6 +357,22 @@ class DistributedBwt:
         mine = [mg for mg in self.plan.merges if self.rank in mg.group]
         self.be.setup(n, itype, self.plan.leaves[self.rank].m, max([mg.L.m for mg in mine] + [1]), max([mg.R.m for mg in mine] + [1]))
         self.timing = {}
+        self.sync_phases = False           # a device synchronisation at every phase border: the phase split of ONE extra step of the bench, never the timed steps
+
+    def warm_communicators(self):
+        """first use of every group this rank belongs to (RCCL creates a communicator on a group's first collective): a tiny all-reduce each, in the
+        same order on every rank, so that the timed steps and their watchdog see collectives, not communicator setup"""
+        dev = "cpu" if dist.get_backend() == "gloo" else self.device
+        for mg in self.plan.merges:
+            if self.rank in mg.group:
+                t = torch.ones(1, dtype=torch.int64, device=dev)
+                dist.all_reduce(t, group=self.groups[mg.idx])
+                assert int(t[0]) == len(mg.group)
+
+    def _now(self):
+        if self.sync_phases and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
 
     def _symstart(self, ranks):
         """C array of a node's text: symbols smaller than code c (pacterm: code c = symbol c + 1, the terminator is smaller than every base)"""
@@ -351,14 +386,14 @@ class DistributedBwt:
     def run(self, d_text):
         n, be, plan, me = self.n, self.be, self.plan, self.rank
         dev = self.device
-        tm = self.timing = {"leaf": 0.0, "anchors": 0.0, "walk": 0.0, "exchange": 0.0, "interleave": 0.0}
-        t0 = time.perf_counter()
+        tm = self.timing = {"leaf": 0.0, "anchors": 0.0, "gather": 0.0, "dict": 0.0, "walk": 0.0, "all_to_all": 0.0, "sort": 0.0, "interleave": 0.0}
+        t0 = self._now()
         leaf = plan.leaves[me]
         be.set_text(d_text)
         my_bwt, gt_cur, p0, h5 = be.leaf(leaf.a, leaf.m)
         node_p0 = {me: p0}
         # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks; leaf histograms for the C arrays -----
-        t1 = time.perf_counter()
+        t1 = self._now()
         tm["leaf"] += t1 - t0
         # (the ranks never visit the host: partial ranks are added on the device, summed over the ranks by one all-reduce, and the walks read them there)
         anchors = torch.zeros(max(1, plan.total_anchors), dtype=torch.int64, device=dev)
@@ -367,7 +402,7 @@ class DistributedBwt:
         if self.world > 1:
             _all_reduce_sum(anchors)
         self.leaf_hist = _all_gather_i64(h5, None, dev) if self.world > 1 else np.array([h5], dtype=np.int64)
-        tm["anchors"] += time.perf_counter() - t1
+        tm["anchors"] += self._now() - t1
         # ---- merge levels ----------------------------------------------------------------------------------
         my_off = 0                  # offset of my slice inside my current node's BWT
         my_node = leaf              # node I currently belong to
@@ -382,8 +417,10 @@ class DistributedBwt:
         return my_bwt, my_off, node_p0[my_node.ranks[0]]
 
     def _merge(self, mg, my_bwt, my_off, gt_cur, my_node_p0, anchors, tm):
-        """one merge of the tree, this rank's part.  What the host sees of it: slice sizes and the split sizes of the two all-to-alls (and the
-        new p0 at the end); anchors, gt bits, ranks and symbols stay on the device."""
+        """one merge of the tree, this rank's part.  What the host sees of it: slice sizes and the split sizes of the all-to-all (and the
+        new p0 at the end); anchors, gt bits, ranks and symbols stay on the device.  Collectives per merge: one small all-gather (slice
+        sizes, p0), ONE all-gather of the packed slices of both sides, two broadcasts + one all-reduce of gt words, one small all-gather
+        of the bucket sizes per tile, one all-to-all(v) of the gap buckets per tile, one small all-gather (new p0, offsets)."""
         n, be, me, dev = self.n, self.be, self.rank, self.device
         grp = self.groups[mg.idx]
         members = mg.group
@@ -392,7 +429,7 @@ class DistributedBwt:
         nL = len(mg.L.ranks)
         a, m, mr = mg.L.a, mg.L.m, mg.R.m
         rbeg, rend = a + m, a + m + mr
-        t0 = time.perf_counter()
+        t0 = self._now()
         # 1. slice sizes and the node p0 of both sides (the symbol of L's p0 entry, which the packed form cannot carry, is the text symbol
         #    in front of L: the library reads it there)
         sz = my_bwt.numel()
@@ -400,14 +437,13 @@ class DistributedBwt:
         sizes = info[:, 0]
         p0L = int(info[0, 1])
         assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
-        offR = np.concatenate([[0], np.cumsum(sizes[nL:])])
-        # 2. BWT(L) to every member as packed slices, 2 bits per symbol (bytes: as they are); the rank dictionary is built from them where it is used
-        parts = []
-        for j in range(nL):
-            cj = int(sizes[j])
-            part = be.pack2(my_bwt) if gi == j else torch.empty(be.packed_len(cj), dtype=torch.uint8, device=dev)
-            _broadcast(part, members[j], grp)
-            parts.append((part, cj))
+        # 2. the packed slices of BOTH sides to every member in ONE all-gather (2 bits per symbol; bytes: as they are).  L's slices become the rank
+        #    dictionary where it is used; an owner later takes its range of BWT(R) out of R's slices, so no second exchange of symbols is needed.
+        #    (Padded to the largest slice: a member's share of a node differs from the others' by the rounding of the rank slices.)
+        chunk = max(1, max(be.packed_len(int(c)) for c in sizes))
+        allpk = _all_gather_padded(be.pack2(my_bwt), chunk, grp)
+        partsL = [(allpk[j], int(sizes[j])) for j in range(nL)]
+        partsR = [(allpk[j], int(sizes[j])) for j in range(nL, gs)]
         # 3. gt bits: L's positions (a, rbeg) are valid on L's members, R's (rbeg, rend] on R's.
         #    Everybody gets both word ranges; partial edge words are merged bit-exactly.
         lw0, lw1 = a >> 5, (rbeg >> 5) + 1
@@ -418,69 +454,69 @@ class DistributedBwt:
         _broadcast(rseg, members[nL], grp)
         be.bits_replace(gt_cur, lseg, lw0, a + 1, rbeg + 1)
         be.bits_replace(gt_cur, rseg, w0, rbeg + 1, rend + 1)
-        t1 = time.perf_counter()
-        tm["exchange"] += t1 - t0
+        t1 = self._now()
+        tm["gather"] += t1 - t0
         # 4. dictionary, then my chain range; the ranks come back sorted and already cut at the borders of the group's rank slices
-        be.build_dict(parts, m, p0L)
+        be.build_dict(partsL, m, p0L)
+        t1b = self._now()
+        tm["dict"] += t1b - t1
         cb = split_even(mg.num_chains, gs)
         c0, c1 = cb[gi], cb[gi + 1]
         lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
-        # my chain range goes in tiles: while tile t+1 walks, the gap buckets of tile t are already on their way (all-to-all(v) of
-        # the ranks, cut on the device at the borders of the group's rank slices; RCCL runs it on its own stream)
-        ntile = max(1, min(int(os.environ.get("B3M_DIST_TILES", "2")), c1 - c0))
+        # B3M_DIST_TILES = t > 1: my chain range goes in t tiles; while tile i+1 walks, the gap buckets of tile i are already on their way
+        # (RCCL runs the all-to-all on its own stream), at the price of one small all-gather of bucket sizes per tile.  Default: one tile,
+        # one all-gather of the bucket sizes, one all-to-all(v).
+        ntile = max(1, min(int(os.environ.get("B3M_DIST_TILES", "1")), c1 - c0))
         tb = split_even(c1 - c0, ntile)
         symstart = self._symstart(mg.L.ranks)
         flights, rc, oseg = [], None, None
+        t_walk = t_a2a = 0.0
         for t in range(ntile):
+            tw0 = self._now()
             ca, cz = c0 + tb[t], c0 + tb[t + 1]
             anc = anchors[mg.anchor_off + ca: mg.anchor_off + cz]
             sr_t, cut, gt_out = be.walk(a, m, mr, symstart, gt_cur, anc, ca, cz - ca, mg.chain_len, lam)
             seg = gt_out[w0:w1]
             oseg = seg.clone() if oseg is None else oseg | seg          # new gt bits of the walked positions (disjoint between tiles and walkers)
             del gt_out
+            tw1 = self._now()
+            t_walk += tw1 - tw0
             send_counts = np.diff(cut)
             rc_t = _all_gather_i64(list(send_counts), grp, dev)          # rc_t[i][j] = i sends to j in this tile
             flights.append(_PendingA2A(sr_t, send_counts, rc_t[:, gi], grp))
             rc = rc_t if rc is None else rc + rc_t
-        del parts
-        t2 = time.perf_counter()
-        tm["walk"] += t2 - t1
+            t_a2a += self._now() - tw1
+        t2 = self._now()
+        tm["walk"] += t_walk
         # new gt bits of R's positions relative to S_a: union over walkers (disjoint positions)
         oseg = oseg.contiguous()
         _all_reduce_sum(oseg, grp)
         gt_new = gt_cur                               # L's bits (a, rbeg) stay; R's become relative to S_a
         be.bits_replace(gt_new, oseg, w0, rbeg, rend)
         be.set_endbit(gt_new, rend, anchors[mg.anchor_off: mg.anchor_off + 1], p0L)
+        t2b = self._now()
+        tm["gather"] += t2b - t2
         # 5. the gap buckets of my slice of the rank space [0, m], from every walker and tile
         got = torch.cat([f.result() for f in flights]) if len(flights) > 1 else flights[0].result()
         del flights
+        t3 = self._now()
+        tm["all_to_all"] += t_a2a + (t3 - t2b)
         nbits = max(1, int(m + 1).bit_length())
         sr_slice = be.sort_u32(got, min(32, nbits))
-        # 6. which range of BWT(R) falls into my slice
+        t4 = self._now()
+        tm["sort"] += t4 - t3
+        # 6. the range of BWT(R) that falls into my slice, out of R's packed slices
         cj = rc.sum(axis=0)                   # cj[j] = suffixes of R owned by j
         Q = np.concatenate([[0], np.cumsum(cj)])
-        # all-to-all of BWT(R) ranges: R member r (global slice [offR[r], offR[r+1])) sends to owner
-        # j the overlap with [Q[j], Q[j+1])
-        send2 = np.zeros(gs, dtype=np.int64)
-        recv2 = np.zeros(gs, dtype=np.int64)
-        if gi >= nL:
-            r = gi - nL
-            for j in range(gs):
-                send2[j] = max(0, min(offR[r + 1], Q[j + 1]) - max(offR[r], Q[j]))
-        for r in range(gs - nL):
-            recv2[nL + r] = max(0, min(offR[r + 1], Q[gi + 1]) - max(offR[r], Q[gi]))
-        src = my_bwt if gi >= nL else torch.empty(0, dtype=torch.uint8, device=dev)
-        bwtR_part = _all_to_all_v(src, send2, recv2, grp)
-        assert bwtR_part.numel() == int(cj[gi])
-        t3 = time.perf_counter()
-        tm["exchange"] += t3 - t2
+        bwtR_part = be.r_bytes(partsR, int(Q[gi]), int(Q[gi + 1]))
         # 7. interleave my slice; its range of BWT(L) comes out of the dictionary
         l0, l1 = lam[gi], (lam[gi + 1] if gi + 1 < gs else m)
         l1 = min(l1, m)
         sr_local = (sr_slice - l0) if l0 else sr_slice
         out = be.interleave(sr_local, be.l_bytes(a, l0, l1), bwtR_part)
+        del partsL, partsR, allpk
         p0P, new_off = self._p0_after_merge(sr_slice, p0L, l0, l1, int(Q[gi]), out.numel(), gi, grp)
-        tm["interleave"] += time.perf_counter() - t3
+        tm["interleave"] += self._now() - t4
         return out, new_off, gt_new, p0P
 
     def _p0_after_merge(self, sr_slice, p0L, l0, l1, q0, out_len, gi, grp):
@@ -502,8 +538,11 @@ class PrefixShardedBwt:
     optional result gather touches the interconnect.  The block-merging path with its all-to-all of
     gap buckets (DistributedBwt) is what a text that cannot be sorted in one piece needs."""
 
-    def __init__(self, n, itype, device, isasamplingrate=0):
+    def __init__(self, n, itype, device, isasamplingrate=0, allow_fallback_without_samples=False):
         from . import engine
+        self.isasamplingrate = int(isasamplingrate)
+        self.allow_fallback_without_samples = allow_fallback_without_samples
+        self.samples_dropped = False       # True once the fallback below has been taken by a job that asked for samples
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n, self.itype, self.device = n, itype, device
@@ -532,7 +571,13 @@ class PrefixShardedBwt:
             pend = _all_gather_i64([0 if refused else self.plan.tie_pending(), sl.numel(), refused], None, self.out.device)
             if int(pend[:, 2].sum()) > 0:
                 self.refusal = "suffix-range shards refused by rank(s) %s: block merging instead" % [int(i) for i in np.nonzero(pend[:, 2])[0]]
+                if self.isasamplingrate and not self.allow_fallback_without_samples:
+                    # the block-merge driver emits no (rank,pos) samples: a caller that asked for them must not get slices without them silently
+                    raise _lib.B3MError(self.refusal + "; the block-merge mode emits no (rank,pos) samples (isasamplingrate=%d was asked for): "
+                                        "construct with allow_fallback_without_samples=True to accept BWT slices alone" % self.isasamplingrate)
                 self.plan.close()
+                self.plan = None
+                self.samples_dropped = bool(self.isasamplingrate)
                 del self.out, sl
                 torch.cuda.empty_cache()
                 self.fallback = DistributedBwt(self.n, self.itype, HipBackend(self.device), self.device)
@@ -559,6 +604,29 @@ class PrefixShardedBwt:
         r = self.plan.result()
         off = r["slice_offset"] if self.world > 1 else 0
         return sl, off, (r["p0"] if r["has_p0"] else None)
+
+
+def _no_plan(job):
+    from . import _lib
+    return _lib.B3MError("this job fell back from suffix-range shards to block merging (%s): it has BWT slices, but no shard plan, no (rank,pos) samples "
+                         "and no per-kernel times" % job.refusal)
+
+
+def _sharded_result(self):
+    """the shard plan's b3m_result of the last step; after the fallback to block merging there is none (a clear error, not a NULL handle)"""
+    if self.plan is None:
+        raise _no_plan(self)
+    return self.plan.result()
+
+
+def _sharded_samples(self):
+    if self.plan is None:
+        raise _no_plan(self)
+    return self.plan.samples()
+
+
+PrefixShardedBwt.result = _sharded_result
+PrefixShardedBwt.samples = _sharded_samples
 
 
 def _all_gather_v(t, sizes):
@@ -683,27 +751,51 @@ def bench_main(a, rank, local_rank, world):
     plan_rate = int(_lib.lib().b3m_plan_sampling_rate(getattr(a, "isasamplingrate", 0), getattr(a, "bwtonly", 0), n))
 
     def make(m):
-        return DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks" else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate)
+        # (a text too skewed for suffix-range shards is constructed by block merging instead; the line then says so and claims no samples)
+        return (DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks"
+                else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate, allow_fallback_without_samples=True))
 
-    def measure(m, steps, warmup, bail=None):
-        wd = threading.Timer(a.blocks_timeout, bail or _bail)
+    def guarded(seconds, bail, fn):
+        wd = threading.Timer(seconds, bail)
         wd.daemon = True
         wd.start()
         try:
-            if inject == "%s:%d" % (m, rank):
-                raise RuntimeError("injected failure (B3M_BENCH_INJECT=%s)" % inject)
+            return fn()
+        finally:
+            wd.cancel()
+
+    def measure(m, steps, warmup, bail=None):
+        bail = bail or _bail
+        if inject == "%s:%d" % (m, rank):
+            raise RuntimeError("injected failure (B3M_BENCH_INJECT=%s)" % inject)
+        # plan + workspace, and the first use of every process group this mode needs (RCCL sets a communicator up on a group's first collective:
+        # seconds each on a fresh node), under a watchdog of their own: the steps' watchdog then times collectives, not their setup
+        def setup():
             job = make(m)
+            if m == "blocks":
+                job.warm_communicators()
+            return job
+        job = guarded(2 * a.blocks_timeout, bail, setup)
+
+        def steps_():
             dt, out, off, p0, fam = _run_mode(job, d_text, steps, warmup, dev, fam_of=(lambda j: j.plan.kernel_times() if getattr(j, "fallback", None) is None else []) if m != "blocks" else None)
             checked = _check_slices(out, off, p0, d_text, n, itype, dev) if getattr(a, "check", True) else None
             del out
-            phases = {k: round(v, 4) for k, v in getattr(job, "timing", {}).items()}
-            levels = len(job.plan.levels) if m == "blocks" else 0
+            merger = job if m == "blocks" else getattr(job, "fallback", None)
+            phases, levels = {}, 0
+            if merger is not None:
+                # the phase split comes from ONE extra step with a device synchronisation at every phase border (the timed steps have none)
+                merger.sync_phases = True
+                job.run(d_text)
+                merger.sync_phases = False
+                phases = {k: round(v, 4) for k, v in merger.timing.items()}
+                levels = len(merger.plan.levels)
             if getattr(job, "fallback", None) is not None:      # a shard refused its range (skewed text): the steps ran as block merges
-                fam, levels, phases = {}, len(job.fallback.plan.levels), {k: round(v, 4) for k, v in job.fallback.timing.items()}
+                fam = {}
             return {"dt": dt, "steps": steps, "fam": fam, "phases": phases, "levels": levels, "job": job, "checked": checked,
-                    "tie_finish_runs": getattr(job, "tie_finish_runs", 0), "refusal": getattr(job, "refusal", None)}
-        finally:
-            wd.cancel()
+                    "tie_finish_runs": getattr(job, "tie_finish_runs", 0), "refusal": getattr(job, "refusal", None),
+                    "samples_dropped": getattr(job, "samples_dropped", False)}
+        return guarded(a.blocks_timeout, bail, steps_)
 
     other = "blocks" if mode != "blocks" else "prefix"
     try:
@@ -717,14 +809,19 @@ def bench_main(a, rank, local_rank, world):
         sys.stderr.flush()
         os._exit(2)
 
+    reported = threading.Event()
+
     def report(res_other):
         """rank 0's ONE JSON line; res_other: the other mode's measurement, None (not run) or {"error": ...}"""
         def summary(r):
             if "error" in r:
                 return r
             out = {"ms_per_step": round(r["dt"] / r["steps"] * 1e3, 3), "value": round(nbases * r["steps"] / r["dt"] / 1e9, 4), "steps": r["steps"],
-                   "merge_levels": r["levels"], "rank0_phase_s": r["phases"], "checked": r["checked"],
-                   "tie_finish_runs": r["tie_finish_runs"]}
+                   "merge_levels": r["levels"], "checked": r["checked"], "tie_finish_runs": r["tie_finish_runs"]}
+            if r["phases"]:
+                out["rank0_phase_s"] = r["phases"]
+                out["rank0_phase_s_what"] = ("one extra step with a device synchronisation at every phase border: leaf sort, anchors (z-ranks), gather (all-gather of both "
+                                             "sides' packed slices + gt words), dict (rank dictionary of BWT(L)), walk (LF chains), all_to_all (gap buckets), sort, interleave")
             if r.get("refusal"):
                 out["fell_back"] = r["refusal"]
             return out
@@ -740,6 +837,8 @@ def bench_main(a, rank, local_rank, world):
         names = {"blocks": "%d GPUs: 1 leaf block per GPU, balanced merges, RCCL all-to-all of gap buckets" % world,
                  "prefix": "%d GPUs: suffix-range shards of the replicated text, no exchange step" % world}
         modes = {mode: summary(res_main)}
+        # only suffix-range shards emit samples; a shard job that fell back to block merging emitted none
+        with_samples = mode == "prefix" and not res_main.get("refusal")
         if res_other is not None:
             modes[other] = summary(res_other)
         res = {
@@ -749,10 +848,16 @@ def bench_main(a, rank, local_rank, world):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
                        "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes, "checked": res_main["checked"],
-                       "isasamplingrate": {"plan": plan_rate, "what": "suffix-range shards emit the (rank,pos) samples of the plan b3m_compute_bwt creates (b3m_plan_sampling_rate)"},
-                       "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices (+ samples) in HBM"},
+                       "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices%s in HBM" % (" + (rank,pos) samples" if with_samples else "")},
             "roofline": roof,
         }
+        if with_samples:
+            res["config"]["isasamplingrate"] = {"plan": plan_rate, "what": "suffix-range shards emit the (rank,pos) samples of the plan b3m_compute_bwt creates (b3m_plan_sampling_rate)"}
+        elif mode == "prefix":
+            res["config"]["isasamplingrate"] = {"plan": 0, "what": "the shards fell back to block merging, which emits no (rank,pos) samples"}
+        if reported.is_set():          # (the watchdog of the other mode and the main thread can both get here: one line)
+            return
+        reported.set()
         print(json.dumps(res), flush=True)
 
     # the other mode (one step) rides in the same line.  It must not be able to take the headline with it: if it fails or a collective of it never
@@ -768,7 +873,7 @@ def bench_main(a, rank, local_rank, world):
             os._exit(0)
         try:
             torch.cuda.empty_cache()
-            res_other = measure(other, 1, 1, bail=_bail_other)
+            res_other = measure(other, max(3, min(a.steps, 5)), 1, bail=_bail_other)
             res_other.pop("job", None)
         except BaseException as ex:   # noqa: BLE001
             sys.stderr.write("[bench] rank %d: mode %s failed: %r; the headline line stands\n" % (rank, other, ex))
@@ -778,5 +883,13 @@ def bench_main(a, rank, local_rank, world):
             os._exit(0)
     if rank == 0:
         report(res_other)
+    sys.stdout.flush()
+    # the line is out; a peer that left early (its watchdog, an error of the other mode) must not hold this rank in the last barrier for ever
+    def _leave():
+        os._exit(0)
+    wd = threading.Timer(30, _leave)
+    wd.daemon = True
+    wd.start()
     dist.barrier()
     dist.destroy_process_group()
+    wd.cancel()

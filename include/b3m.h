@@ -288,6 +288,9 @@ int b3m_dist_walk(b3m_dist_plan *p, uint64_t a, uint64_t m, uint64_t mr, const u
                   const uint64_t *bounds, int nbounds, uint32_t *d_sorted_out, uint64_t *cuts_out, uint64_t *count_out, void *stream);
 /* bytes of BWT(L)[l0, l1) out of the dictionary; L's p0 entry reads the symbol in front of L (position a - 1, circular), taken from the text */
 int b3m_dist_l_bytes(b3m_dist_plan *p, uint64_t a, uint64_t l0, uint64_t l1, uint8_t *d_out, void *stream);
+/* bytes [q0, q1) of BWT(R) out of R's packed slices in rank order (d_parts[i]: part_syms[i] symbols in the form of b3m_dist_pack2): the members of a merge
+ * exchange the packed slices of BOTH sides in ONE all-gather; the dictionary is built from L's, an owner takes its range of BWT(R) from R's here */
+int b3m_dist_r_bytes(b3m_dist_plan *p, const uint8_t *const *d_parts, const uint64_t *part_syms, int nparts, uint64_t q0, uint64_t q1, uint8_t *d_out, void *stream);
 /* gt plumbing of a merge on the device: bit `bit` of d_gt_abs = [d_anchor[0] > p0L] (the end bit of the parent node), and
  * bits [bit_begin, bit_end) of one absolute-position bit array copied into another (partial edge words merged under a mask) */
 int b3m_dist_endbit(b3m_dist_plan *p, uint32_t *d_gt_abs, uint64_t bit, const int64_t *d_anchor, uint64_t p0L, void *stream);

@@ -123,6 +123,18 @@ class OracleBackend:
             out[self.p0L - l0] = self.sym[(a - 1) % self.n]      # the entry of L's first suffix: the symbol in front of L
         return torch.from_numpy(out)
 
+    def _unpack(self, t, cnt):
+        if self.itype == "bytestream":
+            return t.numpy()[:cnt].copy()
+        v = t.numpy().astype(np.int64)
+        codes = np.stack([(v >> (2 * k)) & 3 for k in range(4)], axis=1).reshape(-1)[:cnt]
+        return (codes + self.sub).astype(np.uint8)
+
+    def r_bytes(self, parts, q0, q1):
+        allr = np.concatenate([self._unpack(t, cnt) for t, cnt in parts]) if parts else np.zeros(0, dtype=np.uint8)
+        assert q1 <= len(allr)
+        return torch.from_numpy(allr[q0:q1].copy())
+
     def sort_u32(self, keys, nbits):
         return torch.sort(keys)[0]
 
