@@ -86,6 +86,9 @@ SYMBOLS = [
     ("b3m_plan_samples", _i, [_p, _p, _u64]),
     ("b3m_plan_histogram", _i, [_p, _p]),
     ("b3m_plan_lf_walk", _i, [_p, _p, _u64, _p, _p, _p]),
+    ("b3m_plan_lf_walk_dev", _i, [_p, _p, _u64, _p, _p, _p]),
+    ("b3m_plan_samples_raw", _i, [_p, ctypes.POINTER(_p), ctypes.POINTER(_u64)]),
+    ("b3m_lf_walk", _i, [_p, _u64, _i, _p, _u64, _p, _p, _u64, _u64, _p, _p, _p, _p]),
     ("b3m_plan_kernel_times", _i, [_p, ctypes.POINTER(KernelTime), _i]),
     ("b3m_histogram", _i, [_p, _u64, _i, _u64, _u64, _p, _p]),
     ("b3m_block_sort", _i, [_p, _u64, _i, _u64, _u64, _p, _p, _p, ctypes.POINTER(_u64), _p]),

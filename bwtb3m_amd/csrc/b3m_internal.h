@@ -282,8 +282,10 @@ void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_b
                     uint64_t chain_first = 0);      // chain_first: global index of this launch's first chain (multi-GPU: each rank walks a chain range)
 // LF walks over the final BWT between (rank,pos) anchors: SA samples + verification (8f rows 1, 3)
 // d_blocks: rank dictionary of the whole BWT (rank_build64), p0 = rank of the terminator entry (~0: none), C = symbol starts
-void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s);
-void lf_walk(const TextView &T, const uint32_t *d_blocks, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
+// (counts are 64-bit: d_sb = 4 * rank_superblocks(m) u64, the counts in front of every superblock of lines; the line headers count from there)
+uint64_t rank_superblocks(uint64_t m);
+void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, uint64_t *d_sb, hipStream_t s);
+void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
              uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
                    RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);

@@ -1294,7 +1294,73 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
  * its (rank,pos) samples.  Verifies every BWT symbol against the text and every chain against the
  * next anchor (checkbwt), and, if sarate > 0, fills sa_out[i] = SA[i*sarate] (bwtcomputessa).
  * pac/pacterm, unsharded plans created with isasamplingrate > 0. */
+/* LF walks over a final 2-bit BWT on the current device: dictionary with 64-bit counts, one chain per anchor.  hist: symbol counts of the text (pacterm: [0] the
+ * terminator, [1..4] the bases; pac: [0..3]); anchors: K (rank,pos) pairs in position order, the first at position 0 (host); p0 = rank of the terminator entry
+ * (~0: none).  SA samples go to sa_out (host) and/or stay in d_sa_keep (device, ceil(n/sarate) u64) for a caller that streams them out itself. */
+static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist, const uint64_t *anchors, uint64_t K, uint64_t sarate,
+                         uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, hipStream_t s)
+{
+	const uint64_t n = T.n;
+	B3M_REQUIRE(K >= 1 && anchors[1] == 0, "anchor at position 0 missing");
+	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
+	const uint64_t nb = rank_blocks(n), nsb = rank_superblocks(n);
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), sb(32 * nsb + 64), p0d(16), danc(16 * K), dsa(d_sa_keep ? 16 : 8 * (nsa + 1)), dmis(16);
+	uint64_t *d_sa = d_sa_keep ? d_sa_keep : dsa.as<uint64_t>();
+	B3M_HIP(hipMemcpyAsync(p0d.p, &p0, 8, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(danc.p, anchors, 16 * K, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
+	if (nsa) B3M_HIP(hipMemsetAsync(d_sa, 0xFF, 8 * nsa, s));
+	rank_build64(d_bwt, n, p0d.as<uint64_t>(), T.type, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), sb.as<uint64_t>(), s);
+	uint64_t C[4];
+	if (T.type == B3M_INPUT_PACTERM) { uint64_t acc = hist[0]; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += hist[c + 1]; } }
+	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += hist[c]; } }
+	lf_walk(T, blocks.as<uint32_t>(), sb.as<uint64_t>(), p0, C, danc.as<uint64_t>(), K, sarate, d_sa, dmis.as<unsigned long long>(), s);
+	unsigned long long mm[2] = {0, 0};
+	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
+	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, d_sa, 8 * nsa, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+}
+
+/* the same as a stage of its own, for a BWT that no single plan produced (the slices of suffix-range shards gathered on one GPU): d_text = the packed text on
+ * the current device with at least 8 readable bytes behind it */
+int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist256, const uint64_t *sample_pairs,
+                uint64_t num_samples, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(d_text && d_bwt && hist256 && sample_pairs && mismatches_out && num_samples >= 1, "b3m_lf_walk: null argument");
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "b3m_lf_walk: pac / pacterm texts (byte alphabets: b3m_plan_lf_walk)");
+	TextView T{(const uint8_t *)d_text, n, num_bases(n, inputtype), inputtype};
+	lf_walk_2bit(T, d_bwt, inputtype == B3M_INPUT_PACTERM ? p0 : ~0ull, hist256, sample_pairs, num_samples, sarate, sa_out, d_sa_out, mismatches_out, (hipStream_t)stream);
+	return 0;
+	B3M_CATCH(1)
+}
+
+static int plan_lf_walk_impl(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, void *stream);
 int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out, uint64_t *mismatches_out, void *stream)
+{
+	return plan_lf_walk_impl(p, d_bwt, sarate, sa_out, nullptr, mismatches_out, stream);
+}
+/* the same with the SA samples left in device memory (d_sa_out: ceil(n/sarate) u64), for a caller that streams them to a file itself; pac / pacterm */
+int b3m_plan_lf_walk_dev(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream)
+{
+	if (!d_sa_out || !sarate) { set_error("b3m_plan_lf_walk_dev: no output array / sarate = 0"); return 1; }
+	return plan_lf_walk_impl(p, d_bwt, sarate, nullptr, d_sa_out, mismatches_out, stream);
+}
+/* the pinned image of the last run's (rank,pos) samples: slot i belongs to position i * rate; a slot that reads (~0, .) is another shard's (suffix-range
+ * shards) -- an unsharded plan has none of those (checked, as b3m_plan_samples does).  Valid until the plan runs again or is destroyed. */
+int b3m_plan_samples_raw(b3m_plan *p, const uint64_t **slots_out, uint64_t *nslots_out)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && slots_out && nslots_out, "b3m_plan_samples_raw: null argument");
+	if (p->nshards == 1 && p->isarate) (void)samples_of(p);
+	*slots_out = p->h_raw; *nslots_out = p->isarate ? p->total_samples : 0;
+	return 0;
+	B3M_CATCH(1)
+}
+static int plan_lf_walk_impl(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, void *stream)
 {
 	B3M_TRY
 	B3M_REQUIRE(p && d_bwt && mismatches_out, "b3m_plan_lf_walk: null argument");
@@ -1309,6 +1375,7 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
 	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	if (p->type == B3M_INPUT_BYTESTREAM || p->type == B3M_INPUT_SYMBOLS32) {
+		B3M_REQUIRE(!d_sa_keep, "b3m_plan_lf_walk_dev: pac / pacterm plans only");
 		// byte alphabet (and wide symbols): the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
 		B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
 		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
@@ -1326,27 +1393,9 @@ int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_
 		mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
 		return 0;
 	}
-	// 2-bit alphabets: rank dictionary of the whole BWT; ranks and positions are 64-bit, the cumulative counts in the line
-	// headers 32-bit (every symbol fewer than 2^32 times: texts up to ~16 G uniform bases)
-	for (int c = 0; c < 5; ++c) B3M_REQUIRE(p->h_hist[c] < (1ull << 32), "LF walk: a symbol occurs 2^32 times or more (rank dictionary headers are 32-bit)");
-	uint64_t nb = rank_blocks(n);
-	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), p0d(16), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
+	// 2-bit alphabets: rank dictionary of the whole BWT with 64-bit counts (a symbol may occur 2^32 times and more: 30 Gbase)
 	const uint64_t p064 = (p->type == B3M_INPUT_PACTERM) ? p->res.p0 : ~0ull;   // pac: no terminator entry
-	B3M_HIP(hipMemcpyAsync(p0d.p, &p064, 8, hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
-	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
-	rank_build64(d_bwt, n, p0d.as<uint64_t>(), p->type, blocks.as<uint32_t>(), scratch.as<uint32_t>(), sws.as<uint32_t>(), s);
-	uint64_t C[4];
-	if (p->type == B3M_INPUT_PACTERM) { uint64_t acc = p->h_hist[0]; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += p->h_hist[c + 1]; } }
-	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += p->h_hist[c]; } }
-	lf_walk(T, blocks.as<uint32_t>(), p064, C, danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
-	unsigned long long mm[2] = {0, 0};
-	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
-	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
-	B3M_HIP(hipStreamSynchronize(s));
-	B3M_HIP(hipGetLastError());
-	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+	lf_walk_2bit(T, d_bwt, p064, p->h_hist.data(), anc.data(), K, sarate, sa_out, d_sa_keep, mismatches_out, s);
 	return 0;
 	B3M_CATCH(1)
 }

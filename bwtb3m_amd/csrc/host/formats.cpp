@@ -195,17 +195,22 @@ static void encode_block(const RLRun *runs, uint64_t nr, std::vector<uint8_t> &o
 	w.align();
 }
 
+void rl_container_ends(uint64_t n, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index, std::vector<uint8_t> &head, std::vector<uint8_t> &tail)
+{
+	head.clear(); tail.clear();
+	put_be64(head, n);
+	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
+	put_be64(tail, index.size());
+	put_be64(tail, 8 + blocks_bytes);
+}
 void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index)
 {
 	FILE *f = fopen(fn.c_str(), "wb");
 	if (!f) throw std::runtime_error("cannot open " + fn + " for writing");
-	std::vector<uint8_t> head; put_be64(head, n);
+	std::vector<uint8_t> head, tail;
+	rl_container_ends(n, blocks_bytes, index, head, tail);
 	fwrite(head.data(), 1, head.size(), f);
 	if (blocks_bytes && fwrite(blocks, 1, blocks_bytes, f) != blocks_bytes) { fclose(f); throw std::runtime_error("short write to " + fn); }
-	std::vector<uint8_t> tail;
-	for (auto &e : index) { put_be64(tail, e.pos); put_be64(tail, e.runs); put_be64(tail, e.syms); }
-	put_be64(tail, index.size());
-	put_be64(tail, 8 + blocks_bytes);
 	fwrite(tail.data(), 1, tail.size(), f);
 	if (fclose(f)) throw std::runtime_error("error closing " + fn);
 }

@@ -183,11 +183,54 @@ void rank_build(const uint8_t *d_bwtL, uint64_t m, const uint32_t *d_p0, int typ
 {
 	rank_build_t<uint32_t>(d_bwtL, m, d_p0, type, d_blocks, d_scratch, scan_ws, s);
 }
-// the same over a BWT of 2^32 symbols and more: the rank of the terminator entry is a 64-bit device scalar (~0: none).  The counts in the
-// line headers stay 32-bit: every symbol must occur fewer than 2^32 times (checked by the caller)
-void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, hipStream_t s)
+// ---- the dictionary with 64-bit counts (LF walks over the FINAL BWT: at 30 Gbase every base occurs 7.5 G times) -------------------------------
+// A line header keeps 32 bits: the counts since the start of the line's SUPERBLOCK (2^sbshift lines = 2^sbshift x 192 symbols < 2^32), and a table
+// sb[superblock][4] of 64-bit counts says what lies in front of the superblock.  The exclusive sums over the lines are taken modulo 2^32 as before
+// (wrap-around is harmless: the difference of two of them less than 2^32 apart is exact); the table is the running sum of those differences.
+__global__ __launch_bounds__(256) void k_rank_sb_diffs(const uint32_t *cnt, uint64_t nb, int sbshift, uint64_t nsb, uint64_t *sb)
 {
-	rank_build_t<uint64_t>(d_bwt, m, d_p0, type, d_blocks, d_scratch, scan_ws, s);
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= 4 * nsb) return;
+	const uint64_t j = i >> 2; const uint32_t c = (uint32_t)(i & 3);
+	sb[i] = j == 0 ? 0ull : (uint64_t)(uint32_t)(cnt[c * nb + (j << sbshift)] - cnt[c * nb + ((j - 1) << sbshift)]);
+}
+__global__ void k_rank_sb_prefix(uint64_t *sb, uint64_t nsb)
+{
+	const uint32_t c = threadIdx.x;
+	if (c >= 4) return;
+	uint64_t acc = 0;
+	for (uint64_t j = 0; j < nsb; ++j) { acc += sb[4 * j + c]; sb[4 * j + c] = acc; }
+}
+__global__ void k_rank_headers_sb(uint32_t *blocks, const uint32_t *cnt, uint64_t nb, int sbshift)
+{
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nb) return;
+	const uint64_t b0 = (b >> sbshift) << sbshift;
+	uint32_t *out = blocks + b * 16;
+	#pragma unroll
+	for (int c = 0; c < 4; ++c) out[c] = cnt[c * nb + b] - cnt[c * nb + b0];
+}
+int rank_sb_shift()
+{
+	// (test switch: small superblocks put texts the oracle can sort across many of them)
+	const char *e = getenv("B3M_RANK_SB_SHIFT");
+	const int v = e ? atoi(e) : 16;
+	return v < 1 ? 1 : (v > 24 ? 24 : v);
+}
+uint64_t rank_superblocks(uint64_t m) { return (rank_blocks(m) >> rank_sb_shift()) + 1; }
+// d_p0: rank of the terminator entry, a 64-bit device scalar (~0: none); d_sb: 4 * rank_superblocks(m) u64
+void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, uint64_t *d_sb, hipStream_t s)
+{
+	B3M_REQUIRE(type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM, "the LF walk's rank dictionary needs a 2-bit alphabet (pac/pacterm)");
+	const uint64_t nb = rank_blocks(m), nsb = rank_superblocks(m);
+	const int sub = (type == B3M_INPUT_PACTERM) ? 1 : 0, sh = rank_sb_shift();
+	uint32_t *cnt = d_scratch, *wc = d_scratch + 4 * nb;
+	hipLaunchKernelGGL(k_rank_pack_words<uint64_t>, dim3(nblk(nb * 12)), dim3(256), 0, s, d_bwt, m, d_p0, sub, d_blocks, wc, nb * 12);
+	hipLaunchKernelGGL(k_rank_line_counts, dim3(nblk(nb)), dim3(256), 0, s, wc, nb, cnt);
+	for (int c = 0; c < 4; ++c) exclusive_sum_u32(cnt + c * nb, nb, scan_ws, s);
+	hipLaunchKernelGGL(k_rank_sb_diffs, dim3(nblk(4 * nsb)), dim3(256), 0, s, cnt, nb, sh, nsb, d_sb);
+	hipLaunchKernelGGL(k_rank_sb_prefix, dim3(1), dim3(64), 0, s, d_sb, nsb);
+	hipLaunchKernelGGL(k_rank_headers_sb, dim3(nblk(nb)), dim3(256), 0, s, d_blocks, cnt, nb, sh);
 }
 
 // the dictionary of BWT(L) from its packed slices (see k_pack2); d_scratch / scan_ws as rank_build
@@ -229,6 +272,12 @@ __device__ __forceinline__ uint32_t rank_query_t(const uint32_t *blocks, RT p0, 
 	// the p0 entry is stored as code 0 but was not counted in the headers
 	if (code == 0 && p0 >= b * RANK_BLK_SYMS && p0 < rho) cnt -= 1;
 	return cnt;
+}
+// the same with 64-bit counts: superblock table + line header (counts since the superblock's start) + the line's own symbols
+__device__ __forceinline__ uint64_t rank_query64(const uint32_t *blocks, const uint64_t *sb, int sbshift, uint64_t p0, uint32_t code, uint64_t rho)
+{
+	const uint64_t b = rho / RANK_BLK_SYMS;
+	return sb[((b >> sbshift) << 2) + code] + (uint64_t)rank_query_t<uint64_t>(blocks, p0, code, rho);
 }
 __device__ __forceinline__ uint32_t rank_query(const RankDict &rd, uint32_t p0, uint32_t code, uint32_t rho) { return rank_query_t<uint32_t>(rd.blocks, p0, code, rho); }
 
@@ -535,7 +584,7 @@ void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_b
 // and SA[r] = p is stored when r is a multiple of the SA sampling rate.  The rank the chain
 // arrives with must be anchor k's (checked).
 // ------------------------------------------------------------------------------------------------
-struct RankDict64 { const uint32_t *blocks; uint64_t m; uint64_t p0; uint64_t C[4]; };     // p0 = ~0: no terminator entry
+struct RankDict64 { const uint32_t *blocks; const uint64_t *sb; int sbshift; uint64_t m; uint64_t p0; uint64_t C[4]; };     // p0 = ~0: no terminator entry
 struct LfWalkArgs {
 	TextView T; RankDict64 rd;
 	const uint64_t *anchors;        // (rank, pos) pairs sorted by pos; pos of anchor 0 is 0
@@ -577,17 +626,17 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 			uint32_t code = (word >> (2 * (off & 15))) & 3u;
 			uint32_t sb = term ? code + 1 : code;
 			bad += sb != st;
-			nr = A.rd.C[code] + rank_query_t<uint64_t>(A.rd.blocks, p0, code, r);
+			nr = A.rd.C[code] + rank_query64(A.rd.blocks, A.rd.sb, A.rd.sbshift, p0, code, r);
 		}
 		r = nr; --p;
 	}
 	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
 	if (r != A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
 }
-void lf_walk(const TextView &T, const uint32_t *d_blocks, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
+void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
              uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
 {
-	LfWalkArgs A{T, RankDict64{d_blocks, T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	LfWalkArgs A{T, RankDict64{d_blocks, d_sb, rank_sb_shift(), T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
 }
 

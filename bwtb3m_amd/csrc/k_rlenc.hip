@@ -12,6 +12,7 @@
 // Bit order MSB first (a stream is bytes; the 32-bit words the kernel ORs are byte-swapped).
 #include "b3m_internal.h"
 #include "host/formats.h"
+#include "host/parfile.h"
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -165,6 +166,13 @@ __global__ __launch_bounds__(256) void k_rl_pack(const uint32_t *rstart, const u
 	s1.close(); s2.close();
 }
 
+// block b's header bytes (code tables, built on the host) dropped at the block's start in the output image: one workgroup per block
+__global__ __launch_bounds__(64) void k_rl_headers(const uint8_t *blob, const uint64_t *src_off, const uint64_t *dst_off, uint8_t *out)
+{
+	const uint64_t a = src_off[blockIdx.x], e = src_off[blockIdx.x + 1], d = dst_off[blockIdx.x];
+	for (uint64_t i = a + threadIdx.x; i < e; i += 64) out[d + (i - a)] = blob[i];
+}
+
 // d_symbols: n bytes in HBM (n < 2^32).  Writes the same file as rl_encode_file.  Returns false if this input is not for the device
 // encoder (a code longer than 32 bits, n out of range): the caller uses the host encoder then.
 bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream)
@@ -235,12 +243,27 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 	B3M_HIP(hipMemcpyAsync(d_o2.p, off_len.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_rl_pack, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, d_tab.as<uint64_t>(),
 	                   d_o1.as<uint64_t>(), d_o2.as<uint64_t>(), d_out.as<uint8_t>());
-	std::vector<uint8_t> blocks(total + 16);
-	B3M_HIP(hipMemcpyAsync(blocks.data(), d_out.p, total, hipMemcpyDeviceToHost, s));
+	// the headers join the code streams in the device image (after the pack kernel: its word-wise ORs and these byte stores may share a word),
+	// and the image leaves for the file in pieces through pinned staging buffers, written at their offsets by a few threads
+	std::vector<uint8_t> blob; std::vector<uint64_t> hsrc(nblocks + 1), hdst(nblocks);
+	for (uint64_t b = 0; b < nblocks; ++b) { hsrc[b] = blob.size(); hdst[b] = index[b].pos - 8; blob.insert(blob.end(), headers[b].begin(), headers[b].end()); }
+	hsrc[nblocks] = blob.size();
+	Buf d_blob(blob.size() + 16), d_hs(8 * (nblocks + 1)), d_hd(8 * nblocks);
+	B3M_HIP(hipMemcpyAsync(d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(d_hs.p, hsrc.data(), 8 * (nblocks + 1), hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemcpyAsync(d_hd.p, hdst.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_rl_headers, dim3((uint32_t)nblocks), dim3(64), 0, s, d_blob.as<uint8_t>(), d_hs.as<uint64_t>(), d_hd.as<uint64_t>(), d_out.as<uint8_t>());
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
-	for (uint64_t b = 0; b < nblocks; ++b) std::copy(headers[b].begin(), headers[b].end(), blocks.begin() + (long)(index[b].pos - 8));
-	rl_write_container(fn, n, blocks.data(), total, index);
+	int dev = 0;
+	B3M_HIP(hipGetDevice(&dev));
+	ParFile pf(fn);
+	std::vector<uint8_t> head, tail;
+	rl_container_ends(n, total, index, head, tail);
+	pf.put(0, head.data(), head.size());
+	pf.put_device(head.size(), d_out.p, total, dev, std::min(numthreads, 8u));
+	pf.put(head.size() + total, tail.data(), tail.size());
+	pf.close();
 	return true;
 }
 

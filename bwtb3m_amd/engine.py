@@ -278,6 +278,19 @@ def bwt_symbols32(symbols, isasamplingrate=0):
         raise
 
 
+def lf_walk(d_text, n, inputtype, d_bwt, p0, hist, samples, sarate=0):
+    """b3m_lf_walk: checkbwt + sampled SA over a BWT that no single plan produced (gathered shard slices); samples: (k, 2) uint64 (rank,pos) pairs in
+    position order.  Returns (symbol mismatches, chain mismatches, SA samples or None)."""
+    smp = np.ascontiguousarray(samples, dtype=np.uint64)
+    h = np.zeros(256, dtype=np.uint64)
+    h[: len(hist)] = np.asarray(hist, dtype=np.uint64)
+    mm = np.zeros(2, dtype=np.uint64)
+    sa = np.zeros((n + sarate - 1) // sarate, dtype=np.uint64) if sarate else None
+    check(lib().b3m_lf_walk(_ptr(d_text), n, _type_id(inputtype), _ptr(d_bwt), int(p0), h.ctypes.data, smp.ctypes.data, smp.shape[0], int(sarate),
+                            sa.ctypes.data if sarate else None, None, mm.ctypes.data, _stream()))
+    return int(mm[0]), int(mm[1]), sa
+
+
 def histogram(d_text, n, inputtype, start, length):
     h = np.zeros(256, dtype=np.uint64)
     check(lib().b3m_histogram(_ptr(d_text), n, _type_id(inputtype), start, length, h.ctypes.data, _stream()))

@@ -188,9 +188,24 @@ int b3m_plan_histogram(const b3m_plan *p, uint64_t *hist256);
  * (/root/reference/src/bwtcomputessa.cpp:39-51) and of checkbwt's verification walk
  * (/root/reference/src/checkbwt.cpp:176-243).  mismatches_out[0] = positions where the BWT symbol differs
  * from the text, [1] = chains that did not arrive at the next anchor's rank (both 0 for a correct BWT).
- * sarate > 0: sa_out[i] = SA[i*sarate], ceil(n/sarate) entries (host).  pac/pacterm, unsharded plans. */
+ * sarate > 0: sa_out[i] = SA[i*sarate], ceil(n/sarate) entries (host).  Unsharded plans (texts of 2^32 symbols and more included: the plan's
+ * sequential shards leave one BWT; the rank dictionary counts in 64 bits, so a symbol may occur 2^32 times and more). */
 int b3m_plan_lf_walk(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *sa_out,
                      uint64_t *mismatches_out, void *stream);
+
+/* the same with the SA samples left in device memory (d_sa_out: ceil(n/sarate) u64): b3m_compute_bwt streams them into X.sa from there; pac / pacterm */
+int b3m_plan_lf_walk_dev(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream);
+/* the pinned host image of the last run's (rank,pos) samples, in place: slot i belongs to position i * rate; a slot that reads (~0, .) is another shard's
+ * (suffix-range shards only).  Valid until the plan runs again or is destroyed.  X.preisa is this image (/root/reference/src/hwtPreIsaToIsa.cpp:64-77). */
+int b3m_plan_samples_raw(b3m_plan *p, const uint64_t **slots_out, uint64_t *nslots_out);
+
+/* The same walks as a stage of its own, over a BWT that no single plan produced -- the slices of suffix-range shards gathered on one GPU (b3m_compute_bwt
+ * with num_gpus > 1).  pac / pacterm.  d_text: the packed text on the current device, 8 readable bytes behind it; p0: rank of the terminator entry (pacterm);
+ * hist256: symbol counts of the text (X.hist); sample_pairs: num_samples (rank,pos) pairs in position order, the first at position 0 (host).  The rank
+ * dictionary counts in 64 bits (superblock table + 32-bit line headers): a symbol may occur 2^32 times and more.  sa_out (host) and/or d_sa_out (device),
+ * each ceil(n/sarate) u64, may be NULL. */
+int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist256, const uint64_t *sample_pairs,
+                uint64_t num_samples, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream);
 
 /* per-kernel-family timing of the last run (HIP events on the run's stream) */
 typedef struct b3m_kernel_time { const char *name; double ms; uint64_t launches; uint64_t alg_bytes; } b3m_kernel_time;

@@ -166,6 +166,40 @@ def test_lf_walk_checkbwt_and_sampled_sa(gpu, oracle, itype, bs):
     plan.close()
 
 
+@pytest.mark.parametrize("itype", ["pacterm", "pac"])
+@pytest.mark.parametrize("sbshift", [1, 3, 7])
+def test_lf_walk_counts_in_64_bits_across_superblocks(gpu, oracle, itype, sbshift, monkeypatch):
+    """the LF walk's rank dictionary counts in 64 bits (a table of counts per superblock of 2^k lines + 32-bit line headers that count from the superblock's
+    start): what lets b3m_plan_lf_walk / .sa / .isa work when a symbol occurs 2^32 times and more (30 Gbase).  B3M_RANK_SB_SHIFT makes the superblocks
+    2, 8 and 128 lines long, so this 300-kbase text spans 782 / 196 / 13 of them; the sampled SA must equal the oracle's.  Also the walk as a stage of
+    its own (b3m_lf_walk: BWT, p0, histogram and samples handed in, as the multi-GPU path of b3m_compute_bwt does)."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    monkeypatch.setenv("B3M_RANK_SB_SHIFT", str(sbshift))
+    b = oracle.synth_repeat_bases(300_011, 78)
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    d = torch.from_numpy(np.concatenate([buf, np.zeros(16, dtype=np.uint8)])).cuda()
+    plan = engine.Plan(n, itype, isasamplingrate=512)
+    out = plan.run(d)
+    m0, m1, ssa = plan.lf_walk(out, sarate=16)
+    assert (m0, m1) == (0, 0) and np.array_equal(ssa.astype(np.int64), sa[::16])
+    res = plan.result()
+    m0, m1, ssa2 = engine.lf_walk(d, n, itype, out, res["p0"], plan.histogram(), plan.samples(), sarate=16)
+    assert (m0, m1) == (0, 0) and np.array_equal(ssa2, ssa)
+    bad = out.clone()
+    h = out.cpu().numpy()
+    term = 0 if itype == "pacterm" else 255
+    i = next(k for k in range(200_000, n) if h[k] != term)
+    j = next(k for k in range(i + 1, n) if h[k] != h[i] and h[k] != term)
+    bad[i], bad[j] = out[j], out[i]
+    m0, m1, _ = engine.lf_walk(d, n, itype, bad, res["p0"], plan.histogram(), plan.samples(), sarate=0)
+    assert m0 + m1 > 0
+    plan.close()
+
+
 def test_cli_bwtonly0_writes_sa_isa(gpu, oracle, tmp_path):
     b = oracle.synth_bases(400_001, 88)
     buf = oracle.pac_encode(b)
