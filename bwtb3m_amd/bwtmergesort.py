@@ -42,6 +42,7 @@ class BwtMergeSort:
         o.copyinputtomemory = options.copyinputtomemory
         o.verbose = options.verbose
         o.blocksize = options.blocksize
+        o.num_gpus = int(getattr(options, "numgpus", 1))
         fd = (logstr or sys.stderr).fileno()
         if lib().b3m_compute_bwt(ctypes.byref(o), fd) != 0:
             raise B3MError(lib().b3m_last_error().decode("utf-8", "replace"))

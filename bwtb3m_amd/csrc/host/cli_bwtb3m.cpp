@@ -45,6 +45,7 @@ int main(int argc, char *argv[])
 			str << "copyinputtomemory=[" << def.copyinputtomemory << "] (copy input file to memory)" << std::endl;
 			str << "largelcpthres=[" << def.largelcpthres << "] (large LCP value threshold)" << std::endl;
 			str << "verbose=[" << def.verbose << "] (verbosity level)" << std::endl;
+			str << "numgpus=[" << def.num_gpus << "] (extension: GPUs of this node to construct on, one host thread and one suffix-range shard each; pac/pacterm)" << std::endl;
 			throw std::runtime_error(str.str());
 		}
 		b3m_options o = def;
@@ -67,6 +68,7 @@ int main(int argc, char *argv[])
 		o.largelcpthres = arginfo.get_numeric("largelcpthres", def.largelcpthres);
 		o.verbose = (uint32_t)arginfo.get_numeric("verbose", 0);
 		o.blocksize = arginfo.get_numeric("blocksize", 0);
+		o.num_gpus = (int32_t)arginfo.get_numeric("numgpus", (uint64_t)def.num_gpus);
 		if (b3m_compute_bwt(&o, 2)) throw std::runtime_error(b3m_last_error());
 		struct rusage ru; getrusage(RUSAGE_SELF, &ru);
 		double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -1,7 +1,17 @@
 // compute_bwt.cpp -- b3m_compute_bwt: the whole job of BwtMergeSort::computeBwt
 // (/root/reference/src/bwtb3m.cpp:63; steps of SURVEY.md 3.1): read the input file, keep the
-// packed text resident in HBM, run the plan, write X.bwt (RL), X.hist, X.meta, X.preisa.
+// packed text resident in HBM, run the plan, write X.bwt (RL), X.hist, X.meta, X.preisa | X.sa X.isa.
+//
+// Three stages, each overlapped inside as far as its data allow:
+//   in   : the file goes straight to HBM (pread into pinned staging pieces by a few threads, one HIP stream each) WHILE the plan is created;
+//   sort : num_gpus = 1: b3m_plan_run.  num_gpus = N > 1 ("one host thread per GPU drives its stream(s)"; the reference's own
+//          parallelism knob behind this call is numthreads=, /root/reference/src/bwtb3m.cpp:48-50): one host thread per device, each with the
+//          plan of one suffix-range shard (b3m_plan_create_sharded: no exchange step; long repeats: the suffix array slices are gathered by peer
+//          copies and every shard finishes its ties, b3m_plan_tie_*), the slices gathered on the first device;
+//   out  : two host threads: X.bwt (run-length / Huffman coded from the BWT in HBM, streamed to the file in pieces) beside X.sa / X.isa (LF walks on a
+//          stream of their own, the samples streamed from HBM) or X.preisa (the plan's pinned sample image, written in place).
 #include "formats.h"
+#include "parfile.h"
 #include "../../../include/b3m.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -9,8 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <stdexcept>
+#include <thread>
 #include <unistd.h>
 
 namespace b3m { void set_error(const std::string &msg); }
@@ -30,7 +42,173 @@ struct Log {
 };
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define B3MCHK(x) do { if (x) throw std::runtime_error(b3m_last_error()); } while (0)
+
+// fn(k) on one host thread per k in [0, count); the first failure is rethrown here (b3m_last_error is thread-local: the text travels with the exception)
+void on_threads(int count, const std::function<void(int)> &fn)
+{
+	std::vector<std::string> err((size_t)count);
+	std::vector<std::thread> th;
+	for (int k = 0; k < count; ++k)
+		th.emplace_back([&, k]() { try { fn(k); } catch (const std::exception &e) { err[(size_t)k] = *e.what() ? e.what() : "unknown error"; } });
+	for (auto &t : th) t.join();
+	for (int k = 0; k < count; ++k) if (!err[(size_t)k].empty()) throw std::runtime_error(count > 1 ? "GPU worker " + std::to_string(k) + ": " + err[(size_t)k] : err[(size_t)k]);
 }
+
+// what the construction stage leaves for the output stage
+struct Built {
+	int dev = 0;                         // device that holds d_bwt and d_text
+	uint8_t *d_bwt = nullptr;            // n symbols (symbols32: n uint32)
+	const void *d_text = nullptr;        // packed text on `dev` (LF walks)
+	b3m_plan *plan = nullptr;            // one GPU: the plan (its samples, its LF walk); several: null
+	uint64_t p0 = 0, num_blocks = 1, levels = 0;
+	uint64_t hist[256] = {0};
+	const uint64_t *pairs = nullptr; uint64_t npairs = 0;     // (rank,pos) samples in position order, host memory
+	std::vector<uint64_t> pairs_store;
+	double ms_sort = 0, ms_gap = 0, ms_interleave = 0;
+};
+
+struct Shard {
+	int dev = 0; b3m_plan *plan = nullptr; uint8_t *d_out = nullptr; b3m_result res{}; uint64_t pending = 0;
+	uint32_t *d_sa = nullptr, *d_pairs = nullptr;            // tie export
+	uint32_t *d_sa_global = nullptr, *d_pairs_all = nullptr; // tie finish
+};
+
+// the devices of an N-GPU run: 0 .. N-1, or what B3M_DEVICES lists (test switch: "0,0,0,0" runs four shards' worth of host threads, plans and peer
+// copies on one GPU)
+std::vector<int> device_list(int N)
+{
+	int ndev = 0;
+	HIPCHK(hipGetDeviceCount(&ndev));
+	std::vector<int> d;
+	if (const char *e = getenv("B3M_DEVICES")) {
+		for (const char *p = e; *p;) { char *q; long v = strtol(p, &q, 10); if (q == p) break; d.push_back((int)v); p = *q == ',' ? q + 1 : q; }
+		if ((int)d.size() != N) throw std::runtime_error("B3M_DEVICES must list exactly numgpus devices");
+		for (int v : d) if (v < 0 || v >= ndev) throw std::runtime_error("B3M_DEVICES names a device this machine does not have");
+		return d;
+	}
+	if (N > ndev) throw std::runtime_error("numgpus=" + std::to_string(N) + " but this machine has " + std::to_string(ndev) + " GPU(s)");
+	for (int k = 0; k < N; ++k) d.push_back(k);
+	return d;
+}
+
+void free_shards(std::vector<Shard> &sh)
+{
+	for (auto &s : sh) {
+		(void)hipSetDevice(s.dev);
+		if (s.plan) b3m_plan_destroy(s.plan);
+		for (void *p : {(void *)s.d_out, (void *)s.d_sa, (void *)s.d_pairs, (void *)s.d_sa_global, (void *)s.d_pairs_all}) if (p) (void)hipFree(p);
+		s = Shard{};
+	}
+}
+
+// N suffix-range shards, one host thread and one device each; d_text0: the packed text on devs[0].  Leaves the whole BWT on devs[0].
+void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint64_t mem, uint64_t rate, const void *d_text0, uint64_t tb, Built &B, std::vector<Shard> &sh,
+                       const Log &log)
+{
+	const int N = (int)devs.size();
+	sh.assign((size_t)N, Shard{});
+	for (int k = 0; k < N; ++k) sh[(size_t)k].dev = devs[(size_t)k];
+	auto run_shard = [&](Shard &s) {
+		B3MCHK(b3m_plan_run(s.plan, b3m_plan_text_buffer(s.plan), s.d_out, nullptr));
+		B3MCHK(b3m_plan_result(s.plan, &s.res));
+		B3MCHK(b3m_plan_tie_pending(s.plan, &s.pending));
+	};
+	const double t0 = now();
+	on_threads(N, [&](int k) {
+		Shard &s = sh[(size_t)k];
+		HIPCHK(hipSetDevice(s.dev));
+		s.plan = b3m_plan_create_sharded(n, type, k, N, mem, rate);
+		if (!s.plan) throw std::runtime_error(b3m_last_error());
+		HIPCHK(hipMalloc((void **)&s.d_out, b3m_plan_slice_capacity(s.plan) + 16));
+		HIPCHK(hipMemcpyPeer(b3m_plan_text_buffer(s.plan), s.dev, d_text0, devs[0], tb));
+		run_shard(s);
+	});
+	const double t1 = now();
+	uint64_t total = 0;
+	for (auto &s : sh) total += s.pending;
+	if (total) {
+		// long repeats (row a6): what the shards' local rounds left tied is finished by prefix doubling over ALL shards' suffix arrays, on every shard
+		// (b3m_plan_tie_*): a shard that kept no suffix array sorts once more with it, the slices and the tied-slot lists are gathered by peer copies
+		if (n >= (1ull << 32)) throw std::runtime_error("long repeats across suffix-range shards of a text of 2^32 symbols and more are not finished collectively yet");
+		on_threads(N, [&](int k) {
+			Shard &s = sh[(size_t)k];
+			HIPCHK(hipSetDevice(s.dev));
+			if (!b3m_plan_has_sa(s.plan)) { B3MCHK(b3m_plan_set_keep_sa(s.plan, 1)); run_shard(s); }
+		});
+		total = 0;
+		for (auto &s : sh) total += s.pending;
+		on_threads(N, [&](int k) {
+			Shard &s = sh[(size_t)k];
+			HIPCHK(hipSetDevice(s.dev));
+			HIPCHK(hipMalloc((void **)&s.d_sa, 4 * s.res.slice_len + 16));
+			HIPCHK(hipMalloc((void **)&s.d_pairs, 8 * s.pending + 16));
+			B3MCHK(b3m_plan_tie_export(s.plan, s.d_sa, s.d_pairs, nullptr));
+		});
+		on_threads(N, [&](int k) {
+			Shard &s = sh[(size_t)k];
+			HIPCHK(hipSetDevice(s.dev));
+			HIPCHK(hipMalloc((void **)&s.d_sa_global, 4 * n + 16));
+			HIPCHK(hipMalloc((void **)&s.d_pairs_all, 8 * total + 16));
+			uint64_t at = 0, my_first = 0;
+			for (int j = 0; j < N; ++j) {
+				const Shard &o = sh[(size_t)j];
+				if (o.res.slice_len) HIPCHK(hipMemcpyPeer(s.d_sa_global + o.res.slice_offset, s.dev, o.d_sa, o.dev, 4 * o.res.slice_len));
+				if (o.pending) HIPCHK(hipMemcpyPeer(s.d_pairs_all + 2 * at, s.dev, o.d_pairs, o.dev, 8 * o.pending));
+				if (j == k) my_first = at;
+				at += o.pending;
+			}
+			B3MCHK(b3m_plan_tie_finish(s.plan, s.d_sa_global, s.d_pairs_all, total, my_first, s.d_out, nullptr));
+			B3MCHK(b3m_plan_result(s.plan, &s.res));
+			(void)hipFree(s.d_sa_global); s.d_sa_global = nullptr;
+			(void)hipFree(s.d_pairs_all); s.d_pairs_all = nullptr;
+		});
+	}
+	const double t2 = now();
+	// the slices tile the rank space: gathered on the first device (the RL encoder and the LF walks read the whole BWT)
+	uint64_t pos = 0;
+	for (auto &s : sh) {
+		if (s.res.slice_offset != pos) throw std::runtime_error("internal: the shards' slices do not tile the rank space");
+		pos += s.res.slice_len;
+	}
+	if (pos != n) throw std::runtime_error("internal: the shards' slices do not cover the rank space");
+	B.dev = devs[0];
+	HIPCHK(hipSetDevice(B.dev));
+	HIPCHK(hipMalloc((void **)&B.d_bwt, n + 16));
+	on_threads(N, [&](int k) {
+		Shard &s = sh[(size_t)k];
+		HIPCHK(hipSetDevice(B.dev));
+		if (s.res.slice_len) HIPCHK(hipMemcpyPeer(B.d_bwt + s.res.slice_offset, B.dev, s.d_out, s.dev, s.res.slice_len));
+	});
+	HIPCHK(hipSetDevice(B.dev));
+	B.d_text = b3m_plan_text_buffer(sh[0].plan);
+	B.num_blocks = 1; B.levels = 0;
+	int have_p0 = 0;
+	for (auto &s : sh) {
+		if (s.res.has_p0) { B.p0 = s.res.p0; ++have_p0; }
+		B.ms_sort = std::max(B.ms_sort, s.res.ms_sort);
+	}
+	if (have_p0 != 1) throw std::runtime_error("internal: the rotation starting at position 0 was placed by " + std::to_string(have_p0) + " shards");
+	B3MCHK(b3m_plan_histogram(sh[0].plan, B.hist));          // (every shard's level 0 sees the whole text: any shard has the text's histogram)
+	// samples: every sampled position got its rank from exactly one shard (slot i of each shard's pinned image = position i * rate)
+	if (rate) {
+		uint64_t nslots = 0; std::vector<const uint64_t *> raw((size_t)N, nullptr);
+		for (int k = 0; k < N; ++k) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(sh[(size_t)k].plan, &raw[(size_t)k], &c)); if (k && c != nslots) throw std::runtime_error("internal: sample tables differ"); nslots = c; }
+		B.pairs_store.assign(2 * nslots, ~0ull);
+		for (int k = 0; k < N; ++k)
+			for (uint64_t i = 0; i < nslots; ++i) if (raw[(size_t)k][2 * i] != ~0ull) {
+				if (B.pairs_store[2 * i] != ~0ull) throw std::runtime_error("internal: a sampled position was ranked by two shards");
+				B.pairs_store[2 * i] = raw[(size_t)k][2 * i]; B.pairs_store[2 * i + 1] = raw[(size_t)k][2 * i + 1];
+			}
+		for (uint64_t i = 0; i < nslots; ++i) if (B.pairs_store[2 * i] == ~0ull) throw std::runtime_error("internal: the (rank,pos) sample of position " + std::to_string(i * rate) + " was written by no shard");
+		B.pairs = B.pairs_store.data(); B.npairs = nslots;
+	}
+	std::map<int, int> distinct;
+	for (int d : devs) distinct[d] = 1;
+	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu suffixes), gather %.3f s\n", N, (int)distinct.size(), t1 - t0, t2 - t1,
+	    (unsigned long long)total, now() - t2);
+}
+}  // namespace
 
 extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly, uint64_t n)
 {
@@ -46,7 +224,15 @@ extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly
 
 extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 {
-	void *d_text = nullptr; uint8_t *d_bwt = nullptr; b3m_plan *plan = nullptr;
+	void *d_text = nullptr; Built B; std::vector<Shard> shards; int dev0 = 0; bool own_bwt = false;
+	auto cleanup = [&]() {
+		free_shards(shards);
+		(void)hipSetDevice(dev0);
+		if (B.plan) b3m_plan_destroy(B.plan);
+		if (d_text) (void)hipFree(d_text);
+		if (own_bwt && B.d_bwt) (void)hipFree(B.d_bwt);
+		b3m::staging_release();
+	};
 	try {
 		if (!o || !o->input_fn || !*o->input_fn) throw std::runtime_error("no input file given");
 		Log log{o->verbose ? log_fd : -1};
@@ -57,14 +243,22 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			throw std::runtime_error(std::string("inputtype=") + tname + " is not supported by this engine yet (supported: bytestream, compactstream, pac, pacterm, utf-8)");
 		std::string outfn = (o->output_fn && *o->output_fn) ? o->output_fn : (std::string((o->tmpprefix && *o->tmpprefix) ? o->tmpprefix : "bwtb3m_out") + ".bwt");
 		std::string prefix = b3m::clip_off(outfn, ".bwt");
+		const unsigned io_threads = std::max(1u, std::min(o->numthreads ? o->numthreads : 1u, 8u));
+		const int ngpus = o->num_gpus > 1 ? o->num_gpus : 1;
 		double t0 = now();
-		std::vector<uint8_t> file = b3m::read_file(o->input_fn);
-		uint64_t n;
+		// ---- in: what kind of file, how many symbols ----------------------------------------------------------------------------
+		const int filetype = type;
+		const std::string infn = o->input_fn;
+		const uint64_t fsize = b3m::file_size(infn);
+		std::vector<uint8_t> file;                            // only the types that are decoded on the host keep a host image
+		uint64_t n = 0;
 		// compactstream (row f4): 2-bit files are a .pac payload behind a 32-byte header; other widths are decoded to bytes on the device
-		uint32_t cbits = 0; uint64_t coff = 0; const int filetype = type;
+		uint32_t cbits = 0; uint64_t coff = 0;
 		int64_t symmap_store[256]; const int64_t *symmap = nullptr;
 		std::vector<int64_t> wide_map;                        // utf-8 above 256 distinct code points: rank -> code point (the text goes as symbols32)
+		const bool direct = type == B3M_INPUT_BYTESTREAM || type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM;   // the file's bytes ARE the packed text
 		if (type == B3M_INPUT_COMPACTSTREAM) {
+			file = b3m::read_file(infn);
 			if (b3m_compact_info(file.data(), file.size(), &cbits, &n, &coff)) throw std::runtime_error(b3m_last_error());
 			file.erase(file.begin(), file.begin() + (long)coff);
 			file.resize(file.size() + 16, 0);
@@ -72,6 +266,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		} else if (type == B3M_INPUT_UTF8) {
 			// utf-8 (row f4): the text is the sequence of code points.  The code points that occur are ranked (order kept) into a byte
 			// alphabet, the ranks are sorted and merged as a bytestream, and the files name the code points again (symmap).
+			file = b3m::read_file(infn);
 			std::vector<uint32_t> cps = b3m::utf8_decode(file);
 			std::vector<uint8_t> seen(0x110000, 0);
 			for (uint32_t c : cps) seen[c] = 1;
@@ -89,17 +284,19 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				for (size_t i = 0; i < cps.size(); ++i) w[i] = (uint32_t)rank[cps[i]];
 				type = B3M_INPUT_SYMBOLS32;
 			} else {
-			for (uint32_t j = k; j < 256; ++j) symmap_store[j] = (int64_t)0x110000 + j;      // (unused ranks: never written)
-			file.resize(cps.size());
-			for (size_t i = 0; i < cps.size(); ++i) file[i] = (uint8_t)rank[cps[i]];
-			symmap = symmap_store;
-			type = B3M_INPUT_BYTESTREAM;
-			file.resize(file.size() + 16, 0);
+				for (uint32_t j = k; j < 256; ++j) symmap_store[j] = (int64_t)0x110000 + j;      // (unused ranks: never written)
+				file.resize(cps.size());
+				for (size_t i = 0; i < cps.size(); ++i) file[i] = (uint8_t)rank[cps[i]];
+				symmap = symmap_store;
+				type = B3M_INPUT_BYTESTREAM;
+				file.resize(file.size() + 16, 0);
 			}
-		} else if (type == B3M_INPUT_BYTESTREAM) n = file.size();
+		} else if (type == B3M_INPUT_BYTESTREAM) n = fsize;
 		else {
-			if (file.size() < 2 || file.back() > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
-			n = (file.size() - 2) * 4 + file.back() + (type == B3M_INPUT_PACTERM ? 1 : 0);
+			uint8_t last = 255;
+			if (fsize >= 2) b3m::read_range(infn, fsize - 1, &last, 1, 1);
+			if (fsize < 2 || last > 3) throw std::runtime_error(std::string(o->input_fn) + " is not a .pac file");
+			n = (fsize - 2) * 4 + last + (type == B3M_INPUT_PACTERM ? 1 : 0);
 		}
 		if (n == 0) throw std::runtime_error("input is empty");
 		log("[V] input %s type %s symbols %llu\n", o->input_fn, tname, (unsigned long long)n);
@@ -114,14 +311,16 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		uint64_t mem = o->mem;
 		const bool wide = type == B3M_INPUT_SYMBOLS32;
 		if ((type == B3M_INPUT_BYTESTREAM || wide) && mem) { log("[V] mem= is not applied to bytestream input (sorted as one block in HBM)\n"); mem = 0; }
+		const bool two_bit = type == B3M_INPUT_PAC || type == B3M_INPUT_PACTERM;
+		const bool sharded = ngpus > 1;
+		if (sharded && !(two_bit && n >= (1ull << 18) && !o->blocksize))
+			throw std::runtime_error("numgpus > 1 constructs pac / pacterm texts of at least 2^18 symbols as suffix-range shards (no blocksize=)");
+		std::vector<int> devs;
+		if (sharded) { devs = device_list(ngpus); dev0 = devs[0]; } else HIPCHK(hipGetDevice(&dev0));
+		HIPCHK(hipSetDevice(dev0));
+		// ---- in: the text to HBM, beside the creation of the plan -------------------------------------------------------------------
 		const double tp0 = now();
-		plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
-		if (!plan) throw std::runtime_error(b3m_last_error());
-		if (*b3m_plan_warning(plan)) Log{log_fd}("[W] %s\n", b3m_plan_warning(plan));       // (whatever verbose= says)
-		log("[V] blocks %llu workspace %.2f GB, plan created in %.3f s (file read %.3f s)\n", (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9,
-		    now() - tp0, tp0 - t0);
-		uint64_t tb = b3m_plan_text_bytes(plan);
-		HIPCHK(hipMalloc((void **)&d_bwt, wide ? 4 * n : n));
+		uint64_t tb = 0; double t_read = 0;
 		if (filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2) {
 			void *d_words = nullptr;
 			HIPCHK(hipMalloc(&d_words, file.size()));
@@ -130,68 +329,149 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			if (b3m_compact_decode(d_words, n, cbits, (uint8_t *)d_text, nullptr)) { (void)hipFree(d_words); throw std::runtime_error(b3m_last_error()); }
 			HIPCHK(hipDeviceSynchronize());
 			(void)hipFree(d_words);
+			tb = n;
 		} else {
-			if (tb > file.size()) throw std::runtime_error("internal: packed size mismatch");
-			HIPCHK(hipMalloc(&d_text, tb + 16));
-			HIPCHK(hipMemcpy(d_text, file.data(), tb, hipMemcpyHostToDevice));
+			// bytes of the packed text (include/b3m.h: bytestream n, symbols32 4 n, pac / pacterm the BWA .pac size; checked against the plan's own figure below)
+			tb = wide ? 4 * n : (two_bit ? (type == B3M_INPUT_PACTERM ? n - 1 : n) / 4 + 2 : n);
+			HIPCHK(hipMalloc(&d_text, tb + 64));
+			HIPCHK(hipMemset((uint8_t *)d_text + (tb & ~63ull), 0, tb + 64 - (tb & ~63ull)));
 		}
-		double t1 = now();
-		if (b3m_plan_run(plan, d_text, d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
-		double t2 = now();
-		b3m_result res; b3m_plan_result(plan, &res);
+		std::string read_err;
+		std::thread reader([&]() {
+			try {
+				const double r0 = now();
+				if (direct) {
+					if (tb != fsize) throw std::runtime_error("internal: packed size mismatch");
+					b3m::read_range_to_device(infn, 0, d_text, tb, dev0, io_threads);
+				}
+				else if (!(filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2)) {
+					HIPCHK(hipSetDevice(dev0));
+					if (tb > file.size()) throw std::runtime_error("internal: packed size mismatch");
+					HIPCHK(hipMemcpy(d_text, file.data(), tb, hipMemcpyHostToDevice));
+				}
+				t_read = now() - r0;
+			} catch (const std::exception &e) { read_err = e.what(); }
+		});
+		std::string plan_err;
+		if (!sharded) {
+			B.plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
+			if (!B.plan) plan_err = b3m_last_error();
+		}
+		reader.join();
+		if (!plan_err.empty()) throw std::runtime_error(plan_err);
+		if (!read_err.empty()) throw std::runtime_error(read_err);
+		const double tp1 = now();
+		// ---- sort -------------------------------------------------------------------------------------------------------------------
+		double t1 = now(), t2 = t1;
+		if (!sharded) {
+			b3m_plan *plan = B.plan;
+			if (*b3m_plan_warning(plan)) Log{log_fd}("[W] %s\n", b3m_plan_warning(plan));       // (whatever verbose= says)
+			log("[V] blocks %llu workspace %.2f GB; plan created and input read into HBM in %.3f s (the file's %.3f GB through pinned pieces: %.3f s, beside the plan)\n",
+			    (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9, tp1 - tp0, tb / 1e9, t_read);
+			if (b3m_plan_text_bytes(plan) != tb && !(filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2)) throw std::runtime_error("internal: packed size mismatch");
+			HIPCHK(hipMalloc((void **)&B.d_bwt, (wide ? 4 * n : n) + 16)); own_bwt = true;
+			t1 = now();
+			if (b3m_plan_run(plan, d_text, B.d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
+			t2 = now();
+			b3m_result res; b3m_plan_result(plan, &res);
+			B.dev = dev0; B.d_text = b3m_plan_text_buffer(plan); B.p0 = res.p0; B.num_blocks = res.num_blocks; B.levels = res.levels;
+			B.ms_sort = res.ms_sort; B.ms_gap = res.ms_gap; B.ms_interleave = res.ms_interleave;
+			if (!wide) b3m_plan_histogram(plan, B.hist);
+			if (res.num_samples) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(plan, &B.pairs, &c)); B.npairs = c; }
+		} else {
+			log("[V] input read into HBM in %.3f s\n", tp1 - tp0);
+			t1 = now();
+			construct_sharded(devs, type, n, mem, anchor_rate, d_text, tb, B, shards, log);
+			own_bwt = true;
+			t2 = now();
+		}
 		// (this process launches every kernel for the first time: `sort` includes the loading of their code objects, 3-14 ms at 3 Gbase; with
 		// HIP_ENABLE_DEFERRED_LOADING=0 the figure is bench.py's ms_per_step and the 2.4 s of loading move in front of the plan: tools/cli_sort_time.py)
-		log("[V] constructed BWT in %.3f s (sort %.1f ms incl. first-launch code loading, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, res.ms_sort, res.ms_gap,
-		    res.ms_interleave, n / (t2 - t1) / 1e9);
-		// X.bwt: written from the BWT in HBM (runs, frequencies and code streams on the device); the host encoder takes what that
-		// one does not (2^32 symbols and more) and B3M_HOST_RL=1 asks for it (both write the same bytes)
+		log("[V] constructed BWT in %.3f s (sort %.1f ms incl. first-launch code loading, gap %.1f ms, interleave %.1f ms), %.3f Gsym/s\n", t2 - t1, B.ms_sort, B.ms_gap,
+		    B.ms_interleave, n / (t2 - t1) / 1e9);
+		// ---- out: X.bwt beside X.sa/X.isa | X.preisa -----------------------------------------------------------------------------
 		const unsigned enc_threads = o->numthreads ? o->numthreads : 1;
-		if (wide) {
-			std::vector<uint32_t> bw(n);
-			HIPCHK(hipMemcpy(bw.data(), d_bwt, 4 * n, hipMemcpyDeviceToHost));
-			b3m::rl_encode_file_wide(outfn, bw.data(), n, 64 * 1024, wide_map.data());
-			std::map<int64_t, uint64_t> hm;
-			for (uint64_t i = 0; i < n; ++i) hm[wide_map[bw[i]]]++;
-			b3m::write_hist_map(prefix + ".hist", hm);
-		} else
-		if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, d_bwt, n, 64 * 1024, enc_threads, symmap, nullptr)) {
-			std::vector<uint8_t> bwt(n);
-			HIPCHK(hipMemcpy(bwt.data(), d_bwt, n, hipMemcpyDeviceToHost));
-			b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, enc_threads, symmap);
-		}
-		if (!wide) {
-			uint64_t hist[256];
-			b3m_plan_histogram(plan, hist);
-			b3m::write_hist(prefix + ".hist", hist, symmap);
-		}
-		std::vector<uint64_t> pairs(2 * res.num_samples);
-		if (res.num_samples) b3m_plan_samples(plan, pairs.data(), res.num_samples);
-		b3m::write_meta(prefix + ".meta", {n, res.num_blocks, res.levels, res.p0, isarate});
-		if (want_sa) {
-			// bwtonly=0 (/root/reference/README.md:63-67): sampled suffix array and its inverse by LF
-			// walks over the final BWT, every symbol and every chain verified on the way
-			std::vector<uint64_t> sa((n + sarate - 1) / sarate);
-			uint64_t mm[2] = {0, 0};
-			if (b3m_plan_lf_walk(plan, d_bwt, sarate, sa.data(), mm, nullptr)) throw std::runtime_error(b3m_last_error());
-			if (mm[0] || mm[1]) throw std::runtime_error("internal error: the LF walk over the constructed BWT does not reproduce the text");
-			b3m::write_sampled(prefix + ".sa", sarate, sa);
-			std::vector<uint64_t> isa((n + isarate - 1) / isarate);
-			for (uint64_t i = 0; i < res.num_samples; ++i) { uint64_t pos = pairs[2 * i + 1]; if (pos % isarate == 0) isa[pos / isarate] = pairs[2 * i]; }
-			b3m::write_sampled(prefix + ".isa", isarate, isa);
-			log("[V] sampled SA (rate %llu) and ISA (rate %llu) by LF walks, BWT verified against the text\n", (unsigned long long)sarate, (unsigned long long)isarate);
-		} else {
-			b3m::write_preisa(prefix + ".preisa", pairs.data(), res.num_samples);
-		}
+		double t_bwt = 0, t_idx = 0;
+		std::string err_bwt, err_idx;
+		std::thread bwt_writer([&]() {
+			try {
+				const double w0 = now();
+				HIPCHK(hipSetDevice(B.dev));
+				hipStream_t s = nullptr;
+				HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+				// X.bwt: written from the BWT in HBM (runs, frequencies and code streams on the device); the host encoder takes what that
+				// one does not (2^32 symbols and more) and B3M_HOST_RL=1 asks for it (both write the same bytes)
+				if (wide) {
+					std::vector<uint32_t> bw(n);
+					HIPCHK(hipMemcpy(bw.data(), B.d_bwt, 4 * n, hipMemcpyDeviceToHost));
+					b3m::rl_encode_file_wide(outfn, bw.data(), n, 64 * 1024, wide_map.data());
+					std::map<int64_t, uint64_t> hm;
+					for (uint64_t i = 0; i < n; ++i) hm[wide_map[bw[i]]]++;
+					b3m::write_hist_map(prefix + ".hist", hm);
+				} else {
+					if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, B.d_bwt, n, 64 * 1024, enc_threads, symmap, s)) {
+						std::vector<uint8_t> bwt(n);
+						HIPCHK(hipMemcpy(bwt.data(), B.d_bwt, n, hipMemcpyDeviceToHost));
+						b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, enc_threads, symmap);
+					}
+					b3m::write_hist(prefix + ".hist", B.hist, symmap);
+				}
+				b3m::write_meta(prefix + ".meta", {n, B.num_blocks, B.levels, B.p0, isarate});
+				(void)hipStreamDestroy(s);
+				t_bwt = now() - w0;
+			} catch (const std::exception &e) { err_bwt = e.what(); }
+		});
+		try {
+			const double w0 = now();
+			if (want_sa) {
+				// bwtonly=0 (/root/reference/README.md:63-67): sampled suffix array and its inverse by LF
+				// walks over the final BWT, every symbol and every chain verified on the way
+				hipStream_t s = nullptr;
+				HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+				const uint64_t nsa = (n + sarate - 1) / sarate;
+				uint64_t mm[2] = {0, 0};
+				uint64_t head[2] = {sarate, nsa};
+				b3m::ParFile pf(prefix + ".sa");
+				pf.put(0, head, 16);
+				if (two_bit) {
+					// the SA samples stay in HBM and leave for the file in pieces (0.75 GB at 3 Gbase and rate 32)
+					uint64_t *d_sa = nullptr;
+					HIPCHK(hipMalloc((void **)&d_sa, 8 * nsa + 16));
+					int rc = B.plan ? b3m_plan_lf_walk_dev(B.plan, B.d_bwt, sarate, d_sa, mm, s)
+					                : b3m_lf_walk(B.d_text, n, type, B.d_bwt, B.p0, B.hist, B.pairs, B.npairs, sarate, nullptr, d_sa, mm, s);
+					if (rc) { (void)hipFree(d_sa); throw std::runtime_error(b3m_last_error()); }
+					if (!(mm[0] || mm[1])) pf.put_device(16, d_sa, 8 * nsa, B.dev, io_threads);
+					(void)hipFree(d_sa);
+				} else {
+					std::vector<uint64_t> sa(nsa);
+					if (b3m_plan_lf_walk(B.plan, B.d_bwt, sarate, sa.data(), mm, s)) throw std::runtime_error(b3m_last_error());
+					pf.put_host(16, sa.data(), 8 * nsa, io_threads);
+				}
+				pf.close();
+				(void)hipStreamDestroy(s);
+				if (mm[0] || mm[1]) throw std::runtime_error("internal error: the LF walk over the constructed BWT does not reproduce the text");
+				std::vector<uint64_t> isa((n + isarate - 1) / isarate);
+				for (uint64_t i = 0; i < B.npairs; ++i) { uint64_t pos = B.pairs[2 * i + 1]; if (pos % isarate == 0) isa[pos / isarate] = B.pairs[2 * i]; }
+				b3m::write_sampled(prefix + ".isa", isarate, isa);
+				log("[V] sampled SA (rate %llu) and ISA (rate %llu) by LF walks, BWT verified against the text\n", (unsigned long long)sarate, (unsigned long long)isarate);
+			} else {
+				b3m::ParFile pf(prefix + ".preisa");
+				pf.put_host(0, B.pairs, 16 * B.npairs, io_threads);
+				pf.close();
+			}
+			t_idx = now() - w0;
+		} catch (const std::exception &e) { err_idx = e.what(); }
+		bwt_writer.join();
+		if (!err_bwt.empty()) throw std::runtime_error(err_bwt);
+		if (!err_idx.empty()) throw std::runtime_error(err_idx);
 		double t3 = now();
-		log("[V] wrote %s (+.hist .meta .preisa) in %.3f s; total %.3f s\n", outfn.c_str(), t3 - t2, t3 - t0);
-		b3m_plan_destroy(plan);
-		(void)hipFree(d_text); (void)hipFree(d_bwt);
+		log("[V] wrote %s (+.hist .meta %s) in %.3f s (RL coding + .bwt %.3f s beside %s %.3f s); total %.3f s\n", outfn.c_str(), want_sa ? ".sa .isa" : ".preisa", t3 - t2, t_bwt,
+		    want_sa ? "LF walks + .sa/.isa" : ".preisa", t_idx, t3 - t0);
+		cleanup();
 		return 0;
 	} catch (const std::exception &e) {
 		b3m::set_error(e.what());
-		if (plan) b3m_plan_destroy(plan);
-		if (d_text) (void)hipFree(d_text);
-		if (d_bwt) (void)hipFree(d_bwt);
+		cleanup();
 		return 1;
 	}
 }

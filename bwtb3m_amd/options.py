@@ -125,3 +125,4 @@ class BwtMergeSortOptions:
         self.largelcpthres = parse_numeric(am.get("largelcpthres", self.getDefaultLargeLCPThres()))
         self.verbose = parse_numeric(am.get("verbose", self.getDefaultVerbose()))
         self.blocksize = parse_numeric(am.get("blocksize", 0))  # extension
+        self.numgpus = parse_numeric(am.get("numgpus", 1))      # extension: GPUs of this node (one host thread + one suffix-range shard each; b3m_options.num_gpus)

@@ -63,6 +63,51 @@ def test_cli_pacterm_file_set(gpu, oracle, tmp_path, extra):
     assert d.returncode == 0 and d.stdout == ref.tobytes()
 
 
+def _files(prefix):
+    return {suf: open(prefix + suf, "rb").read() for suf in (".bwt", ".hist", ".meta", ".preisa", ".sa", ".isa") if os.path.exists(prefix + suf)}
+
+
+@pytest.mark.parametrize("kind,ngpus,bwtonly", [("c2", 4, 1), ("c2", 3, 0), ("repeat", 4, 0), ("repeat", 2, 1)])
+def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ngpus, bwtonly):
+    """b3m_compute_bwt honours num_gpus (CLI key numgpus=): one host thread per device, one suffix-range shard each, the slices gathered on the first
+    device, which writes the files.  Here the same device is listed N times (B3M_DEVICES=0,0,..: N threads, N plans, peer copies within one GPU).
+    C2 (5 Mbase pacterm) against the oracle; a repeat-rich text whose shards need the collective finish of long repeats (suffix array slices gathered
+    by peer copies, b3m_plan_tie_*).  Every file must equal, byte for byte, what numgpus=1 writes (/root/reference/src/bwtb3m.cpp:48-50,62-63:
+    numthreads= is the reference's knob behind the same call)."""
+    from bwtb3m_amd import _lib, synth
+    L = _lib.lib()
+    if kind == "c2":
+        buf = synth.pac_file_bytes(5_000_000, synth.SEED_BASE + 1)
+    else:
+        b = oracle.synth_repeat_bases(700_001, 5)
+        b[400_000:440_000] = b[100_000:140_000]            # a 40-kb copy: ties that no shard can finish from its own suffixes
+        b[600_000:600_900] = 2                             # a homopolymer run
+        buf = oracle.pac_encode(b)
+    inp = tmp_path / "in.pac"
+    inp.write_bytes(np.asarray(buf, dtype=np.uint8).tobytes())
+    outs = {}
+    for N in (1, ngpus):
+        out = str(tmp_path / ("g%d.bwt" % N))
+        env = dict(os.environ, B3M_DEVICES=",".join(["0"] * N)) if N > 1 else dict(os.environ)
+        r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=%d" % bwtonly, "outputfilename=" + out, "verbose=1", "numgpus=%d" % N,
+                            "isasamplingrate=2048", str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        if N > 1:
+            assert ("%d suffix-range shards" % N).encode() in r.stderr
+            if kind == "repeat":
+                assert b"tie finish" in r.stderr and b"(0 suffixes)" not in r.stderr, r.stderr.decode()
+        outs[N] = _files(out[:-4])
+    assert set(outs[1]) == set(outs[ngpus]) == ({".bwt", ".hist", ".meta", ".preisa"} if bwtonly else {".bwt", ".hist", ".meta", ".sa", ".isa"})
+    for suf in outs[1]:
+        assert outs[1][suf] == outs[ngpus][suf], suf
+    s = oracle.symbols_from_file_bytes(np.asarray(buf, dtype=np.uint8), "pacterm")
+    assert np.array_equal(_decode(L, str(tmp_path / ("g%d.bwt" % ngpus))), oracle.bwt(s))
+    # more GPUs than the machine has, without the test switch: refused with a message
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "numgpus=64", "outputfilename=" + str(tmp_path / "no.bwt"), str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={k: v for k, v in os.environ.items() if k != "B3M_DEVICES"})
+    assert r.returncode != 0 and b"numgpus=64" in r.stderr
+
+
 def test_python_compute_bwt_bytestream(gpu, oracle, tmp_path):
     # BASELINE.json configs[0]: inputtype=bytestream bwtonly=1, through the mirrored interface
     from bwtb3m_amd import ArgInfo, BwtMergeSortOptions, BwtMergeSort, B3MError, _lib

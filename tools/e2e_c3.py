@@ -34,6 +34,30 @@ for bwtonly in (1, 0, 0):          # (the second bwtonly=0 run is the warm one: 
     h = hashlib.sha256(sym.tobytes()).hexdigest()
     print("decode %.1f s; decoded BWT == device BWT: %s" % (time.time() - t0, h == href), flush=True)
     assert h == href
+# numgpus=8 with the one device listed eight times (B3M_DEVICES: eight host threads, eight shard plans, peer copies inside one GPU): the files must be
+# the ones numgpus=1 wrote, byte for byte
+def fhash(fn):
+    h = hashlib.sha256()
+    with open(fn, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+if "--no-numgpus" not in sys.argv:
+    for bwtonly in (1, 0):
+        out = os.path.join(tmp, "c3g_%d.bwt" % bwtonly)
+        t0 = time.time()
+        r = subprocess.run(["/root/repo/bin/bwtb3m", "inputtype=pacterm", "bwtonly=%d" % bwtonly, "numthreads=16", "verbose=1", "numgpus=8", "outputfilename=" + out, pac],
+                           capture_output=True, text=True, env=dict(os.environ, B3M_DEVICES="0,0,0,0,0,0,0,0"))
+        print("bwtb3m numgpus=8 (one device listed 8 times) bwtonly=%d: rc %d, %.1f s wall" % (bwtonly, r.returncode, time.time() - t0), flush=True)
+        print("\n".join(r.stderr.strip().splitlines()[-12:]), flush=True)
+        assert r.returncode == 0
+        for suf in ((".bwt", ".hist", ".meta", ".preisa") if bwtonly else (".bwt", ".hist", ".meta", ".sa", ".isa")):
+            a, b = os.path.join(tmp, "c3_%d%s" % (bwtonly, suf)), os.path.join(tmp, "c3g_%d%s" % (bwtonly, suf))
+            same = fhash(a) == fhash(b)
+            print("   %s: numgpus=8 file == numgpus=1 file: %s" % (suf, same), flush=True)
+            assert same
+            if suf != ".meta":
+                os.remove(b)
 t0 = time.time()
 r = subprocess.run(["/root/repo/bin/bwtb3mtobwa", os.path.join(tmp, "c3_0.bwt"), os.path.join(tmp, "bwa.bwt"), os.path.join(tmp, "bwa.sa")], capture_output=True, text=True)
 print("bwtb3mtobwa rc %d, %.1f s; %s" % (r.returncode, time.time() - t0, r.stderr.strip()[-300:]), flush=True)
