@@ -2,6 +2,8 @@
 // device-level entry points (include/b3m.h).  Role of
 // libmaus2::suffixsort::bwtb3m::BwtMergeSortTemplate::computeBwt steps 3-9.
 #include "b3m_internal.h"
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -162,6 +164,9 @@ struct b3m_plan {
 	uint64_t *h_raw = nullptr;             // pinned image of d_samples, copied on the run's own stream (a pageable copy of 47 MB cost 30 ms per C3 step)
 	bool h_raw_pinned = false;
 	bool samples_pending = false;          // h_raw is newer than h_samples
+	bool samples_lazy = false;             // a large sample table (dense sampling: 750 MB at rate 64 and 3 Gbase) stays in HBM after a run and comes to the host when somebody
+	                                       // asks for it (samples_of); b3m_compute_bwt streams X.preisa from the device image instead (b3m_plan_samples_device)
+	bool raw_stale = false;                // lazy: h_raw is older than d_samples
 	std::vector<uint64_t> h_hist;          // 256
 	Timeline tl;
 	double kms[KF_COUNT]{}; uint64_t klaunch[KF_COUNT]{}; uint64_t kbytes[KF_COUNT]{};
@@ -409,7 +414,8 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	B3M_HIP(hipMemcpy(p->d_anchor_pos, ap.data(), 8 * ap.size(), hipMemcpyHostToDevice));
 	B3M_HIP(hipMemcpy(p->d_endpos, ep.data(), 8 * B, hipMemcpyHostToDevice));
 	p->h_hist.assign(256, 0);
-	if (nsamp) {
+	p->samples_lazy = 16 * nsamp > (64ull << 20);
+	if (nsamp && !p->samples_lazy) {
 		// pinned if the host can spare it (a dense sampling of a long text may not fit what the driver is willing to pin)
 		if (hipHostMalloc((void **)&p->h_raw, 16 * nsamp, hipHostMallocDefault) == hipSuccess) p->h_raw_pinned = true;
 		else { (void)hipGetLastError(); p->h_raw = (uint64_t *)malloc(16 * nsamp); B3M_REQUIRE(p->h_raw != nullptr, "out of host memory for the (rank,pos) samples"); }
@@ -431,7 +437,7 @@ uint64_t b3m_plan_slice_capacity(const b3m_plan *p) { return p ? (p->nshards > 1
 void b3m_plan_destroy(b3m_plan *p)
 {
 	if (!p) return;
-	if (p->h_raw) { if (p->h_raw_pinned) (void)hipHostFree(p->h_raw); else free(p->h_raw); }
+	if (p->h_raw) { if (p->h_raw_pinned) (void)hipHostFree(p->h_raw); else free(p->h_raw); }     // (a lazy table's image is malloc'ed: h_raw_pinned stays false)
 	if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
 	if (p->d_pack) (void)hipFree(p->d_pack);
 	if (p->d_isa_cache) (void)hipFree(p->d_isa_cache);
@@ -499,6 +505,11 @@ static const std::vector<uint64_t> &samples_of(b3m_plan *p)
 {
 	if (p->samples_pending) {
 		p->h_samples.clear();
+		if (p->samples_lazy && p->raw_stale) {
+			if (!p->h_raw) { p->h_raw = (uint64_t *)malloc(16 * p->total_samples); B3M_REQUIRE(p->h_raw != nullptr, "out of host memory for the (rank,pos) samples"); }
+			B3M_HIP(hipMemcpy(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+			p->raw_stale = false;
+		}
 		const uint64_t *raw = p->h_raw;
 		if (p->nshards > 1) {
 			for (uint64_t i = 0; i < p->total_samples; ++i)
@@ -755,7 +766,8 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	uint64_t p0pair[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
 	// the samples leave on the same stream into pinned memory; the host-side list is made from them when somebody asks (samples_of)
-	if (p->isarate && p->total_samples) B3M_HIP(hipMemcpyAsync(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost, s));
+	if (p->isarate && p->total_samples && !p->samples_lazy) B3M_HIP(hipMemcpyAsync(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost, s));
+	p->raw_stale = p->samples_lazy;
 	B3M_HIP(hipEventRecord(ev1, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
@@ -932,7 +944,8 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 	B3M_HIP(hipGetLastError());
 	if (p0pair[0] != ~0ull) { p->res.p0 = p0pair[0]; p->res.has_p0 = 1; }
 	if (mine && p->isarate && p->total_samples) {
-		B3M_HIP(hipMemcpy(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		if (p->samples_lazy) p->raw_stale = true;
+		else B3M_HIP(hipMemcpy(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
 		p->samples_pending = true;
 	}
 	p->tie_left = 0;
@@ -1355,8 +1368,52 @@ int b3m_plan_samples_raw(b3m_plan *p, const uint64_t **slots_out, uint64_t *nslo
 {
 	B3M_TRY
 	B3M_REQUIRE(p && slots_out && nslots_out, "b3m_plan_samples_raw: null argument");
-	if (p->nshards == 1 && p->isarate) (void)samples_of(p);
+	if (p->samples_lazy && p->isarate) (void)samples_of(p);          // (a large table lives in HBM: this brings it over; b3m_plan_samples_device does not)
+	else if (p->nshards == 1 && p->isarate && p->samples_pending) {
+		// every multiple of the rate is a suffix of the text: a slot that still reads "empty" means a sort kernel lost a sample (looked at in place, by a
+		// few threads: at rate 64 the image of a 3-Gbase text is 750 MB, and the copy samples_of makes of it is not needed here)
+		const uint64_t *raw = p->h_raw; const uint64_t N = p->total_samples;
+		std::atomic<uint64_t> bad(~0ull);
+		auto scan = [&](uint64_t a, uint64_t e) { for (uint64_t i = a; i < e; ++i) if (raw[2 * i] == ~0ull) { uint64_t cur = bad.load(); while (i < cur && !bad.compare_exchange_weak(cur, i)) {} return; } };
+		const unsigned T = N > (1u << 20) ? 4 : 1;
+		std::vector<std::thread> th;
+		for (unsigned t = 1; t < T; ++t) th.emplace_back(scan, N * t / T, N * (t + 1) / T);
+		scan(0, N / T);
+		for (auto &x : th) x.join();
+		B3M_REQUIRE(bad.load() == ~0ull, "internal: the (rank,pos) sample of position " + std::to_string(bad.load() * p->isarate) + " was not written by the sort");
+	}
 	*slots_out = p->h_raw; *nslots_out = p->isarate ? p->total_samples : 0;
+	return 0;
+	B3M_CATCH(1)
+}
+__global__ void k_count_empty_slots(const uint64_t *slots, uint64_t n, unsigned long long *out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool e = i < n && slots[2 * i] == ~0ull;
+	const unsigned long long m = __ballot(e);
+	if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+/* the device image of the last run's (rank,pos) samples (slot i = position i * rate; (~0, .) = another shard's) and the number of its slots nobody wrote
+ * (an unsharded plan must have none: the caller checks).  Valid until the plan runs again or is destroyed. */
+int b3m_plan_samples_device(b3m_plan *p, const uint64_t **d_slots_out, uint64_t *nslots_out, uint64_t *empty_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && d_slots_out && nslots_out, "b3m_plan_samples_device: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t N = p->isarate ? p->total_samples : 0;
+	*d_slots_out = p->d_samples; *nslots_out = N;
+	if (empty_out) {
+		*empty_out = 0;
+		if (N) {
+			DevBuf c(16);
+			B3M_HIP(hipMemsetAsync(c.p, 0, 8, s));
+			hipLaunchKernelGGL(k_count_empty_slots, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, s, p->d_samples, N, c.as<unsigned long long>());
+			unsigned long long h = 0;
+			B3M_HIP(hipMemcpyAsync(&h, c.p, 8, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			*empty_out = h;
+		}
+	}
 	return 0;
 	B3M_CATCH(1)
 }

@@ -64,6 +64,7 @@ struct Built {
 	uint64_t p0 = 0, num_blocks = 1, levels = 0;
 	uint64_t hist[256] = {0};
 	const uint64_t *pairs = nullptr; uint64_t npairs = 0;     // (rank,pos) samples in position order, host memory
+	const uint64_t *d_pairs = nullptr;                        // or (one GPU, X.preisa only) their image in HBM
 	std::vector<uint64_t> pairs_store;
 	double ms_sort = 0, ms_gap = 0, ms_interleave = 0;
 };
@@ -377,7 +378,13 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			B.dev = dev0; B.d_text = b3m_plan_text_buffer(plan); B.p0 = res.p0; B.num_blocks = res.num_blocks; B.levels = res.levels;
 			B.ms_sort = res.ms_sort; B.ms_gap = res.ms_gap; B.ms_interleave = res.ms_interleave;
 			if (!wide) b3m_plan_histogram(plan, B.hist);
-			if (res.num_samples) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(plan, &B.pairs, &c)); B.npairs = c; }
+			if (res.num_samples && !want_sa) {
+				// X.preisa is the sample table as it stands in HBM: streamed to the file from there
+				uint64_t c = 0, empty = 0;
+				B3MCHK(b3m_plan_samples_device(plan, &B.d_pairs, &c, &empty, nullptr));
+				if (empty) throw std::runtime_error("internal: " + std::to_string(empty) + " (rank,pos) samples were not written by the sort");
+				B.npairs = c;
+			} else if (res.num_samples) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(plan, &B.pairs, &c)); B.npairs = c; }
 		} else {
 			log("[V] input read into HBM in %.3f s\n", tp1 - tp0);
 			t1 = now();
@@ -432,6 +439,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				uint64_t mm[2] = {0, 0};
 				uint64_t head[2] = {sarate, nsa};
 				b3m::ParFile pf(prefix + ".sa");
+				pf.reserve(16 + 8 * nsa);
 				pf.put(0, head, 16);
 				if (two_bit) {
 					// the SA samples stay in HBM and leave for the file in pieces (0.75 GB at 3 Gbase and rate 32)
@@ -456,7 +464,9 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				log("[V] sampled SA (rate %llu) and ISA (rate %llu) by LF walks, BWT verified against the text\n", (unsigned long long)sarate, (unsigned long long)isarate);
 			} else {
 				b3m::ParFile pf(prefix + ".preisa");
-				pf.put_host(0, B.pairs, 16 * B.npairs, io_threads);
+				pf.reserve(16 * B.npairs);
+				if (B.d_pairs) pf.put_device(0, B.d_pairs, 16 * B.npairs, B.dev, io_threads);
+				else pf.put_host(0, B.pairs, 16 * B.npairs, io_threads);
 				pf.close();
 			}
 			t_idx = now() - w0;

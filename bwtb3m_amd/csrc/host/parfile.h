@@ -13,13 +13,17 @@ class ParFile {
 public:
 	explicit ParFile(const std::string &fn);             // created / truncated; throws std::runtime_error
 	~ParFile();
+	// the final size, if known: the file is extended and mapped, and pieces are copied into the mapping instead of written with pwrite (buffered writes to
+	// ONE file take its inode lock one at a time, whatever the number of threads; page faults on a shared mapping do not)
+	void reserve(uint64_t total_bytes);
 	void put(uint64_t off, const void *p, uint64_t bytes);                                      // this thread
 	void put_host(uint64_t off, const void *p, uint64_t bytes, unsigned threads);               // host memory, split over threads
 	void put_device(uint64_t off, const void *d_p, uint64_t bytes, int device, unsigned threads); // device memory through pinned staging
 	void close();                                        // throws on a failed close; the destructor closes silently
 	const std::string &name() const { return fn_; }
 private:
-	std::string fn_; int fd_;
+	std::string fn_; int fd_; uint8_t *map_ = nullptr; uint64_t map_bytes_ = 0;
+	void store(uint64_t off, const void *p, uint64_t bytes);
 };
 
 uint64_t file_size(const std::string &fn);

@@ -260,6 +260,7 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 	ParFile pf(fn);
 	std::vector<uint8_t> head, tail;
 	rl_container_ends(n, total, index, head, tail);
+	pf.reserve(head.size() + total + tail.size());
 	pf.put(0, head.data(), head.size());
 	pf.put_device(head.size(), d_out.p, total, dev, std::min(numthreads, 8u));
 	pf.put(head.size() + total, tail.data(), tail.size());

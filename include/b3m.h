@@ -201,6 +201,11 @@ int b3m_plan_lf_walk_dev(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate, uin
  * (suffix-range shards only).  Valid until the plan runs again or is destroyed.  X.preisa is this image (/root/reference/src/hwtPreIsaToIsa.cpp:64-77). */
 int b3m_plan_samples_raw(b3m_plan *p, const uint64_t **slots_out, uint64_t *nslots_out);
 
+/* the DEVICE image of the same table (slots as above) and the number of slots nobody wrote (empty_out may be NULL).  A table above 64 MB (dense sampling:
+ * bwtonly=1 samples every 64th position, 750 MB at 3 Gbase) is not copied to the host by b3m_plan_run at all; the host-side accessors fetch it when asked,
+ * b3m_compute_bwt streams X.preisa from here. */
+int b3m_plan_samples_device(b3m_plan *p, const uint64_t **d_slots_out, uint64_t *nslots_out, uint64_t *empty_out, void *stream);
+
 /* The same walks as a stage of its own, over a BWT that no single plan produced -- the slices of suffix-range shards gathered on one GPU (b3m_compute_bwt
  * with num_gpus > 1).  pac / pacterm.  d_text: the packed text on the current device, 8 readable bytes behind it; p0: rank of the terminator entry (pacterm);
  * hist256: symbol counts of the text (X.hist); sample_pairs: num_samples (rank,pos) pairs in position order, the first at position 0 (host).  The rank
