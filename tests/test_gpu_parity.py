@@ -1183,6 +1183,19 @@ def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
     assert int((ranks_by_k < 0).sum()) == 0
     chains, bad_sym, bad_chain = _lf_chain_check(torch, d_text, n, full, ranks_by_k, rate, 256)
     assert chains > 28000 and (bad_sym, bad_chain) == (0, 0), (chains, bad_sym, bad_chain)
+    # ... and ALL chains on the device: the library's LF walk over the eight gathered slices (b3m_lf_walk: checkbwt semantics over every one of the
+    # 30,000,000,001 symbols).  Every base occurs 7.5 G times here: the rank dictionary counts in 64 bits (superblock table + 32-bit line headers).
+    pairs = np.stack([ranks_by_k.astype(np.uint64), np.arange(len(ranks_by_k), dtype=np.uint64) * np.uint64(rate)], axis=1)
+    assert max(ht[1:5]) >= 1 << 32
+    text_p = torch.cat([d_text, torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    del d_text
+    m0, m1, _ = engine.lf_walk(text_p, n, itype, full, p0s[0], ht, pairs)
+    assert (m0, m1) == (0, 0)
+    bad_i = n - 12345                                    # a corrupted symbol at a rank far above 2^32 is caught
+    keep = int(full[bad_i]); full[bad_i] = (keep % 4) + 1 if keep != 0 else 1
+    if int(full[bad_i]) != keep:
+        m0, m1, _ = engine.lf_walk(text_p, n, itype, full, p0s[0], ht, pairs)
+        assert m0 + m1 > 0
 
 
 def test_merge_with_skewed_rank_list_40mbase(gpu):
