@@ -7,6 +7,7 @@
 // suffixes still tied (next K symbols, segmented by tie group) until all groups are singletons
 // or n symbols have been compared (equal rotations of a periodic text).
 #include "b3m_internal.h"
+#include <chrono>
 #include "b3m_text.h"
 
 namespace b3m {
@@ -802,6 +803,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		if (isa ? h >= T.n : off >= T.n) break;         // compared >= n symbols: equal rotations
 		if (max_rounds && rounds >= max_rounds) break;
 		++rounds;
+		const auto t_round = std::chrono::steady_clock::now();
+		double ms_splits = 0;
 		if (dbg >= 3) {      // census of the tie groups entering this round: elements in groups of size < 2^k
 			std::vector<uint32_t> g(u);
 			B3M_HIP(hipMemcpyAsync(g.data(), gid, 4ull * u, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
@@ -869,6 +872,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 					h_n = read_count();
 					++passes;
 				}
+				ms_splits = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
 				if (dbg >= 3) fprintf(stderr, "[b3m]   large groups: %u split passes, %u slots in pieces of one key\n", passes, h_n);
 				// (the table in hid is dead: the tiles and the pieces of one key write the heads there)
 				hipLaunchKernelGGL(k_tie_tile<2>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)kx, (const uint32_t *)vx, (const uint32_t *)pid,
@@ -914,6 +918,9 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		uint32_t *U2 = vx, *gid2 = vy;
 		hipLaunchKernelGGL(k_tie_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, U, u, U2, gid2);
 		B3M_HIP(hipStreamSynchronize(s));
+		if (dbg >= 2) fprintf(stderr, "[b3m]   round %llu: %.2f ms on %llu slots (%.2f ms until the splits were through%s), %u left\n", (unsigned long long)rounds,
+		                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), (unsigned long long)u, ms_splits,
+		                      dbg >= 3 ? "; includes the census" : "", h_u);
 		vx = U; vy = gid; U = U2; gid = gid2;
 		u = h_u;
 		h *= 2;

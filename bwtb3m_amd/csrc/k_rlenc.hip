@@ -15,6 +15,8 @@
 #include "host/parfile.h"
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <memory>
 #include <thread>
 
 namespace b3m {
@@ -173,98 +175,119 @@ __global__ __launch_bounds__(64) void k_rl_headers(const uint8_t *blob, const ui
 	for (uint64_t i = a + threadIdx.x; i < e; i += 64) out[d + (i - a)] = blob[i];
 }
 
-// d_symbols: n bytes in HBM (n < 2^32).  Writes the same file as rl_encode_file.  Returns false if this input is not for the device
-// encoder (a code longer than 32 bits, n out of range): the caller uses the host encoder then.
+// d_symbols: n bytes in HBM.  Writes the same file as rl_encode_file.  Returns false if this input is not for the device encoder (a code
+// longer than 32 bits, a stretch of 2^31 symbols with fewer runs than one block holds): the caller uses the host encoder then.
+// The BWT is taken in SEGMENTS of at most 2^31 symbols (run starts are 32-bit offsets into the segment; B3M_RL_SEG: test switch): a segment
+// begins at a run head, encodes the whole blocks of runs_per_block runs that lie inside it -- never its last run, which may go on behind the
+// segment's end -- and the next segment begins where its last block ended.  The blocks of the file are the same ones, whatever the segments.
 bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream)
 {
 	hipStream_t s = (hipStream_t)hip_stream;
 	if (!runs_per_block) runs_per_block = 64 * 1024;
 	if (!numthreads) numthreads = 1;
-	if (n == 0 || n >= (1ull << 32) || runs_per_block > (1u << 24)) return false;
+	if (n == 0 || runs_per_block > (1u << 24)) return false;
 	const uint32_t rpb = (uint32_t)runs_per_block;
-	const uint64_t ntiles = (n + RL_TILE - 1) / RL_TILE;
-	Buf tiles(4 * (ntiles + 1)), scan_ws(4 * scan_ws_elems(ntiles + 1));
-	hipLaunchKernelGGL(k_rl_count, dim3((uint32_t)ntiles), dim3(256), 0, s, d_symbols, n, tiles.as<uint32_t>());
-	B3M_HIP(hipMemsetAsync(tiles.as<uint32_t>() + ntiles, 0, 4, s));
-	exclusive_sum_u32(tiles.as<uint32_t>(), ntiles + 1, scan_ws.as<uint32_t>(), s);
-	uint32_t R32 = 0;
-	B3M_HIP(hipMemcpyAsync(&R32, tiles.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, s));
-	B3M_HIP(hipStreamSynchronize(s));
-	const uint64_t R = R32;
-	B3M_REQUIRE(R >= 1, "internal: no runs found");
-	const uint64_t nblocks = (R + rpb - 1) / rpb;
-	Buf rstart(4 * (R + 2)), rsym(R + 16), hist(4ull * RL_HIST * nblocks);
-	hipLaunchKernelGGL(k_rl_runs, dim3((uint32_t)ntiles), dim3(256), 0, s, d_symbols, n, tiles.as<uint32_t>(), R, rstart.as<uint32_t>(), rsym.as<uint8_t>());
-	hipLaunchKernelGGL(k_rl_hist, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, hist.as<uint32_t>());
-	std::vector<uint32_t> h((size_t)RL_HIST * nblocks);
-	B3M_HIP(hipMemcpyAsync(h.data(), hist.p, 4ull * RL_HIST * nblocks, hipMemcpyDeviceToHost, s));
-	B3M_HIP(hipStreamSynchronize(s));
-	// ---- host: tables, headers, sizes ----
-	std::vector<uint64_t> tables(513 * nblocks), off_sym(nblocks), off_len(nblocks), bytes1(nblocks), bytes2(nblocks);
-	std::vector<std::vector<uint8_t>> headers(nblocks);
-	std::atomic<uint64_t> next(0); std::atomic<bool> too_long(false);
-	auto work = [&]() {
-		RLBlockTables t;
-		for (;;) {
-			const uint64_t b = next.fetch_add(1);
-			if (b >= nblocks) return;
-			const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
-			const uint64_t nr = std::min<uint64_t>(rpb, R - b * rpb);
-			rl_block_header(hb, hb + 256, nr, symmap, headers[b], t);
-			uint64_t s1 = 0, s2 = hb[513];
-			uint64_t *tb = tables.data() + 513 * b;
-			for (int c = 0; c < 256; ++c) { tb[c] = (t.scode[c] << 8) | t.slen[c]; s1 += (uint64_t)hb[c] * t.slen[c]; if (t.slen[c] > 32) too_long = true; }
-			for (int l = 0; l <= 256; ++l) { tb[256 + l] = (t.ccode[l] << 8) | t.clen[l]; s2 += (uint64_t)hb[256 + l] * t.clen[l]; if (t.clen[l] > 32) too_long = true; }
-			bytes1[b] = (s1 + 7) / 8; bytes2[b] = (s2 + 7) / 8;
-		}
-	};
-	{
-		std::vector<std::thread> th;
-		const unsigned T = (unsigned)std::min<uint64_t>(numthreads, nblocks);
-		for (unsigned i = 1; i < T; ++i) th.emplace_back(work);
-		work();
-		for (auto &x : th) x.join();
-	}
-	if (too_long) return false;
-	std::vector<RLIndexEntry> index(nblocks);
-	uint64_t pos = 0;                                   // offsets inside the block area (the file adds 8 bytes in front)
-	for (uint64_t b = 0; b < nblocks; ++b) {
-		const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
-		index[b] = {8 + pos, std::min<uint64_t>(rpb, R - b * rpb), (uint64_t)hb[514] | ((uint64_t)hb[515] << 32)};
-		off_sym[b] = pos + headers[b].size();
-		off_len[b] = off_sym[b] + bytes1[b];
-		pos = off_len[b] + bytes2[b];
-	}
-	const uint64_t total = pos;
-	Buf d_out(((total + 3) & ~3ull) + 16), d_tab(8 * tables.size()), d_o1(8 * nblocks), d_o2(8 * nblocks);
-	B3M_HIP(hipMemsetAsync(d_out.p, 0, ((total + 3) & ~3ull) + 16, s));
-	B3M_HIP(hipMemcpyAsync(d_tab.p, tables.data(), 8 * tables.size(), hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(d_o1.p, off_sym.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(d_o2.p, off_len.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
-	hipLaunchKernelGGL(k_rl_pack, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, d_tab.as<uint64_t>(),
-	                   d_o1.as<uint64_t>(), d_o2.as<uint64_t>(), d_out.as<uint8_t>());
-	// the headers join the code streams in the device image (after the pack kernel: its word-wise ORs and these byte stores may share a word),
-	// and the image leaves for the file in pieces through pinned staging buffers, written at their offsets by a few threads
-	std::vector<uint8_t> blob; std::vector<uint64_t> hsrc(nblocks + 1), hdst(nblocks);
-	for (uint64_t b = 0; b < nblocks; ++b) { hsrc[b] = blob.size(); hdst[b] = index[b].pos - 8; blob.insert(blob.end(), headers[b].begin(), headers[b].end()); }
-	hsrc[nblocks] = blob.size();
-	Buf d_blob(blob.size() + 16), d_hs(8 * (nblocks + 1)), d_hd(8 * nblocks);
-	B3M_HIP(hipMemcpyAsync(d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(d_hs.p, hsrc.data(), 8 * (nblocks + 1), hipMemcpyHostToDevice, s));
-	B3M_HIP(hipMemcpyAsync(d_hd.p, hdst.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
-	hipLaunchKernelGGL(k_rl_headers, dim3((uint32_t)nblocks), dim3(64), 0, s, d_blob.as<uint8_t>(), d_hs.as<uint64_t>(), d_hd.as<uint64_t>(), d_out.as<uint8_t>());
-	B3M_HIP(hipStreamSynchronize(s));
-	B3M_HIP(hipGetLastError());
+	uint64_t seg_max = 1ull << 31;
+	if (const char *e = getenv("B3M_RL_SEG")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024 && v < seg_max) seg_max = v; }
 	int dev = 0;
 	B3M_HIP(hipGetDevice(&dev));
-	ParFile pf(fn);
+	std::unique_ptr<ParFile> pf;
+	std::vector<RLIndexEntry> index;
+	uint64_t fpos = 8;                                    // file offset of the next block (8 bytes of n in front)
+	for (uint64_t a = 0; a < n;) {
+		const uint64_t len = std::min<uint64_t>(seg_max, n - a);
+		const bool last = a + len == n;
+		const uint8_t *sym = d_symbols + a;
+		const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+		Buf tiles(4 * (ntiles + 1)), scan_ws(4 * scan_ws_elems(ntiles + 1));
+		hipLaunchKernelGGL(k_rl_count, dim3((uint32_t)ntiles), dim3(256), 0, s, sym, len, tiles.as<uint32_t>());
+		B3M_HIP(hipMemsetAsync(tiles.as<uint32_t>() + ntiles, 0, 4, s));
+		exclusive_sum_u32(tiles.as<uint32_t>(), ntiles + 1, scan_ws.as<uint32_t>(), s);
+		uint32_t R32 = 0;
+		B3M_HIP(hipMemcpyAsync(&R32, tiles.as<uint32_t>() + ntiles, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		const uint64_t Rall = R32;                          // run heads inside the segment
+		B3M_REQUIRE(Rall >= 1, "internal: no runs found");
+		const uint64_t R = last ? Rall : ((Rall - 1) / rpb) * rpb;      // runs this segment encodes: whole blocks, not its last run
+		if (R == 0) return false;                           // (2^31 symbols in fewer runs than a block holds: the host encoder's case)
+		const uint64_t nblocks = (R + rpb - 1) / rpb;
+		Buf rstart(4 * (Rall + 2)), rsym(Rall + 16), hist(4ull * RL_HIST * nblocks);
+		hipLaunchKernelGGL(k_rl_runs, dim3((uint32_t)ntiles), dim3(256), 0, s, sym, len, tiles.as<uint32_t>(), Rall, rstart.as<uint32_t>(), rsym.as<uint8_t>());
+		hipLaunchKernelGGL(k_rl_hist, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, hist.as<uint32_t>());
+		std::vector<uint32_t> h((size_t)RL_HIST * nblocks);
+		uint32_t used32 = 0;                                // symbols the encoded runs cover = start of run R
+		B3M_HIP(hipMemcpyAsync(h.data(), hist.p, 4ull * RL_HIST * nblocks, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipMemcpyAsync(&used32, rstart.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		const uint64_t used = last ? len : used32;
+		B3M_REQUIRE(used >= 1 && used <= len, "internal: segment of the run-length encoder out of range");
+		// ---- host: tables, headers, sizes ----
+		std::vector<uint64_t> tables(513 * nblocks), off_sym(nblocks), off_len(nblocks), bytes1(nblocks), bytes2(nblocks);
+		std::vector<std::vector<uint8_t>> headers(nblocks);
+		std::atomic<uint64_t> next(0); std::atomic<bool> too_long(false);
+		auto work = [&]() {
+			RLBlockTables t;
+			for (;;) {
+				const uint64_t b = next.fetch_add(1);
+				if (b >= nblocks) return;
+				const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
+				const uint64_t nr = std::min<uint64_t>(rpb, R - b * rpb);
+				rl_block_header(hb, hb + 256, nr, symmap, headers[b], t);
+				uint64_t s1 = 0, s2 = hb[513];
+				uint64_t *tb = tables.data() + 513 * b;
+				for (int c = 0; c < 256; ++c) { tb[c] = (t.scode[c] << 8) | t.slen[c]; s1 += (uint64_t)hb[c] * t.slen[c]; if (t.slen[c] > 32) too_long = true; }
+				for (int l = 0; l <= 256; ++l) { tb[256 + l] = (t.ccode[l] << 8) | t.clen[l]; s2 += (uint64_t)hb[256 + l] * t.clen[l]; if (t.clen[l] > 32) too_long = true; }
+				bytes1[b] = (s1 + 7) / 8; bytes2[b] = (s2 + 7) / 8;
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			const unsigned T = (unsigned)std::min<uint64_t>(numthreads, nblocks);
+			for (unsigned i = 1; i < T; ++i) th.emplace_back(work);
+			work();
+			for (auto &x : th) x.join();
+		}
+		if (too_long) return false;
+		uint64_t pos = 0;                                   // offsets inside this segment's image
+		std::vector<uint64_t> hdst(nblocks);
+		for (uint64_t b = 0; b < nblocks; ++b) {
+			const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
+			index.push_back({fpos + pos, std::min<uint64_t>(rpb, R - b * rpb), (uint64_t)hb[514] | ((uint64_t)hb[515] << 32)});
+			hdst[b] = pos;
+			off_sym[b] = pos + headers[b].size();
+			off_len[b] = off_sym[b] + bytes1[b];
+			pos = off_len[b] + bytes2[b];
+		}
+		const uint64_t total = pos;
+		Buf d_out(((total + 3) & ~3ull) + 16), d_tab(8 * tables.size()), d_o1(8 * nblocks), d_o2(8 * nblocks);
+		B3M_HIP(hipMemsetAsync(d_out.p, 0, ((total + 3) & ~3ull) + 16, s));
+		B3M_HIP(hipMemcpyAsync(d_tab.p, tables.data(), 8 * tables.size(), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(d_o1.p, off_sym.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(d_o2.p, off_len.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_rl_pack, dim3((uint32_t)nblocks), dim3(256), 0, s, rstart.as<uint32_t>(), rsym.as<uint8_t>(), R, rpb, d_tab.as<uint64_t>(),
+		                   d_o1.as<uint64_t>(), d_o2.as<uint64_t>(), d_out.as<uint8_t>());
+		// the headers join the code streams in the device image (after the pack kernel: its word-wise ORs and these byte stores may share a word),
+		// and the image leaves for the file in pieces through pinned staging buffers, written at their offsets by a few threads
+		std::vector<uint8_t> blob; std::vector<uint64_t> hsrc(nblocks + 1);
+		for (uint64_t b = 0; b < nblocks; ++b) { hsrc[b] = blob.size(); blob.insert(blob.end(), headers[b].begin(), headers[b].end()); }
+		hsrc[nblocks] = blob.size();
+		Buf d_blob(blob.size() + 16), d_hs(8 * (nblocks + 1)), d_hd(8 * nblocks);
+		B3M_HIP(hipMemcpyAsync(d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(d_hs.p, hsrc.data(), 8 * (nblocks + 1), hipMemcpyHostToDevice, s));
+		B3M_HIP(hipMemcpyAsync(d_hd.p, hdst.data(), 8 * nblocks, hipMemcpyHostToDevice, s));
+		hipLaunchKernelGGL(k_rl_headers, dim3((uint32_t)nblocks), dim3(64), 0, s, d_blob.as<uint8_t>(), d_hs.as<uint64_t>(), d_hd.as<uint64_t>(), d_out.as<uint8_t>());
+		B3M_HIP(hipStreamSynchronize(s));
+		B3M_HIP(hipGetLastError());
+		if (!pf) pf.reset(new ParFile(fn));
+		pf->put_device(fpos, d_out.p, total, dev, std::min(numthreads, 8u));
+		fpos += total;
+		a += used;
+	}
 	std::vector<uint8_t> head, tail;
-	rl_container_ends(n, total, index, head, tail);
-	pf.reserve(head.size() + total + tail.size());
-	pf.put(0, head.data(), head.size());
-	pf.put_device(head.size(), d_out.p, total, dev, std::min(numthreads, 8u));
-	pf.put(head.size() + total, tail.data(), tail.size());
-	pf.close();
+	rl_container_ends(n, fpos - 8, index, head, tail);
+	pf->put(0, head.data(), head.size());
+	pf->put(fpos, tail.data(), tail.size());
+	pf->close();
 	return true;
 }
 

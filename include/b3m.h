@@ -327,7 +327,8 @@ int b3m_dist_interleave(b3m_dist_plan *p, const uint32_t *d_sr, const uint8_t *d
  * DESIGN.md. */
 int b3m_rl_write(const char *fn, const uint8_t *symbols, uint64_t n, uint64_t runs_per_block);
 /* the same file (byte for byte) from symbols that are still in HBM: the device finds the runs, counts every block's symbol / run-length
- * frequencies and packs both code streams at their final offsets; the host builds the code tables and headers.  n < 2^32. */
+ * frequencies and packs both code streams at their final offsets; the host builds the code tables and headers.  Texts of any length: the BWT is taken in
+ * segments of at most 2^31 symbols that end on block borders. */
 int b3m_rl_write_device(const char *fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, void *stream);
 /* decodeRun() loop of /root/reference/src/bwtb3mdecoderl.cpp:34: n_out = symbol count;
  * symbols_out may be NULL to query the length only */

@@ -7,6 +7,8 @@ repeat-rich and periodic inputs (circular comparisons, /root/reference/README.md
 """
 import itertools
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1698,6 +1700,19 @@ def test_rl_container_written_from_hbm_equals_the_host_encoder(gpu, kind, tmp_pa
         assert L.b3m_rl_write_device(fd, ctypes.c_void_p(d.data_ptr()), len(a), rpb, None) == 0, L.b3m_last_error()
         hb, db = open(fh, "rb").read(), open(fd, "rb").read()
         assert len(hb) == len(db) and hb == db, (kind, k, len(hb), len(db))
+        # the device encoder takes a long BWT in segments that end on block borders (2^31 symbols each: texts of 2^32 symbols and more); here the segments
+        # are 1 K - 150 K symbols (B3M_RL_SEG), many per file, and the file must still be the same one.  A stretch with fewer runs than a block holds is
+        # refused (the host encoder's case), never written wrong.
+        for seg in (1024, 20_011, 150_000):
+            os.environ["B3M_RL_SEG"] = str(seg)
+            try:
+                rc = L.b3m_rl_write_device(fd, ctypes.c_void_p(d.data_ptr()), len(a), rpb, None)
+            finally:
+                del os.environ["B3M_RL_SEG"]
+            if rc != 0:
+                assert b"host encoder" in L.b3m_last_error() and kind in ("one_symbol", "escapes", "dna_runs", "dna", "bytes256"), (kind, k, seg, L.b3m_last_error())
+                continue
+            assert open(fd, "rb").read() == hb, (kind, k, seg)
         out = np.zeros(len(a), dtype=np.uint8); n = ctypes.c_uint64(0)
         assert L.b3m_rl_read(fd, out.ctypes.data, len(a), ctypes.byref(n)) == 0 and n.value == len(a) and np.array_equal(out, a)
 
