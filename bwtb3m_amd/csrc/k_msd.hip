@@ -1606,10 +1606,14 @@ constexpr uint64_t V3_MIN_RATE = 256;    // sampling rates below this take k_fin
 
 #define B3M_CE(a, b) { const uint32_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; }
 
-template <int WPC>
-__global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
+// THREADS = 512 (12 records per thread, 80 registers: three workgroups = 24 waves per CU) or 1024 (6 records per thread: at 64 registers two
+// workgroups = 32 waves per CU, all the CU holds; B3M_FINISH_V3=4)
+template <int WPC, int THREADS = 512>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
 {
-	constexpr int F_THREADS = 512, F_CAP = 6144, F_PER = 12, F_WAVES = 8;
+	constexpr int F_THREADS = THREADS, F_CAP = 6144, F_PER = F_CAP / THREADS, F_WAVES = THREADS / 64;
+	constexpr int NQ = THREADS == 512 ? 4 : (V3_WL + THREADS - 1) / THREADS;      // work-list items per thread
+	static_assert(F_CAP % THREADS == 0 && NQ * THREADS >= V3_WL && (F_BINS / 2) / THREADS >= 4, "k_finish_v3: thread count");
 	constexpr int ENT_N = F_CAP + 16, TABW_N = F_BINS / 2 + 4, GF_N = F_CAP / 64 + 2;
 	constexpr int E_IDX = 4, E_LOW = 17;                              // entry = low key bits << 17 | index << 4 | special << 3 | predecessor symbol
 	constexpr uint32_t E_SPECIAL = 8u, T_START = 0x1FFFu;             // table half-word after the scan: start (13 bits) | min(count, 7) << 13
@@ -1835,18 +1839,18 @@ __global__ __launch_bounds__(512, 2 * WPC) void k_finish_v3(FinishSrc S, int fbi
 	};
 	const uint32_t nwl = s_wl;
 	if (nwl <= (uint32_t)V3_WL) {
-		uint32_t bin[4], st[4], c[4], e0[4], e1[4], e2[4], e3[4];
+		uint32_t bin[NQ], st[NQ], c[NQ], e0[NQ], e1[NQ], e2[NQ], e3[NQ];
 		#pragma unroll
-		for (int q = 0; q < 4; ++q) { const uint32_t i = q * F_THREADS + tid; bin[q] = i < nwl ? wl[i] : 0xFFFFu; }
+		for (int q = 0; q < NQ; ++q) { const uint32_t i = q * F_THREADS + tid; bin[q] = i < nwl ? wl[i] : 0xFFFFu; }
 		#pragma unroll
-		for (int q = 0; q < 4; ++q) {
+		for (int q = 0; q < NQ; ++q) {
 			const uint32_t t = tab16[bin[q] & (uint32_t)(F_BINS - 1)];
 			st[q] = apad + (t & T_START); c[q] = bin[q] == 0xFFFFu ? 0u : t >> 13;
 		}
 		#pragma unroll
-		for (int q = 0; q < 4; ++q) { LDS_CHK(st[q] + 3, ENT_N); e0[q] = ent[st[q]]; e1[q] = ent[st[q] + 1]; e2[q] = ent[st[q] + 2]; e3[q] = ent[st[q] + 3]; }
+		for (int q = 0; q < NQ; ++q) { LDS_CHK(st[q] + 3, ENT_N); e0[q] = ent[st[q]]; e1[q] = ent[st[q] + 1]; e2[q] = ent[st[q] + 2]; e3[q] = ent[st[q] + 3]; }
 		#pragma unroll
-		for (int q = 0; q < 4; ++q) {
+		for (int q = 0; q < NQ; ++q) {
 			if ((uint32_t)(q * F_THREADS) >= nwl) break;         // (uniform)
 			if (c[q] < 2u) continue;                               // (no bin)
 			LDS_CHK(st[q] - apad + c[q], m + 1);
@@ -2679,6 +2683,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3 == 2) hipLaunchKernelGGL(k_finish_v3<2>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+				else if (v3 == 4) hipLaunchKernelGGL((k_finish_v3<3, 1024>), dim3(bfb - bfa), dim3(1024), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else if (gather) {
