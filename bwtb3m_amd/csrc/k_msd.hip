@@ -902,14 +902,17 @@ __device__ __forceinline__ void wave_sync()
 
 struct SortOut { SaOut sa; uint8_t *bwt; uint64_t start; uint32_t *p0; uint32_t *overflow; uint32_t overflow_cap; uint32_t *tiebits; int pb; SampleOut smp; };
 
+constexpr uint32_t OVF_ONE_BIN = 0x80000000u;
 // a sub-bucket the in-kernel sort cannot finish: (start, size) goes to the overflow list (lane 0 only)
 // (word 1 of the table: set once a range was pushed whose records are only known to share their BUCKET; ranges that are one bin of a finish
 // share the bin's bits as well, and the rounds on the list start behind what every range shares)
 __device__ __forceinline__ void ovf_push(const SortOut &O, uint32_t b0, uint32_t m, bool one_bin = false)
 {
 	uint32_t k = atomicAdd(&O.overflow[0], 1u);
-	if (k < O.overflow_cap) { O.overflow[2 + 2 * k] = b0; O.overflow[3 + 2 * k] = m; }   // 8-byte aligned pairs: u64 = size << 32 | start
-	if (!one_bin) atomicOr(&O.overflow[1], 1u);
+	// 8-byte aligned pairs: u64 = (size | one bin << 31) << 32 | start (a range is below 2^31 records: the finish that lists a bin holds a few thousand, the
+	// whole-bucket paths stop at the sort's 2^32 - 1 records ... of which a single bucket never holds half)
+	if (k < O.overflow_cap) { O.overflow[2 + 2 * k] = b0; O.overflow[3 + 2 * k] = m | (one_bin ? OVF_ONE_BIN : 0u); }
+	if (!one_bin) atomicOr(&O.overflow[1], (m & OVF_ONE_BIN) ? 3u : 1u);       // (bit 1: a range of 2^31 records and more -- one bucket of a text of one symbol -- the flag bit is part of its size)
 }
 
 // one wave sorts the m <= LS_CAP records it holds in r (lane l: records l, l+64, ...), destined
@@ -2264,13 +2267,13 @@ __global__ __launch_bounds__(256) void k_tie_fix_list(TextView T, const uint32_t
 }
 
 // sorted (size << 32 | start) pairs -> sizes (scanned into list offsets by the caller) and starts
-__global__ void k_ovf_split(const uint64_t *pairs, uint32_t nov, uint32_t *sizes, uint32_t *b0)
+__global__ void k_ovf_split(const uint64_t *pairs, uint32_t nov, uint32_t *sizes, uint32_t *b0, uint32_t size_mask)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j > nov) return;
 	if (j == nov) { sizes[j] = 0; return; }
 	uint64_t p = pairs[j];
-	sizes[j] = (uint32_t)(p >> 32); b0[j] = (uint32_t)p;
+	sizes[j] = (uint32_t)(p >> 32) & size_mask; b0[j] = (uint32_t)p;
 }
 
 // list of the suffix-array slots of the overflow buckets: U[s] = slot, gid[s] = bucket start
@@ -2902,9 +2905,18 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
 		radix_sort_u64(pk, nullptr, ws.keyA, nullptr, nov, 32, ws.radix, s, nullptr, &rk, nullptr);
 		if (rk == pk) { B3M_HIP(hipMemcpyAsync(ws.keyA, pk, 8ull * nov, hipMemcpyDeviceToDevice, s)); rk = ws.keyA; }
+		if (getenv("B3M_DEBUG") && atoi(getenv("B3M_DEBUG")) >= 3) {
+			std::vector<uint64_t> hp(nov);
+			B3M_HIP(hipMemcpyAsync(hp.data(), rk, 8ull * nov, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
+			uint64_t nb = 0, eb = 0, no = 0, eo = 0, big_o = 0;
+			for (uint64_t v : hp) { const uint32_t sz = (uint32_t)(v >> 32); if ((sz & OVF_ONE_BIN) && !(novw[1] & 2u)) { ++nb; eb += sz & ~OVF_ONE_BIN; } else { ++no; eo += sz; big_o = std::max<uint64_t>(big_o, sz); } }
+			fprintf(stderr, "[b3m] overflow ranges: %llu single bins with %llu records; %llu other ranges with %llu records (largest %llu)\n", (unsigned long long)nb, (unsigned long long)eb,
+			        (unsigned long long)no, (unsigned long long)eo, (unsigned long long)big_o);
+		}
 		// the overflow table is dead now: reuse it for (off, b0)
 		uint32_t *d_off = M.overflow, *d_b0 = M.overflow + nov + 1;
-		hipLaunchKernelGGL(k_ovf_split, dim3(nblk((uint64_t)nov + 1)), dim3(256), 0, s, rk, nov, d_off, d_b0);
+		const uint32_t size_mask = (novw[1] & 2u) ? 0xFFFFFFFFu : ~OVF_ONE_BIN;
+		hipLaunchKernelGGL(k_ovf_split, dim3(nblk((uint64_t)nov + 1)), dim3(256), 0, s, rk, nov, d_off, d_b0, size_mask);
 		exclusive_sum_u32(d_off, (uint64_t)nov + 1, ws.scan_ws, s);
 		uint32_t total32 = 0;
 		B3M_HIP(hipMemcpyAsync(&total32, d_off + nov, 4, hipMemcpyDeviceToHost, s));
