@@ -7,8 +7,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
 KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true, 0>",
-             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3>", "ties": "b3m::k_tie_fix",
-             "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk"}
+             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3, 512>", "ties": "b3m::k_tie_fix",
+             "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk4"}
 
 
 def add_kernel_times(fam, kernel_times):
