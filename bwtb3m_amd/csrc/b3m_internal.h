@@ -148,6 +148,8 @@ struct MsdWs {
 	void *gtiles = nullptr; uint64_t gtiles_cap = 0;
 	uint32_t *tfirst = nullptr;
 	uint32_t *cbase0 = nullptr; uint64_t cbase0_cap = 0;    // one-pass shards: where the records of level-0 chunk c start (+ two scalars behind the columns)
+	// k_bucket_finish recursing into its sub-buckets above the wave sort's capacity: two sets of (start[], end[], list[0] = count, ids) for up to sub_cap of them
+	uint32_t *sub_st[2] = {nullptr, nullptr}, *sub_en[2] = {nullptr, nullptr}, *sub_list[2] = {nullptr, nullptr}; uint64_t sub_cap = 0;
 };
 uint64_t msd_ws_bytes(uint64_t cap, uint64_t span);
 void msd_ws_carve(MsdWs &ws, void *base, uint64_t cap, uint64_t span);
