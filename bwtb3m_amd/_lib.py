@@ -66,6 +66,7 @@ SYMBOLS = [
     ("b3m_plan_slice_capacity", _u64, [_p]),
     ("b3m_plan_destroy", None, [_p]),
     ("b3m_plan_num_blocks", _u64, [_p]),
+    ("b3m_plan_host_tier", _i, [_p]),
     ("b3m_plan_warning", _cp, [_p]),
     ("b3m_plan_workspace_bytes", _u64, [_p]),
     ("b3m_plan_text_bytes", _u64, [_p]),

@@ -162,6 +162,8 @@ struct SliceHook { int nslices; void (*fn)(void *ctx, uint64_t first, uint64_t l
 struct TextArrival { int n; hipEvent_t ev[16]; uint64_t bytes_ready[16]; };
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
+	bool no_defer = false;            // suffix-range shards run one after the other by ONE plan (texts below 2^32 symbols in the host tier): nobody gathers the shards' suffix
+	                                  // arrays, so a shard finishes its long repeats itself, by key-extension rounds to the end
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
 	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
 	uint8_t *sa_hi = nullptr;                    // texts of 2^32 symbols and more: bits 32.. of the suffix array entries (MSD path)

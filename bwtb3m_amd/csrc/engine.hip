@@ -133,6 +133,9 @@ struct b3m_plan {
 	int keep_sa = 0;                                      // b3m_plan_set_keep_sa: the next runs keep the whole suffix array of the sort (tie export needs it)
 	int sa_hint = 0;                                      // the last run's BWT-only sort had to start over with the suffix array kept (repeat-rich text): the next ones keep it from the start
 	int seq_shards = 1;                                   // texts of 2^32 symbols and more on one GPU: the suffix-range shards of the one block, one after the other
+	bool host_tier = false;                               // ... and a text below 2^32 symbols whose memory target no merge tree can meet: the same sequential shards, their slices
+	                                                      // meant to leave for pinned host memory as they are finished (b3m_plan_run_host): the BWT is never in HBM as a whole
+	uint64_t seq_half = 0;                                // sequential shards: d_bwt[0] holds two slices (one is copied out while the next shard sorts)
 	std::vector<Leaf> leaves;
 	std::vector<MergeT> merges;
 	std::vector<std::vector<int>> level_merges;         // merge ids per level
@@ -311,6 +314,29 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		blocksize = n;
 		p->shard_cap = n / p->seq_shards + n / 64 + (1ull << 20);
 	}
+	// HOST TIER.  The part of a merge tree's workspace that does not shrink with the blocks -- text, two BWT arrays, gt bits, the ranks of a merge: 7.25 bytes
+	// per symbol -- is what `mem=` could not get below (the reference meets a small mem= with files, /root/reference/README.md:42,46).  Sequential suffix-range
+	// shards need the text (0.25 B/symbol) and ONE shard's sort; their slices of the BWT are final when the shard is through and leave for pinned host memory
+	// (b3m_plan_run_host: two slice buffers, the copy of one behind the sort of the next).  Taken when no merge tree fits the target (B3M_FORCE_SPILL=S: test switch).
+	if (nshards == 1 && p->seq_shards == 1 && blocksize == 0 && (inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM) && n >= (1ull << 18)) {
+		const char *fe = getenv("B3M_FORCE_SPILL");
+		int S = fe ? atoi(fe) : 0;
+		if (S < 2 && mem) {
+			const uint64_t fixed_tree = packed_text_bytes(n, inputtype) + 2 * n + n / 2 + (64ull << 20);
+			const uint64_t bmin = std::max<uint64_t>(1024, n / 1024);
+			const bool tree_fits = fixed_tree + blocksort_ws_bytes(bmin) + 9 * n / 2 <= budget;      // (the test the block-size loop below ends on)
+			if (!tree_fits)
+				for (int t = 2; t <= 1024 && S < 2; ++t) {
+					const uint64_t cap = std::min<uint64_t>(n, n / t + n / 64 + (1ull << 20));
+					if (packed_text_bytes(n, inputtype) + 2 * (cap + 512) + blocksort_ws_bytes(cap, n, true) + 24 * (n / (isasamplingrate ? isasamplingrate : n) + 1) + (4ull << 20) <= budget) S = t;
+				}
+		}
+		if (S >= 2) {
+			p->seq_shards = S; p->host_tier = true;
+			blocksize = n;
+			p->shard_cap = std::min<uint64_t>(n, n / (uint64_t)S + n / 64 + (1ull << 20));
+		}
+	}
 	// per-suffix bytes of the leaf sort workspace ~ 2*(8+4) + 1 + 12 + radix scratch: see blocksort_ws_bytes
 	if (blocksize == 0) {
 		// fixed part: text, 2 bwt arrays, gt; merge part needs ranks (8 B per R suffix) + rank blocks
@@ -334,7 +360,9 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	auto take = [&](uint64_t bytes) { uint64_t o = off; off += al256(bytes); return o; };
 	p->text_cap = al256(packed_text_bytes(n, inputtype) + 64);
 	uint64_t o_text = take(p->text_cap);
-	const uint64_t bwt_cap = (nshards > 1) ? p->shard_cap : n;
+	// (sequential shards: a device-resident run writes into the caller's n bytes; a host-memory run needs two slices here, not n bytes)
+	p->seq_half = p->seq_shards > 1 ? al256(p->shard_cap + 16) : 0;
+	const uint64_t bwt_cap = (nshards > 1) ? p->shard_cap : (p->seq_shards > 1 ? 2 * p->seq_half : n);
 	const bool sharded_sort = nshards > 1 || p->seq_shards > 1;
 	uint64_t o_bwt0 = take(bwt_cap + 16), o_bwt1 = take(B > 1 ? n + 16 : 16);
 	p->gt_words = (n + 1 + 31) / 32 + 2;
@@ -446,6 +474,9 @@ void b3m_plan_destroy(b3m_plan *p)
 	delete p;
 }
 uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 0; }
+/* 0, or the number of sequential suffix-range shards of a plan in the HOST TIER: a text below 2^32 symbols whose memory target no merge tree can meet.  Such a
+ * plan keeps the text and ONE shard's sort in HBM; b3m_plan_run_host sends every slice of the BWT to (pinned) host memory as its shard finishes. */
+int b3m_plan_host_tier(const b3m_plan *p) { return p && p->host_tier ? p->seq_shards : 0; }
 const char *b3m_plan_warning(const b3m_plan *p) { return p ? p->warning.c_str() : ""; }
 uint64_t b3m_plan_workspace_bytes(const b3m_plan *p) { return p ? p->ws_bytes : 0; }
 uint64_t b3m_plan_text_bytes(const b3m_plan *p) { return p ? packed_text_bytes(p->n, p->type) : 0; }
@@ -552,6 +583,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		if (!p->copy_stream) B3M_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
 		d_bwt_out = p->d_bwt[0];                    // one block: the leaf sort writes here; several: the last level is copied here
 		sink.d_bwt = d_bwt_out;
+		B3M_REQUIRE(!(p->seq_shards > 1 && p->packed_out), "host-memory runs of sequential shards hand the BWT over one byte per symbol");
 		if (p->packed_out && !p->d_pack) B3M_HIP(hipMalloc((void **)&p->d_pack, (((p->n + 3) / 4 + 15) & ~15ull) + 16));
 		p->e2e = b3m_e2e_times{};
 	}
@@ -621,16 +653,32 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
 		// slots of other shards stay "empty"; samples written by the sort itself: a slot nobody wrote is found by samples_of
 		if (p->isarate && (nsh > 1 || smp_in_kernel)) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
+		const bool seq_host = host && p->seq_shards > 1;         // the slices leave for host memory one by one: two slice buffers in d_bwt[0]
+		std::vector<hipEvent_t> gone;                            // gone[sh]: slice sh has left its buffer
+		p->bs.no_defer = p->seq_shards > 1;
 		for (int sh = (p->seq_shards > 1 ? 0 : p->shard); sh < (p->seq_shards > 1 ? p->seq_shards : p->shard + 1); ++sh) {
+			uint8_t *slice_dst = seq_host ? p->d_bwt[0] + (uint64_t)(sh & 1) * p->seq_half : nullptr;
+			if (seq_host && sh >= 2) B3M_HIP(hipStreamWaitEvent(s, gone[(size_t)sh - 2], 0));
 			B3M_HIP(hipMemsetAsync(p->d_p0tmp + k, 0xFF, 4, s));
 			// one block: its BWT is the result and goes straight to the caller's buffer
 			p->bs.d_symhist_out = (sh == 0 || p->seq_shards == 1) ? p->d_hist + 256 * k : nullptr;      // the histogram of the whole block falls out of every shard's level-0 totals: taken once
 			p->bs.slice_hook = (host && B == 1 && nsh == 1) ? &hook : nullptr;
 			p->bs.arrival = streaming_text ? &arrival : nullptr;
 			p->bs.samples = smp_in_kernel ? &smp_cfg : nullptr;
-			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a, p->d_p0tmp + k, sh, nsh, need_sa);
+			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, seq_host ? slice_dst : (B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a), p->d_p0tmp + k, sh, nsh, need_sa);
+			if (seq_host) {
+				// the shard's slice is final: off to host memory on the copy stream, behind the sort of the next shard
+				B3M_REQUIRE(so.kept_len <= p->seq_half, "internal: a sequential shard's slice is larger than its buffer");
+				hipEvent_t done = tl->get(), left = tl->get();
+				B3M_HIP(hipEventRecord(done, s));
+				B3M_HIP(hipStreamWaitEvent(p->copy_stream, done, 0));
+				if (so.kept_len) B3M_HIP(hipMemcpyAsync(h_bwt_out + acc, slice_dst, so.kept_len, hipMemcpyDeviceToHost, p->copy_stream));
+				B3M_HIP(hipEventRecord(left, p->copy_stream));
+				gone.push_back(left); sink.evs.push_back(done); sink.evs.push_back(left);
+				sink.copied += so.kept_len;
+			}
 			p->bs.d_symhist_out = nullptr; p->bs.slice_hook = nullptr; p->bs.arrival = nullptr; p->bs.samples = nullptr;
-			if (host && B == 1 && so.late_writes) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
+			if (host && B == 1 && so.late_writes && !seq_host) sink.copied = 0;       // slices were rewritten after they left: everything is copied again below
 			if (p->seq_shards > 1) B3M_REQUIRE(so.slice_offset == acc, "internal: suffix-range shards do not tile the rank space");
 			if (so.reran_with_sa) p->sa_hint = 1;
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;

@@ -226,12 +226,15 @@ extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly
 extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 {
 	void *d_text = nullptr; Built B; std::vector<Shard> shards; int dev0 = 0; bool own_bwt = false;
+	void *h_text = nullptr; uint8_t *h_bwt = nullptr;      // host tier: the text comes from, the BWT goes to pinned host memory
 	auto cleanup = [&]() {
 		free_shards(shards);
 		(void)hipSetDevice(dev0);
 		if (B.plan) b3m_plan_destroy(B.plan);
 		if (d_text) (void)hipFree(d_text);
 		if (own_bwt && B.d_bwt) (void)hipFree(B.d_bwt);
+		if (h_text) b3m_host_free(h_text);
+		if (h_bwt) b3m_host_free(h_bwt);
 		b3m::staging_release();
 	};
 	try {
@@ -322,6 +325,24 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		// ---- in: the text to HBM, beside the creation of the plan -------------------------------------------------------------------
 		const double tp0 = now();
 		uint64_t tb = 0; double t_read = 0;
+		// with a memory target the plan comes first: it says whether the text goes to HBM or -- host tier: no merge tree meets the target, the text is sorted as
+		// sequential suffix-range shards whose slices leave for pinned host memory -- is handed over from host memory (b3m_plan_run_host)
+		int spill = 0;
+		if (!sharded && mem && direct && two_bit) {
+			B.plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
+			if (!B.plan) throw std::runtime_error(b3m_last_error());
+			spill = b3m_plan_host_tier(B.plan);
+		}
+		if (spill) {
+			tb = b3m_plan_text_bytes(B.plan);
+			if (tb != fsize) throw std::runtime_error("internal: packed size mismatch");
+			h_text = b3m_host_alloc(tb + 64);
+			h_bwt = (uint8_t *)b3m_host_alloc(n + 16);
+			if (!h_text || !h_bwt) throw std::runtime_error("out of pinned host memory for the host tier (text and BWT)");
+			const double r0 = now();
+			b3m::read_range(infn, 0, h_text, tb, io_threads);
+			t_read = now() - r0;
+		} else
 		if (filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2) {
 			void *d_words = nullptr;
 			HIPCHK(hipMalloc(&d_words, file.size()));
@@ -341,6 +362,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		std::thread reader([&]() {
 			try {
 				const double r0 = now();
+				if (spill) return;
 				if (direct) {
 					if (tb != fsize) throw std::runtime_error("internal: packed size mismatch");
 					b3m::read_range_to_device(infn, 0, d_text, tb, dev0, io_threads);
@@ -354,7 +376,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			} catch (const std::exception &e) { read_err = e.what(); }
 		});
 		std::string plan_err;
-		if (!sharded) {
+		if (!sharded && !B.plan) {
 			B.plan = b3m_plan_create(n, type, o->blocksize, mem, anchor_rate);
 			if (!B.plan) plan_err = b3m_last_error();
 		}
@@ -370,10 +392,26 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 			log("[V] blocks %llu workspace %.2f GB; plan created and input read into HBM in %.3f s (the file's %.3f GB through pinned pieces: %.3f s, beside the plan)\n",
 			    (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9, tp1 - tp0, tb / 1e9, t_read);
 			if (b3m_plan_text_bytes(plan) != tb && !(filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2)) throw std::runtime_error("internal: packed size mismatch");
+			if (spill) {
+				log("[V] host tier: mem=%llu is below what a merge tree needs (7.25 bytes per symbol whatever the blocks): %d sequential suffix-range shards, the text from and the "
+				    "BWT to pinned host memory\n", (unsigned long long)mem, spill);
+				t1 = now();
+				if (b3m_plan_run_host(plan, h_text, h_bwt, nullptr, nullptr)) throw std::runtime_error(b3m_last_error());
+				t2 = now();
+				if (want_sa) {
+					// the LF walks that make X.sa / X.isa read the whole BWT and a rank dictionary of it: 1.7 bytes per symbol of HBM beside the plan
+					const uint64_t need = b3m_plan_workspace_bytes(plan) + n + 2 * (n / 3) + 8 * ((n + sarate - 1) / sarate);
+					if (need > mem) Log{log_fd}("[W] mem=%llu is exceeded by the LF walks of bwtonly=0 (the whole BWT and its rank dictionary in HBM: %.2f GB with the plan); "
+					                            "bwtonly=1 stays inside it\n", (unsigned long long)mem, need / 1e9);
+					HIPCHK(hipMalloc((void **)&B.d_bwt, n + 16)); own_bwt = true;
+					HIPCHK(hipMemcpy(B.d_bwt, h_bwt, n, hipMemcpyHostToDevice));
+				}
+			} else {
 			HIPCHK(hipMalloc((void **)&B.d_bwt, (wide ? 4 * n : n) + 16)); own_bwt = true;
 			t1 = now();
 			if (b3m_plan_run(plan, d_text, B.d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
 			t2 = now();
+			}
 			b3m_result res; b3m_plan_result(plan, &res);
 			B.dev = dev0; B.d_text = b3m_plan_text_buffer(plan); B.p0 = res.p0; B.num_blocks = res.num_blocks; B.levels = res.levels;
 			B.ms_sort = res.ms_sort; B.ms_gap = res.ms_gap; B.ms_interleave = res.ms_interleave;
@@ -415,6 +453,12 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 					std::map<int64_t, uint64_t> hm;
 					for (uint64_t i = 0; i < n; ++i) hm[wide_map[bw[i]]]++;
 					b3m::write_hist_map(prefix + ".hist", hm);
+				} else if (!B.d_bwt && h_bwt) {
+					// host tier, bwtonly=1: the BWT is in pinned host memory; the device encoder takes it one segment at a time (a sixteenth of the memory target)
+					const uint64_t seg = std::max<uint64_t>(1ull << 24, mem / 16);
+					if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device_from_host(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap, s, seg))
+						b3m::rl_encode_file(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap);
+					b3m::write_hist(prefix + ".hist", B.hist, symmap);
 				} else {
 					if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, B.d_bwt, n, 64 * 1024, enc_threads, symmap, s)) {
 						std::vector<uint8_t> bwt(n);

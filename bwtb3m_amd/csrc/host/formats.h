@@ -40,6 +40,9 @@ void rl_block_header(const uint32_t *sf256, const uint32_t *cf257, uint64_t nr, 
 // and headers here.  false: not an input for it (empty, 2^32 symbols or more, a code above 32 bits): use rl_encode_file
 bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream);
 // what stands in front of and behind the blocks of a container: n; the index, its size and its offset
+// the same from a BWT in (pinned) host memory, brought to HBM one segment of at most seg_limit symbols at a time (host tier)
+bool rl_encode_device_from_host(const std::string &fn, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream,
+                                uint64_t seg_limit);
 void rl_container_ends(uint64_t n, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index, std::vector<uint8_t> &head, std::vector<uint8_t> &tail);
 void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index);
 std::vector<RLIndexEntry> rl_index(const std::string &fn);

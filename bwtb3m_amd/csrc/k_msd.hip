@@ -2996,12 +2996,12 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// a suffix-range shard of the whole text cannot rank the suffixes of the other shards: after the same few key-extension
 		// rounds it hands what is left to the caller, who finishes it by prefix doubling over ALL shards' suffix arrays
 		// (b3m_plan_tie_export / b3m_plan_tie_finish): O(log longest repeat) rounds there too
-		const bool defer = nshards > 1 && start == 0 && len_in == T.n;
+		const bool defer = nshards > 1 && start == 0 && len_in == T.n && !ws.no_defer;
 		const uint64_t R0 = 4;
 		const uint64_t off0 = getenv("B3M_TIE_FROM_0") ? 0 : ovf_syms;      // (switch: the rounds start at symbol 0, as they did before)
 		// a block of a merge tree: the same few rounds, then prefix doubling inside the block and its overhang (tie_rounds_domain):
 		// the first time round the caller is asked to sort the block again with the overhang behind it (out.want_ext)
-		const bool tree = !whole && !defer && !no_tree_doubling();
+		const bool tree = !whole && !defer && !no_tree_doubling() && !(nshards > 1 && ws.no_defer);      // (a sequential shard holds a rank range of the text, not a block: key extension to the end)
 		// 36-bit positions: key extension until nothing is left (an inverse suffix array of 2^32 and more entries does not fit beside the sort: no doubling,
 		// O(longest repeat / 21) rounds)
 		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, sa.hi, ws.tie_hi, off0);

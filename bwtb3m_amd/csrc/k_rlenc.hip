@@ -180,7 +180,20 @@ __global__ __launch_bounds__(64) void k_rl_headers(const uint8_t *blob, const ui
 // The BWT is taken in SEGMENTS of at most 2^31 symbols (run starts are 32-bit offsets into the segment; B3M_RL_SEG: test switch): a segment
 // begins at a run head, encodes the whole blocks of runs_per_block runs that lie inside it -- never its last run, which may go on behind the
 // segment's end -- and the next segment begins where its last block ended.  The blocks of the file are the same ones, whatever the segments.
+// h_symbols != null: the BWT lies in host memory (host tier: it never was in HBM as a whole) and every segment is brought to a staging buffer of seg_max bytes first
+static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
+                           void *hip_stream, uint64_t seg_limit);
 bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream)
+{
+	return rl_encode_impl(fn, d_symbols, nullptr, n, runs_per_block, numthreads, symmap, hip_stream, 0);
+}
+bool rl_encode_device_from_host(const std::string &fn, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream,
+                                uint64_t seg_limit)
+{
+	return rl_encode_impl(fn, nullptr, h_symbols, n, runs_per_block, numthreads, symmap, hip_stream, seg_limit);
+}
+static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
+                           void *hip_stream, uint64_t seg_limit)
 {
 	hipStream_t s = (hipStream_t)hip_stream;
 	if (!runs_per_block) runs_per_block = 64 * 1024;
@@ -188,7 +201,10 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 	if (n == 0 || runs_per_block > (1u << 24)) return false;
 	const uint32_t rpb = (uint32_t)runs_per_block;
 	uint64_t seg_max = 1ull << 31;
+	if (seg_limit >= 1024 && seg_limit < seg_max) seg_max = seg_limit;
 	if (const char *e = getenv("B3M_RL_SEG")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024 && v < seg_max) seg_max = v; }
+	std::unique_ptr<Buf> stage;                           // host source: the segment's symbols in HBM
+	if (h_symbols) stage.reset(new Buf(std::min(seg_max, n) + 16));
 	int dev = 0;
 	B3M_HIP(hipGetDevice(&dev));
 	std::unique_ptr<ParFile> pf;
@@ -197,7 +213,8 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 	for (uint64_t a = 0; a < n;) {
 		const uint64_t len = std::min<uint64_t>(seg_max, n - a);
 		const bool last = a + len == n;
-		const uint8_t *sym = d_symbols + a;
+		const uint8_t *sym = d_symbols ? d_symbols + a : stage->as<uint8_t>();
+		if (h_symbols) B3M_HIP(hipMemcpyAsync(stage->p, h_symbols + a, len, hipMemcpyHostToDevice, s));
 		const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
 		Buf tiles(4 * (ntiles + 1)), scan_ws(4 * scan_ws_elems(ntiles + 1));
 		hipLaunchKernelGGL(k_rl_count, dim3((uint32_t)ntiles), dim3(256), 0, s, sym, len, tiles.as<uint32_t>());

@@ -72,6 +72,11 @@ class Plan:
         return int(lib().b3m_plan_num_blocks(self._h))
 
     @property
+    def host_tier(self):
+        """0, or the number of sequential shards of a plan in the host tier (b3m_plan_host_tier)"""
+        return int(lib().b3m_plan_host_tier(self._h))
+
+    @property
     def warning(self):
         """'' or what the caller should be told (a mem= target that cannot be met: b3m_plan_warning)"""
         return lib().b3m_plan_warning(self._h).decode()

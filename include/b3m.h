@@ -110,6 +110,12 @@ b3m_plan *b3m_plan_create_sharded(uint64_t n, int inputtype, int shard, int nsha
 uint64_t  b3m_plan_slice_capacity(const b3m_plan *p);
 void      b3m_plan_destroy(b3m_plan *p);
 uint64_t  b3m_plan_num_blocks(const b3m_plan *p);
+/* HOST TIER (role of the reference's mem= / tmpprefix= files, /root/reference/README.md:42,46, /root/reference/src/bwtb3m.cpp:47,53): a pac / pacterm plan whose
+ * memory target no merge tree can meet (the tree's text, two BWT arrays, gt bits and rank lists are 7.25 bytes per symbol whatever the blocks) sorts the text
+ * as SEQUENTIAL suffix-range shards instead: HBM holds the text (0.25 B/symbol) and one shard's sort; b3m_plan_run_host sends every shard's slice of the BWT to
+ * (pinned) host memory through two slice buffers while the next shard sorts, so the BWT is never in HBM as a whole.  Returns the number of shards, 0 for any
+ * other plan.  (b3m_plan_run of such a plan still writes the caller's n device bytes.)  Long repeats are finished shard by shard, by key-extension rounds. */
+int       b3m_plan_host_tier(const b3m_plan *p);
 /* "" or what the caller should be told about the plan: a mem= target below the footprint of the smallest blocks is exceeded, and said
  * so here (b3m_compute_bwt prints it as a [W] line whatever verbose= says; mem= itself: /root/reference/README.md:42) */
 const char *b3m_plan_warning(const b3m_plan *p);

@@ -401,6 +401,82 @@ def test_mem_target_that_cannot_be_met_is_said_not_hidden(gpu, oracle, tmp_path)
     assert r.returncode == 0 and b"[W] mem=8388608 cannot be met" in r.stderr, r.stderr.decode()
 
 
+@pytest.mark.parametrize("kind", ["uniform", "repeat"])
+def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monkeypatch):
+    """HOST TIER (role of the reference's mem= / tmp files, /root/reference/README.md:42,46): a plan whose memory target no merge tree can meet sorts the text as
+    sequential suffix-range shards; b3m_plan_run_host sends every slice of the BWT to pinned host memory while the next shard sorts (two slice buffers in HBM).
+    Forced here on a text the oracle can sort (B3M_FORCE_SPILL=5); long repeats are finished shard by shard (key extension to the end)."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    monkeypatch.setenv("B3M_FORCE_SPILL", "5")
+    if kind == "uniform":
+        b = oracle.synth_bases(700_003, 9)
+    else:
+        b = oracle.synth_repeat_bases(700_003, 9)
+        b[500_000:512_000] = b[40_000:52_000]                 # a 12-kb copy
+        b[300_000:300_700] = 1
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    plan = engine.Plan(n, "pacterm", isasamplingrate=1024)
+    assert plan.host_tier == 5 and plan.num_blocks == 1
+    d = torch.from_numpy(np.concatenate([buf, np.zeros(16, dtype=np.uint8)])).cuda()
+    out = plan.run(d)                                          # device-resident: the caller's n bytes
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    h_text = torch.from_numpy(np.concatenate([buf, np.zeros(64, dtype=np.uint8)])).pin_memory()
+    h_out = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    t = plan.run_host(h_text, h_out)
+    assert np.array_equal(h_out.numpy(), ref) and t["streamed_bytes"] == n
+    r = plan.result()
+    assert r["p0"] == int(np.nonzero(sa == 0)[0][0])
+    smp = plan.samples()
+    isa = np.empty_like(sa); isa[sa] = np.arange(n)
+    assert len(smp) == (n + 1023) // 1024 and np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    assert plan.lf_walk(out, sarate=0)[:2] == (0, 0)
+    plan.close()
+
+
+def test_host_tier_is_taken_when_no_merge_tree_meets_mem(gpu, tmp_path):
+    """40 Mbase with mem=256m: a merge tree needs 7.25 bytes per symbol whatever its blocks (290 MB + its sorts); the plan goes to the host tier instead of
+    exceeding the target (workspace inside mem=), its BWT equals the one-block plan's (LF-verified), and bin/bwtb3m mem=256m writes the files of an
+    unconstrained run, byte for byte (bwtonly=1 inside the target; bwtonly=0 says that its LF walks exceed it)."""
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    itype, d_text, n = synth.config_input_device("c3", size=40_000_000, device="cuda")
+    mem = 256 << 20
+    plan = engine.Plan(n, itype, mem=mem, isasamplingrate=4096)
+    S = plan.host_tier
+    assert S >= 2 and plan.warning == "" and plan.workspace_bytes <= mem, (S, plan.warning, plan.workspace_bytes)
+    h_text = d_text.cpu().pin_memory()
+    h_out = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    plan.run_host(h_text, h_out)
+    one = engine.Plan(n, itype, isasamplingrate=4096)
+    ref = one.run(d_text)
+    torch.cuda.synchronize()
+    assert one.lf_walk(ref, sarate=0)[:2] == (0, 0) and bool(torch.equal(ref.cpu(), h_out))
+    assert one.result()["p0"] == plan.result()["p0"] and np.array_equal(one.samples(), plan.samples())
+    plan.close(); one.close()
+    inp = tmp_path / "t.pac"
+    inp.write_bytes(d_text.cpu().numpy()[: (n - 1) // 4 + 2].tobytes())
+    for bwtonly in (1, 0):
+        outs = {}
+        for tag, extra in (("free", []), ("tier", ["mem=256m"])):
+            out = str(tmp_path / ("%s%d.bwt" % (tag, bwtonly)))
+            r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=%d" % bwtonly, "verbose=1", "outputfilename=" + out] + extra + [str(inp)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()
+            if extra:
+                assert b"host tier" in r.stderr and b"cannot be met" not in r.stderr, r.stderr.decode()
+                assert (b"[W] mem=" in r.stderr and b"LF walks" in r.stderr) == (bwtonly == 0), r.stderr.decode()
+            outs[tag] = _files(out[:-4])
+        assert set(outs["free"]) == set(outs["tier"])
+        for suf in outs["free"]:
+            assert outs["free"][suf] == outs["tier"][suf], (bwtonly, suf)
+
+
 @pytest.mark.gpu
 def test_seek_index_consumers_sortpreisa_and_bwtdecodeblock(gpu, oracle, tmp_path):
     """row f4, consumers of the container's seek index: X.preisa -> sorted isa (/root/reference/src/sortPreIsa.cpp:62,95-96), then text[low, low+len)

@@ -5,7 +5,13 @@ import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from bwtb3m_amd import engine, synth, _lib
 import ctypes
-nb = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
+def fhash(fn):
+    h = hashlib.sha256()
+    with open(fn, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+nb = int(float(sys.argv[1])) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 3_000_000_000
 tmp = "/tmp/b3m_e2e"; os.makedirs(tmp, exist_ok=True)
 itype, d_text, n = synth.config_input_device("c3", size=nb, device="cuda")
 buf = d_text.cpu().numpy()
@@ -41,12 +47,6 @@ for bwtonly in (1, 0, 0, 1):       # (the later runs are the warm ones: files in
     assert h == href
 # numgpus=8 with the one device listed eight times (B3M_DEVICES: eight host threads, eight shard plans, peer copies inside one GPU): the files must be
 # the ones numgpus=1 wrote, byte for byte
-def fhash(fn):
-    h = hashlib.sha256()
-    with open(fn, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 24), b""):
-            h.update(blk)
-    return h.hexdigest()
 if "--no-numgpus" not in sys.argv:
     for bwtonly in (1, 0):
         out = os.path.join(tmp, "c3g_%d.bwt" % bwtonly)
@@ -63,6 +63,21 @@ if "--no-numgpus" not in sys.argv:
             assert same
             if suf != ".meta":
                 os.remove(b)
+# host tier: mem=8g is below what a merge tree needs at this size (7.25 B/symbol = 21.75 GB): sequential suffix-range shards, the BWT through pinned host
+# memory; the files must be the unconstrained run's
+if "--host-tier" in sys.argv:
+    out = os.path.join(tmp, "c3t_1.bwt")
+    t0 = time.time()
+    r = subprocess.run(["/root/repo/bin/bwtb3m", "inputtype=pacterm", "bwtonly=1", "numthreads=16", "verbose=1", "mem=8g", "outputfilename=" + out, pac], capture_output=True, text=True)
+    print("bwtb3m mem=8g bwtonly=1 (host tier): rc %d, %.1f s wall" % (r.returncode, time.time() - t0), flush=True)
+    print("\n".join(r.stderr.strip().splitlines()[-12:]), flush=True)
+    assert r.returncode == 0
+    for suf in (".bwt", ".hist", ".meta", ".preisa"):
+        a, b = os.path.join(tmp, "c3_1" + suf), os.path.join(tmp, "c3t_1" + suf)
+        same = fhash(a) == fhash(b)
+        print("   %s: mem=8g file == unconstrained file: %s" % (suf, same), flush=True)
+        assert same
+        os.remove(b)
 t0 = time.time()
 r = subprocess.run(["/root/repo/bin/bwtb3mtobwa", os.path.join(tmp, "c3_0.bwt"), os.path.join(tmp, "bwa.bwt"), os.path.join(tmp, "bwa.sa")], capture_output=True, text=True)
 print("bwtb3mtobwa rc %d, %.1f s; %s" % (r.returncode, time.time() - t0, r.stderr.strip()[-300:]), flush=True)
