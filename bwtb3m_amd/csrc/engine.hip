@@ -325,10 +325,16 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 			const uint64_t fixed_tree = packed_text_bytes(n, inputtype) + 2 * n + n / 2 + (64ull << 20);
 			const uint64_t bmin = std::max<uint64_t>(1024, n / 1024);
 			const bool tree_fits = fixed_tree + blocksort_ws_bytes(bmin) + 9 * n / 2 <= budget;      // (the test the block-size loop below ends on)
+			// (the arena of such a plan, as it is carved below: text, two slice buffers, one shard's sort, the sample table, small tables)
+			auto seq_arena = [&](uint64_t cap) {
+				const uint64_t nsmp = isasamplingrate ? (n + isasamplingrate - 1) / isasamplingrate : 0;
+				return al256(al256(packed_text_bytes(n, inputtype) + 64)) + al256(2 * al256(cap + 16) + 16) + al256(blocksort_ws_bytes(cap, n, true)) + al256(16 * (nsmp + 1)) + (1ull << 20);
+			};
 			if (!tree_fits)
-				for (int t = 2; t <= 1024 && S < 2; ++t) {
+				for (int t = 2; t <= 4096 && S < 2; ++t) {
 					const uint64_t cap = std::min<uint64_t>(n, n / t + n / 64 + (1ull << 20));
-					if (packed_text_bytes(n, inputtype) + 2 * (cap + 512) + blocksort_ws_bytes(cap, n, true) + 24 * (n / (isasamplingrate ? isasamplingrate : n) + 1) + (4ull << 20) <= budget) S = t;
+					if (seq_arena(cap) <= budget) S = t;
+					if (n / t < n / 64) break;                     // (more shards no longer shrink the slack-dominated capacity)
 				}
 		}
 		if (S >= 2) {
@@ -366,7 +372,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	const bool sharded_sort = nshards > 1 || p->seq_shards > 1;
 	uint64_t o_bwt0 = take(bwt_cap + 16), o_bwt1 = take(B > 1 ? n + 16 : 16);
 	p->gt_words = (n + 1 + 31) / 32 + 2;
-	uint64_t o_gt0 = take(4 * p->gt_words), o_gt1 = take(4 * p->gt_words);
+	uint64_t o_gt0 = take(B > 1 ? 4 * p->gt_words : 16), o_gt1 = take(B > 1 ? 4 * p->gt_words : 16);      // (gt bits: merges only)
 	// blocks of a merge tree are sorted with room for an overhang behind them (long repeats: tie_rounds_domain)
 	const uint64_t ovh = (B > 1 && !sharded_sort) ? std::min(block_overhang(), p->blocksize / 8) : 0;
 	const uint64_t sort_cap = sharded_sort ? p->shard_cap : p->blocksize + ovh;

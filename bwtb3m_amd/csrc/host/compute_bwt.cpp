@@ -389,6 +389,9 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (!sharded) {
 			b3m_plan *plan = B.plan;
 			if (*b3m_plan_warning(plan)) Log{log_fd}("[W] %s\n", b3m_plan_warning(plan));       // (whatever verbose= says)
+			if (spill) log("[V] blocks %llu workspace %.2f GB; plan created, %.3f GB of text read into pinned host memory (%.3f s) and %.3f GB pinned for the BWT: %.3f s\n",
+			               (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9, tb / 1e9, t_read, n / 1e9, tp1 - tp0);
+			else
 			log("[V] blocks %llu workspace %.2f GB; plan created and input read into HBM in %.3f s (the file's %.3f GB through pinned pieces: %.3f s, beside the plan)\n",
 			    (unsigned long long)b3m_plan_num_blocks(plan), b3m_plan_workspace_bytes(plan) / 1e9, tp1 - tp0, tb / 1e9, t_read);
 			if (b3m_plan_text_bytes(plan) != tb && !(filetype == B3M_INPUT_COMPACTSTREAM && cbits != 2)) throw std::runtime_error("internal: packed size mismatch");
