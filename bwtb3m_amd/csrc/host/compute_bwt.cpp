@@ -110,6 +110,16 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	const int N = (int)devs.size();
 	sh.assign((size_t)N, Shard{});
 	for (int k = 0; k < N; ++k) sh[(size_t)k].dev = devs[(size_t)k];
+	// direct peer access between the devices of the run (xGMI), where the platform grants it: the text, the slices and -- long repeats -- the suffix array
+	// slices travel by hipMemcpyPeer, which falls back to staging through the host without it
+	{
+		std::map<int, int> distinct;
+		for (int d : devs) distinct[d] = 1;
+		for (auto &a : distinct) {
+			HIPCHK(hipSetDevice(a.first));
+			for (auto &b : distinct) if (b.first != a.first) { int can = 0; if (hipDeviceCanAccessPeer(&can, a.first, b.first) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b.first, 0); (void)hipGetLastError(); }
+		}
+	}
 	auto run_shard = [&](Shard &s) {
 		B3MCHK(b3m_plan_run(s.plan, b3m_plan_text_buffer(s.plan), s.d_out, nullptr));
 		B3MCHK(b3m_plan_result(s.plan, &s.res));

@@ -67,7 +67,7 @@ def _files(prefix):
     return {suf: open(prefix + suf, "rb").read() for suf in (".bwt", ".hist", ".meta", ".preisa", ".sa", ".isa") if os.path.exists(prefix + suf)}
 
 
-@pytest.mark.parametrize("kind,ngpus,bwtonly", [("c2", 4, 1), ("c2", 3, 0), ("repeat", 4, 0), ("repeat", 2, 1)])
+@pytest.mark.parametrize("kind,ngpus,bwtonly", [("c2", 4, 1), ("c2", 3, 0), ("repeat", 4, 0), ("repeat", 2, 1), ("pac", 3, 1), ("pac", 2, 0)])
 def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ngpus, bwtonly):
     """b3m_compute_bwt honours num_gpus (CLI key numgpus=): one host thread per device, one suffix-range shard each, the slices gathered on the first
     device, which writes the files.  Here the same device is listed N times (B3M_DEVICES=0,0,..: N threads, N plans, peer copies within one GPU).
@@ -76,8 +76,11 @@ def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ng
     numthreads= is the reference's knob behind the same call)."""
     from bwtb3m_amd import _lib, synth
     L = _lib.lib()
+    itype = "pac" if kind == "pac" else "pacterm"
     if kind == "c2":
         buf = synth.pac_file_bytes(5_000_000, synth.SEED_BASE + 1)
+    elif kind == "pac":
+        buf = oracle.pac_encode(oracle.synth_repeat_bases(400_003, 31))          # circular text, no terminator
     else:
         b = oracle.synth_repeat_bases(700_001, 5)
         b[400_000:440_000] = b[100_000:140_000]            # a 40-kb copy: ties that no shard can finish from its own suffixes
@@ -89,7 +92,7 @@ def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ng
     for N in (1, ngpus):
         out = str(tmp_path / ("g%d.bwt" % N))
         env = dict(os.environ, B3M_DEVICES=",".join(["0"] * N)) if N > 1 else dict(os.environ)
-        r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=%d" % bwtonly, "outputfilename=" + out, "verbose=1", "numgpus=%d" % N,
+        r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=" + itype, "bwtonly=%d" % bwtonly, "outputfilename=" + out, "verbose=1", "numgpus=%d" % N,
                             "isasamplingrate=2048", str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0, r.stderr.decode()
         if N > 1:
@@ -100,12 +103,15 @@ def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ng
     assert set(outs[1]) == set(outs[ngpus]) == ({".bwt", ".hist", ".meta", ".preisa"} if bwtonly else {".bwt", ".hist", ".meta", ".sa", ".isa"})
     for suf in outs[1]:
         assert outs[1][suf] == outs[ngpus][suf], suf
-    s = oracle.symbols_from_file_bytes(np.asarray(buf, dtype=np.uint8), "pacterm")
+    s = oracle.symbols_from_file_bytes(np.asarray(buf, dtype=np.uint8), itype)
     assert np.array_equal(_decode(L, str(tmp_path / ("g%d.bwt" % ngpus))), oracle.bwt(s))
-    # more GPUs than the machine has, without the test switch: refused with a message
-    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "numgpus=64", "outputfilename=" + str(tmp_path / "no.bwt"), str(inp)],
+    # more GPUs than the machine has, without the test switch: refused with a message; so is a byte alphabet (suffix-range shards are for pac / pacterm)
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=" + itype, "numgpus=64", "outputfilename=" + str(tmp_path / "no.bwt"), str(inp)],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={k: v for k, v in os.environ.items() if k != "B3M_DEVICES"})
     assert r.returncode != 0 and b"numgpus=64" in r.stderr
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=bytestream", "numgpus=2", "outputfilename=" + str(tmp_path / "no.bwt"), str(inp)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, B3M_DEVICES="0,0"))
+    assert r.returncode != 0 and b"numgpus > 1 constructs pac / pacterm" in r.stderr
 
 
 def test_python_compute_bwt_bytestream(gpu, oracle, tmp_path):
@@ -401,7 +407,7 @@ def test_mem_target_that_cannot_be_met_is_said_not_hidden(gpu, oracle, tmp_path)
     assert r.returncode == 0 and b"[W] mem=8388608 cannot be met" in r.stderr, r.stderr.decode()
 
 
-@pytest.mark.parametrize("kind", ["uniform", "repeat"])
+@pytest.mark.parametrize("kind", ["uniform", "repeat", "pac"])
 def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monkeypatch):
     """HOST TIER (role of the reference's mem= / tmp files, /root/reference/README.md:42,46): a plan whose memory target no merge tree can meet sorts the text as
     sequential suffix-range shards; b3m_plan_run_host sends every slice of the BWT to pinned host memory while the next shard sorts (two slice buffers in HBM).
@@ -409,6 +415,7 @@ def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monke
     torch = gpu
     from bwtb3m_amd import engine
     monkeypatch.setenv("B3M_FORCE_SPILL", "5")
+    itype = "pac" if kind == "pac" else "pacterm"
     if kind == "uniform":
         b = oracle.synth_bases(700_003, 9)
     else:
@@ -416,11 +423,11 @@ def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monke
         b[500_000:512_000] = b[40_000:52_000]                 # a 12-kb copy
         b[300_000:300_700] = 1
     buf = oracle.pac_encode(b)
-    s = oracle.symbols_from_file_bytes(buf, "pacterm")
+    s = oracle.symbols_from_file_bytes(buf, itype)
     ref = oracle.bwt(s)
     sa = oracle.sa_circular(s)
     n = len(s)
-    plan = engine.Plan(n, "pacterm", isasamplingrate=1024)
+    plan = engine.Plan(n, itype, isasamplingrate=1024)
     assert plan.host_tier == 5 and plan.num_blocks == 1
     d = torch.from_numpy(np.concatenate([buf, np.zeros(16, dtype=np.uint8)])).cuda()
     out = plan.run(d)                                          # device-resident: the caller's n bytes
