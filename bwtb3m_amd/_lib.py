@@ -91,6 +91,7 @@ SYMBOLS = [
     ("b3m_plan_samples_raw", _i, [_p, ctypes.POINTER(_p), ctypes.POINTER(_u64)]),
     ("b3m_plan_samples_device", _i, [_p, ctypes.POINTER(_p), ctypes.POINTER(_u64), ctypes.POINTER(_u64), _p]),
     ("b3m_lf_walk", _i, [_p, _u64, _i, _p, _u64, _p, _p, _u64, _u64, _p, _p, _p, _p]),
+    ("b3m_check_bwt", _i, [_cp, _cp, _cp, _i, _p]),
     ("b3m_plan_kernel_times", _i, [_p, ctypes.POINTER(KernelTime), _i]),
     ("b3m_histogram", _i, [_p, _u64, _i, _u64, _u64, _p, _p]),
     ("b3m_block_sort", _i, [_p, _u64, _i, _u64, _u64, _p, _p, _p, ctypes.POINTER(_u64), _p]),

@@ -1390,6 +1390,28 @@ static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, c
 	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
 }
 
+/* byte alphabets (and 32-bit symbols): the walk over the LF array of the whole BWT (n < 2^32) */
+static void lf_walk_bytes_any(const TextView &T, const uint8_t *d_bwt, const uint64_t *anchors, uint64_t K, uint64_t sarate, uint64_t *sa_out, uint64_t *mismatches_out, hipStream_t s)
+{
+	const uint64_t n = T.n;
+	B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
+	B3M_REQUIRE(K >= 1 && anchors[1] == 0, "anchor at position 0 missing");
+	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
+	DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
+	RadixWs rw; radix_ws_carve(rw, rws.p, n);
+	B3M_HIP(hipMemcpyAsync(danc.p, anchors, 16 * K, hipMemcpyHostToDevice, s));
+	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
+	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
+	lf_walk_bytes(T, d_bwt, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), lf.as<uint32_t>(), rw,
+	              danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
+	unsigned long long mm[2] = {0, 0};
+	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
+	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+}
+
 /* the same as a stage of its own, for a BWT that no single plan produced (the slices of suffix-range shards gathered on one GPU): d_text = the packed text on
  * the current device with at least 8 readable bytes behind it */
 int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist256, const uint64_t *sample_pairs,
@@ -1398,8 +1420,13 @@ int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_
 	B3M_TRY
 	require_device();
 	B3M_REQUIRE(d_text && d_bwt && hist256 && sample_pairs && mismatches_out && num_samples >= 1, "b3m_lf_walk: null argument");
-	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "b3m_lf_walk: pac / pacterm texts (byte alphabets: b3m_plan_lf_walk)");
+	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM || inputtype == B3M_INPUT_BYTESTREAM, "b3m_lf_walk: bytestream, pac and pacterm texts");
 	TextView T{(const uint8_t *)d_text, n, num_bases(n, inputtype), inputtype};
+	if (inputtype == B3M_INPUT_BYTESTREAM) {
+		B3M_REQUIRE(!d_sa_out, "b3m_lf_walk: SA samples of a byte text go to host memory (sa_out)");
+		lf_walk_bytes_any(T, d_bwt, sample_pairs, num_samples, sarate, sa_out, mismatches_out, (hipStream_t)stream);
+		return 0;
+	}
 	lf_walk_2bit(T, d_bwt, inputtype == B3M_INPUT_PACTERM ? p0 : ~0ull, hist256, sample_pairs, num_samples, sarate, sa_out, d_sa_out, mismatches_out, (hipStream_t)stream);
 	return 0;
 	B3M_CATCH(1)
@@ -1484,24 +1511,10 @@ static int plan_lf_walk_impl(b3m_plan *p, const uint8_t *d_bwt, uint64_t sarate,
 	uint64_t K = p->h_samples.size() / 2;
 	const std::vector<uint64_t> &anc = p->h_samples;
 	B3M_REQUIRE(anc[1] == 0, "anchor at position 0 missing");
-	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	if (p->type == B3M_INPUT_BYTESTREAM || p->type == B3M_INPUT_SYMBOLS32) {
 		B3M_REQUIRE(!d_sa_keep, "b3m_plan_lf_walk_dev: pac / pacterm plans only");
 		// byte alphabet (and wide symbols): the LF array itself (one stable sort of the BWT by symbol) instead of a rank dictionary
-		B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
-		DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
-		RadixWs rw; radix_ws_carve(rw, rws.p, n);
-		B3M_HIP(hipMemcpyAsync(danc.p, anc.data(), 16 * K, hipMemcpyHostToDevice, s));
-		B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
-		B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
-		lf_walk_bytes(T, d_bwt, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), lf.as<uint32_t>(), rw,
-		              danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
-		unsigned long long mm[2] = {0, 0};
-		B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
-		if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
-		B3M_HIP(hipStreamSynchronize(s));
-		B3M_HIP(hipGetLastError());
-		mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+		lf_walk_bytes_any(T, d_bwt, anc.data(), K, sarate, sa_out, mismatches_out, s);
 		return 0;
 	}
 	// 2-bit alphabets: rank dictionary of the whole BWT with 64-bit counts (a symbol may occur 2^32 times and more: 30 Gbase)

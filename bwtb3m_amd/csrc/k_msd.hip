@@ -1625,7 +1625,9 @@ constexpr uint64_t V3_MIN_RATE = 256;    // sampling rates below this take k_fin
 
 // THREADS = 512 (12 records per thread, 80 registers: three workgroups = 24 waves per CU) or 1024 (6 records per thread: at 64 registers two
 // workgroups = 32 waves per CU, all the CU holds; B3M_FINISH_V3=4)
-template <int WPC, int THREADS = 512>
+// NOMAP (timing only, WRONG results: B3M_FINISH_V3=5): the bucket's records are read from a contiguous range instead of through the slot -> run map: what the map's two
+// phases and the dependent loads in front of the records cost
+template <int WPC, int THREADS = 512, bool NOMAP = false>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finish_v3(FinishSrc S, int fbits, uint32_t b_first, const FinishLists *Lp, SortOut O)
 {
 	constexpr int F_THREADS = THREADS, F_CAP = 6144, F_PER = F_CAP / THREADS, F_WAVES = THREADS / 64;
@@ -1666,6 +1668,15 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
 	// ---- slots -> runs (see finish_bucket) ----
 	const uint32_t glast = (m - 1) >> 6;
+	if (NOMAP) {
+		if (tid <= glast) { gda[tid] = make_uint4(64u, 64u, 64u, s0 + (tid << 6)); gdb[tid] = make_uint4(0u, 0u, 0u, 0u); }
+		if (tid == 0) { s_slow = 0u; s_tl = 0u; s_sp = 0u; s_bl = 0u; }
+		#pragma unroll
+		for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
+		if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }
+		if (tid < 12) ent[apad + m + tid] = 0u;
+		__syncthreads();
+	} else {
 	{
 		const uint32_t *row = S.runpre + tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
 		const uint32_t tc = tid < nch ? tid : nch - 1, tn = tc + 1 < nch ? tc + 1 : tc;
@@ -1702,6 +1713,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	if (s_slow) {
 		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
 		return;
+	}
 	}
 	// the record of index e of the bucket (slot e of its rank range before sorting), through the slot -> run map
 	auto rec_adr = [&](const uint32_t e) -> uint32_t {
@@ -2712,6 +2724,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3 == 2) hipLaunchKernelGGL(k_finish_v3<2>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3 == 4) hipLaunchKernelGGL((k_finish_v3<3, 1024>), dim3(bfb - bfa), dim3(1024), 0, s, FS, fbits, bfa, dl, O);
+				else if (v3 == 5) hipLaunchKernelGGL((k_finish_v3<3, 512, true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else if (gather) {

@@ -220,6 +220,12 @@ int b3m_plan_samples_device(b3m_plan *p, const uint64_t **d_slots_out, uint64_t 
 int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist256, const uint64_t *sample_pairs,
                 uint64_t num_samples, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream);
 
+/* The reference's verifier as one call (role of `checkbwt [-i type] X.bwt text`, /root/reference/src/checkbwt.cpp:26-243): X.bwt is decoded, BWT and text go to
+ * HBM, and one LF chain per (rank,pos) pair of X.preisa -- or of X.isa, where only that exists -- is walked over the text on the device; every symbol and every
+ * chain closure is checked.  mismatches_out as b3m_plan_lf_walk; log lines ("[V] gok=1", the reference's last line) to log_fd.  bytestream, pac, pacterm.
+ * bin/checkbwt is the program. */
+int b3m_check_bwt(const char *bwt_fn, const char *text_fn, const char *inputtype, int log_fd, uint64_t *mismatches_out);
+
 /* per-kernel-family timing of the last run (HIP events on the run's stream) */
 typedef struct b3m_kernel_time { const char *name; double ms; uint64_t launches; uint64_t alg_bytes; } b3m_kernel_time;
 int b3m_plan_kernel_times(const b3m_plan *p, b3m_kernel_time *out, int cap);

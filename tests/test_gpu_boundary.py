@@ -484,6 +484,36 @@ def test_host_tier_is_taken_when_no_merge_tree_meets_mem(gpu, tmp_path):
             assert outs["free"][suf] == outs["tier"][suf], (bwtonly, suf)
 
 
+@pytest.mark.parametrize("itype,bwtonly", [("pacterm", 1), ("pacterm", 0), ("pac", 1), ("bytestream", 1)])
+def test_cli_checkbwt_verifies_on_the_device(gpu, oracle, tmp_path, itype, bwtonly):
+    """the reference's verifier as a program (/root/reference/src/checkbwt.cpp:248-285: `checkbwt [-i type] X.bwt text`): LF chains between the (rank,pos) pairs of
+    X.preisa (bwtonly=1) or X.isa (bwtonly=0), over the text, on the device; "[V] gok=1" for the files bin/bwtb3m wrote, gok=0 once the text differs in one
+    symbol; like the reference it leaves with status 0 once the walk has run, and with a message and status 1 when a file is missing."""
+    if itype == "bytestream":
+        t = oracle.synth_bytes(300_001, 77)
+        data = t.tobytes()
+    else:
+        data = oracle.pac_encode(oracle.synth_repeat_bases(400_002, 12)).tobytes()
+    text = tmp_path / "t.in"
+    text.write_bytes(data)
+    out = str(tmp_path / "t.bwt")
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=" + itype, "bwtonly=%d" % bwtonly, "isasamplingrate=4096", "outputfilename=" + out, str(text)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    c = subprocess.run([os.path.join(ROOT, "bin", "checkbwt"), "-i", itype, out, str(text)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 0 and b"[V] gok=1" in c.stderr and c.stdout == b"", c.stderr.decode()
+    bad = bytearray(data)
+    bad[len(bad) // 3] ^= 0x10                                   # one base (or byte) of the text changed
+    wrong = tmp_path / "wrong.in"
+    wrong.write_bytes(bytes(bad))
+    c = subprocess.run([os.path.join(ROOT, "bin", "checkbwt"), "-i", itype, out, str(wrong)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 0 and b"[V] gok=0" in c.stderr and b"[E] failure" in c.stderr, c.stderr.decode()
+    c = subprocess.run([os.path.join(ROOT, "bin", "checkbwt"), "-i", itype, str(tmp_path / "nope.bwt"), str(text)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 1 and c.stderr.strip() != b""
+    c = subprocess.run([os.path.join(ROOT, "bin", "checkbwt"), "-i", "klingon", out, str(text)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 1 and b"unknown/unsupported input type" in c.stderr
+
+
 @pytest.mark.gpu
 def test_seek_index_consumers_sortpreisa_and_bwtdecodeblock(gpu, oracle, tmp_path):
     """row f4, consumers of the container's seek index: X.preisa -> sorted isa (/root/reference/src/sortPreIsa.cpp:62,95-96), then text[low, low+len)
