@@ -233,6 +233,7 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 // ------------------------------------------------------------------------------------------------
 constexpr int MP_GROUP = 512, MP_ROW = 9;               // pieces above MP_GROUP slots are split further; table row = piece start >> MP_ROW
 constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
+static int tt_count_max() { const char *e = getenv("B3M_TT_COUNT"); const int v = e ? atoi(e) : TT_COUNT; return v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v); }      // measurement switch
 static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
 
 // flag[s] = 1 if the group of slot s has more than TT_GROUP members (hid[s] = list index of the group's head); flag[u] = 0
@@ -267,7 +268,7 @@ template <int MODE>
 __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint32_t *U, const uint32_t *gid, uint64_t u, uint32_t *idx,
                                                          const uint32_t *isa, uint64_t off, uint32_t *hid,
                                                          const uint64_t *kin, const uint32_t *vin, const uint32_t *pb,
-                                                         const uint64_t *kin1, const uint32_t *vin1, int kshift)
+                                                         const uint64_t *kin1, const uint32_t *vin1, int kshift, int count_max)
 {
 	// kshift = 12 where the key leaves room (pacterm: 48 bits, ranks: 32): the slot inside the tile rides in the low bits, every key of the tile is
 	// distinct and one 64-bit compare per pair orders them (0: 64-bit keys, ties are broken by the slot in a second compare)
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 	}
 	__syncthreads();
 	const uint32_t gmax = red[3];
-	if (gmax <= (uint32_t)TT_COUNT) {
+	if (gmax <= (uint32_t)count_max) {
 		// ---- every member counts the members of its group in front of it in (key, slot) order ----
 		uint64_t mk[TT_PER]; uint32_t mv[TT_PER]; uint32_t dst[TT_PER];
 		#pragma unroll
@@ -852,8 +853,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 				if (h_n == 0) any_large = false;
 			}
 			if (h_n == 0) {
-				if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
-				else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
+				if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
+				else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 			} else {
 				if (isa) hipLaunchKernelGGL(k_tie_keyvals<true>, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, (const uint32_t *)isa, h, kx, vx);
 				else hipLaunchKernelGGL(k_tie_keyvals<false>, dim3(nblk(u)), dim3(256), 0, s, T, U, idx, u, (const uint32_t *)nullptr, off, kx, vx);
@@ -876,7 +877,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 				if (dbg >= 3) fprintf(stderr, "[b3m]   large groups: %u split passes, %u slots in pieces of one key\n", passes, h_n);
 				// (the table in hid is dead: the tiles and the pieces of one key write the heads there)
 				hipLaunchKernelGGL(k_tie_tile<2>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)kx, (const uint32_t *)vx, (const uint32_t *)pid,
-				                   (const uint64_t *)ky, (const uint32_t *)vy, kshift);
+				                   (const uint64_t *)ky, (const uint32_t *)vy, kshift, tt_count_max());
 				if (h_n) hipLaunchKernelGGL(k_msd_leftover, dim3(nblk(u)), dim3(256), 0, s, (const uint32_t *)U, (const uint32_t *)gid, (const uint32_t *)pid, (const uint32_t *)vx, (const uint32_t *)vy, u, idx, hid);
 			}
 		} else {
@@ -903,8 +904,8 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			const uint64_t hu = (u + 1) / 2;
 			uint32_t *U_L = reinterpret_cast<uint32_t *>(kx + hu), *gid_L = U_L + nL, *lpos = reinterpret_cast<uint32_t *>(ky + hu);
 			if (nL) hipLaunchKernelGGL(k_tie_large_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, gid, U, u, U_L, gid_L, lpos);
-			if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
-			else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift);
+			if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
+			else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 			if (nL) tie_round_lsd(T, idx, nullptr, nullptr, U_L, gid_L, nL, kx, ky, vx, vy, hid, lpos, isa, h, off, gbits, radix, s);
 			if (dbg >= 3) fprintf(stderr, "[b3m]   tiles: %u, %llu slots of large groups through the radix sorts\n", ntile, (unsigned long long)nL);
 		}

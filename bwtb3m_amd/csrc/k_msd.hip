@@ -2517,7 +2517,10 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			uint64_t mx = 0; for (uint32_t d = lo; d < hi; ++d) mx = std::max<uint64_t>(mx, tot[d]);
 			throw Error("suffix-range shard larger than the workspace (skewed input): shard " + std::to_string(shard) + " of " + std::to_string(nshards) + " would hold " +
 			            std::to_string(len) + " suffixes (level-0 digits " + std::to_string(lo) + ".." + std::to_string(hi) + ", the heaviest has " + std::to_string(mx) +
-			            "), the workspace " + std::to_string(ws.cap) + ": use block mode or fewer shards");
+			            "), the workspace " + std::to_string(ws.cap) + (ws.no_defer
+			                ? ": the shards of this plan run one after the other inside a memory target (host tier); a shard is whole level-0 digits, and this text's heaviest one does not fit: "
+			                  "raise mem= (about 30 bytes per suffix of the heaviest digit, beside the text) or leave it out"
+			                : ": use block mode or fewer shards"));
 		}
 		// The shard's level 0 only has bins for its own digits [lo, hi).  Where the text is so long that D0 + D1 bits leave final
 		// buckets above the LDS sort's size (n > ~6 G: 30 Gbase has 2^23 of them), the shard spends the bins it does not need for

@@ -248,7 +248,7 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
             for p in plans:
                 p.close()
     except Exception as ex:   # noqa: BLE001
-        if form == 2 and "suffix-range shard larger than the workspace" in str(ex):
+        if form in (2, 5) and "suffix-range shard larger than the workspace" in str(ex):
             desc += " (shards refused: one level-0 digit heavier than a shard's slack -- the documented limit for skewed composition)"
         else:
             ok = False; desc += " EXC " + repr(ex)[:400]
