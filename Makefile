@@ -13,7 +13,7 @@ HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
 HOST_OBJS  := $(patsubst $(CSRC)/host/%.cpp,$(OBJDIR)/host_%.o,$(filter-out $(CSRC)/host/cli_%.cpp,$(HOST_SRCS)))
 HDRS       := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/host/*.h) include/b3m.h
 
-all: $(LIB) bin/bwtb3m bin/bwtb3mdecoderl bin/bwtb3mtobwa bin/sortPreIsa bin/bwtdecodeblock bin/checkbwt oracle
+all: $(LIB) bin/bwtb3m bin/bwtb3mdecoderl bin/bwtb3mtobwa bin/sortPreIsa bin/bwtdecodeblock bin/checkbwt bin/bwtcomputessa oracle
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)

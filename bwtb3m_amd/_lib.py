@@ -92,6 +92,8 @@ SYMBOLS = [
     ("b3m_plan_samples_device", _i, [_p, ctypes.POINTER(_p), ctypes.POINTER(_u64), ctypes.POINTER(_u64), _p]),
     ("b3m_lf_walk", _i, [_p, _u64, _i, _p, _u64, _p, _p, _u64, _u64, _p, _p, _p, _p]),
     ("b3m_check_bwt", _i, [_cp, _cp, _cp, _i, _p]),
+    ("b3m_lf_walk_job", _i, [_p, _p, _p]),
+    ("b3m_compute_ssa", _i, [_cp, _u64, _u64, _i]),
     ("b3m_plan_kernel_times", _i, [_p, ctypes.POINTER(KernelTime), _i]),
     ("b3m_histogram", _i, [_p, _u64, _i, _u64, _u64, _p, _p]),
     ("b3m_block_sort", _i, [_p, _u64, _i, _u64, _u64, _p, _p, _p, ctypes.POINTER(_u64), _p]),

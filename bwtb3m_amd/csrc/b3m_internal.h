@@ -289,10 +289,14 @@ void gap_walk_bytes(const TextView &T, const uint32_t *d_occ, const uint8_t *d_b
 // (counts are 64-bit: d_sb = 4 * rank_superblocks(m) u64, the counts in front of every superblock of lines; the line headers count from there)
 uint64_t rank_superblocks(uint64_t m);
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, uint64_t *d_sb, hipStream_t s);
+// extras of a walk: ISA samples (isa_out[p / isarate] = rank of the rotation at p, for the multiples of isarate: bwtcomputessa makes X.isa from a sparser X.preisa this way) and
+// nocheck (no text to compare the symbols with: T.b is not read; the chain closures are still checked)
+struct LfExtra { uint64_t isarate = 0; uint64_t *d_isa_out = nullptr; bool nocheck = false; };
 void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
-             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
+             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s, const LfExtra &X = LfExtra());
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
-                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s);
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s,
+                   const LfExtra &X = LfExtra());
 void interleave(const uint32_t *d_sr, const uint8_t *d_bwtL, uint64_t m, const uint8_t *d_bwtR, uint64_t mr,
                 uint8_t *d_out, uint32_t *d_tile_q /* scratch: tiles+1 */, hipStream_t s);
 uint64_t interleave_tiles(uint64_t total);

@@ -1365,14 +1365,17 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
  * terminator, [1..4] the bases; pac: [0..3]); anchors: K (rank,pos) pairs in position order, the first at position 0 (host); p0 = rank of the terminator entry
  * (~0: none).  SA samples go to sa_out (host) and/or stay in d_sa_keep (device, ceil(n/sarate) u64) for a caller that streams them out itself. */
 static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist, const uint64_t *anchors, uint64_t K, uint64_t sarate,
-                         uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, hipStream_t s)
+                         uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, hipStream_t s, uint64_t isarate = 0, uint64_t *isa_out = nullptr, bool nocheck = false)
 {
 	const uint64_t n = T.n;
 	B3M_REQUIRE(K >= 1 && anchors[1] == 0, "anchor at position 0 missing");
 	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
 	const uint64_t nb = rank_blocks(n), nsb = rank_superblocks(n);
-	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), sb(32 * nsb + 64), p0d(16), danc(16 * K), dsa(d_sa_keep ? 16 : 8 * (nsa + 1)), dmis(16);
+	const uint64_t nisa = (isarate && isa_out) ? (n + isarate - 1) / isarate : 0;
+	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), sb(32 * nsb + 64), p0d(16), danc(16 * K), dsa(d_sa_keep ? 16 : 8 * (nsa + 1)), dmis(16), disa(8 * (nisa + 1));
 	uint64_t *d_sa = d_sa_keep ? d_sa_keep : dsa.as<uint64_t>();
+	if (nisa) B3M_HIP(hipMemsetAsync(disa.p, 0xFF, 8 * nisa, s));
+	LfExtra X; X.isarate = nisa ? isarate : 0; X.d_isa_out = disa.as<uint64_t>(); X.nocheck = nocheck;
 	B3M_HIP(hipMemcpyAsync(p0d.p, &p0, 8, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemcpyAsync(danc.p, anchors, 16 * K, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
@@ -1381,35 +1384,63 @@ static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, c
 	uint64_t C[4];
 	if (T.type == B3M_INPUT_PACTERM) { uint64_t acc = hist[0]; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += hist[c + 1]; } }
 	else { uint64_t acc = 0; for (int c = 0; c < 4; ++c) { C[c] = acc; acc += hist[c]; } }
-	lf_walk(T, blocks.as<uint32_t>(), sb.as<uint64_t>(), p0, C, danc.as<uint64_t>(), K, sarate, d_sa, dmis.as<unsigned long long>(), s);
+	lf_walk(T, blocks.as<uint32_t>(), sb.as<uint64_t>(), p0, C, danc.as<uint64_t>(), K, sarate, d_sa, dmis.as<unsigned long long>(), s, X);
 	unsigned long long mm[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
 	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, d_sa, 8 * nsa, hipMemcpyDeviceToHost, s));
+	if (nisa) B3M_HIP(hipMemcpyAsync(isa_out, disa.p, 8 * nisa, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
 	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
 }
 
 /* byte alphabets (and 32-bit symbols): the walk over the LF array of the whole BWT (n < 2^32) */
-static void lf_walk_bytes_any(const TextView &T, const uint8_t *d_bwt, const uint64_t *anchors, uint64_t K, uint64_t sarate, uint64_t *sa_out, uint64_t *mismatches_out, hipStream_t s)
+static void lf_walk_bytes_any(const TextView &T, const uint8_t *d_bwt, const uint64_t *anchors, uint64_t K, uint64_t sarate, uint64_t *sa_out, uint64_t *mismatches_out, hipStream_t s,
+                              uint64_t isarate = 0, uint64_t *isa_out = nullptr, bool nocheck = false)
 {
 	const uint64_t n = T.n;
 	B3M_REQUIRE(n < (1ull << 32), "byte LF walk: n out of range");
 	B3M_REQUIRE(K >= 1 && anchors[1] == 0, "anchor at position 0 missing");
 	const uint64_t nsa = sarate ? (n + sarate - 1) / sarate : 0;
-	DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16);
+	const uint64_t nisa = (isarate && isa_out) ? (n + isarate - 1) / isarate : 0;
+	DevBuf k0(8 * n), k1(8 * n), v0(4 * n), v1(4 * n), lf(4 * n), rws(radix_ws_bytes(n)), danc(16 * K), dsa(8 * (nsa + 1)), dmis(16), disa(8 * (nisa + 1));
 	RadixWs rw; radix_ws_carve(rw, rws.p, n);
+	if (nisa) B3M_HIP(hipMemsetAsync(disa.p, 0xFF, 8 * nisa, s));
+	LfExtra X; X.isarate = nisa ? isarate : 0; X.d_isa_out = disa.as<uint64_t>(); X.nocheck = nocheck;
 	B3M_HIP(hipMemcpyAsync(danc.p, anchors, 16 * K, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
 	B3M_HIP(hipMemsetAsync(dsa.p, 0xFF, 8 * (nsa + 1), s));
 	lf_walk_bytes(T, d_bwt, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), lf.as<uint32_t>(), rw,
-	              danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s);
+	              danc.as<uint64_t>(), K, sarate, dsa.as<uint64_t>(), dmis.as<unsigned long long>(), s, X);
 	unsigned long long mm[2] = {0, 0};
 	B3M_HIP(hipMemcpyAsync(mm, dmis.p, 16, hipMemcpyDeviceToHost, s));
 	if (nsa && sa_out) B3M_HIP(hipMemcpyAsync(sa_out, dsa.p, 8 * nsa, hipMemcpyDeviceToHost, s));
+	if (nisa) B3M_HIP(hipMemcpyAsync(isa_out, disa.p, 8 * nisa, hipMemcpyDeviceToHost, s));
 	B3M_HIP(hipStreamSynchronize(s));
 	B3M_HIP(hipGetLastError());
 	mismatches_out[0] = mm[0]; mismatches_out[1] = mm[1];
+}
+
+/* the walks as one job description: everything b3m_lf_walk takes, plus ISA samples (isa_out[i] = rank of the rotation at position i * isarate, host) and a text that may
+ * be absent (d_text = NULL: the symbols are not compared, the chain closures still are): what bwtcomputessa needs (/root/reference/src/bwtcomputessa.cpp:39-51) */
+int b3m_lf_walk_job(const b3m_lf_job *j, uint64_t *mismatches_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(j && j->d_bwt && j->hist256 && j->sample_pairs && mismatches_out && j->num_samples >= 1, "b3m_lf_walk_job: null argument");
+	B3M_REQUIRE(j->inputtype == B3M_INPUT_PAC || j->inputtype == B3M_INPUT_PACTERM || j->inputtype == B3M_INPUT_BYTESTREAM, "b3m_lf_walk_job: bytestream, pac and pacterm texts");
+	static const uint8_t no_text[64] = {0};
+	const bool nocheck = j->d_text == nullptr;
+	TextView T{nocheck ? no_text : (const uint8_t *)j->d_text, j->n, num_bases(j->n, j->inputtype), j->inputtype};
+	if (j->inputtype == B3M_INPUT_BYTESTREAM) {
+		B3M_REQUIRE(!j->d_sa_out, "b3m_lf_walk_job: SA samples of a byte text go to host memory (sa_out)");
+		lf_walk_bytes_any(T, j->d_bwt, j->sample_pairs, j->num_samples, j->sarate, j->sa_out, mismatches_out, (hipStream_t)stream, j->isarate, j->isa_out, nocheck);
+		return 0;
+	}
+	lf_walk_2bit(T, j->d_bwt, j->inputtype == B3M_INPUT_PACTERM ? j->p0 : ~0ull, j->hist256, j->sample_pairs, j->num_samples, j->sarate, j->sa_out, j->d_sa_out, mismatches_out,
+	             (hipStream_t)stream, j->isarate, j->isa_out, nocheck);
+	return 0;
+	B3M_CATCH(1)
 }
 
 /* the same as a stage of its own, for a BWT that no single plan produced (the slices of suffix-range shards gathered on one GPU): d_text = the packed text on

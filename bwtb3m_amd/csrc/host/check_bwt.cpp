@@ -117,3 +117,75 @@ extern "C" int b3m_check_bwt(const char *bwt_fn, const char *text_fn, const char
 		return 1;
 	}
 }
+
+// b3m_compute_ssa: bwtcomputessa (/root/reference/src/bwtcomputessa.cpp:24-58; the pipeline of /root/reference/README.md:63-67): X.sa and X.isa from X.bwt and the hint
+// file X.preisa, without the text.  The symbols say which walk: {0 once, 1..4} = a pacterm text (2-bit rank dictionary, the 0 is the terminator entry), at most {0..3} = a
+// circular 2-bit text, anything else the byte LF array (fewer than 2^32 symbols).
+extern "C" int b3m_compute_ssa(const char *bwt_fn, uint64_t sasamplingrate, uint64_t isasamplingrate, int log_fd)
+{
+	uint8_t *d_bwt = nullptr;
+	auto cleanup = [&]() { if (d_bwt) (void)hipFree(d_bwt); b3m::staging_release(); };
+	try {
+		if (!bwt_fn) throw std::runtime_error("b3m_compute_ssa: null argument");
+		const uint64_t sarate = sasamplingrate ? sasamplingrate : 32, isarate = isasamplingrate ? isasamplingrate : 32;
+		const std::string bwtname = bwt_fn, prefix = b3m::clip_off(bwtname, ".bwt");
+		const unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+		const uint64_t n = b3m::rl_length(bwtname);
+		if (n == 0) throw std::runtime_error("bwtcomputessa: " + bwtname + " is empty");
+		std::vector<uint8_t> sym(n);
+		bool bad = false;
+		if (b3m::rl_decode_array(bwtname, sym.data(), n, threads, &bad) != n || bad) throw std::runtime_error("bwtcomputessa: " + bwtname + " does not decode to " + std::to_string(n) + " byte symbols");
+		// symbol counts: X.hist (reader /root/reference/src/bwtdecodeblock.cpp:150-173) or counted from the BWT (a permutation of the text)
+		uint64_t hist[256] = {0};
+		if (b3m::file_exists(prefix + ".hist")) { for (auto &kv : b3m::read_hist(prefix + ".hist")) if (kv.first >= 0 && kv.first < 256) hist[kv.first] = kv.second; }
+		else for (uint64_t i = 0; i < n; ++i) hist[sym[i]]++;
+		int maxsym = 0; for (int c = 0; c < 256; ++c) if (hist[c]) maxsym = c;
+		const int type = (maxsym <= 4 && maxsym == 4 && hist[0] == 1) ? B3M_INPUT_PACTERM : (maxsym <= 3 ? B3M_INPUT_PAC : B3M_INPUT_BYTESTREAM);
+		uint64_t p0 = 0;
+		if (type == B3M_INPUT_PACTERM) { const void *z = memchr(sym.data(), 0, n); if (!z) throw std::runtime_error("bwtcomputessa: X.hist names a terminator the BWT does not hold"); p0 = (uint64_t)((const uint8_t *)z - sym.data()); }
+		if (type == B3M_INPUT_BYTESTREAM && n >= (1ull << 32)) throw std::runtime_error("bwtcomputessa: byte alphabets of 2^32 symbols and more are not supported");
+		if (!b3m::file_exists(prefix + ".preisa")) throw std::runtime_error("bwtcomputessa: " + prefix + ".preisa does not exist (the hint file bwtb3m writes with bwtonly=1)");
+		std::vector<uint8_t> raw = b3m::read_file(prefix + ".preisa");
+		if (raw.size() % 16 || raw.empty()) throw std::runtime_error(prefix + ".preisa: size is not a positive multiple of 16");
+		std::vector<uint64_t> pairs(raw.size() / 8);
+		memcpy(pairs.data(), raw.data(), raw.size());
+		const uint64_t K = pairs.size() / 2;
+		{
+			bool sorted = true;
+			for (uint64_t i = 1; i < K && sorted; ++i) sorted = pairs[2 * i + 1] > pairs[2 * i - 1];
+			if (!sorted) {
+				std::vector<std::pair<uint64_t, uint64_t>> v(K);
+				for (uint64_t i = 0; i < K; ++i) v[i] = {pairs[2 * i + 1], pairs[2 * i]};
+				std::sort(v.begin(), v.end());
+				for (uint64_t i = 0; i < K; ++i) { pairs[2 * i] = v[i].second; pairs[2 * i + 1] = v[i].first; }
+			}
+			for (uint64_t i = 0; i < K; ++i) if (pairs[2 * i] >= n || pairs[2 * i + 1] >= n) throw std::runtime_error("bwtcomputessa: a (rank,pos) pair of " + prefix + ".preisa lies outside the text");
+		}
+		if (pairs[1] != 0) throw std::runtime_error("bwtcomputessa: " + prefix + ".preisa has no pair for position 0");
+		HIPCHK(hipMalloc((void **)&d_bwt, n + 16));
+		HIPCHK(hipMemcpy(d_bwt, sym.data(), n, hipMemcpyHostToDevice));
+		std::vector<uint8_t>().swap(sym);
+		std::vector<uint64_t> sa((n + sarate - 1) / sarate), isa((n + isarate - 1) / isarate);
+		b3m_lf_job job;
+		memset(&job, 0, sizeof job);
+		job.d_text = nullptr; job.n = n; job.inputtype = type; job.d_bwt = d_bwt; job.p0 = p0; job.hist256 = hist;
+		job.sample_pairs = pairs.data(); job.num_samples = K; job.sarate = sarate; job.sa_out = sa.data(); job.isarate = isarate; job.isa_out = isa.data();
+		uint64_t mm[2] = {0, 0};
+		logf(log_fd, "[V] bwtcomputessa: %llu symbols (%s walk), %llu chains, SA rate %llu, ISA rate %llu\n", (unsigned long long)n,
+		     type == B3M_INPUT_BYTESTREAM ? "byte LF array" : (type == B3M_INPUT_PACTERM ? "2-bit dictionary, terminated" : "2-bit dictionary"), (unsigned long long)K,
+		     (unsigned long long)sarate, (unsigned long long)isarate);
+		if (b3m_lf_walk_job(&job, mm, nullptr)) throw std::runtime_error(b3m_last_error());
+		if (mm[1]) throw std::runtime_error("bwtcomputessa: " + std::to_string(mm[1]) + " chains do not arrive at the rank of their pair: " + bwtname + " and " + prefix + ".preisa do not belong together");
+		for (uint64_t v : sa) if (v == ~0ull) throw std::runtime_error("bwtcomputessa: internal: a suffix array sample was not reached");
+		for (uint64_t v : isa) if (v == ~0ull) throw std::runtime_error("bwtcomputessa: internal: an inverse suffix array sample was not reached");
+		b3m::write_sampled(prefix + ".sa", sarate, sa);
+		b3m::write_sampled(prefix + ".isa", isarate, isa);
+		logf(log_fd, "[V] wrote %s.sa and %s.isa\n", prefix.c_str(), prefix.c_str());
+		cleanup();
+		return 0;
+	} catch (const std::exception &e) {
+		b3m::set_error(e.what());
+		cleanup();
+		return 1;
+	}
+}

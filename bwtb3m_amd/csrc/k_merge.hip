@@ -592,6 +592,7 @@ struct LfWalkArgs {
 	uint64_t sarate;                // 0: no SA samples
 	uint64_t *sa_out;               // ceil(n / sarate) positions
 	unsigned long long *mismatch;   // [0] symbol mismatches, [1] chain closure mismatches
+	uint64_t isarate; uint64_t *isa_out; int nocheck;      // LfExtra
 };
 __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 {
@@ -606,26 +607,28 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	const uint64_t pend = A.anchors[2 * k + 1];
 	uint32_t bad = 0;
 	// the text is read 16 bases (one big-endian word) at a time, one word ahead of the walk
+	const bool chk = !A.nocheck;
 	const uint32_t *tw = reinterpret_cast<const uint32_t *>(T.b);
 	uint64_t wi = p > pend ? (p - 1) >> 4 : 0;
-	uint32_t word = p > pend ? __builtin_bswap32(tw[wi]) : 0u, wnext = (p > pend && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
+	uint32_t word = (chk && p > pend) ? __builtin_bswap32(tw[wi]) : 0u, wnext = (chk && p > pend && wi > 0) ? __builtin_bswap32(tw[wi - 1]) : 0u;
 	while (p > pend) {
 		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
+		if (A.isarate && (p == T.n ? 0 : p) % A.isarate == 0) A.isa_out[(p == T.n ? 0 : p) / A.isarate] = r;
 		if (r >= T.n) { bad += 1; break; }                 // a corrupt BWT can send the walk anywhere: stop the chain (counted: symbol mismatch + closure)
 		const uint64_t q = p - 1;
-		if ((q >> 4) != wi) { wi = q >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
+		if (chk && (q >> 4) != wi) { wi = q >> 4; word = wnext; wnext = wi > 0 ? __builtin_bswap32(tw[wi - 1]) : 0u; }
 		const uint32_t base = (word >> (2u * (15u - (uint32_t)(q & 15)))) & 3u;
 		const uint32_t st = term ? (q == T.n - 1 ? 0u : base + 1u) : base;     // symbol preceding the rotation at p
 		uint64_t nr;
 		if (term && r == p0) {                          // the BWT holds the terminator here
-			bad += st != 0;
+			bad += (chk && st != 0) ? 1u : 0u;
 			nr = 0;                                      // the rotation starting with the terminator is the smallest
 		} else {
 			const uint64_t b = r / RANK_BLK_SYMS; const uint32_t off = (uint32_t)(r - b * RANK_BLK_SYMS);
 			uint32_t word = A.rd.blocks[b * 16 + 4 + (off >> 4)];
 			uint32_t code = (word >> (2 * (off & 15))) & 3u;
 			uint32_t sb = term ? code + 1 : code;
-			bad += sb != st;
+			bad += (chk && sb != st) ? 1u : 0u;
 			nr = A.rd.C[code] + rank_query64(A.rd.blocks, A.rd.sb, A.rd.sbshift, p0, code, r);
 		}
 		r = nr; --p;
@@ -634,9 +637,10 @@ __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 	if (r != A.anchors[2 * k]) atomicAdd(&A.mismatch[1], 1ull);
 }
 void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
-             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
+             uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s, const LfExtra &X)
 {
-	LfWalkArgs A{T, RankDict64{d_blocks, d_sb, rank_sb_shift(), T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	LfWalkArgs A{T, RankDict64{d_blocks, d_sb, rank_sb_shift(), T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch,
+	             X.isarate, X.d_isa_out, X.nocheck ? 1 : 0};
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
 }
 
@@ -656,6 +660,7 @@ __global__ void k_lf_from_sorted(const uint32_t *sorted_idx, uint64_t n, uint32_
 struct LfWalkBytesArgs {
 	TextView T; const uint8_t *bwt; const uint32_t *lf;
 	const uint64_t *anchors; uint64_t nanchors; uint64_t sarate; uint64_t *sa_out; unsigned long long *mismatch;
+	uint64_t isarate; uint64_t *isa_out; int nocheck;      // LfExtra
 };
 __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 {
@@ -669,8 +674,11 @@ __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 	uint32_t bad = 0;
 	while (p > pend) {
 		if (A.sarate && r % A.sarate == 0) A.sa_out[r / A.sarate] = (p == T.n ? 0 : p);
-		const uint32_t have = T.type == B3M_INPUT_SYMBOLS32 ? reinterpret_cast<const uint32_t *>(A.bwt)[r] : A.bwt[r];
-		bad += have != sym_at(T, p - 1);                // the symbol preceding the rotation at p
+		if (A.isarate && (p == T.n ? 0 : p) % A.isarate == 0) A.isa_out[(p == T.n ? 0 : p) / A.isarate] = r;
+		if (!A.nocheck) {
+			const uint32_t have = T.type == B3M_INPUT_SYMBOLS32 ? reinterpret_cast<const uint32_t *>(A.bwt)[r] : A.bwt[r];
+			bad += have != sym_at(T, p - 1);            // the symbol preceding the rotation at p
+		}
 		r = A.lf[r]; --p;
 	}
 	if (bad) atomicAdd(&A.mismatch[0], (unsigned long long)bad);
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(256) void k_lf_walk_bytes(LfWalkBytesArgs A)
 }
 // d_keys/d_keys2 (n u64 each), d_vals/d_vals2 (n u32 each): sort buffers; d_lf: n u32
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,
-                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s)
+                   RadixWs &rw, const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate, uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s, const LfExtra &X)
 {
 	const uint64_t n = T.n;
 	const int wide = T.type == B3M_INPUT_SYMBOLS32;      // (d_bwt: n uint32 symbols below 2^21)
@@ -686,7 +694,7 @@ void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, ui
 	uint64_t *rk; uint32_t *rv;
 	radix_sort_u64(d_keys, d_vals, d_keys2, d_vals2, n, wide ? WIDE_BITS : 8, rw, s, nullptr, &rk, &rv);
 	hipLaunchKernelGGL(k_lf_from_sorted, dim3(nblk(n)), dim3(256), 0, s, rv, n, d_lf);
-	LfWalkBytesArgs A{T, d_bwt, d_lf, d_anchors, nanchors, sarate, d_sa_out, d_mismatch};
+	LfWalkBytesArgs A{T, d_bwt, d_lf, d_anchors, nanchors, sarate, d_sa_out, d_mismatch, X.isarate, X.d_isa_out, X.nocheck ? 1 : 0};
 	if (nanchors) hipLaunchKernelGGL(k_lf_walk_bytes, dim3(nblk(nanchors)), dim3(256), 0, s, A);
 }
 

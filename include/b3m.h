@@ -220,6 +220,23 @@ int b3m_plan_samples_device(b3m_plan *p, const uint64_t **d_slots_out, uint64_t 
 int b3m_lf_walk(const void *d_text, uint64_t n, int inputtype, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist256, const uint64_t *sample_pairs,
                 uint64_t num_samples, uint64_t sarate, uint64_t *sa_out, uint64_t *d_sa_out, uint64_t *mismatches_out, void *stream);
 
+/* The walks as one job description: what b3m_lf_walk takes, plus ISA samples (isa_out[i] = rank of the rotation at position i * isarate: host memory, ceil(n/isarate)
+ * entries) and a text that may be absent (d_text = NULL: symbols are not compared, chain closures still are).  Role of BwtComputeSSA::computeSSA
+ * (/root/reference/src/bwtcomputessa.cpp:39-51): X.sa and X.isa at any rates from X.bwt and the sparser pairs of X.preisa, no text needed. */
+typedef struct b3m_lf_job {
+	const void    *d_text;          /* packed text on the device, or NULL */
+	uint64_t       n; int inputtype;
+	const uint8_t *d_bwt; uint64_t p0; const uint64_t *hist256;
+	const uint64_t *sample_pairs; uint64_t num_samples;      /* (rank,pos) in position order, the first at position 0 (host) */
+	uint64_t       sarate;  uint64_t *sa_out;  uint64_t *d_sa_out;
+	uint64_t       isarate; uint64_t *isa_out;
+} b3m_lf_job;
+int b3m_lf_walk_job(const b3m_lf_job *job, uint64_t *mismatches_out, void *stream);
+/* bwtcomputessa as one call (/root/reference/README.md:63-67: after bwtonly=1, X.preisa is the hint file for "the bwtcomputessa program to compute a sampled suffix array
+ * and sampled inverse suffix array"): X.bwt is decoded, the chains between the pairs of X.preisa are walked on the device, X.sa and X.isa are written (layout of
+ * /root/reference/src/sasubsample.cpp:34-57).  Defaults of the reference's program: both rates 32.  bin/bwtcomputessa is the program. */
+int b3m_compute_ssa(const char *bwt_fn, uint64_t sasamplingrate, uint64_t isasamplingrate, int log_fd);
+
 /* The reference's verifier as one call (role of `checkbwt [-i type] X.bwt text`, /root/reference/src/checkbwt.cpp:26-243): X.bwt is decoded, BWT and text go to
  * HBM, and one LF chain per (rank,pos) pair of X.preisa -- or of X.isa, where only that exists -- is walked over the text on the device; every symbol and every
  * chain closure is checked.  mismatches_out as b3m_plan_lf_walk; log lines ("[V] gok=1", the reference's last line) to log_fd.  bytestream, pac, pacterm.

@@ -514,6 +514,43 @@ def test_cli_checkbwt_verifies_on_the_device(gpu, oracle, tmp_path, itype, bwton
     assert c.returncode == 1 and b"unknown/unsupported input type" in c.stderr
 
 
+@pytest.mark.parametrize("itype", ["pacterm", "pac", "bytestream"])
+def test_cli_bwtcomputessa_after_bwtonly1(gpu, oracle, tmp_path, itype):
+    """the documented pipeline of bwtonly=1 (/root/reference/README.md:63-67): bwtb3m writes the hint file X.preisa, `bwtcomputessa [sasamplingrate=] [isasamplingrate=] X.bwt`
+    (/root/reference/src/bwtcomputessa.cpp:24-58) makes X.sa and X.isa from X.bwt and the hints alone -- here by LF walks on the device, no text: the samples must be the
+    oracle's, at rates finer than the hint file's; hints of another text are refused."""
+    if itype == "bytestream":
+        data = oracle.synth_bytes(250_003, 78).tobytes()
+        s = np.frombuffer(data, dtype=np.uint8)
+    else:
+        buf = oracle.pac_encode(oracle.synth_repeat_bases(350_001, 13))
+        data = buf.tobytes()
+        s = oracle.symbols_from_file_bytes(buf, itype)
+    text = tmp_path / "t.in"
+    text.write_bytes(data)
+    out = str(tmp_path / "t.bwt")
+    r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=" + itype, "bwtonly=1", "outputfilename=" + out, str(text)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and not os.path.exists(out[:-4] + ".sa"), r.stderr.decode()
+    c = subprocess.run([os.path.join(ROOT, "bin", "bwtcomputessa"), "sasamplingrate=16", "isasamplingrate=8", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 0, c.stderr.decode()
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    isa = np.empty_like(sa); isa[sa] = np.arange(n)
+    fsa = np.fromfile(out[:-4] + ".sa", dtype=np.uint64)
+    fisa = np.fromfile(out[:-4] + ".isa", dtype=np.uint64)
+    assert int(fsa[0]) == 16 and int(fsa[1]) == (n + 15) // 16 and np.array_equal(fsa[2:].astype(np.int64), sa[::16])
+    assert int(fisa[0]) == 8 and int(fisa[1]) == (n + 7) // 8 and np.array_equal(fisa[2:].astype(np.int64), isa[::8])
+    # default rates of the program: 32 / 32
+    c = subprocess.run([os.path.join(ROOT, "bin", "bwtcomputessa"), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode == 0 and int(np.fromfile(out[:-4] + ".sa", dtype=np.uint64)[0]) == 32 and int(np.fromfile(out[:-4] + ".isa", dtype=np.uint64)[0]) == 32
+    # hints that belong to another BWT: the chains do not close
+    pre = np.fromfile(out[:-4] + ".preisa", dtype=np.uint64).reshape(-1, 2).copy()
+    pre[5:40, 0] = pre[5:40, 0][::-1]
+    pre.tofile(out[:-4] + ".preisa")
+    c = subprocess.run([os.path.join(ROOT, "bin", "bwtcomputessa"), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert c.returncode != 0 and b"do not belong together" in c.stderr, c.stderr.decode()
+
+
 @pytest.mark.gpu
 def test_seek_index_consumers_sortpreisa_and_bwtdecodeblock(gpu, oracle, tmp_path):
     """row f4, consumers of the container's seek index: X.preisa -> sorted isa (/root/reference/src/sortPreIsa.cpp:62,95-96), then text[low, low+len)
