@@ -595,7 +595,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	}
 	const uint64_t n = p->n, B = p->leaves.size();
 	Timeline *tl = &p->tl;
-	tl->reset(); tl->stream = s; tl->enabled = true;
+	tl->reset(); tl->stream = s; tl->enabled = !(getenv("B3M_NO_TIMELINE") && atoi(getenv("B3M_NO_TIMELINE")));      // (measurement switch: no per-family HIP events)
 	hipEvent_t ev0 = tl->get(), ev1 = tl->get();
 	TextArrival arrival{}; bool streaming_text = false;
 	if (host) {
