@@ -160,10 +160,17 @@ struct SliceHook { int nslices; void (*fn)(void *ctx, uint64_t first, uint64_t l
 // bytes_ready[i] bytes of the packed text are in place.  The chunk-local level 0 needs no global pass over the text before it starts,
 // so it runs piece by piece behind the copy; every other path waits for the last event first.
 struct TextArrival { int n; hipEvent_t ev[16]; uint64_t bytes_ready[16]; };
+// suffixes that the direct comparisons of the record sort (k_tie_fix: records with equal key fields, groups of up to 32) have placed for good although they agree with a
+// neighbour on `keys` sort keys or more: prefix doubling on a list alone must be able to look their rank up (tie_rounds_sparse); keys = 0: none are collected
+struct TieExtras { uint32_t *cnt = nullptr, *slot = nullptr, *pos_lo = nullptr; uint8_t *pos_hi = nullptr; uint32_t cap = 0, keys = 0; };
 struct BlockSortWs {
 	uint64_t cap = 0;                 // max block length
 	bool no_defer = false;            // suffix-range shards run one after the other by ONE plan (texts below 2^32 symbols in the host tier): nobody gathers the shards' suffix
-	                                  // arrays, so a shard finishes its long repeats itself, by key-extension rounds to the end
+	                                  // arrays, so a shard finishes its long repeats itself, by key-extension rounds to the end -- unless the plan keeps a list of tied suffixes
+	                                  // over all its shards (sparse_room entries still free there): then the shard stops after the usual few rounds and hands over what is left
+	                                  // (out.tie_left, out.tie_depth), which the plan finishes by prefix doubling on that list alone (engine.hip: sparse_tie_finish)
+	uint64_t sparse_room = 0;
+	TieExtras extras;                 // (with sparse_room: where the shard lists what its direct comparisons placed among long repeats)
 	uint64_t *keyA = nullptr, *keyB = nullptr;   // LSD: key ping-pong ; MSD: 8-byte records A/B
 	uint32_t *idxA = nullptr, *idxB = nullptr;   // LSD: idx ping-pong ; MSD: idxA = suffix array
 	uint8_t *sa_hi = nullptr;                    // texts of 2^32 symbols and more: bits 32.. of the suffix array entries (MSD path)
@@ -196,6 +203,9 @@ struct BlockSortOut {
 	bool used_msd = false;
 	uint64_t tie_left = 0;            // suffix-range shard: slots still tied after the local rounds (finished globally), their list and labels in ws
 	uint32_t *tie_U = nullptr, *tie_gid = nullptr;
+	uint64_t tie_depth = 0;           // symbols every group of that list agrees on (in the text itself: the key rounds have seen them)
+	uint64_t extras = 0;              // entries the shard's direct comparisons added to ws.extras (may exceed its cap: then the plan's list is incomplete)
+	bool tie_refused = false;         // a sequential shard had more tied suffixes left than the plan's list had room for: it finished them itself (key extension to the end)
 	bool late_writes = false;         // slices handed to the hook were written again later (listed buckets, overflow list): copy the whole result again
 	bool symhist_done = false;        // ws.d_symhist_out was filled
 	bool samples_done = false;        // ws.samples was served: every sample of a suffix sorted here sits in its slot
@@ -229,6 +239,11 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
                     uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0, uint8_t *idx_hi = nullptr, uint8_t *tmp_hi = nullptr,
                     uint64_t sym_off = 0, bool isa_sparse = false);      // isa_sparse: entries may be unset (isa_sparse_from_slots); sym_off: symbols every group of the list shares in front of depth0's key (the record sort's reading: key_at_off)
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
+// prefix doubling on a list alone (k_blocksort.hip): the plans that run suffix-range shards one after the other finish the union of what the shards left tied with it
+void sparse_rank_placed(const uint64_t *pos, uint64_t cnt, const uint64_t *xpos, const uint64_t *xrank, uint64_t nx, uint64_t *rank, hipStream_t s);
+uint64_t tie_rounds_sparse(const TextView &T, uint32_t *idx, uint8_t *idx_hi, uint8_t *tmp_hi, uint64_t slots, uint64_t u, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
+                           uint32_t *scan_ws, RadixWs &radix, const uint64_t *pos, uint64_t *rank, const uint64_t *gslot, uint64_t cnt, uint32_t *d_missing,
+                           uint64_t d0, uint64_t X, hipStream_t s, uint64_t *left, uint32_t *missing);
 // the inverse suffix array with entries for the listed slots only (their suffix -> the slot), every other one unset: tie_rounds(..., isa_sparse = true)
 void isa_sparse_from_slots(const uint32_t *d_sa, uint64_t len, const uint32_t *d_slots, uint64_t total, uint32_t *d_isa, hipStream_t s);
 void emit_bwt_list(const TextView &T, const uint32_t *U, uint64_t u, const uint32_t *d_sa, uint64_t start, uint8_t *d_bwt, uint32_t *d_p0, hipStream_t s,

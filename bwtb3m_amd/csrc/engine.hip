@@ -2,6 +2,7 @@
 // device-level entry points (include/b3m.h).  Role of
 // libmaus2::suffixsort::bwtb3m::BwtMergeSortTemplate::computeBwt steps 3-9.
 #include "b3m_internal.h"
+#include "b3m_text.h"
 #include <atomic>
 #include <thread>
 #include <algorithm>
@@ -182,10 +183,33 @@ struct b3m_plan {
 	int packed_out = 0;                    // host-memory runs hand the BWT over 2-bit packed (b3m_plan_set_packed_output)
 	uint8_t *d_pack = nullptr;             // its device image
 	b3m_e2e_times e2e{};
+	// sequential suffix-range shards (texts of 2^32 symbols and more, the host tier): what the shards' few key-extension rounds leave tied, in rank order over all shards
+	// (slot inside the shard, position, first of its group), and what their direct comparisons placed among long repeats (TieExtras); finished by prefix doubling on
+	// that list alone when the last shard is through (sparse_tie_finish).  10 bytes per entry, cap entries of each kind.
+	struct SparseTies {
+		uint64_t cap = 0;
+		uint32_t *slot = nullptr, *pos_lo = nullptr; uint8_t *pos_hi = nullptr, *head = nullptr;       // tied
+		uint32_t *xslot = nullptr, *xpos_lo = nullptr; uint8_t *xpos_hi = nullptr; uint32_t *xcnt = nullptr;      // placed, but among long repeats
+		struct Part { uint64_t first, count, xfirst, xcount, slice_off; };
+		std::vector<Part> parts;
+		uint64_t count = 0, xcount = 0, dmin = 0, dmax = 0;
+		bool complete = true;
+	} sp;
 };
 
 static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
 
+// entries of each kind a plan of sequential shards keeps for the long repeats of its text (b3m_plan::SparseTies): a tenth of a shard's sort (the finish works in the
+// sort's buffers: 2 + 3 * 2 tenths of its record buffers), i.e. 2 bytes per suffix of a shard beside the ~50 of its sort.  B3M_SPARSE_TIES=c: at most c entries (test
+// switch; 0: the shards finish their repeats themselves, as before round 4)
+static uint64_t sparse_ties_cap(uint64_t n, uint64_t shard_cap)
+{
+	const char *e = getenv("B3M_SPARSE_TIES");
+	uint64_t c = shard_cap / 10;
+	if (n >= (1ull << 32)) c = std::min<uint64_t>(c, shard_cap / 16);      // (the list buffers of such a sort: tie_cap)
+	if (e) c = std::min<uint64_t>(c, strtoull(e, nullptr, 10));
+	return c;
+}
 static void chains_for(uint64_t mr, uint64_t &chain_len, uint64_t &num_chains)
 {
 	const uint64_t target = 512ull * 1024;      // lanes to fill: 256 CUs x 32 waves x 64
@@ -328,7 +352,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 			// (the arena of such a plan, as it is carved below: text, two slice buffers, one shard's sort, the sample table, small tables)
 			auto seq_arena = [&](uint64_t cap) {
 				const uint64_t nsmp = isasamplingrate ? (n + isasamplingrate - 1) / isasamplingrate : 0;
-				return al256(al256(packed_text_bytes(n, inputtype) + 64)) + al256(2 * al256(cap + 16) + 16) + al256(blocksort_ws_bytes(cap, n, true)) + al256(16 * (nsmp + 1)) + (1ull << 20);
+				return al256(20 * sparse_ties_cap(n, cap) + 64) + al256(al256(packed_text_bytes(n, inputtype) + 64)) + al256(2 * al256(cap + 16) + 16) + al256(blocksort_ws_bytes(cap, n, true)) + al256(16 * (nsmp + 1)) + (1ull << 20);
 			};
 			if (!tree_fits)
 				for (int t = 2; t <= 4096 && S < 2; ++t) {
@@ -407,6 +431,8 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	}
 	p->total_samples = nsamp;
 	uint64_t o_sm = take(16 * (nsamp + 1)), o_sc = take(4 * (B + 1));
+	p->sp.cap = p->seq_shards > 1 ? sparse_ties_cap(n, p->shard_cap) : 0;
+	uint64_t o_sp = take(p->sp.cap ? 20 * p->sp.cap + 64 : 16);
 	p->ws_bytes = off;
 	if (mem && off > mem) {
 		// a memory target below what the smallest blocks need is exceeded, but never silently (the reference's mem= counts host RAM and
@@ -438,6 +464,12 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	p->d_hist = (uint64_t *)(A + o_hist); p->d_p0pairs = (uint64_t *)(A + o_p0p); p->d_p0tmp = (uint32_t *)(A + o_p0t);
 	p->d_endrank = (uint32_t *)(A + o_er); p->d_endpos = (uint64_t *)(A + o_ep);
 	p->d_samples = (uint64_t *)(A + o_sm); p->d_sample_cnt = (uint32_t *)(A + o_sc);
+	if (p->sp.cap) {
+		const uint64_t c = p->sp.cap;
+		p->sp.slot = (uint32_t *)(A + o_sp); p->sp.pos_lo = p->sp.slot + c; p->sp.xslot = p->sp.pos_lo + c; p->sp.xpos_lo = p->sp.xslot + c;
+		p->sp.pos_hi = (uint8_t *)(p->sp.xpos_lo + c); p->sp.head = p->sp.pos_hi + c; p->sp.xpos_hi = p->sp.head + c;
+		p->sp.xcnt = (uint32_t *)(A + o_sp + 19 * c + ((64 - (19 * c) % 64) % 64));      // (19 bytes per entry pair used; the counter behind them, aligned)
+	}
 	// static tables: anchor positions, leaf end positions
 	std::vector<uint64_t> ap(p->total_anchors + 1, 0), ep(B, 0);
 	for (auto &M : p->merges) {
@@ -534,6 +566,118 @@ struct HostSink {            // SliceHook context of a host-memory run
 		k->evs.push_back(e); k->copied += last - first;
 	}
 };
+}
+
+// ---- sequential suffix-range shards and long repeats (row a6): the plan's list of what the shards left tied (b3m_plan::SparseTies) ----
+__global__ void k_sp_export(const uint32_t *U, const uint32_t *gid, const uint32_t *sa, const uint8_t *sa_hi, uint64_t left, uint32_t *slot, uint32_t *pos_lo, uint8_t *pos_hi, uint8_t *head)
+{
+	uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= left) return;
+	const uint32_t r = U[j];
+	slot[j] = r; pos_lo[j] = sa[r]; pos_hi[j] = sa_hi ? sa_hi[r] : (uint8_t)0;
+	head[j] = (j == 0 || gid[j] != gid[j - 1]) ? 1 : 0;
+}
+// the list as the rounds want it: U = every slot, hid = heads (max-scanned into group labels by the caller)
+__global__ void k_sp_list(const uint8_t *head, uint64_t cnt, uint32_t *U, uint32_t *hid)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e < cnt) { U[e] = (uint32_t)e; hid[e] = head[e] ? (uint32_t)e : 0u; }
+}
+__global__ void k_sp_positions(const uint32_t *lo, const uint8_t *hi, uint64_t cnt, uint64_t *out)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e < cnt) out[e] = (uint64_t)lo[e] | ((uint64_t)hi[e] << 32);
+}
+__global__ void k_sp_gslots(const uint32_t *slot, uint64_t first, uint64_t count, uint64_t slice_off, uint64_t *out)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e < count) out[first + e] = slice_off + slot[first + e];
+}
+// the finished list back into the result: BWT symbol at the suffix's global rank (into the BWT itself, or as (rank, symbol) for a result that has left for host
+// memory), p0, the (rank,pos) sample
+__global__ void k_sp_patch(TextView T, const uint32_t *idx, const uint8_t *idx_hi, const uint64_t *gslot, uint64_t cnt, uint8_t *bwt, uint8_t *sym_out, uint64_t *p0pair,
+                           uint64_t *samples, uint64_t rate)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= cnt) return;
+	const uint64_t i = (uint64_t)idx[e] | (idx_hi ? (uint64_t)idx_hi[e] << 32 : 0ull), g = gslot[e];
+	const uint8_t c = (uint8_t)sym_at(T, i ? i - 1 : T.n - 1);
+	if (bwt) bwt[g] = c; else sym_out[e] = c;
+	if (i == 0) { p0pair[0] = g; p0pair[1] = 0; }
+	if (samples && i % rate == 0) { samples[2 * (i / rate)] = g; samples[2 * (i / rate) + 1] = i; }
+}
+/* d_bwt: the whole BWT on the device (a device-resident run), or null: the symbols go to h_bwt, which every slice has reached already */
+static void sparse_tie_finish(b3m_plan *p, const TextView &T, uint8_t *d_bwt, uint8_t *h_bwt, hipStream_t s)
+{
+	b3m_plan::SparseTies &L = p->sp;
+	const uint64_t Tn = L.count, Ex = L.complete ? L.xcount : 0, M = Tn + Ex;
+	if (Tn == 0) return;
+	BlockSortWs &ws = p->bs;
+	const bool big = p->n >= (1ull << 32);
+	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	blocksort_ensure_ties(ws);
+	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
+	if (big) { Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB; }
+	B3M_REQUIRE(Tn <= (big ? ws.tie_cap : ws.cap) && 2 * Tn + 3 * M + 64 <= ws.cap, "internal: the list of tied suffixes is larger than the buffers of its finish");
+	uint32_t *idx = ws.idxA; uint8_t *idx_hi = big ? ws.sa_hi : nullptr, *tmp_hi = big ? ws.tie_hi : nullptr;
+	B3M_HIP(hipMemcpyAsync(idx, L.pos_lo, 4 * Tn, hipMemcpyDeviceToDevice, s));
+	if (big) B3M_HIP(hipMemcpyAsync(idx_hi, L.pos_hi, Tn, hipMemcpyDeviceToDevice, s));
+	hipLaunchKernelGGL(k_sp_list, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint8_t *)L.head, Tn, Bf[0], Bf[1]);
+	inclusive_max_u32(Bf[1], Tn, ws.scan_ws, s);
+	// behind the rounds' keys (Tn of each record buffer): global ranks of the list's slots, the positions to look ranks up by, their ranks
+	uint64_t *gslot = ws.keyA + Tn + 8, *posS = gslot + Tn + 8, *rank = posS + M + 8;         // keyA: Tn + Tn + M + M (+ pads)
+	uint64_t *ptmp = ws.keyB + Tn + 8;                                                       // keyB: Tn + M
+	uint32_t *d_missing = reinterpret_cast<uint32_t *>(ptmp + M + 8);
+	for (const auto &pt : L.parts)
+		if (pt.count) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.count + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.slot, pt.first, pt.count, pt.slice_off, gslot);
+	const uint64_t K = (uint64_t)key_symbols(T.type), X = L.dmax;
+	uint64_t left = 0, rounds = 0;
+	if (!L.complete) {
+		// a shard finished its own repeats (no room on the list) or placed more suffixes among long repeats than the list holds: the targets of a doubling round
+		// could be missing, so the list is finished as a shard would have finished it, by key extension to the end
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, 0, nullptr, 0, idx_hi, tmp_hi, L.dmin);
+	} else {
+		// key extension until every group agrees on 2X symbols and more, then doubling on the list (tie_rounds_sparse)
+		const uint64_t rt0 = (2 * X + 1 - L.dmin + K - 1) / K;
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, rt0, nullptr, 0, idx_hi, tmp_hi, L.dmin);
+		if (left && rounds >= rt0) {
+			hipLaunchKernelGGL(k_sp_positions, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.pos_lo, (const uint8_t *)L.pos_hi, Tn, posS);
+			if (Ex) hipLaunchKernelGGL(k_sp_positions, dim3((uint32_t)((Ex + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xpos_lo, (const uint8_t *)L.xpos_hi, Ex, posS + Tn);
+			// the placed ones' global ranks wait in the sort's second buffer until the table is in order
+			for (const auto &pt : L.parts)
+				if (pt.xcount) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.xcount + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xslot, pt.xfirst, pt.xcount, pt.slice_off, rank);
+			// (pos, rank) of the placed ones, then all positions in order
+			uint64_t *xpos = ptmp;         // a copy of the placed ones' positions, unsorted, beside their ranks
+			if (Ex) B3M_HIP(hipMemcpyAsync(xpos, posS + Tn, 8 * Ex, hipMemcpyDeviceToDevice, s));
+			int nbits = 1; while ((1ull << nbits) < p->n + 1 && nbits < 64) ++nbits;
+			uint64_t *sorted = nullptr;
+			uint64_t *stmp = rank + Ex + 8;         // (M entries: inside keyA's 3 M behind gslot)
+			radix_sort_u64(posS, nullptr, stmp, nullptr, M, nbits, ws.radix, s, nullptr, &sorted, nullptr);
+			// ranks, in the table's order: placed ones first (their final rank), then the list's slots (tie_rounds_sparse: k_sp_init)
+			uint64_t *rtab = sorted == posS ? stmp : posS;
+			sparse_rank_placed(sorted, M, xpos, rank, Ex, rtab, s);
+			uint32_t missing = 0;
+			const uint64_t d0 = L.dmin + rt0 * K;
+			if (dbg >= 2) fprintf(stderr, "[b3m] list finish: %llu tied + %llu placed entries, %llu key rounds to %llu symbols, %llu left for doubling (threshold %llu)\n",
+			                      (unsigned long long)Tn, (unsigned long long)Ex, (unsigned long long)rounds, (unsigned long long)d0, (unsigned long long)left, (unsigned long long)X);
+			rounds += tie_rounds_sparse(T, idx, idx_hi, tmp_hi, Tn, left, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, sorted, rtab, gslot, M, d_missing, d0, X, s, &left, &missing);
+			B3M_REQUIRE(missing == 0, "internal: prefix doubling on the list of tied suffixes met " + std::to_string(missing) + " suffixes that are not on it");
+		}
+	}
+	p->res.tie_rounds += rounds;
+	// symbols, p0 and samples of everything that was on the list
+	uint8_t *sym = reinterpret_cast<uint8_t *>(ptmp);
+	uint64_t *smp = (p->isarate && p->total_samples) ? p->d_samples : nullptr;
+	hipLaunchKernelGGL(k_sp_patch, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, T, (const uint32_t *)idx, (const uint8_t *)idx_hi, (const uint64_t *)gslot, Tn, d_bwt, sym, p->d_p0pairs, smp,
+	                   p->isarate ? p->isarate : 1);
+	if (!d_bwt) {
+		std::vector<uint64_t> hg(Tn); std::vector<uint8_t> hs(Tn);
+		B3M_HIP(hipMemcpyAsync(hg.data(), gslot, 8 * Tn, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipMemcpyAsync(hs.data(), sym, Tn, hipMemcpyDeviceToHost, s));
+		B3M_HIP(hipStreamSynchronize(s));
+		B3M_HIP(hipStreamSynchronize(p->copy_stream));            // every slice has arrived
+		for (uint64_t e = 0; e < Tn; ++e) h_bwt[hg[e]] = hs[e];
+	}
 }
 
 // the run's samples as a host list, in position order (slot k of the pinned image holds position k * rate); a shard keeps only the
@@ -662,6 +806,11 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		const bool seq_host = host && p->seq_shards > 1;         // the slices leave for host memory one by one: two slice buffers in d_bwt[0]
 		std::vector<hipEvent_t> gone;                            // gone[sh]: slice sh has left its buffer
 		p->bs.no_defer = p->seq_shards > 1;
+		// what the shards leave tied goes onto the plan's list (SparseTies) and is finished when the last shard is through
+		b3m_plan::SparseTies &L = p->sp;
+		L.parts.clear(); L.count = L.xcount = 0; L.dmin = ~0ull; L.dmax = 0; L.complete = true;
+		const bool sparse = p->seq_shards > 1 && L.cap > 0 && B == 1;
+		if (sparse) B3M_HIP(hipMemsetAsync(L.xcnt, 0, 4, s));
 		for (int sh = (p->seq_shards > 1 ? 0 : p->shard); sh < (p->seq_shards > 1 ? p->seq_shards : p->shard + 1); ++sh) {
 			uint8_t *slice_dst = seq_host ? p->d_bwt[0] + (uint64_t)(sh & 1) * p->seq_half : nullptr;
 			if (seq_host && sh >= 2) B3M_HIP(hipStreamWaitEvent(s, gone[(size_t)sh - 2], 0));
@@ -671,6 +820,9 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			p->bs.slice_hook = (host && B == 1 && nsh == 1) ? &hook : nullptr;
 			p->bs.arrival = streaming_text ? &arrival : nullptr;
 			p->bs.samples = smp_in_kernel ? &smp_cfg : nullptr;
+			p->bs.sparse_room = sparse ? L.cap - L.count : 0;
+			p->bs.extras = TieExtras{};
+			if (sparse) { p->bs.extras.cnt = L.xcnt; p->bs.extras.slot = L.xslot; p->bs.extras.pos_lo = L.xpos_lo; p->bs.extras.pos_hi = L.xpos_hi; p->bs.extras.cap = (uint32_t)L.cap; }
 			block_sort(T, lf.a, lf.m, p->bs, s, tl, so, seq_host ? slice_dst : (B == 1 ? d_bwt_out + acc : p->d_bwt[0] + lf.a), p->d_p0tmp + k, sh, nsh, need_sa);
 			if (seq_host) {
 				// the shard's slice is final: off to host memory on the copy stream, behind the sort of the next shard
@@ -689,7 +841,24 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			if (so.reran_with_sa) p->sa_hint = 1;
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
 			p->d_sa_slice = so.d_sa; p->slice_off = so.slice_offset; p->slice_len = so.kept_len;
-			B3M_REQUIRE(!(so.tie_left && p->seq_shards > 1), "internal: deferred ties in a sequential shard");
+			if (p->seq_shards > 1) {
+				B3M_REQUIRE(!so.tie_left || (sparse && L.count + so.tie_left <= L.cap), "internal: deferred ties in a sequential shard");
+				if (sparse) {
+					uint32_t xc = 0;
+					B3M_HIP(hipMemcpyAsync(&xc, L.xcnt, 4, hipMemcpyDeviceToHost, s));
+					B3M_HIP(hipStreamSynchronize(s));
+					if (xc > L.cap) { L.complete = false; xc = (uint32_t)L.cap; B3M_HIP(hipMemcpyAsync(L.xcnt, &xc, 4, hipMemcpyHostToDevice, s)); B3M_HIP(hipStreamSynchronize(s)); }
+					if (so.tie_refused) L.complete = false;
+					if (so.tie_left) {
+						hipLaunchKernelGGL(k_sp_export, dim3((uint32_t)((so.tie_left + 255) / 256)), dim3(256), 0, s, (const uint32_t *)so.tie_U, (const uint32_t *)so.tie_gid, (const uint32_t *)p->bs.idxA,
+						                   (const uint8_t *)(n >= (1ull << 32) ? p->bs.sa_hi : nullptr), so.tie_left, L.slot + L.count, L.pos_lo + L.count, L.pos_hi + L.count, L.head + L.count);
+						L.dmin = std::min(L.dmin, so.tie_depth); L.dmax = std::max(L.dmax, so.tie_depth);
+					}
+					L.parts.push_back({L.count, so.tie_left, L.xcount, (uint64_t)xc - L.xcount, so.slice_offset});
+					L.count += so.tie_left; L.xcount = xc;
+				}
+				so.tie_left = 0;
+			}
 			p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 			p->res.tie_elements += so.tie_elements;
 			p->res.tie_overhang = std::max<uint64_t>(p->res.tie_overhang, so.overhang);
@@ -704,7 +873,14 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			}
 			acc += so.kept_len;
 		}
-		if (p->seq_shards > 1) { B3M_REQUIRE(acc == lf.m, "internal: suffix-range shards do not cover the block"); p->res.slice_offset = 0; p->res.slice_len = acc; }
+		if (p->seq_shards > 1) {
+			B3M_REQUIRE(acc == lf.m, "internal: suffix-range shards do not cover the block"); p->res.slice_offset = 0; p->res.slice_len = acc;
+			p->tie_left = 0;
+			if (sparse && L.count) {
+				Scope sc(tl, KF_TIES, 0);
+				sparse_tie_finish(p, T, seq_host ? nullptr : d_bwt_out, h_bwt_out, s);
+			}
+		}
 		else { p->res.slice_offset = so.slice_offset; p->res.slice_len = so.kept_len; }
 		{
 			if (B > 1 && p->type == B3M_INPUT_BYTESTREAM) hipLaunchKernelGGL(k_emit_gt_ptr, dim3((uint32_t)((lf.m + 255) / 256)), dim3(256), 0, s, so.d_sa, lf.m, lf.a, p->d_p0tmp + k, p->d_gt[0]);

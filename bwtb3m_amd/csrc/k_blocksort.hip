@@ -931,6 +931,141 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 	return rounds;
 }
 // ------------------------------------------------------------------------------------------------
+// Prefix doubling ON A LIST ALONE (row a6 for suffix-range shards that ONE plan runs one after the other: texts of 2^32 symbols and more, the host
+// tier).  Nobody holds the suffix array of the whole text there, so there is no inverse suffix array to read ranks from.  What there is: the list of
+// every suffix that agrees with another one on X symbols or more (each shard hands over what its few key-extension rounds left tied), in rank order,
+// i.e. a suffix array of the listed suffixes among themselves (idx, cnt slots).  That is enough: when every group on the list agrees on d >= 2X
+// symbols, the suffix h = d - X symbols behind a listed one agrees with its neighbour's on d - h = X symbols, so it is ON THE LIST, and its rank
+// there (its slot when it is placed for good, the first slot of its group otherwise) is a key that orders the group.  Members with equal keys agree
+// on h + d = 2d - X symbols: (d - X) doubles per round, O(log longest repeat) rounds, every one of them on the list only.  Ranks are looked up by
+// position: pos[] ascending, rank[k] = rank of the suffix at pos[k] (binary search; the list is a small fraction of the text).
+// ------------------------------------------------------------------------------------------------
+struct SparseRanks { const uint64_t *pos; uint64_t *rank; uint64_t cnt; const uint64_t *gslot; uint32_t *missing; };
+__device__ __forceinline__ uint64_t sparse_find(const uint64_t *pos, uint64_t cnt, uint64_t x)
+{
+	uint64_t lo = 0, hi = cnt;
+	while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (pos[mid] < x) lo = mid + 1; else hi = mid; }
+	return (lo < cnt && pos[lo] == x) ? lo : ~0ull;
+}
+__device__ __forceinline__ uint64_t sparse_key(const SparseRanks &R, const TextView &T, uint64_t i, uint64_t h)
+{
+	uint64_t q = i + h;
+	if (q >= T.n) { if (T.type == B3M_INPUT_PACTERM) return 0; q -= T.n; }      // (pacterm: a tied suffix has d > h symbols in front of the terminator: not reached)
+	const uint64_t k = sparse_find(R.pos, R.cnt, q);
+	if (k == ~0ull) { atomicAdd(R.missing, 1u); return 0; }
+	return R.rank[k] + 1u;
+}
+// ranks of the suffixes the record sort placed for good among long repeats (TieExtras): xpos / xrank, nx of them, in any order
+__global__ void k_sp_rank_placed(const uint64_t *pos, uint64_t cnt, const uint64_t *xpos, const uint64_t *xrank, uint64_t nx, uint64_t *rank)
+{
+	uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= nx) return;
+	const uint64_t k = sparse_find(pos, cnt, xpos[x]);
+	if (k != ~0ull) rank[k] = xrank[x];
+}
+__global__ void k_sp_init(SparseRanks R, const uint32_t *idx, const uint8_t *idx_hi, uint64_t slots)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= slots) return;
+	const uint64_t k = sparse_find(R.pos, R.cnt, (uint64_t)idx[e] | (idx_hi ? (uint64_t)idx_hi[e] << 32 : 0ull));
+	if (k == ~0ull) atomicAdd(R.missing, 1u); else R.rank[k] = R.gslot[e];
+}
+__global__ void k_sp_refresh(SparseRanks R, const uint32_t *U, const uint32_t *hid, const uint32_t *idx, const uint8_t *idx_hi, uint64_t u)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t r = U[s];
+	const uint64_t k = sparse_find(R.pos, R.cnt, (uint64_t)idx[r] | (idx_hi ? (uint64_t)idx_hi[r] << 32 : 0ull));
+	if (k == ~0ull) atomicAdd(R.missing, 1u); else R.rank[k] = R.gslot[U[hid[s]]];
+}
+__global__ void k_sp_keys(SparseRanks R, TextView T, uint64_t h, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, uint64_t u, uint64_t *nk, uint32_t *slot)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t r = U[s];
+	nk[s] = sparse_key(R, T, (uint64_t)idx[r] | (idx_hi ? (uint64_t)idx_hi[r] << 32 : 0ull), h);
+	slot[s] = (uint32_t)s;
+}
+__global__ void k_sp_gather(SparseRanks R, TextView T, uint64_t h, const uint32_t *U, const uint32_t *idx, const uint8_t *idx_hi, const uint32_t *slot_final,
+                            uint64_t u, uint32_t *tmp_idx, uint8_t *tmp_hi, uint64_t *tmp_key)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= u) return;
+	const uint32_t r = U[slot_final[s]];
+	const uint32_t i = idx[r], hi = idx_hi ? idx_hi[r] : 0u;
+	tmp_idx[s] = i;
+	if (idx_hi) tmp_hi[s] = (uint8_t)hi;
+	tmp_key[s] = sparse_key(R, T, (uint64_t)i | ((uint64_t)hi << 32), h);
+}
+void sparse_rank_placed(const uint64_t *pos, uint64_t cnt, const uint64_t *xpos, const uint64_t *xrank, uint64_t nx, uint64_t *rank, hipStream_t s)
+{
+	if (nx) hipLaunchKernelGGL(k_sp_rank_placed, dim3(nblk(nx)), dim3(256), 0, s, pos, cnt, xpos, xrank, nx, rank);
+}
+// idx / idx_hi: the listed suffixes in rank order, `slots` of them (changed in place), gslot[e] = rank of slot e in the whole text; B[0] / B[1]: the u slots still
+// tied and their group labels; pos / rank: the table, cnt >= slots entries (pos ascending; the ranks of entries that are not slots of the list are in place,
+// sparse_rank_placed; the slots' are filled here); d0: symbols every group agrees on (> X; 2X and more is what makes every round a doubling); X: see above.
+// Returns the rounds run; *left = slots still tied (rotations equal over n symbols); *missing = lookups that found no entry (must be 0).
+uint64_t tie_rounds_sparse(const TextView &T, uint32_t *idx, uint8_t *idx_hi, uint8_t *tmp_hi, uint64_t slots, uint64_t u, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
+                           uint32_t *scan_ws, RadixWs &radix, const uint64_t *pos, uint64_t *rank, const uint64_t *gslot, uint64_t cnt, uint32_t *d_missing,
+                           uint64_t d0, uint64_t X, hipStream_t s, uint64_t *left, uint32_t *missing)
+{
+	B3M_REQUIRE(!idx_hi || tmp_hi, "internal: tie rounds with 36-bit positions need a byte buffer");
+	B3M_REQUIRE(d0 > X && X >= 1, "internal: prefix doubling on a list needs groups that agree on more symbols than the listing threshold");
+	int kbits = 1; while ((1ull << kbits) < T.n + 2 && kbits < 64) ++kbits;       // keys: rank in the whole text + 1
+	int gbits = 1; while ((1ull << gbits) < slots + 1 && gbits < 32) ++gbits;     // labels: slots of the list
+	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
+	SparseRanks R{pos, rank, cnt, gslot, d_missing};
+	B3M_HIP(hipMemsetAsync(d_missing, 0, 4, s));
+	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	uint64_t rounds = 0, d = d0;
+	uint32_t h_u = 0;
+	if (u) {
+		// ranks: its own for everything that is placed for good, the first of its group's for what is still tied
+		hipLaunchKernelGGL(k_sp_init, dim3(nblk(slots)), dim3(256), 0, s, R, (const uint32_t *)idx, (const uint8_t *)idx_hi, slots);
+		hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
+		inclusive_max_u32(hid, u, scan_ws, s);
+		hipLaunchKernelGGL(k_sp_refresh, dim3(nblk(u)), dim3(256), 0, s, R, (const uint32_t *)U, (const uint32_t *)hid, (const uint32_t *)idx, (const uint8_t *)idx_hi, u);
+	}
+	while (u > 0 && d < T.n) {
+		const uint64_t h = d - X;
+		++rounds;
+		hipLaunchKernelGGL(k_sp_keys, dim3(nblk(u)), dim3(256), 0, s, R, T, h, (const uint32_t *)U, (const uint32_t *)idx, (const uint8_t *)idx_hi, u, kx, vx);
+		uint64_t *rk; uint32_t *rv;
+		radix_sort_u64(kx, vx, ky, vy, u, kbits, radix, s, nullptr, &rk, &rv);
+		uint64_t *gk = (rk == kx) ? ky : kx;
+		uint32_t *vidle = (rv == vx) ? vy : vx;
+		hipLaunchKernelGGL(k_tie_gidkeys, dim3(nblk(u)), dim3(256), 0, s, gid, rv, u, gk);
+		uint64_t *rk2; uint32_t *rv2;
+		radix_sort_u64(gk, rv, rk, vidle, u, gbits, radix, s, nullptr, &rk2, &rv2);
+		uint64_t *tmp_key = (rk2 == gk) ? rk : gk;
+		uint32_t *tmp_idx = (rv2 == rv) ? vidle : rv;
+		hipLaunchKernelGGL(k_sp_gather, dim3(nblk(u)), dim3(256), 0, s, R, T, h, (const uint32_t *)U, (const uint32_t *)idx, (const uint8_t *)idx_hi, (const uint32_t *)rv2, u, tmp_idx, tmp_hi, tmp_key);
+		hipLaunchKernelGGL(k_tie_apply, dim3(nblk(u)), dim3(256), 0, s, U, gid, tmp_idx, (const uint8_t *)tmp_hi, tmp_key, u, idx, idx_hi, hid, (const uint32_t *)nullptr);
+		inclusive_max_u32(hid, u, scan_ws, s);
+		hipLaunchKernelGGL(k_sp_refresh, dim3(nblk(u)), dim3(256), 0, s, R, (const uint32_t *)U, (const uint32_t *)hid, (const uint32_t *)idx, (const uint8_t *)idx_hi, u);      // every key of this round has been read
+		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
+		exclusive_sum_u32(flag, u + 1, scan_ws, s);
+		B3M_HIP(hipMemcpyAsync(&h_u, flag + u, 4, hipMemcpyDeviceToHost, s));
+		// the sorts' value buffers are free now: the compacted list goes there, then the pairs swap
+		uint32_t *U2 = vx, *gid2 = vy;
+		hipLaunchKernelGGL(k_tie_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, U, u, U2, gid2);
+		B3M_HIP(hipStreamSynchronize(s));
+		if (dbg >= 2) fprintf(stderr, "[b3m]   list round %llu: by the rank %llu symbols on (groups agree on %llu), %llu slots, %u left\n", (unsigned long long)rounds, (unsigned long long)h,
+		                      (unsigned long long)d, (unsigned long long)u, h_u);
+		vx = U; vy = gid; U = U2; gid = gid2;
+		u = h_u;
+		d = 2 * d - X;
+	}
+	B[0] = U; B[1] = gid; B[2] = vx; B[3] = vy;
+	if (left) *left = u;
+	uint32_t miss = 0;
+	B3M_HIP(hipMemcpyAsync(&miss, d_missing, 4, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	if (missing) *missing = miss;
+	return rounds;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ties of a block of a merge tree (the bound on a block's repeat cost the reference
 // gets from lcpnext / largelcpthres, src/bwtb3m.cpp:55).  The block [start, start+own) is sorted together
 // with an overhang [start+own, start+D) of the text behind it; after a few key-extension rounds the tied

@@ -2207,7 +2207,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_bucket_finish(const uint64_t *r
 // set no bits); the length guard only keeps a corrupt bitmap from running away.
 // The launch covers the records [lo, hi) (tie groups never cross a bucket, so slices of whole buckets are independent).
 __device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tiebits, uint64_t len, uint64_t q, uint32_t eq_syms, const SaOut &sa, uint8_t *bwt, uint64_t start, uint32_t *p0,
-                                          const SampleOut &smp)
+                                          const SampleOut &smp, const TieExtras &X)
 {
 	{
 		{
@@ -2237,6 +2237,25 @@ __device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tie
 			if (x == start) *p0 = (uint32_t)(pos + a);
 			if (sample_hit(smp, (uint32_t)x)) sample_put(smp, pos + a, x);
 		}
+		if (X.keys) {
+			// (sequential suffix-range shards) members that agree with a neighbour on X.keys sort keys or more are listed with their slot: they are placed for good,
+			// but the doubling rounds on the plan's list of tied suffixes must find their rank (b3m_internal.h: TieExtras)
+			bool prev = false;
+			for (uint32_t a = 0; a < g; ++a) {
+				const uint64_t x = sa_get(sa, pos + a);
+				bool next = false;
+				if (a + 1 < g) {
+					const uint64_t y = sa_get(sa, pos + a + 1);
+					next = true;
+					for (uint32_t d = 0; d < X.keys && next; ++d) next = key_at(T, x, d) == key_at(T, y, d);
+				}
+				if (prev || next) {
+					const uint32_t k = atomicAdd(X.cnt, 1u);
+					if (k < X.cap) { X.slot[k] = (uint32_t)(pos + a); X.pos_lo[k] = (uint32_t)x; if (X.pos_hi) X.pos_hi[k] = (uint8_t)(x >> 32); }
+				}
+				prev = next;
+			}
+		}
 		}
 	}
 }
@@ -2251,14 +2270,15 @@ __device__ __forceinline__ uint32_t tie_starts(const uint32_t *tiebits, uint64_t
 	if ((w << 5) + 32 > hi) starts &= (1u << (hi - (w << 5))) - 1u;
 	return starts;
 }
-__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp)
+__global__ void k_tie_fix(TextView T, const uint32_t *tiebits, uint64_t len, uint64_t lo, uint64_t hi, uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp,
+                          TieExtras X)
 {
 	uint64_t w = (lo >> 5) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if ((w << 5) >= hi) return;
 	uint32_t starts = tie_starts(tiebits, w, lo, hi);
 	while (starts) {
 		uint32_t k = __ffs(starts) - 1; starts &= starts - 1;
-		tie_group(T, tiebits, len, (w << 5) + k, eq_syms, sa, bwt, start, p0, smp);
+		tie_group(T, tiebits, len, (w << 5) + k, eq_syms, sa, bwt, start, p0, smp, X);
 	}
 }
 // The same in two steps (whole blocks): the groups are few (0.3 % of the records) and each costs a chain of dependent gathers, so a
@@ -2296,11 +2316,11 @@ __global__ __launch_bounds__(256) void k_tie_collect(const uint32_t *tiebits, ui
 	}
 }
 __global__ __launch_bounds__(256) void k_tie_fix_list(TextView T, const uint32_t *tiebits, uint64_t len, const uint32_t *list, const uint32_t *counter, uint32_t cap,
-                                                      uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp)
+                                                      uint32_t eq_syms, SaOut sa, uint8_t *bwt, uint64_t start, uint32_t *p0, SampleOut smp, TieExtras X)
 {
 	uint32_t cnt = *counter; cnt = cnt < cap ? cnt : cap;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
-		tie_group(T, tiebits, len, list[i], eq_syms, sa, bwt, start, p0, smp);
+		tie_group(T, tiebits, len, list[i], eq_syms, sa, bwt, start, p0, smp, X);
 }
 
 // sorted (size << 32 | start) pairs -> sizes (scanned into list offsets by the caller) and starts
@@ -2738,7 +2758,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				else hipLaunchKernelGGL((k_finish_lds<false, 512>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, (const uint32_t *)nullptr, 0u, dl, O);
 			}
 			if (nsl > 1) {
-				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0, O.smp);
+				if (rb > ra) hipLaunchKernelGGL(k_tie_fix, dim3(nblk((rb + 31) / 32 - ra / 32)), dim3(256), 0, s, T, ws.t[0], len, ra, rb, eq_syms, sa, d_bwt, start, d_p0, O.smp, TieExtras{});
 				ws.slice_hook->fn(ws.slice_hook->ctx, ra, rb);
 			}
 		}
@@ -2923,19 +2943,22 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	if (!sliced || out.late_writes) {
 		Scope sc(tl, KF_TIES, len / 8);
 		const int tie_two_step = getenv("B3M_TIE_TWO_STEP") ? atoi(getenv("B3M_TIE_TWO_STEP")) : 1;      // measurement switch
+		// (sequential shards of a plan that keeps a list of tied suffixes: what the direct comparisons place among long repeats is listed too, TieExtras)
+		TieExtras xtra{};
+		if (nshards > 1 && start == 0 && len_in == T.n && ws.no_defer && ws.sparse_room > 0 && ws.extras.cnt) { xtra = ws.extras; xtra.keys = 4; }      // (4 = R0, the key rounds a shard runs before it hands over)
 		if (tie_two_step && len >= (1ull << 22) && len < (1ull << 32)) {
 			// both record buffers are free by now: the list of group starts goes into one of them
 			uint32_t *glist = reinterpret_cast<uint32_t *>(ws.keyB), *gcnt = reinterpret_cast<uint32_t *>(M.lists) + 60;
 			const uint32_t gcap = (uint32_t)std::min<uint64_t>(2 * ws.cap, 0xFFFFFFF0ull);
 			B3M_HIP(hipMemsetAsync(gcnt, 0, 4, s));
 			hipLaunchKernelGGL(k_tie_collect, dim3(nblk((len + 31) / 32, 256 * TIE_WPT)), dim3(256), 0, s, ws.t[0], len, glist, gcap, gcnt);
-			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0, O.smp);
+			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0, O.smp, xtra);
 			if (getenv("B3M_DEBUG")) {
 				uint32_t ng = 0; B3M_HIP(hipMemcpyAsync(&ng, gcnt, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
 				fprintf(stderr, "[b3m] tie fix: %u groups of records with equal key fields\n", ng);
 			}
 		} else
-			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0, O.smp);
+			hipLaunchKernelGGL(k_tie_fix, dim3(nblk((len + 31) / 32)), dim3(256), 0, s, T, ws.t[0], len, (uint64_t)0, len, eq_syms, sa, d_bwt, start, d_p0, O.smp, xtra);
 	}
 	stage("tie fix");
 	uint32_t novw[2] = {0, 0}, nlist[3] = {0, 0, 0};
@@ -3020,10 +3043,20 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		const bool tree = !whole && !defer && !no_tree_doubling() && !(nshards > 1 && ws.no_defer);      // (a sequential shard holds a rank range of the text, not a block: key extension to the end)
 		// 36-bit positions: key extension until nothing is left (an inverse suffix array of 2^32 and more entries does not fit beside the sort: no doubling,
 		// O(longest repeat / 21) rounds)
-		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, sa.hi, ws.tie_hi, off0);
+		// ... unless the plan that runs the shards one after the other keeps a list of what they leave tied (ws.sparse_room): then the shard stops after the
+		// usual few rounds, as every other sort does, and the plan finishes the union of those lists by prefix doubling ON THE LIST (engine.hip: sparse_tie_finish)
+		const bool sdefer = nshards > 1 && start == 0 && len_in == T.n && ws.no_defer && ws.sparse_room > 0;
+		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, sdefer ? R0 : 0, nullptr, 0, sa.hi, ws.tie_hi, off0);
 		else
-		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0);
-		if (big) { /* finished above */ }
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree || sdefer) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0);
+		if (sdefer && left && out.tie_rounds >= R0) {
+			if (left <= ws.sparse_room) { out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1]; out.tie_depth = off0 + R0 * (uint64_t)key_symbols(T.type); }
+			else {         // no room on the plan's list: to the end here, as without it
+				out.tie_refused = true;
+				out.tie_rounds += tie_rounds(T, sa.lo, left, R0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, big ? sa.hi : nullptr, big ? ws.tie_hi : nullptr, off0);
+			}
+		}
+		if (big || sdefer) { /* finished above, or handed over */ }
 		else if (left && tree && out.tie_rounds >= R0) {
 			if (allow_ext) { out.want_ext = true; goto leave_fallback; }
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }

@@ -446,6 +446,68 @@ def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monke
     plan.close()
 
 
+def _long_repeat_bases(oracle, nb, seed):
+    """random bases with planted long repeats of both kinds: families above 32 copies (their suffixes reach the list-based rounds: a 16-mer above 32 records) -- a 2-kb
+    segment 40 times, a tandem array, a homopolymer run -- and two-copy repeats (finished by the record sort's direct comparisons) that the copies of a family run into."""
+    b = oracle.synth_bases(nb, seed)
+    seg = b[10_000:12_000].copy()
+    tail = b[20_000:26_000].copy()
+    at = 60_000
+    for c in range(40):
+        b[at:at + 2_000] = seg
+        if c in (7, 23): b[at + 2_000:at + 8_000] = tail       # two of the copies go on with the same 6 kb: the family's suffixes near its end look into a two-copy repeat
+        at += 2_000 + (6_000 if c in (7, 23) else 0) + 37 + 13 * c
+    assert at < 330_000
+    b[400_000:403_000] = np.tile(np.array([0, 1, 2, 3, 3, 1, 0, 2, 2, 1, 3, 0], dtype=b.dtype), 250)      # tandem array, unit 12
+    b[450_000:451_500] = 3
+    b[520_000:535_000] = b[340_000:355_000]                   # a 15-kb two-copy repeat
+    return b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("itype", ["pacterm", "pac"])
+@pytest.mark.parametrize("cap", ["", "0", "300"])
+def test_sequential_shards_finish_long_repeats_by_doubling_on_their_list(gpu, oracle, itype, cap, monkeypatch):
+    """Row a6 for plans that run suffix-range shards one after the other (the host tier; texts of 2^32 symbols and more): every shard stops after four key-extension
+    rounds and hands over what is left tied; the plan finishes the union by prefix doubling ON THAT LIST (tie_rounds_sparse: the rank of the suffix d - X symbols on is
+    looked up by position among the listed suffixes and those the direct comparisons placed among long repeats) -- O(log longest repeat) rounds, the bound the
+    reference gets from lcpnext / largelcpthres (/root/reference/src/bwtb3m.cpp:55).  B3M_SPARSE_TIES=0: no list, every shard extends keys to the end (round 3's form:
+    hundreds of rounds, same bytes); =300: a list too small for this text (shards that do not fit finish themselves, the rest is finished by key extension)."""
+    torch = gpu
+    from bwtb3m_amd import engine
+    monkeypatch.setenv("B3M_FORCE_SPILL", "4")
+    if cap: monkeypatch.setenv("B3M_SPARSE_TIES", cap)
+    b = _long_repeat_bases(oracle, 1_600_001, 21)
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    plan = engine.Plan(n, itype, isasamplingrate=512)
+    assert plan.host_tier == 4
+    d = torch.from_numpy(np.concatenate([buf, np.zeros(16, dtype=np.uint8)])).cuda()
+    out = plan.run(d)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    r = plan.result()
+    assert r["tie_elements"] > 80_000, r
+    if cap == "": assert r["tie_rounds"] < 40, r
+    if cap == "0": assert r["tie_rounds"] > 100, r
+    isa = np.empty_like(sa); isa[sa] = np.arange(n)
+    def check_side_results():
+        rr = plan.result()
+        assert rr["p0"] == int(isa[0])
+        smp = plan.samples()
+        assert len(smp) == (n + 511) // 512 and np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    check_side_results()
+    h_text = torch.from_numpy(np.concatenate([buf, np.zeros(64, dtype=np.uint8)])).pin_memory()
+    h_out = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    plan.run_host(h_text, h_out)                               # the slices have left for host memory when the list is finished: its symbols follow them
+    assert np.array_equal(h_out.numpy(), ref)
+    check_side_results()
+    plan.close()
+
+
 def test_host_tier_is_taken_when_no_merge_tree_meets_mem(gpu, tmp_path):
     """40 Mbase with mem=256m: a merge tree needs 7.25 bytes per symbol whatever its blocks (290 MB + its sorts); the plan goes to the host tier instead of
     exceeding the target (workspace inside mem=), its BWT equals the one-block plan's (LF-verified), and bin/bwtb3m mem=256m writes the files of an

@@ -1117,9 +1117,10 @@ def test_beyond_2_32_symbols_one_gpu(gpu):
 
 
 def test_repeat_rich_text_beyond_2_32_symbols(gpu):
-    """n = 2^32 + 12345 with planted repeats (a copy, a tandem array, a homopolymer run, some of them at positions above 2^32): the overflow
-    list of such a text is finished by key-extension rounds with 36-bit positions (no inverse suffix array of 2^32 entries: no prefix
-    doubling there).  Round 2 refused this input.  Verified by the LF walk over every symbol (64-bit ranks)."""
+    """n = 2^32 + 12345 with planted repeats (a copy, a tandem array, a homopolymer run, a 200-kbase segment in 40 copies; the copy and the run of A reach positions above 2^32).
+    No inverse suffix array of 2^32 entries fits beside the sort: the two sequential shards stop after four key-extension rounds and the plan finishes the union
+    of what they left tied by prefix doubling on that list (tie_rounds_sparse) -- a bounded number of rounds, where round 3 extended keys to the end (a 200-kbase
+    repeat: 10^4 rounds).  Round 2 refused this input.  Verified by the LF walk over every symbol (64-bit ranks)."""
     torch = gpu
     from bwtb3m_amd import benchutil, engine, synth
     nb = (1 << 32) + 12344
@@ -1131,11 +1132,15 @@ def test_repeat_rich_text_beyond_2_32_symbols(gpu):
     d_text[700_000_000:700_000_000 + 1500] = pat.repeat(500)                                  # tandem array, unit 12 bases, 6 kbase
     d_text[hi_byte - 3000:hi_byte - 2500] = 0                                                  # 2 kbase of A just below 2^32
     d_text[900_000_000:900_000_000 + 300] = 0xFF                                               # 1.2 kbase of T
+    seg = d_text[50_000_000:50_050_000].clone()                                                # 200 kbase, 40 copies (a 16-mer above 32 records: the list-based rounds)
+    for c in range(40):
+        at = 100_000_000 + c * 24_000_000 + 17 * c
+        d_text[at:at + 50_000] = seg
     plan = engine.Plan(n, itype, isasamplingrate=1 << 16)
     out = plan.run(d_text)
     torch.cuda.synchronize()
     r = plan.result()
-    assert r["tie_rounds"] > 50 and r["tie_elements"] > 1000, r
+    assert r["tie_rounds"] < 40 and r["tie_elements"] > 8_000_000, r
     assert int(out[r["p0"]]) == 0
     m0, m1, _ = plan.lf_walk(out, sarate=0)
     assert (m0, m1) == (0, 0)
