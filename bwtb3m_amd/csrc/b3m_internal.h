@@ -35,11 +35,17 @@ struct TextView {
 
 // Symbols per 64-bit sort key and tag width, by input type (DESIGN.md "sort key").
 //   bytestream: 8 symbols, no tag.  pac: 32 symbols, no tag (circular, no terminator).
-//   pacterm: KSYM_PACTERM symbols in the high bits, 5-bit tag in the low bits:
+//   pacterm: KSYM_PACTERM (29) symbols in the high bits, 5-bit tag in the low bits:
 //            tag = offset of the terminator inside the window, 31 = no terminator.
 constexpr int KSYM_BYTES = 8;
 constexpr int KSYM_PAC = 32;
-constexpr int KSYM_PACTERM = 21;
+// 2 * K + 5 tag bits + 1 <= 64: K <= 29.  29 since round 4 (21 before): a key round of the list-based rounds covers 29 bases, so a repeat-rich text needs fewer
+// slot-rounds (genome-like text at C3 size: 227.6 -> 215.8 ms, profiles/NOTES_r04.md); the price is 64-bit keys in the tiles of those rounds (no room for the slot in
+// the key's low bits: two compares per pair) and 8 instead of 6 byte-wise splits of a large group.  -DB3M_KSYM_PACTERM=21 builds the old form.
+#ifndef B3M_KSYM_PACTERM
+#define B3M_KSYM_PACTERM 29
+#endif
+constexpr int KSYM_PACTERM = B3M_KSYM_PACTERM;
 constexpr int KSYM_WIDE = 3, WIDE_BITS = 21;      // symbols32: three 21-bit symbols per key (63 bits)
 constexpr int TAGBITS_PACTERM = 5;
 constexpr uint32_t TAG_NORMAL = 31;

@@ -232,7 +232,12 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 // ones by a bitonic network over the tile, keyed (group, key).
 // ------------------------------------------------------------------------------------------------
 constexpr int MP_GROUP = 512, MP_ROW = 9;               // pieces above MP_GROUP slots are split further; table row = piece start >> MP_ROW
+// (tiles of 2048 slots / 256 threads, 32 KB of LDS: four workgroups per CU; 4096 / 512 until round 4: 227 -> 222 ms on the genome-like text.  -DB3M_TT_LARGE: the old form)
+#ifdef B3M_TT_LARGE
 constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
+#else
+constexpr int TT_STRIDE = 1024, TT_GROUP = 1024, TT_CAP = 2048, TT_THREADS = 256, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
+#endif
 static int tt_count_max() { const char *e = getenv("B3M_TT_COUNT"); const int v = e ? atoi(e) : TT_COUNT; return v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v); }      // measurement switch
 static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
 

@@ -2344,6 +2344,16 @@ __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, ui
 	if (gid) gid[s] = b0[lo];
 }
 
+// the same with one wave per range (a repeat-rich genome: a million ranges of a few hundred slots): consecutive lanes write consecutive slots, no search
+__global__ __launch_bounds__(256) void k_fill_overflow_ranges(const uint32_t *off, const uint32_t *b0, uint32_t nov, uint32_t *U, uint32_t *gid)
+{
+	const uint32_t lane = threadIdx.x & 63u, nw = gridDim.x * 4u;
+	for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < nov; j += nw) {
+		const uint32_t o = off[j], sz = off[j + 1] - o, b = b0[j];
+		for (uint32_t t = lane; t < sz; t += 64u) { U[o + t] = b + t; if (gid) gid[o + t] = b; }
+	}
+}
+
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                     uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own, bool allow_ext)
 {
@@ -3014,14 +3024,19 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_REQUIRE(total <= ws.tie_cap, "repeat-rich input of 2^32 symbols and more: " + std::to_string(total) + " suffixes are left to the list-based rounds, whose buffers hold " +
 			            std::to_string(ws.tie_cap) + " (a sixteenth of the sort): use more shards");
 		}
-		hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, Bf[0], Bf[1]);
+		const bool by_range = total / nov >= 16 && !(getenv("B3M_FILL_BY_SLOT") && atoi(getenv("B3M_FILL_BY_SLOT")));      // (few slots per range: one thread per slot and a search keep the lanes busy)
+		auto fill_list = [&](uint32_t *U, uint32_t *gid) {
+			if (by_range) hipLaunchKernelGGL(k_fill_overflow_ranges, dim3(std::min<uint32_t>((nov + 3) / 4, 32768u)), dim3(256), 0, s, (const uint32_t *)d_off, (const uint32_t *)d_b0, nov, U, gid);
+			else hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, U, gid);
+		};
+		fill_list(Bf[0], Bf[1]);
 		// the list of slots is needed twice more (ranks of everything ever listed; the symbols of the finished slots): a copy behind the rounds' keys in the
 		// first record buffer (the rounds use total 64-bit keys of it) instead of two more binary searches per slot (3.1 ms each for the 332 M of a genome-like text)
 		uint32_t *U_keep = (!big && 12 * total + 64 <= 8 * ws.cap) ? reinterpret_cast<uint32_t *>(ws.keyA + total + 4) : nullptr;
 		if (U_keep) B3M_HIP(hipMemcpyAsync(U_keep, Bf[0], 4 * total, hipMemcpyDeviceToDevice, s));
 		auto slots_again = [&](uint32_t *dst) {
 			if (U_keep) B3M_HIP(hipMemcpyAsync(dst, U_keep, 4 * total, hipMemcpyDeviceToDevice, s));
-			else hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, dst, (uint32_t *)nullptr);
+			else fill_list(dst, nullptr);
 		};
 		stage("overflow list filled");
 		B3M_HIP(hipStreamSynchronize(s));
