@@ -183,8 +183,7 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
     d_text = pac_image(torch, b)
     n = nb + (1 if itype == "pacterm" else 0)
     form = int(rng.integers(0, 6))
-    if form == 5 and any(p[1] > 20_000 for p in planted):
-        form = 0                                      # (the host tier finishes long repeats by key-extension rounds: a 300-kb repeat is 14,000 of them)
+    if os.environ.get("FUZZ_FORM"): form = int(os.environ["FUZZ_FORM"])      # (a sweep of one form)
     alt = int(rng.integers(0, 8))                     # alternative paths of the block sort on an eighth of the cases each
     _set_env(B3M_L0_LOCAL=0 if alt == 1 else None, B3M_NO_FAST_FINISH=1 if alt == 2 else None, B3M_TIE_TWO_STEP=0 if alt == 3 else None,
              B3M_LVL2_MIN=0 if alt == 4 else None, B3M_NO_LEVEL2=1 if alt == 5 else None, B3M_L1_ORDER=1 if alt == 6 else None, B3M_XCD_ORDER=0 if alt == 7 else None)
@@ -197,6 +196,7 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
         one = plan.run(d_text).clone(); torch.cuda.synchronize()
         lf = plan.lf_walk(one, sarate=0)[:2]
         ok &= lf == (0, 0); desc += " LF %s rounds %d" % (lf, plan.result()["tie_rounds"])
+        one_p0, one_smp = plan.result()["p0"], (plan.samples() if form == 5 else None)
         plan.close()
         if form == 1:
             nblk = int(rng.integers(2, 6)) if rng.integers(0, 3) else int(rng.integers(6, 41))
@@ -238,8 +238,10 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
             h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
             plan.run_host(h_text, h_out)
             ok &= bool(torch.equal(h_out, one.cpu()))
+            ok &= plan.result()["p0"] == one_p0 and np.array_equal(plan.samples(), one_smp)
             out = plan.run(d_text); torch.cuda.synchronize()
-            ok &= bool(torch.equal(out, one)); desc += " host tier %d shards" % S
+            ok &= bool(torch.equal(out, one)); desc += " host tier %d shards, rounds %d" % (S, plan.result()["tie_rounds"])
+            ok &= plan.result()["p0"] == one_p0 and np.array_equal(plan.samples(), one_smp)
             plan.close()
         elif form == 2:
             ns = int(rng.integers(2, 17))
