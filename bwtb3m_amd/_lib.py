@@ -83,6 +83,11 @@ SYMBOLS = [
     ("b3m_plan_tie_pending", _i, [_p, ctypes.POINTER(_u64)]),
     ("b3m_plan_tie_export", _i, [_p, _p, _p, _p]),
     ("b3m_plan_tie_finish", _i, [_p, _p, _p, _u64, _u64, _p, _p]),
+    ("b3m_plan_set_tie_mode", _i, [_p, _i]),
+    ("b3m_plan_list_counts", _i, [_p, ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_u64), ctypes.POINTER(_i)]),
+    ("b3m_plan_list_fits", _i, [_p, _u64, _u64]),
+    ("b3m_plan_list_export", _i, [_p, _p, _p, _p]),
+    ("b3m_plan_list_finish", _i, [_p, _p, _u64, _p, _u64, _u64, _u64, _i, _p, _p]),
     ("b3m_plan_result", _i, [_p, ctypes.POINTER(Result)]),
     ("b3m_plan_samples", _i, [_p, _p, _u64]),
     ("b3m_plan_histogram", _i, [_p, _p]),

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdio>
 #include <exception>
+#include <functional>
 
 namespace b3m {
 
@@ -131,6 +132,7 @@ struct MergeT {
 struct b3m_plan {
 	uint64_t n = 0; int type = 0; uint64_t blocksize = 0; uint64_t isarate = 0;
 	int shard = 0, nshards = 1; uint64_t shard_cap = 0;   // suffix-range shard of a single-block plan
+	int tie_mode = 0;                                     // suffix-range shard: B3M_TIES_* (how long repeats that reach over shards are finished)
 	int keep_sa = 0;                                      // b3m_plan_set_keep_sa: the next runs keep the whole suffix array of the sort (tie export needs it)
 	int sa_hint = 0;                                      // the last run's BWT-only sort had to start over with the suffix array kept (repeat-rich text): the next ones keep it from the start
 	int seq_shards = 1;                                   // texts of 2^32 symbols and more on one GPU: the suffix-range shards of the one block, one after the other
@@ -331,6 +333,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		p->shard_cap = n / nshards + n / 64 + (1ull << 20);    // whole level-0 digits: ~n/256 of imbalance, generous slack
 		if (p->shard_cap > n) p->shard_cap = n;
 		B3M_REQUIRE(p->shard_cap < (1ull << 32), "a suffix-range shard must stay below 2^32 suffixes: use more shards");
+		p->tie_mode = n >= (1ull << 32) ? B3M_TIES_LOCAL : B3M_TIES_SA;
 	} else if (n >= (1ull << 32)) {
 		// one GPU, more than 2^32 suffixes: the same shards, run one after the other inside b3m_plan_run (the packed text is
 		// resident once; every shard scans it again and keeps its range of level-0 digits)
@@ -431,7 +434,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	}
 	p->total_samples = nsamp;
 	uint64_t o_sm = take(16 * (nsamp + 1)), o_sc = take(4 * (B + 1));
-	p->sp.cap = p->seq_shards > 1 ? sparse_ties_cap(n, p->shard_cap) : 0;
+	p->sp.cap = (p->seq_shards > 1 || nshards > 1) ? sparse_ties_cap(n, p->shard_cap) : 0;
 	uint64_t o_sp = take(p->sp.cap ? 20 * p->sp.cap + 64 : 16);
 	p->ws_bytes = off;
 	if (mem && off > mem) {
@@ -593,71 +596,102 @@ __global__ void k_sp_gslots(const uint32_t *slot, uint64_t first, uint64_t count
 	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e < count) out[first + e] = slice_off + slot[first + e];
 }
-// the finished list back into the result: BWT symbol at the suffix's global rank (into the BWT itself, or as (rank, symbol) for a result that has left for host
-// memory), p0, the (rank,pos) sample
-__global__ void k_sp_patch(TextView T, const uint32_t *idx, const uint8_t *idx_hi, const uint64_t *gslot, uint64_t cnt, uint8_t *bwt, uint8_t *sym_out, uint64_t *p0pair,
-                           uint64_t *samples, uint64_t rate)
+// the finished list back into the result: BWT symbol at the suffix's global rank (into the BWT -- the part [first, first + len) of it that d_bwt holds -- or as
+// (rank, symbol) for a result that has left for host memory), p0, the (rank,pos) sample
+__global__ void k_sp_patch(TextView T, const uint32_t *idx, const uint8_t *idx_hi, const uint64_t *gslot, uint64_t cnt, uint8_t *bwt, uint64_t first, uint64_t len, uint8_t *sym_out,
+                           uint64_t *p0pair, uint64_t *samples, uint64_t rate)
 {
 	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= cnt) return;
 	const uint64_t i = (uint64_t)idx[e] | (idx_hi ? (uint64_t)idx_hi[e] << 32 : 0ull), g = gslot[e];
 	const uint8_t c = (uint8_t)sym_at(T, i ? i - 1 : T.n - 1);
-	if (bwt) bwt[g] = c; else sym_out[e] = c;
+	if (!bwt) sym_out[e] = c;
+	if (g - first >= len) return;                  // another shard's slot
+	if (bwt) bwt[g - first] = c;
 	if (i == 0) { p0pair[0] = g; p0pair[1] = 0; }
 	if (samples && i % rate == 0) { samples[2 * (i / rate)] = g; samples[2 * (i / rate) + 1] = i; }
 }
-/* d_bwt: the whole BWT on the device (a device-resident run), or null: the symbols go to h_bwt, which every slice has reached already */
-static void sparse_tie_finish(b3m_plan *p, const TextView &T, uint8_t *d_bwt, uint8_t *h_bwt, hipStream_t s)
+// records of the lists that travel between shards (b3m_plan_list_export): (global rank | first of its group << 63, position)
+constexpr uint64_t REC_HEAD = 1ull << 63;
+__global__ void k_sp_records(const uint32_t *slot, const uint32_t *pos_lo, const uint8_t *pos_hi, const uint8_t *head, uint64_t cnt, uint64_t slice_off, uint64_t *rec)
 {
-	b3m_plan::SparseTies &L = p->sp;
-	const uint64_t Tn = L.count, Ex = L.complete ? L.xcount : 0, M = Tn + Ex;
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= cnt) return;
+	rec[2 * e] = (slice_off + slot[e]) | ((head && head[e]) ? REC_HEAD : 0ull);
+	rec[2 * e + 1] = (uint64_t)pos_lo[e] | ((uint64_t)pos_hi[e] << 32);
+}
+__global__ void k_sp_from_records(const uint64_t *rec, uint64_t cnt, uint32_t *idx, uint8_t *idx_hi, uint32_t *U, uint32_t *hid, uint64_t *gslot)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= cnt) return;
+	const uint64_t r = rec[2 * e], q = rec[2 * e + 1];
+	idx[e] = (uint32_t)q; if (idx_hi) idx_hi[e] = (uint8_t)(q >> 32);
+	U[e] = (uint32_t)e; hid[e] = (e == 0 || (r & REC_HEAD)) ? (uint32_t)e : 0u;
+	gslot[e] = r & ~REC_HEAD;
+}
+__global__ void k_sp_placed_from_records(const uint64_t *rec, uint64_t cnt, uint64_t *xpos, uint64_t *xrank)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e < cnt) { xrank[e] = rec[2 * e] & ~REC_HEAD; xpos[e] = rec[2 * e + 1]; }
+}
+__global__ void k_sp_tied_positions(const uint32_t *idx, const uint8_t *idx_hi, uint64_t cnt, uint64_t *out)
+{
+	uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e < cnt) out[e] = (uint64_t)idx[e] | (idx_hi ? (uint64_t)idx_hi[e] << 32 : 0ull);
+}
+// The finish of a list of Tn tied and Ex placed suffixes (of one plan's sequential shards, or of all shards of a run over several GPUs), in the buffers of the plan's sort.
+//   load_tied(idx, idx_hi, U, hid, gslot): positions of the listed suffixes in rank order, U = every slot, hid[e] = e at the first of a group else 0, gslot = global ranks
+//   load_placed(xpos, xrank): the placed ones, any order
+//   d_bwt: the part [bwt_first, bwt_first + bwt_len) of the BWT on the device, or null: the symbols go to h_bwt (the whole BWT in host memory, every slice arrived)
+struct SparseBufs { uint32_t *idx; uint8_t *idx_hi; uint32_t *U, *hid; uint64_t *gslot, *xpos, *xrank; };
+typedef std::function<void(const SparseBufs &)> SparseLoad;
+static void sparse_finish_core(b3m_plan *p, const TextView &T, uint64_t Tn, uint64_t Ex, bool complete, uint64_t dmin, uint64_t dmax, const SparseLoad &load_tied, const SparseLoad &load_placed,
+                               uint8_t *d_bwt, uint64_t bwt_first, uint64_t bwt_len, uint8_t *h_bwt, hipStream_t s)
+{
 	if (Tn == 0) return;
+	if (!complete) Ex = 0;
+	const uint64_t M = Tn + Ex;
 	BlockSortWs &ws = p->bs;
 	const bool big = p->n >= (1ull << 32);
 	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
 	blocksort_ensure_ties(ws);
 	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 	if (big) { Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB; }
-	B3M_REQUIRE(Tn <= (big ? ws.tie_cap : ws.cap) && 2 * Tn + 3 * M + 64 <= ws.cap, "internal: the list of tied suffixes is larger than the buffers of its finish");
+	B3M_REQUIRE(Tn <= (big ? ws.tie_cap : ws.cap) && 2 * Tn + 3 * M + 64 <= ws.cap, "the list of tied suffixes (" + std::to_string(Tn) + " + " + std::to_string(Ex) +
+	            ") is larger than the buffers of its finish (a shard's sort of " + std::to_string(ws.cap) + " suffixes)");
 	uint32_t *idx = ws.idxA; uint8_t *idx_hi = big ? ws.sa_hi : nullptr, *tmp_hi = big ? ws.tie_hi : nullptr;
-	B3M_HIP(hipMemcpyAsync(idx, L.pos_lo, 4 * Tn, hipMemcpyDeviceToDevice, s));
-	if (big) B3M_HIP(hipMemcpyAsync(idx_hi, L.pos_hi, Tn, hipMemcpyDeviceToDevice, s));
-	hipLaunchKernelGGL(k_sp_list, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint8_t *)L.head, Tn, Bf[0], Bf[1]);
-	inclusive_max_u32(Bf[1], Tn, ws.scan_ws, s);
 	// behind the rounds' keys (Tn of each record buffer): global ranks of the list's slots, the positions to look ranks up by, their ranks
-	uint64_t *gslot = ws.keyA + Tn + 8, *posS = gslot + Tn + 8, *rank = posS + M + 8;         // keyA: Tn + Tn + M + M (+ pads)
+	uint64_t *gslot = ws.keyA + Tn + 8, *posS = gslot + Tn + 8, *rank = posS + M + 8;         // keyA: Tn + Tn + M + Ex + M (+ pads)
 	uint64_t *ptmp = ws.keyB + Tn + 8;                                                       // keyB: Tn + M
 	uint32_t *d_missing = reinterpret_cast<uint32_t *>(ptmp + M + 8);
-	for (const auto &pt : L.parts)
-		if (pt.count) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.count + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.slot, pt.first, pt.count, pt.slice_off, gslot);
-	const uint64_t K = (uint64_t)key_symbols(T.type), X = L.dmax;
+	load_tied(SparseBufs{idx, idx_hi, Bf[0], Bf[1], gslot, nullptr, nullptr});
+	inclusive_max_u32(Bf[1], Tn, ws.scan_ws, s);
+	const uint64_t K = (uint64_t)key_symbols(T.type), X = dmax;
 	uint64_t left = 0, rounds = 0;
-	if (!L.complete) {
+	if (!complete) {
 		// a shard finished its own repeats (no room on the list) or placed more suffixes among long repeats than the list holds: the targets of a doubling round
 		// could be missing, so the list is finished as a shard would have finished it, by key extension to the end
-		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, 0, nullptr, 0, idx_hi, tmp_hi, L.dmin);
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, 0, nullptr, 0, idx_hi, tmp_hi, dmin);
 	} else {
 		// key extension until every group agrees on 2X symbols and more, then doubling on the list (tie_rounds_sparse)
-		const uint64_t rt0 = (2 * X + 1 - L.dmin + K - 1) / K;
-		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, rt0, nullptr, 0, idx_hi, tmp_hi, L.dmin);
+		const uint64_t rt0 = (2 * X + 1 - dmin + K - 1) / K;
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, rt0, nullptr, 0, idx_hi, tmp_hi, dmin);
 		if (left && rounds >= rt0) {
-			hipLaunchKernelGGL(k_sp_positions, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.pos_lo, (const uint8_t *)L.pos_hi, Tn, posS);
-			if (Ex) hipLaunchKernelGGL(k_sp_positions, dim3((uint32_t)((Ex + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xpos_lo, (const uint8_t *)L.xpos_hi, Ex, posS + Tn);
-			// the placed ones' global ranks wait in the sort's second buffer until the table is in order
-			for (const auto &pt : L.parts)
-				if (pt.xcount) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.xcount + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xslot, pt.xfirst, pt.xcount, pt.slice_off, rank);
-			// (pos, rank) of the placed ones, then all positions in order
-			uint64_t *xpos = ptmp;         // a copy of the placed ones' positions, unsorted, beside their ranks
-			if (Ex) B3M_HIP(hipMemcpyAsync(xpos, posS + Tn, 8 * Ex, hipMemcpyDeviceToDevice, s));
+			hipLaunchKernelGGL(k_sp_tied_positions, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint32_t *)idx, (const uint8_t *)idx_hi, Tn, posS);
+			// the placed ones: positions behind the list's in the table to be, a copy of them and their global ranks beside it until the table is in order
+			uint64_t *xpos = ptmp;
+			if (Ex) {
+				load_placed(SparseBufs{nullptr, nullptr, nullptr, nullptr, nullptr, xpos, rank});
+				B3M_HIP(hipMemcpyAsync(posS + Tn, xpos, 8 * Ex, hipMemcpyDeviceToDevice, s));
+			}
 			int nbits = 1; while ((1ull << nbits) < p->n + 1 && nbits < 64) ++nbits;
 			uint64_t *sorted = nullptr;
 			uint64_t *stmp = rank + Ex + 8;         // (M entries: inside keyA's 3 M behind gslot)
 			radix_sort_u64(posS, nullptr, stmp, nullptr, M, nbits, ws.radix, s, nullptr, &sorted, nullptr);
-			// ranks, in the table's order: placed ones first (their final rank), then the list's slots (tie_rounds_sparse: k_sp_init)
 			uint64_t *rtab = sorted == posS ? stmp : posS;
 			sparse_rank_placed(sorted, M, xpos, rank, Ex, rtab, s);
 			uint32_t missing = 0;
-			const uint64_t d0 = L.dmin + rt0 * K;
+			const uint64_t d0 = dmin + rt0 * K;
 			if (dbg >= 2) fprintf(stderr, "[b3m] list finish: %llu tied + %llu placed entries, %llu key rounds to %llu symbols, %llu left for doubling (threshold %llu)\n",
 			                      (unsigned long long)Tn, (unsigned long long)Ex, (unsigned long long)rounds, (unsigned long long)d0, (unsigned long long)left, (unsigned long long)X);
 			rounds += tie_rounds_sparse(T, idx, idx_hi, tmp_hi, Tn, left, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, sorted, rtab, gslot, M, d_missing, d0, X, s, &left, &missing);
@@ -668,8 +702,8 @@ static void sparse_tie_finish(b3m_plan *p, const TextView &T, uint8_t *d_bwt, ui
 	// symbols, p0 and samples of everything that was on the list
 	uint8_t *sym = reinterpret_cast<uint8_t *>(ptmp);
 	uint64_t *smp = (p->isarate && p->total_samples) ? p->d_samples : nullptr;
-	hipLaunchKernelGGL(k_sp_patch, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, T, (const uint32_t *)idx, (const uint8_t *)idx_hi, (const uint64_t *)gslot, Tn, d_bwt, sym, p->d_p0pairs, smp,
-	                   p->isarate ? p->isarate : 1);
+	hipLaunchKernelGGL(k_sp_patch, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, T, (const uint32_t *)idx, (const uint8_t *)idx_hi, (const uint64_t *)gslot, Tn, d_bwt, bwt_first, bwt_len, sym,
+	                   p->d_p0pairs, smp, p->isarate ? p->isarate : 1);
 	if (!d_bwt) {
 		std::vector<uint64_t> hg(Tn); std::vector<uint8_t> hs(Tn);
 		B3M_HIP(hipMemcpyAsync(hg.data(), gslot, 8 * Tn, hipMemcpyDeviceToHost, s));
@@ -678,6 +712,25 @@ static void sparse_tie_finish(b3m_plan *p, const TextView &T, uint8_t *d_bwt, ui
 		B3M_HIP(hipStreamSynchronize(p->copy_stream));            // every slice has arrived
 		for (uint64_t e = 0; e < Tn; ++e) h_bwt[hg[e]] = hs[e];
 	}
+}
+/* the list of ONE plan's sequential shards; d_bwt: the whole BWT on the device (a device-resident run), or null: the symbols go to h_bwt */
+static void sparse_tie_finish(b3m_plan *p, const TextView &T, uint8_t *d_bwt, uint8_t *h_bwt, hipStream_t s)
+{
+	b3m_plan::SparseTies &L = p->sp;
+	const uint64_t Tn = L.count, Ex = L.xcount;
+	auto load_tied = [&](const SparseBufs &b) {
+		B3M_HIP(hipMemcpyAsync(b.idx, L.pos_lo, 4 * Tn, hipMemcpyDeviceToDevice, s));
+		if (b.idx_hi) B3M_HIP(hipMemcpyAsync(b.idx_hi, L.pos_hi, Tn, hipMemcpyDeviceToDevice, s));
+		hipLaunchKernelGGL(k_sp_list, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint8_t *)L.head, Tn, b.U, b.hid);
+		for (const auto &pt : L.parts)
+			if (pt.count) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.count + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.slot, pt.first, pt.count, pt.slice_off, b.gslot);
+	};
+	auto load_placed = [&](const SparseBufs &b) {
+		hipLaunchKernelGGL(k_sp_positions, dim3((uint32_t)((Ex + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xpos_lo, (const uint8_t *)L.xpos_hi, Ex, b.xpos);
+		for (const auto &pt : L.parts)
+			if (pt.xcount) hipLaunchKernelGGL(k_sp_gslots, dim3((uint32_t)((pt.xcount + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xslot, pt.xfirst, pt.xcount, pt.slice_off, b.xrank);
+	};
+	sparse_finish_core(p, T, Tn, Ex, L.complete, L.dmin, L.dmax, load_tied, load_placed, d_bwt, 0, p->n, h_bwt, s);
 }
 
 // the run's samples as a host list, in position order (slot k of the pinned image holds position k * rate); a shard keeps only the
@@ -805,11 +858,11 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		if (p->isarate && (nsh > 1 || smp_in_kernel)) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
 		const bool seq_host = host && p->seq_shards > 1;         // the slices leave for host memory one by one: two slice buffers in d_bwt[0]
 		std::vector<hipEvent_t> gone;                            // gone[sh]: slice sh has left its buffer
-		p->bs.no_defer = p->seq_shards > 1;
+		p->bs.no_defer = p->seq_shards > 1 || (p->nshards > 1 && p->tie_mode != B3M_TIES_SA);
 		// what the shards leave tied goes onto the plan's list (SparseTies) and is finished when the last shard is through
 		b3m_plan::SparseTies &L = p->sp;
 		L.parts.clear(); L.count = L.xcount = 0; L.dmin = ~0ull; L.dmax = 0; L.complete = true;
-		const bool sparse = p->seq_shards > 1 && L.cap > 0 && B == 1;
+		const bool sparse = (p->seq_shards > 1 || (p->nshards > 1 && p->tie_mode == B3M_TIES_LIST)) && L.cap > 0 && B == 1;
 		if (sparse) B3M_HIP(hipMemsetAsync(L.xcnt, 0, 4, s));
 		for (int sh = (p->seq_shards > 1 ? 0 : p->shard); sh < (p->seq_shards > 1 ? p->seq_shards : p->shard + 1); ++sh) {
 			uint8_t *slice_dst = seq_host ? p->d_bwt[0] + (uint64_t)(sh & 1) * p->seq_half : nullptr;
@@ -841,7 +894,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 			if (so.reran_with_sa) p->sa_hint = 1;
 			p->tie_left = so.tie_left; p->tie_U = so.tie_U; p->tie_gid = so.tie_gid;
 			p->d_sa_slice = so.d_sa; p->slice_off = so.slice_offset; p->slice_len = so.kept_len;
-			if (p->seq_shards > 1) {
+			if (p->seq_shards > 1 || sparse) {
 				B3M_REQUIRE(!so.tie_left || (sparse && L.count + so.tie_left <= L.cap), "internal: deferred ties in a sequential shard");
 				if (sparse) {
 					uint32_t xc = 0;
@@ -857,7 +910,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 					L.parts.push_back({L.count, so.tie_left, L.xcount, (uint64_t)xc - L.xcount, so.slice_offset});
 					L.count += so.tie_left; L.xcount = xc;
 				}
-				so.tie_left = 0;
+				so.tie_left = 0; p->tie_left = 0;
 			}
 			p->res.tie_rounds = std::max(p->res.tie_rounds, so.tie_rounds);
 			p->res.tie_elements += so.tie_elements;
@@ -1179,6 +1232,78 @@ int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pa
 		p->samples_pending = true;
 	}
 	p->tie_left = 0;
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* ---- the same bound from lists instead of suffix arrays (include/b3m.h: B3M_TIES_LIST) ---- */
+int b3m_plan_set_tie_mode(b3m_plan *p, int mode)
+{
+	if (!p || mode < B3M_TIES_SA || mode > B3M_TIES_LOCAL) { set_error("b3m_plan_set_tie_mode: bad argument"); return 1; }
+	if (p->nshards <= 1) { set_error("b3m_plan_set_tie_mode: not a suffix-range shard"); return 1; }
+	if (mode == B3M_TIES_SA && p->n >= (1ull << 32)) { set_error("b3m_plan_set_tie_mode: texts of 2^32 symbols and more have no suffix-array form of the tie finish"); return 1; }
+	p->tie_mode = mode; return 0;
+}
+int b3m_plan_list_counts(const b3m_plan *p, uint64_t *tied_out, uint64_t *placed_out, uint64_t *depth_out, int *complete_out)
+{
+	if (!p || !tied_out || !placed_out || !depth_out || !complete_out) { set_error("null argument"); return 1; }
+	*tied_out = p->sp.count; *placed_out = p->sp.xcount; *depth_out = p->sp.count ? p->sp.dmax : 0; *complete_out = p->sp.complete ? 1 : 0;
+	return 0;
+}
+/* does the union of all shards' lists fit the buffers this shard would finish it in (its sort's workspace)?  If not: B3M_TIES_LOCAL and run again */
+int b3m_plan_list_fits(const b3m_plan *p, uint64_t tied_total, uint64_t placed_total)
+{
+	if (!p) return 0;
+	const BlockSortWs &ws = p->bs;
+	const bool big = p->n >= (1ull << 32);
+	return tied_total <= (big ? ws.tie_cap : ws.cap) && 2 * tied_total + 3 * (tied_total + placed_total) + 64 <= ws.cap;
+}
+int b3m_plan_list_export(b3m_plan *p, uint64_t *d_tied_out, uint64_t *d_placed_out, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && p->nshards > 1 && p->tie_mode == B3M_TIES_LIST, "b3m_plan_list_export: a suffix-range shard in list mode (b3m_plan_set_tie_mode) is needed");
+	const b3m_plan::SparseTies &L = p->sp;
+	B3M_REQUIRE((d_tied_out || !L.count) && (d_placed_out || !L.xcount), "b3m_plan_list_export: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	if (L.count) hipLaunchKernelGGL(k_sp_records, dim3((uint32_t)((L.count + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.slot, (const uint32_t *)L.pos_lo, (const uint8_t *)L.pos_hi,
+	                                (const uint8_t *)L.head, L.count, p->slice_off, d_tied_out);
+	if (L.xcount) hipLaunchKernelGGL(k_sp_records, dim3((uint32_t)((L.xcount + 255) / 256)), dim3(256), 0, s, (const uint32_t *)L.xslot, (const uint32_t *)L.xpos_lo, (const uint8_t *)L.xpos_hi,
+	                                 (const uint8_t *)nullptr, L.xcount, p->slice_off, d_placed_out);
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	return 0;
+	B3M_CATCH(1)
+}
+/* d_tied_all: the tied records of ALL shards, concatenated in shard order (2 * tied_total u64); d_placed_all: their placed records, any order; depth_min / depth_max: over
+ * the shards that reported tied suffixes; complete: every shard's list was.  Repairs this shard's slice of the BWT in d_bwt_slice (+ p0, samples). */
+int b3m_plan_list_finish(b3m_plan *p, const uint64_t *d_tied_all, uint64_t tied_total, const uint64_t *d_placed_all, uint64_t placed_total, uint64_t depth_min, uint64_t depth_max,
+                         int complete, uint8_t *d_bwt_slice, void *stream)
+{
+	B3M_TRY
+	B3M_REQUIRE(p && p->nshards > 1 && p->tie_mode == B3M_TIES_LIST, "b3m_plan_list_finish: a suffix-range shard in list mode (b3m_plan_set_tie_mode) is needed");
+	B3M_REQUIRE((d_tied_all || !tied_total) && (d_placed_all || !placed_total) && (d_bwt_slice || p->slice_len == 0), "b3m_plan_list_finish: null argument");
+	if (tied_total == 0) return 0;
+	B3M_REQUIRE(depth_min >= 1 && depth_max >= depth_min, "b3m_plan_list_finish: bad depths");
+	hipStream_t s = (hipStream_t)stream;
+	const uint64_t n = p->n;
+	TextView T{p->d_text, n, num_bases(n, p->type), p->type};
+	auto load_tied = [&](const SparseBufs &b) {
+		hipLaunchKernelGGL(k_sp_from_records, dim3((uint32_t)((tied_total + 255) / 256)), dim3(256), 0, s, d_tied_all, tied_total, b.idx, b.idx_hi, b.U, b.hid, b.gslot);
+	};
+	auto load_placed = [&](const SparseBufs &b) {
+		hipLaunchKernelGGL(k_sp_placed_from_records, dim3((uint32_t)((placed_total + 255) / 256)), dim3(256), 0, s, d_placed_all, placed_total, b.xpos, b.xrank);
+	};
+	sparse_finish_core(p, T, tied_total, placed_total, complete != 0, depth_min, depth_max, load_tied, load_placed, d_bwt_slice ? d_bwt_slice : p->d_bwt[0], p->slice_off, p->slice_len, nullptr, s);
+	uint64_t p0pair[2] = {~0ull, 0};
+	B3M_HIP(hipMemcpyAsync(p0pair, p->d_p0pairs, 16, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	B3M_HIP(hipGetLastError());
+	if (p0pair[0] != ~0ull) { p->res.p0 = p0pair[0]; p->res.has_p0 = 1; }
+	if (p->isarate && p->total_samples) {
+		if (p->samples_lazy) p->raw_stale = true;
+		else B3M_HIP(hipMemcpy(p->h_raw, p->d_samples, 16 * p->total_samples, hipMemcpyDeviceToHost));
+		p->samples_pending = true;
+	}
 	return 0;
 	B3M_CATCH(1)
 }

@@ -6,8 +6,8 @@
 //   in   : the file goes straight to HBM (pread into pinned staging pieces by a few threads, one HIP stream each) WHILE the plan is created;
 //   sort : num_gpus = 1: b3m_plan_run.  num_gpus = N > 1 ("one host thread per GPU drives its stream(s)"; the reference's own
 //          parallelism knob behind this call is numthreads=, /root/reference/src/bwtb3m.cpp:48-50): one host thread per device, each with the
-//          plan of one suffix-range shard (b3m_plan_create_sharded: no exchange step; long repeats: the suffix array slices are gathered by peer
-//          copies and every shard finishes its ties, b3m_plan_tie_*), the slices gathered on the first device;
+//          plan of one suffix-range shard (b3m_plan_create_sharded: no exchange step; long repeats: the shards' lists of tied suffixes are gathered by peer
+//          copies and every shard finishes the union, b3m_plan_list_*), the slices gathered on the first device;
 //   out  : two host threads: X.bwt (run-length / Huffman coded from the BWT in HBM, streamed to the file in pieces) beside X.sa / X.isa (LF walks on a
 //          stream of their own, the samples streamed from HBM) or X.preisa (the plan's pinned sample image, written in place).
 #include "formats.h"
@@ -70,9 +70,10 @@ struct Built {
 };
 
 struct Shard {
-	int dev = 0; b3m_plan *plan = nullptr; uint8_t *d_out = nullptr; b3m_result res{}; uint64_t pending = 0;
-	uint32_t *d_sa = nullptr, *d_pairs = nullptr;            // tie export
-	uint32_t *d_sa_global = nullptr, *d_pairs_all = nullptr; // tie finish
+	int dev = 0; b3m_plan *plan = nullptr; uint8_t *d_out = nullptr; b3m_result res{};
+	uint64_t tied = 0, placed = 0, depth = 0;                // what the shard's run left on its list (b3m_plan_list_counts)
+	uint64_t *d_tied = nullptr, *d_placed = nullptr;         // its records (b3m_plan_list_export)
+	uint64_t *d_tied_all = nullptr, *d_placed_all = nullptr; // the union on this shard's device (b3m_plan_list_finish)
 };
 
 // the devices of an N-GPU run: 0 .. N-1, or what B3M_DEVICES lists (test switch: "0,0,0,0" runs four shards' worth of host threads, plans and peer
@@ -98,7 +99,7 @@ void free_shards(std::vector<Shard> &sh)
 	for (auto &s : sh) {
 		(void)hipSetDevice(s.dev);
 		if (s.plan) b3m_plan_destroy(s.plan);
-		for (void *p : {(void *)s.d_out, (void *)s.d_sa, (void *)s.d_pairs, (void *)s.d_sa_global, (void *)s.d_pairs_all}) if (p) (void)hipFree(p);
+		for (void *p : {(void *)s.d_out, (void *)s.d_tied, (void *)s.d_placed, (void *)s.d_tied_all, (void *)s.d_placed_all}) if (p) (void)hipFree(p);
 		s = Shard{};
 	}
 }
@@ -123,7 +124,6 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	auto run_shard = [&](Shard &s) {
 		B3MCHK(b3m_plan_run(s.plan, b3m_plan_text_buffer(s.plan), s.d_out, nullptr));
 		B3MCHK(b3m_plan_result(s.plan, &s.res));
-		B3MCHK(b3m_plan_tie_pending(s.plan, &s.pending));
 	};
 	const double t0 = now();
 	on_threads(N, [&](int k) {
@@ -133,47 +133,60 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 		if (!s.plan) throw std::runtime_error(b3m_last_error());
 		HIPCHK(hipMalloc((void **)&s.d_out, b3m_plan_slice_capacity(s.plan) + 16));
 		HIPCHK(hipMemcpyPeer(b3m_plan_text_buffer(s.plan), s.dev, d_text0, devs[0], tb));
+		B3MCHK(b3m_plan_set_tie_mode(s.plan, B3M_TIES_LIST));
 		run_shard(s);
 	});
 	const double t1 = now();
-	uint64_t total = 0;
-	for (auto &s : sh) total += s.pending;
+	// long repeats (row a6): every shard stopped after a few key-extension rounds and kept a LIST of what was left tied (and of what its direct comparisons placed
+	// among long repeats); the lists are gathered by peer copies -- 16 bytes per listed suffix, not the suffix arrays -- and every shard finishes the union by prefix
+	// doubling on it (b3m_plan_list_*), then repairs its own slice.  A union too large for a shard's workspace: the shards with leftovers sort again and finish them
+	// themselves (B3M_TIES_LOCAL: key extension, correct but not bounded)
+	uint64_t total = 0, placed = 0, dmin = ~0ull, dmax = 0; int complete = 1;
+	for (auto &s : sh) {
+		int c = 1;
+		B3MCHK(b3m_plan_list_counts(s.plan, &s.tied, &s.placed, &s.depth, &c));
+		total += s.tied; placed += s.placed; complete &= c;
+		if (s.tied) { dmin = std::min(dmin, s.depth); dmax = std::max(dmax, s.depth); }
+	}
+	bool local = false;
 	if (total) {
-		// long repeats (row a6): what the shards' local rounds left tied is finished by prefix doubling over ALL shards' suffix arrays, on every shard
-		// (b3m_plan_tie_*): a shard that kept no suffix array sorts once more with it, the slices and the tied-slot lists are gathered by peer copies
-		if (n >= (1ull << 32)) throw std::runtime_error("long repeats across suffix-range shards of a text of 2^32 symbols and more are not finished collectively yet");
-		on_threads(N, [&](int k) {
-			Shard &s = sh[(size_t)k];
-			HIPCHK(hipSetDevice(s.dev));
-			if (!b3m_plan_has_sa(s.plan)) { B3MCHK(b3m_plan_set_keep_sa(s.plan, 1)); run_shard(s); }
-		});
-		total = 0;
-		for (auto &s : sh) total += s.pending;
-		on_threads(N, [&](int k) {
-			Shard &s = sh[(size_t)k];
-			HIPCHK(hipSetDevice(s.dev));
-			HIPCHK(hipMalloc((void **)&s.d_sa, 4 * s.res.slice_len + 16));
-			HIPCHK(hipMalloc((void **)&s.d_pairs, 8 * s.pending + 16));
-			B3MCHK(b3m_plan_tie_export(s.plan, s.d_sa, s.d_pairs, nullptr));
-		});
-		on_threads(N, [&](int k) {
-			Shard &s = sh[(size_t)k];
-			HIPCHK(hipSetDevice(s.dev));
-			HIPCHK(hipMalloc((void **)&s.d_sa_global, 4 * n + 16));
-			HIPCHK(hipMalloc((void **)&s.d_pairs_all, 8 * total + 16));
-			uint64_t at = 0, my_first = 0;
-			for (int j = 0; j < N; ++j) {
-				const Shard &o = sh[(size_t)j];
-				if (o.res.slice_len) HIPCHK(hipMemcpyPeer(s.d_sa_global + o.res.slice_offset, s.dev, o.d_sa, o.dev, 4 * o.res.slice_len));
-				if (o.pending) HIPCHK(hipMemcpyPeer(s.d_pairs_all + 2 * at, s.dev, o.d_pairs, o.dev, 8 * o.pending));
-				if (j == k) my_first = at;
-				at += o.pending;
-			}
-			B3MCHK(b3m_plan_tie_finish(s.plan, s.d_sa_global, s.d_pairs_all, total, my_first, s.d_out, nullptr));
-			B3MCHK(b3m_plan_result(s.plan, &s.res));
-			(void)hipFree(s.d_sa_global); s.d_sa_global = nullptr;
-			(void)hipFree(s.d_pairs_all); s.d_pairs_all = nullptr;
-		});
+		bool fits = true;
+		for (auto &s : sh) fits = fits && b3m_plan_list_fits(s.plan, total, placed);
+		if (!fits) {
+			local = true;
+			on_threads(N, [&](int k) {
+				Shard &s = sh[(size_t)k];
+				if (!s.tied) return;
+				HIPCHK(hipSetDevice(s.dev));
+				B3MCHK(b3m_plan_set_tie_mode(s.plan, B3M_TIES_LOCAL));
+				run_shard(s);
+			});
+		} else {
+			on_threads(N, [&](int k) {
+				Shard &s = sh[(size_t)k];
+				HIPCHK(hipSetDevice(s.dev));
+				HIPCHK(hipMalloc((void **)&s.d_tied, 16 * s.tied + 16));
+				HIPCHK(hipMalloc((void **)&s.d_placed, 16 * s.placed + 16));
+				B3MCHK(b3m_plan_list_export(s.plan, s.d_tied, s.d_placed, nullptr));
+			});
+			on_threads(N, [&](int k) {
+				Shard &s = sh[(size_t)k];
+				HIPCHK(hipSetDevice(s.dev));
+				HIPCHK(hipMalloc((void **)&s.d_tied_all, 16 * total + 16));
+				HIPCHK(hipMalloc((void **)&s.d_placed_all, 16 * placed + 16));
+				uint64_t at = 0, xat = 0;
+				for (int j = 0; j < N; ++j) {
+					const Shard &o = sh[(size_t)j];
+					if (o.tied) HIPCHK(hipMemcpyPeer(s.d_tied_all + 2 * at, s.dev, o.d_tied, o.dev, 16 * o.tied));
+					if (o.placed) HIPCHK(hipMemcpyPeer(s.d_placed_all + 2 * xat, s.dev, o.d_placed, o.dev, 16 * o.placed));
+					at += o.tied; xat += o.placed;
+				}
+				B3MCHK(b3m_plan_list_finish(s.plan, s.d_tied_all, total, s.d_placed_all, placed, dmin, dmax, complete, s.d_out, nullptr));
+				B3MCHK(b3m_plan_result(s.plan, &s.res));
+				(void)hipFree(s.d_tied_all); s.d_tied_all = nullptr;
+				(void)hipFree(s.d_placed_all); s.d_placed_all = nullptr;
+			});
+		}
 	}
 	const double t2 = now();
 	// the slices tile the rank space: gathered on the first device (the RL encoder and the LF walks read the whole BWT)
@@ -216,8 +229,8 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	}
 	std::map<int, int> distinct;
 	for (int d : devs) distinct[d] = 1;
-	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu suffixes), gather %.3f s\n", N, (int)distinct.size(), t1 - t0, t2 - t1,
-	    (unsigned long long)total, now() - t2);
+	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu tied + %llu placed suffixes on the shards' lists%s), gather %.3f s\n", N,
+	    (int)distinct.size(), t1 - t0, t2 - t1, (unsigned long long)total, (unsigned long long)placed, local ? ": too many for a shard's workspace, finished shard by shard" : "", now() - t2);
 }
 }  // namespace
 

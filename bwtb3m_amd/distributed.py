@@ -548,8 +548,10 @@ class PrefixShardedBwt:
         self.n, self.itype, self.device = n, itype, device
         self.plan = engine.Plan(n, itype, isasamplingrate=isasamplingrate, shard=self.rank, nshards=self.world)
         self.out = torch.empty(self.plan.slice_capacity, dtype=torch.uint8, device=device)
-        self.tie_finish_runs = 0           # steps that needed the collective finish of long repeats (decided once per plan: from the first such step on
-                                           # the shard keeps its suffix array, b3m_plan_set_keep_sa, and every step repeats the finish)
+        self.tie_finish_runs = 0           # steps that needed the collective finish of long repeats
+        self.local_ties = False            # the union of the shards' lists did not fit a shard's workspace: every shard finishes its own repeats from then on
+        if self.world > 1:
+            self.plan.set_tie_mode(engine.Plan.TIES_LIST)
         self.fallback = None               # the block-merge driver, once some shard has refused its range (skewed text): see run()
 
     def run(self, d_text):
@@ -568,7 +570,8 @@ class PrefixShardedBwt:
             refused, sl = 1, self.out[:0]
         if self.world > 1:
             # one small all-gather per step: who refused, and (long repeats, row a6) what the local rounds left tied on any shard
-            pend = _all_gather_i64([0 if refused else self.plan.tie_pending(), sl.numel(), refused], None, self.out.device)
+            t, x, depth, complete = (0, 0, 0, True) if refused or self.local_ties else self.plan.list_counts()
+            pend = _all_gather_i64([t, sl.numel(), refused, x, depth, 1 if complete else 0], None, self.out.device)
             if int(pend[:, 2].sum()) > 0:
                 self.refusal = "suffix-range shards refused by rank(s) %s: block merging instead" % [int(i) for i in np.nonzero(pend[:, 2])[0]]
                 if self.isasamplingrate and not self.allow_fallback_without_samples:
@@ -582,25 +585,23 @@ class PrefixShardedBwt:
                 torch.cuda.empty_cache()
                 self.fallback = DistributedBwt(self.n, self.itype, HipBackend(self.device), self.device)
                 return self.fallback.run(d_text)
-            # ties: finished by prefix doubling over all shards' suffix arrays
+            # ties (row a6): every shard kept a LIST of what its rounds left tied (and of what its direct comparisons placed among long repeats); the records -- 16 bytes
+            # per listed suffix -- go to every rank in two all-gathers and every rank finishes the union by prefix doubling on the list (engine.finish_shard_lists).
+            # A union too large for a shard's workspace: from this step on the shards finish their repeats themselves (key extension, no collective step)
             if int(pend[:, 0].sum()) > 0:
                 from . import engine
-                if not self.plan.has_sa():                       # a BWT-only run kept no suffix array: once more, with it
-                    engine.rerun_for_ties(self.plan, d_text, self.out)
-                    pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
+                tied, placed = int(pend[:, 0].sum()), int(pend[:, 3].sum())
+                fits = _all_gather_i64([1 if self.plan.list_fits(tied, placed) else 0], None, sl.device)
+                if int(fits[:, 0].min()) == 0:
+                    self.plan.set_tie_mode(engine.Plan.TIES_LOCAL)
+                    self.local_ties = True
+                    sl = self.plan.run(d_text, self.out)
                 else:
-                    pend = _all_gather_i64([self.plan.tie_pending(), sl.numel()], None, sl.device)
-                sizes, counts, me = pend[:, 1], pend[:, 0], self.rank
-
-                def gather_sa(sa):
-                    return _all_gather_v(sa, sizes)
-
-                def gather_pairs(pairs):
-                    allp = _all_gather_v(pairs.reshape(-1), 2 * counts).reshape(-1, 2)
-                    return allp, int(counts[:me].sum())
-
-                engine.finish_shard_ties(self.plan, sl, gather_sa, gather_pairs)
-                self.tie_finish_runs += 1
+                    depths = [int(d) for d, t in zip(pend[:, 4], pend[:, 0]) if t]
+                    gathered = lambda mine: (_all_gather_v(mine[0].reshape(-1), 2 * pend[:, 0]).reshape(-1, 2), _all_gather_v(mine[1].reshape(-1), 2 * pend[:, 3]).reshape(-1, 2),
+                                             min(depths), max(depths), bool(pend[:, 5].min()))
+                    engine.finish_shard_lists(self.plan, sl, gathered)
+                    self.tie_finish_runs += 1
         r = self.plan.result()
         off = r["slice_offset"] if self.world > 1 else 0
         return sl, off, (r["p0"] if r["has_p0"] else None)

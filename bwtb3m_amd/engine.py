@@ -160,6 +160,33 @@ class Plan:
     def tie_finish(self, sa_global, pairs_all, my_first, d_bwt_slice):
         check(lib().b3m_plan_tie_finish(self._h, _ptr(sa_global), _ptr(pairs_all), pairs_all.shape[0], int(my_first), _ptr(d_bwt_slice), _stream()))
 
+    # ---- the same bound from lists instead of suffix arrays (include/b3m.h: B3M_TIES_LIST): see finish_shard_lists() ----
+    TIES_SA, TIES_LIST, TIES_LOCAL = 0, 1, 2
+
+    def set_tie_mode(self, mode):
+        check(lib().b3m_plan_set_tie_mode(self._h, int(mode)))
+
+    def list_counts(self):
+        """-> (tied, placed, depth, complete) of this shard's last run in list mode"""
+        t, x, d, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int(0)
+        check(lib().b3m_plan_list_counts(self._h, ctypes.byref(t), ctypes.byref(x), ctypes.byref(d), ctypes.byref(c)))
+        return int(t.value), int(x.value), int(d.value), bool(c.value)
+
+    def list_fits(self, tied_total, placed_total):
+        return bool(lib().b3m_plan_list_fits(self._h, int(tied_total), int(placed_total)))
+
+    def list_export(self, device):
+        """-> (tied records, placed records): int64 tensors [k, 2] = (global rank | first-of-group << 63, position)"""
+        t, x, _, _ = self.list_counts()
+        tied = torch.empty((max(1, t), 2), dtype=torch.int64, device=device)
+        placed = torch.empty((max(1, x), 2), dtype=torch.int64, device=device)
+        check(lib().b3m_plan_list_export(self._h, _ptr(tied), _ptr(placed), _stream()))
+        return tied[:t], placed[:x]
+
+    def list_finish(self, tied_all, placed_all, depth_min, depth_max, complete, d_bwt_slice):
+        check(lib().b3m_plan_list_finish(self._h, _ptr(tied_all), tied_all.shape[0], _ptr(placed_all), placed_all.shape[0], int(depth_min), int(depth_max),
+                                         1 if complete else 0, _ptr(d_bwt_slice), _stream()))
+
     def result(self):
         r = _lib.Result()
         check(lib().b3m_plan_result(self._h, ctypes.byref(r)))
@@ -235,6 +262,17 @@ def finish_shard_ties(plan, out_slice, gather_sa, gather_pairs):
     pairs_all, my_first = gather_pairs(pairs)
     if pairs_all.shape[0]:
         plan.tie_finish(sa_global.contiguous(), pairs_all.contiguous(), my_first, out_slice)
+
+
+def finish_shard_lists(plan, out_slice, gather):
+    """The same from lists (plans in list mode, Plan.set_tie_mode(Plan.TIES_LIST)): gather((tied, placed, depth, complete)) -> (every shard's tied records concatenated
+    in shard order, all placed records, smallest and largest depth over the shards that reported tied suffixes, all complete).  Called by EVERY shard (collectively) after
+    its run; a union that does not fit a shard's workspace (Plan.list_fits) is the caller's to handle: TIES_LOCAL and run again."""
+    tied, placed = plan.list_export(out_slice.device)
+    _, _, depth, complete = plan.list_counts()
+    tied_all, placed_all, dmin, dmax, all_complete = gather((tied, placed, depth, complete))
+    if tied_all.shape[0]:
+        plan.list_finish(tied_all.contiguous(), placed_all.contiguous(), dmin, dmax, all_complete, out_slice)
 
 
 def bwt_device(file_bytes, inputtype, blocksize=0, isasamplingrate=0, keep_sa=False):

@@ -172,6 +172,24 @@ int b3m_plan_tie_pending(const b3m_plan *p, uint64_t *count_out);
 int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs_out, void *stream);
 int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pairs_all, uint64_t total, uint64_t my_first, uint8_t *d_bwt_slice, void *stream);
 
+/* The same bound WITHOUT the shards' suffix arrays (round 4; the only form for texts of 2^32 symbols and more): with b3m_plan_set_tie_mode(plan, B3M_TIES_LIST) a shard's run
+ * stops after the same few rounds and keeps a LIST of what is left -- (global rank | first-of-group flag in bit 63, position) per tied suffix, in rank order -- plus the
+ * suffixes its direct comparisons placed for good among long repeats ("placed": their rank is final, the doubling rounds must be able to look it up).  The caller gathers
+ * every shard's records (b3m_plan_list_export; 16 bytes per suffix on the list instead of 4 per suffix of the text: one small all-gather between GPUs), concatenates the tied
+ * ones in shard order, and every shard calls b3m_plan_list_finish on the union: prefix doubling on the list alone (the rank of the suffix d - X symbols on is looked up among
+ * the listed ones), after which the shard's slice of the BWT, p0 and samples are final.  b3m_plan_list_counts: complete = 0 means the shard's list overflowed (it then
+ * finished its own repeats by key extension, or dropped placed entries): the union is still finished correctly, by key extension (not bounded).
+ * B3M_TIES_LOCAL: the shard finishes its long repeats itself by key extension (no collective step at all).  b3m_compute_bwt (numgpus > 1) uses the list. */
+#define B3M_TIES_SA    0    /* b3m_plan_tie_* over all shards' suffix arrays (default below 2^32 symbols) */
+#define B3M_TIES_LIST  1
+#define B3M_TIES_LOCAL 2    /* (default for shards of texts of 2^32 symbols and more) */
+int b3m_plan_set_tie_mode(b3m_plan *p, int mode);
+int b3m_plan_list_counts(const b3m_plan *p, uint64_t *tied_out, uint64_t *placed_out, uint64_t *depth_out, int *complete_out);
+int b3m_plan_list_fits(const b3m_plan *p, uint64_t tied_total, uint64_t placed_total);      /* 1: this shard's workspace can finish a union list of that size */
+int b3m_plan_list_export(b3m_plan *p, uint64_t *d_tied_out /* 2 * tied */, uint64_t *d_placed_out /* 2 * placed */, void *stream);
+int b3m_plan_list_finish(b3m_plan *p, const uint64_t *d_tied_all, uint64_t tied_total, const uint64_t *d_placed_all, uint64_t placed_total, uint64_t depth_min, uint64_t depth_max,
+                         int complete, uint8_t *d_bwt_slice, void *stream);
+
 typedef struct b3m_result {
 	uint64_t n, num_blocks, levels;
 	uint64_t p0;                 /* rank of the rotation starting at position 0 (pacterm: BWA "primary") */

@@ -77,7 +77,42 @@ def case_small(rng, O, engine):
     return ok, desc
 
 
-def run_shards(torch, engine, d_text, n, itype, ns, isarate=0):
+def run_shards(torch, engine, d_text, n, itype, ns, isarate=0, lists=None):
+    if lists is None: lists = os.environ.get("FUZZ_SHARD_LISTS", "") == "1"
+    if lists or n >= (1 << 32): return run_shards_lists(torch, engine, d_text, n, itype, ns, isarate)
+    return run_shards_sa(torch, engine, d_text, n, itype, ns, isarate)
+
+
+def run_shards_lists(torch, engine, d_text, n, itype, ns, isarate=0):
+    """the same with the shards in LIST mode (include/b3m.h: B3M_TIES_LIST): what the shards' rounds leave tied travels as 16-byte records, every shard finishes the
+    union by prefix doubling on it (a union too large for a shard's workspace: the shards with leftovers run again in LOCAL mode)"""
+    plans, slices = [], []
+    for k in range(ns):
+        plan = engine.Plan(n, itype, shard=k, nshards=ns, isasamplingrate=isarate)
+        plan.set_tie_mode(engine.Plan.TIES_LIST)
+        slices.append(plan.run(d_text).clone()); plans.append(plan)
+    torch.cuda.synchronize()
+    counts = [p.list_counts() for p in plans]
+    tied, placed = sum(c[0] for c in counts), sum(c[1] for c in counts)
+    if tied:
+        if not all(p.list_fits(tied, placed) for p in plans):
+            for k, p in enumerate(plans):
+                if counts[k][0]:
+                    p.set_tie_mode(engine.Plan.TIES_LOCAL)
+                    slices[k] = p.run(d_text).clone()
+            torch.cuda.synchronize()
+            return plans, slices, tied
+        exported = [p.list_export("cuda") for p in plans]
+        tied_all = torch.cat([e[0] for e in exported]); placed_all = torch.cat([e[1] for e in exported])
+        depths = [c[2] for c in counts if c[0]]
+        gathered = (tied_all, placed_all, min(depths), max(depths), all(c[3] for c in counts))
+        for k, p in enumerate(plans):
+            engine.finish_shard_lists(p, slices[k], lambda mine: gathered)
+        torch.cuda.synchronize()
+    return plans, slices, tied
+
+
+def run_shards_sa(torch, engine, d_text, n, itype, ns, isarate=0):
     """all ns suffix-range shards of a text on this one GPU, as the ranks of a multi-GPU run would: each plan runs, and if any shard's local
     rounds left suffixes tied (long repeats) all of them finish collectively over the gathered suffix arrays"""
     plans, slices = [], []
@@ -121,7 +156,7 @@ def case_shards(rng, O, engine, torch):
     desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d alt=%d" % (itype, nb, kind, ns, geo, isar, alt)
     try:
         d_text = torch.from_numpy(np.asarray(buf)).cuda()
-        plans, slices, _ = run_shards(torch, engine, d_text, n, itype, ns, isar)
+        plans, slices, _ = run_shards(torch, engine, d_text, n, itype, ns, isar, lists=True if (ns & 1) else None)      # (odd shard counts: the list form of the tie finish)
         off, ok, smp = 0, True, []
         for p, sl in zip(plans, slices):
             r = p.result()
@@ -245,7 +280,7 @@ def case_large(rng, engine, torch, lo=24_000_000, hi=400_000_000):
             plan.close()
         elif form == 2:
             ns = int(rng.integers(2, 17))
-            plans, slices, ties = run_shards(torch, engine, d_text, n, itype, ns)
+            plans, slices, ties = run_shards(torch, engine, d_text, n, itype, ns, lists=True if (ns & 1) else None)
             ok &= bool(torch.equal(torch.cat(slices), one)); desc += " shards %d (ties %d)" % (ns, ties)
             for p in plans:
                 p.close()

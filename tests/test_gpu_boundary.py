@@ -98,7 +98,7 @@ def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ng
         if N > 1:
             assert ("%d suffix-range shards" % N).encode() in r.stderr
             if kind == "repeat":
-                assert b"tie finish" in r.stderr and b"(0 suffixes)" not in r.stderr, r.stderr.decode()
+                assert b"tie finish" in r.stderr and b"(0 tied" not in r.stderr, r.stderr.decode()
         outs[N] = _files(out[:-4])
     assert set(outs[1]) == set(outs[ngpus]) == ({".bwt", ".hist", ".meta", ".preisa"} if bwtonly else {".bwt", ".hist", ".meta", ".sa", ".isa"})
     for suf in outs[1]:
@@ -506,6 +506,34 @@ def test_sequential_shards_finish_long_repeats_by_doubling_on_their_list(gpu, or
     assert np.array_equal(h_out.numpy(), ref)
     check_side_results()
     plan.close()
+
+
+@pytest.mark.parametrize("itype,ns", [("pacterm", 3), ("pac", 5), ("pacterm", 8)])
+def test_shards_finish_long_repeats_from_their_lists(gpu, oracle, itype, ns):
+    """The collective tie finish of suffix-range shards WITHOUT their suffix arrays (include/b3m.h: B3M_TIES_LIST; what b3m_compute_bwt numgpus=N does): every shard keeps
+    a list of what its four rounds left tied (16-byte records: global rank, position) and of what its direct comparisons placed among long repeats; every shard finishes the
+    union by prefix doubling on the list and repairs its own slice, p0 and samples.  All shards on this one GPU, against the oracle."""
+    torch = gpu
+    import fuzzlib
+    from bwtb3m_amd import engine
+    b = _long_repeat_bases(oracle, 1_600_001, 33)
+    buf = oracle.pac_encode(b)
+    s = oracle.symbols_from_file_bytes(buf, itype)
+    ref = oracle.bwt(s)
+    sa = oracle.sa_circular(s)
+    n = len(s)
+    d = torch.from_numpy(np.concatenate([buf, np.zeros(16, dtype=np.uint8)])).cuda()
+    plans, slices, tied = fuzzlib.run_shards_lists(torch, engine, d, n, itype, ns, isarate=512)
+    assert tied > 50_000
+    assert np.array_equal(torch.cat(slices).cpu().numpy(), ref)
+    assert max(p.result()["tie_rounds"] for p in plans) < 40
+    isa = np.empty_like(sa); isa[sa] = np.arange(n)
+    p0s = [p.result()["p0"] for p in plans if p.result()["has_p0"]]
+    assert p0s == [int(isa[0])]
+    smp = np.concatenate([p.samples() for p in plans])
+    assert len(smp) == (n + 511) // 512 and np.array_equal(isa[smp[:, 1].astype(np.int64)], smp[:, 0].astype(np.int64))
+    for p in plans:
+        p.close()
 
 
 def test_host_tier_is_taken_when_no_merge_tree_meets_mem(gpu, tmp_path):
