@@ -199,7 +199,7 @@ struct BlockSortWs {
 // cap = suffixes sorted at once; span = length of the text range they are drawn from (> cap for a suffix-range shard; 0 = cap)
 uint64_t blocksort_ws_bytes(uint64_t cap, uint64_t span = 0, bool lazy_ties = false);
 void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span = 0, bool lazy_ties = false);
-void blocksort_ensure_ties(BlockSortWs &ws);       // no-op unless the tie buffers are lazy and not there yet
+void blocksort_ensure_ties(BlockSortWs &ws, uint64_t need = 0);       // no-op unless the tie buffers are lazy and not there yet; texts of 2^32 symbols and more: buffers for `need` tied suffixes
 void blocksort_release(BlockSortWs &ws);           // frees what blocksort_ensure_ties allocated
 struct BlockSortOut {
 	uint32_t *d_sa = nullptr;         // points into ws (valid until next sort) : sorted positions

@@ -208,7 +208,6 @@ static uint64_t sparse_ties_cap(uint64_t n, uint64_t shard_cap)
 {
 	const char *e = getenv("B3M_SPARSE_TIES");
 	uint64_t c = shard_cap / 10;
-	if (n >= (1ull << 32)) c = std::min<uint64_t>(c, shard_cap / 16);      // (the list buffers of such a sort: tie_cap)
 	if (e) c = std::min<uint64_t>(c, strtoull(e, nullptr, 10));
 	return c;
 }
@@ -654,7 +653,7 @@ static void sparse_finish_core(b3m_plan *p, const TextView &T, uint64_t Tn, uint
 	BlockSortWs &ws = p->bs;
 	const bool big = p->n >= (1ull << 32);
 	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
-	blocksort_ensure_ties(ws);
+	blocksort_ensure_ties(ws, Tn);
 	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 	if (big) { Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB; }
 	B3M_REQUIRE(Tn <= (big ? ws.tie_cap : ws.cap) && 2 * Tn + 3 * M + 64 <= ws.cap, "the list of tied suffixes (" + std::to_string(Tn) + " + " + std::to_string(Ex) +
@@ -1256,7 +1255,8 @@ int b3m_plan_list_fits(const b3m_plan *p, uint64_t tied_total, uint64_t placed_t
 	if (!p) return 0;
 	const BlockSortWs &ws = p->bs;
 	const bool big = p->n >= (1ull << 32);
-	return tied_total <= (big ? ws.tie_cap : ws.cap) && 2 * tied_total + 3 * (tied_total + placed_total) + 64 <= ws.cap;
+	(void)big;      // (its list buffers grow on demand: blocksort_ensure_ties)
+	return 2 * tied_total + 3 * (tied_total + placed_total) + 64 <= ws.cap;
 }
 int b3m_plan_list_export(b3m_plan *p, uint64_t *d_tied_out, uint64_t *d_placed_out, void *stream)
 {

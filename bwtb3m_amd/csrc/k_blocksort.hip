@@ -231,9 +231,11 @@ __global__ void k_emit_bwt_list(TextView T, const uint32_t *U, uint64_t u, const
 // (k_tie_large_*).  Groups of up to TT_COUNT members are ordered by counting (each member counts the smaller ones), larger
 // ones by a bitonic network over the tile, keyed (group, key).
 // ------------------------------------------------------------------------------------------------
-constexpr int MP_GROUP = 512, MP_ROW = 9;               // pieces above MP_GROUP slots are split further; table row = piece start >> MP_ROW
+constexpr int MP_GROUP = 512, MP_ROW = 9;               // pieces above MP_GROUP slots are split further; table row = piece start >> MP_ROW  (256 / 8 measured: 208 -> 216 ms on the genome-like text)
 // (tiles of 2048 slots / 256 threads, 32 KB of LDS: four workgroups per CU; 4096 / 512 until round 4: 227 -> 222 ms on the genome-like text.  -DB3M_TT_LARGE: the old form)
-#ifdef B3M_TT_LARGE
+#if defined(B3M_TT_TINY)
+constexpr int TT_STRIDE = 512, TT_GROUP = 512, TT_CAP = 1024, TT_THREADS = 128, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
+#elif defined(B3M_TT_LARGE)
 constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
 #else
 constexpr int TT_STRIDE = 1024, TT_GROUP = 1024, TT_CAP = 2048, TT_THREADS = 256, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 	__shared__ uint64_t sk[TT_CAP];                  // keys
 	__shared__ uint32_t sv[TT_CAP];                  // suffixes
 	__shared__ uint16_t sg[TT_CAP];                  // group of the slot, counted inside the tile from 1 (0xFFFF: padding)
-	__shared__ uint16_t gs[TT_CAP + 2];              // first slot of group g; gs[groups + 1] = m
+	__shared__ __attribute__((aligned(4))) uint16_t gs[TT_CAP + 2];              // first slot of group g; gs[groups + 1] = m
 	__shared__ uint32_t wtot[TT_THREADS / 64];
 	__shared__ uint32_t red[4];
 	const uint32_t tid = threadIdx.x;
@@ -363,12 +365,24 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 				const uint32_t g = sg[p], b = gs[g], en = gs[g + 1];
 				const uint64_t my = sk[p];
 				uint32_t less = 0;
-				if (kshift) { for (uint32_t j = b; j < en; ++j) less += sk[j] < my ? 1u : 0u; }
-				else for (uint32_t j = b; j < en; ++j) { const uint64_t kj = sk[j]; less += (kj < my || (kj == my && j < p)) ? 1u : 0u; }
+				for (uint32_t j = b; j < en; ++j) less += sk[j] < my ? 1u : 0u;
 				mk[k] = my; mv[k] = sv[p]; dst[k] = b + less;
 			}
 		}
 		__syncthreads();
+		if (!kshift) {
+			// 64-bit keys carry no slot: members with EQUAL keys counted the same place.  They stay one group, in any order: each takes the next free slot
+			// behind that place (16-bit counters, two per word, in the group-start table, which nobody reads any more) -- one LDS atomic per member instead
+			// of a second compare per pair
+			uint32_t *eq = reinterpret_cast<uint32_t *>(gs);
+			for (uint32_t t = tid; t < (uint32_t)(TT_CAP + 2) / 2u; t += TT_THREADS) eq[t] = 0u;
+			__syncthreads();
+			#pragma unroll
+			for (int k = 0; k < TT_PER; ++k) if (dst[k] != 0xFFFFFFFFu) {
+				const uint32_t d = dst[k], old = atomicAdd(&eq[d >> 1], (d & 1u) ? 0x10000u : 1u);
+				dst[k] = d + ((d & 1u) ? (old >> 16) : (old & 0xFFFFu));
+			}
+		}
 		#pragma unroll
 		for (int k = 0; k < TT_PER; ++k) if (dst[k] != 0xFFFFFFFFu) { sk[dst[k]] = mk[k]; sv[dst[k]] = mv[k]; }
 		__syncthreads();
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 //   (pieces are longer than 512 slots: a row has one piece): counts, then places.
 // A chunk of 1024 slots meets at most three pieces (one that began in front of it, two that begin inside): three LDS histograms.
 // ------------------------------------------------------------------------------------------------
-constexpr int MP_CHUNK = 1024, MP_THREADS = 256, MP_PER = MP_CHUNK / MP_THREADS;
+constexpr int MP_CHUNK = 2 << MP_ROW, MP_THREADS = MP_CHUNK / 4, MP_PER = MP_CHUNK / MP_THREADS;
 static_assert(MP_CHUNK <= 2 * MP_GROUP && (1 << MP_ROW) <= MP_GROUP, "at most two pieces begin inside a chunk, one piece per table row");
 static_assert(MP_GROUP <= TT_COUNT, "what the splits leave is ordered by counting");
 
@@ -734,8 +748,27 @@ void blocksort_ws_carve(BlockSortWs &ws, void *base, uint64_t cap, uint64_t span
 	ws.d_scalars = (uint32_t *)p;
 }
 
-void blocksort_ensure_ties(BlockSortWs &ws)
+void blocksort_ensure_ties(BlockSortWs &ws, uint64_t need)
 {
+	if (ws.sa_hi) {
+		// texts of 2^32 symbols and more: list buffers for a sixteenth of the sort are part of the workspace (a text with few repeats never needs more); a repeat-rich one
+		// (a tenth to a half of a genome's suffixes share their first 16 bases with 32 others) gets larger ones on demand, kept for the plan's later runs
+		if (need <= ws.tie_cap) return;
+		const uint64_t c = std::min<uint64_t>(ws.cap, need + need / 8 + (1ull << 20));
+		const uint64_t one = al(4 * (c + 1));
+		void *a = nullptr;
+		if (hipMalloc(&a, 5 * one + al(c + 1)) != hipSuccess) {
+			(void)hipGetLastError();
+			throw Error("repeat-rich input of 2^32 symbols and more: " + std::to_string(need) + " suffixes are left to the list-based rounds and there is no HBM left for their buffers (" +
+			            std::to_string((5 * one + c) / 1000000) + " MB beside the plan's workspace): use more shards (a smaller mem=)");
+		}
+		if (ws.tie_alloc) (void)hipFree(ws.tie_alloc);
+		ws.tie_alloc = a;
+		for (int i = 1; i < 6; ++i) ws.t[i] = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(a) + (uint64_t)(i - 1) * one);
+		ws.tie_hi = static_cast<uint8_t *>(a) + 5 * one;
+		ws.tie_cap = c;
+		return;
+	}
 	if (!ws.lazy_ties || ws.t[1]) return;
 	const uint64_t one = al(4 * (ws.cap + 1));
 	if (hipMalloc(&ws.tie_alloc, 5 * one) != hipSuccess) {
@@ -747,7 +780,7 @@ void blocksort_ensure_ties(BlockSortWs &ws)
 }
 void blocksort_release(BlockSortWs &ws)
 {
-	if (ws.tie_alloc) { (void)hipFree(ws.tie_alloc); ws.tie_alloc = nullptr; for (int i = 1; i < 6; ++i) ws.t[i] = nullptr; }
+	if (ws.tie_alloc) { (void)hipFree(ws.tie_alloc); ws.tie_alloc = nullptr; for (int i = 1; i < 6; ++i) ws.t[i] = nullptr; if (ws.sa_hi) { ws.tie_hi = nullptr; ws.tie_cap = 0; } }
 }
 
 // Rounds on the list (U, gid) of u tied slots.  idx = the suffix array being built.  Buffers: kx/ky

@@ -3015,14 +3015,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemcpyAsync(&total32, d_off + nov, 4, hipMemcpyDeviceToHost, s));
 		B3M_HIP(hipStreamSynchronize(s));
 		const uint64_t total = total32;
-		blocksort_ensure_ties(ws);                             // (lazy in one-block plans: uniform text never comes here)
+		blocksort_ensure_ties(ws, total);                      // (lazy in one-block plans: uniform text never comes here; texts of 2^32 symbols and more: larger buffers on demand)
 		// texts of 2^32 symbols and more: list buffers of tie_cap entries (the tie bitmap sits in t[0]), positions in two arrays
 		uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 		if (big) {
 			Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB;
 			B3M_REQUIRE(ws.t[5] != nullptr && ws.tie_hi != nullptr, "internal: workspace has no list buffers for positions above 2^32");
 			B3M_REQUIRE(total <= ws.tie_cap, "repeat-rich input of 2^32 symbols and more: " + std::to_string(total) + " suffixes are left to the list-based rounds, whose buffers hold " +
-			            std::to_string(ws.tie_cap) + " (a sixteenth of the sort): use more shards");
+			            std::to_string(ws.tie_cap) + ": use more shards");
 		}
 		const bool by_range = total / nov >= 16 && !(getenv("B3M_FILL_BY_SLOT") && atoi(getenv("B3M_FILL_BY_SLOT")));      // (few slots per range: one thread per slot and a search keep the lanes busy)
 		auto fill_list = [&](uint32_t *U, uint32_t *gid) {

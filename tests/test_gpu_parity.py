@@ -1152,6 +1152,26 @@ def test_repeat_rich_text_beyond_2_32_symbols(gpu):
     plan.close()
 
 
+def test_genome_like_text_beyond_2_32_symbols(gpu):
+    """4.4 Gbase of the genome-like text (interspersed repeat families, tandem arrays, segmental duplications: bwtb3m_amd.synth.genome_like_device), two sequential shards:
+    a ninth of its suffixes reach the list-based rounds -- more than the list buffers a sort of 2^32 symbols and more carries (a sixteenth of the shard: round 3 refused such
+    a text whatever the shard count); they grow on demand now (blocksort_ensure_ties), and what the shards' rounds leave tied is finished by prefix doubling on the plan's
+    list.  LF-verified over every symbol."""
+    torch = gpu
+    from bwtb3m_amd import engine, synth
+    nb = 4_400_000_000
+    d_text = synth.genome_like_device(nb, 7, "cuda")
+    n = nb + 1
+    plan = engine.Plan(n, "pacterm", isasamplingrate=1 << 16)
+    out = plan.run(d_text)
+    torch.cuda.synchronize()
+    r = plan.result()
+    assert r["tie_elements"] > n // 16 and r["tie_rounds"] < 40, r
+    assert int(out[r["p0"]]) == 0
+    assert plan.lf_walk(out, sarate=0)[:2] == (0, 0)
+    plan.close()
+
+
 def test_c5_geometry_shards_of_8_on_one_gpu(gpu):
     """BASELINE configs[4] geometry: n = 30,000,000,001, the suffix-range shards of an 8-GPU run rehearsed one after the other on ONE GPU
     (each GPU of the node would hold the same 7.5 GB text and sort 3.75 G suffixes).  The slices must tile the rank space, every sampled

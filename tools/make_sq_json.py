@@ -7,7 +7,7 @@ import json
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
-WANT = ("k_finish_v3", "k_l1_gather", "k_l0_pass", "k_finish_fast", "k_tie_fix_list", "k_gap_walk4", "k_u32_pass", "k_u32_finish", "k_interleave", "k_tie_tile")
+WANT = ("k_finish_v3", "k_l1_gather", "k_l0_pass", "k_finish_fast", "k_tie_fix_list", "k_gap_walk4", "k_u32_pass", "k_u32_finish", "k_interleave", "k_tie_tile", "k_msd_scatter", "k_msd_count", "k_msd_repid", "k_tie_keyvals", "k_isa_slots", "k_bucket_finish")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
 for f in sorted(glob.glob("gpurun_out/%s_sq_p*/**/*counter_collection.csv" % tag, recursive=True)):
