@@ -264,6 +264,8 @@ void emit_gt_from_text(const TextView &T, uint64_t start, uint64_t len, uint32_t
 // sample of position k*rate -> pairs[k - first] = (rank + rank_off, pos); slots of other shards stay untouched
 void emit_samples(const uint32_t *d_sa, const uint8_t *d_sa_hi, uint64_t len, uint64_t rate, uint64_t rank_off, uint64_t *d_pairs, uint64_t first, uint64_t cap,
                   hipStream_t s);
+struct RankQueries { int n = 0; const uint64_t *pos[8]; uint32_t *accum[8]; uint64_t count[8]; };      // up to 8 lists of (position -> rank added to accum)
+void rank_of_positions_multi(const TextView &T, const uint32_t *d_sa, uint64_t len, const RankQueries &Q, hipStream_t s);
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum /* += */, hipStream_t s);
 void compact_decode(const uint8_t *d_words, uint64_t n, uint32_t bits, uint8_t *d_out, hipStream_t s);

@@ -940,13 +940,17 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		}
 		if (B > 1) {
 			Scope sc(tl, KF_ANCHOR, 0);
-			// end bit: [S_{a+m} > S_a]
-			rank_of_positions(T, so.d_sa, lf.m, p->d_endpos + k, 1, p->d_endrank + k, s);
-			hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, p->d_endrank + k, p->d_p0pairs + 2 * k, p->d_gt[0], lf.a + lf.m);
-			// anchors of every merge that has this leaf on its left side
+			// end bit: [S_{a+m} > S_a], and the anchors of every merge that has this leaf on its left side: one launch of all the searches
+			RankQueries Q;
+			auto add = [&](const uint64_t *pos, uint32_t *acc, uint64_t c) {
+				if (Q.n == 8) { rank_of_positions_multi(T, so.d_sa, lf.m, Q, s); Q.n = 0; }
+				Q.pos[Q.n] = pos; Q.accum[Q.n] = acc; Q.count[Q.n] = c; ++Q.n;
+			};
+			add(p->d_endpos + k, p->d_endrank + k, 1);
 			for (auto &M : p->merges)
-				if ((int)k >= M.L.lo && (int)k < M.L.hi)
-					rank_of_positions(T, so.d_sa, lf.m, p->d_anchor_pos + M.anchor_off, M.num_chains, p->d_anchors + M.anchor_off, s);
+				if ((int)k >= M.L.lo && (int)k < M.L.hi) add(p->d_anchor_pos + M.anchor_off, p->d_anchors + M.anchor_off, M.num_chains);
+			rank_of_positions_multi(T, so.d_sa, lf.m, Q, s);
+			hipLaunchKernelGGL(k_set_endbit, dim3(1), dim3(64), 0, s, p->d_endrank + k, p->d_p0pairs + 2 * k, p->d_gt[0], lf.a + lf.m);
 		}
 	}
 	// leaf histograms -> host (row a4); also needed for the C arrays of the merges

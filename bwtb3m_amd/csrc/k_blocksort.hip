@@ -1434,6 +1434,32 @@ SampleOut make_sample_out(uint64_t *pairs, uint64_t rate, uint64_t first, uint64
 	S.inv = inv; S.lim = 0xFFFFFFFFu / odd;
 	return S;
 }
+// several lists of queries against the same sorted block in one launch (a leaf's end rank and its anchors for every merge it is on the left of: the searches are chains
+// of dependent loads, one launch of all of them costs what the longest list costs)
+__global__ void k_rank_of_multi(TextView T, const uint32_t *sa, uint64_t len, RankQueries Q)
+{
+	uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int g = 0;
+	while (g < Q.n && q >= Q.count[g]) { q -= Q.count[g]; ++g; }
+	if (g >= Q.n) return;
+	const uint64_t x = Q.pos[g][q] % T.n;
+	const uint64_t kx = key_at(T, x, 0);          // the query's first key once, not at every step of the search
+	uint64_t lo = 0, hi = len;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		const uint64_t y = sa[mid];
+		int c = 0;
+		if (y != x) { const uint64_t ky = key_at(T, y, 0); c = ky != kx ? (ky < kx ? -1 : 1) : compare_rotations(T, y, x); }
+		if (c < 0) lo = mid + 1; else hi = mid;
+	}
+	atomicAdd(&Q.accum[g][q], (uint32_t)lo);
+}
+void rank_of_positions_multi(const TextView &T, const uint32_t *d_sa, uint64_t len, const RankQueries &Q, hipStream_t s)
+{
+	uint64_t total = 0;
+	for (int g = 0; g < Q.n; ++g) total += Q.count[g];
+	if (total) hipLaunchKernelGGL(k_rank_of_multi, dim3(nblk(total, 64)), dim3(64), 0, s, T, d_sa, len, Q);
+}
 void rank_of_positions(const TextView &T, const uint32_t *d_sa, uint64_t len, const uint64_t *d_pos, uint64_t count,
                        uint32_t *d_rank_accum, hipStream_t s)
 {
