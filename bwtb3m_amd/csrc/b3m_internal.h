@@ -243,7 +243,7 @@ uint64_t block_overhang();        // symbols of overhang a plan leaves room for 
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
                     uint64_t max_rounds = 0, uint32_t *isa = nullptr, uint64_t h0 = 0, uint8_t *idx_hi = nullptr, uint8_t *tmp_hi = nullptr,
-                    uint64_t sym_off = 0, bool isa_sparse = false);      // isa_sparse: entries may be unset (isa_sparse_from_slots); sym_off: symbols every group of the list shares in front of depth0's key (the record sort's reading: key_at_off)
+                    uint64_t sym_off = 0, bool isa_sparse = false, bool labels_are_heads = false);      // labels_are_heads: B[1][s] is the list index of the first slot of s's group (what this function leaves behind; saves the first round a scan).  isa_sparse: entries may be unset (isa_sparse_from_slots); sym_off: symbols every group of the list shares in front of depth0's key (the record sort's reading: key_at_off)
 void isa_from_sa(const uint32_t *d_sa, uint64_t len, uint32_t *d_isa, hipStream_t s);
 // prefix doubling on a list alone (k_blocksort.hip): the plans that run suffix-range shards one after the other finish the union of what the shards left tied with it
 void sparse_rank_placed(const uint64_t *pos, uint64_t cnt, const uint64_t *xpos, const uint64_t *xrank, uint64_t nx, uint64_t *rank, hipStream_t s);

@@ -670,11 +670,11 @@ static void sparse_finish_core(b3m_plan *p, const TextView &T, uint64_t Tn, uint
 	if (!complete) {
 		// a shard finished its own repeats (no room on the list) or placed more suffixes among long repeats than the list holds: the targets of a doubling round
 		// could be missing, so the list is finished as a shard would have finished it, by key extension to the end
-		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, 0, nullptr, 0, idx_hi, tmp_hi, dmin);
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, 0, nullptr, 0, idx_hi, tmp_hi, dmin, false, true);
 	} else {
 		// key extension until every group agrees on 2X symbols and more, then doubling on the list (tie_rounds_sparse)
 		const uint64_t rt0 = (2 * X + 1 - dmin + K - 1) / K;
-		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, rt0, nullptr, 0, idx_hi, tmp_hi, dmin);
+		rounds = tie_rounds(T, idx, Tn, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, Tn, s, &left, rt0, nullptr, 0, idx_hi, tmp_hi, dmin, false, true);
 		if (left && rounds >= rt0) {
 			hipLaunchKernelGGL(k_sp_tied_positions, dim3((uint32_t)((Tn + 255) / 256)), dim3(256), 0, s, (const uint32_t *)idx, (const uint8_t *)idx_hi, Tn, posS);
 			// the placed ones: positions behind the list's in the table to be, a copy of them and their global ranks beside it until the table is in order

@@ -80,13 +80,13 @@ __global__ void k_tie_flags(const uint32_t *hid, uint64_t u, uint32_t *flag)
 	bool h0 = hid[s] == (uint32_t)s, h1 = (s + 1 == u) ? true : (hid[s + 1] == (uint32_t)(s + 1));
 	flag[s] = (h0 && h1) ? 0u : 1u;
 }
-// compaction: U == nullptr means the identity list (first round after the radix sort)
+// compaction: U == nullptr means the identity list (first round after the radix sort).  hid[s] = list index of the head of s's group (max-scanned)
 __global__ void k_tie_compact(const uint32_t *flag_scan, const uint32_t *hid, const uint32_t *U, uint64_t u, uint32_t *U2, uint32_t *gid2)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u) return;
 	bool h0 = hid[s] == (uint32_t)s, h1 = (s + 1 == u) ? true : (hid[s + 1] == (uint32_t)(s + 1));
-	if (!(h0 && h1)) { uint32_t p = flag_scan[s]; U2[p] = U ? U[s] : (uint32_t)s; gid2[p] = hid[s]; }
+	if (!(h0 && h1)) { uint32_t p = flag_scan[s]; U2[p] = U ? U[s] : (uint32_t)s; gid2[p] = flag_scan[hid[s]]; }      // label = index of the group's head in the NEW list (the head is kept with its group)
 }
 // keys of the next K symbols for the list; value = slot
 // (idx_hi: bits 32.. of the positions, texts of 2^32 symbols and more; null otherwise)
@@ -405,12 +405,34 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 			}
 		}
 	}
-	// ---- back into the slots; heads of the groups as they are now ----
-	for (uint32_t p = tid; p < m; p += TT_THREADS) {
-		const uint64_t s = (uint64_t)a + p;
-		idx[U[s]] = sv[p];
-		const bool head = p == 0 || sg[p] != sg[p - 1] || (sk[p] >> kshift) != (sk[p - 1] >> kshift);
-		hid[s] = head ? (uint32_t)s : 0u;
+	// ---- back into the slots; every slot learns the list index of the head of its group as it is now (a tile holds whole groups: no scan over the list is needed) ----
+	{
+		uint32_t hl[TT_PER], last = 0;                 // (local index of the last head at or in front of the slot) + 1, inside this thread's consecutive slots; 0: none yet
+		#pragma unroll
+		for (int k = 0; k < TT_PER; ++k) {
+			const uint32_t p = tid * TT_PER + k;
+			if (p < m) {
+				const bool head = p == 0 || sg[p] != sg[p - 1] || (sk[p] >> kshift) != (sk[p - 1] >> kshift);
+				if (head) last = p + 1;
+			}
+			hl[k] = last;
+		}
+		const uint32_t inc = wave_incl_max(last);
+		uint32_t carry = __shfl_up(inc, 1, 64);
+		if ((tid & 63u) == 0u) carry = 0u;
+		__syncthreads();                               // (wtot: the head counts of the fetch are read by now)
+		if ((tid & 63u) == 63u) wtot[tid >> 6] = inc;
+		__syncthreads();
+		for (uint32_t w = 0; w < (tid >> 6); ++w) carry = carry > wtot[w] ? carry : wtot[w];
+		#pragma unroll
+		for (int k = 0; k < TT_PER; ++k) {
+			const uint32_t p = tid * TT_PER + k;
+			if (p < m) {
+				const uint64_t s = (uint64_t)a + p;
+				idx[U[s]] = sv[p];
+				hid[s] = a + (hl[k] ? hl[k] : carry) - 1u;
+			}
+		}
 	}
 }
 
@@ -577,7 +599,7 @@ __global__ void k_msd_leftover(const uint32_t *U, const uint32_t *gid, const uin
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= u || !(pid[s] & MSD_PID)) return;
 	idx[U[s]] = (pid[s] & MSD_LOC) ? V1[s] : V[s];
-	hid[s] = tile_head<2>(gid, pid, s) ? (uint32_t)s : 0u;
+	hid[s] = (pid[s] & MSD_PID) - 1u;              // the piece of one key is a group: its first slot is the head of all its members
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +838,7 @@ static void tie_round_lsd(const TextView &T, uint32_t *idx, uint8_t *idx_hi, uin
 
 uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth0, uint64_t *kx, uint64_t *ky, uint32_t *B[6],
                     uint32_t *scan_ws, RadixWs &radix, uint64_t len_for_labels, hipStream_t s, uint64_t *left,
-                    uint64_t max_rounds, uint32_t *isa, uint64_t h0, uint8_t *idx_hi, uint8_t *tmp_hi, uint64_t sym_off, bool isa_sparse)
+                    uint64_t max_rounds, uint32_t *isa, uint64_t h0, uint8_t *idx_hi, uint8_t *tmp_hi, uint64_t sym_off, bool isa_sparse, bool labels_are_heads)
 {
 	B3M_REQUIRE(!(idx_hi && isa), "internal: prefix doubling is not available for positions above 2^32");
 	B3M_REQUIRE(!idx_hi || tmp_hi, "internal: tie rounds with 36-bit positions need a byte buffer");
@@ -826,11 +848,16 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 	uint64_t rounds = 0;
 	uint32_t h_u = 0;
 	uint64_t h = h0;
-	if (isa && u) {
+	// labels: any values that are equal inside a group and differ between neighbouring groups -- or, from the first compaction of this function on (and where the caller
+	// says so), the LIST INDEX OF THE GROUP'S HEAD: what the rounds need of a group (is it large, where does it start) is then read from the label, without a scan over the list
+	bool heads = labels_are_heads;
+	auto head_index = [&]() -> const uint32_t * {         // list index of the head of every slot's group
+		if (heads) return gid;
 		hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
 		inclusive_max_u32(hid, u, scan_ws, s);
-		hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);
-	}
+		return hid;
+	};
+	if (isa && u) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, head_index(), idx, u, isa);
 	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
 	// tiles (k_tie_tile): 32-bit positions; B3M_NO_TIE_TILES=1 keeps every round on the radix sorts
 	const bool tiles_ok = !idx_hi && !(getenv("B3M_NO_TIE_TILES") && atoi(getenv("B3M_NO_TIE_TILES")));
@@ -872,6 +899,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			} else if (nq) hipLaunchKernelGGL(k_isa_search, dim3(nblk(nq)), dim3(256), 0, s, T, (const uint32_t *)idx, T.n, (const uint32_t *)Q, nq, isa);
 		}
 		const uint32_t ntile = (uint32_t)((u + TT_STRIDE - 1) / TT_STRIDE);
+		bool used_lsd = false;
 		const int kshift = (isa || key_off_bits(T.type) <= 52) ? 12 : 0;      // (k_tie_tile: the slot in the key's low bits)
 		if (tiles_ok && msd_on && u >= 8192 && u < (1ull << 30)) {
 			// ---- tiles; large groups are split by the key's bytes first ----
@@ -883,10 +911,9 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			uint32_t h_n = 0, h_c[64];
 			auto read_count = [&]() { B3M_HIP(hipMemcpyAsync(h_c, cnt, 256, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s)); uint64_t t = 0; for (int i = 0; i < 64; ++i) t += h_c[i]; return (uint32_t)std::min<uint64_t>(t, 0xFFFFFFFFull); };
 			if (any_large) {
-				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
-				inclusive_max_u32(hid, u, scan_ws, s);
+				const uint32_t *hix = head_index();
 				B3M_HIP(hipMemsetAsync(cnt, 0, 256, s));
-				hipLaunchKernelGGL(k_msd_init, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint32_t *)hid, (const uint32_t *)gid, u, pid, cnt, act);
+				hipLaunchKernelGGL(k_msd_init, dim3(nchunk), dim3(MP_THREADS), 0, s, hix, (const uint32_t *)gid, u, pid, cnt, act);
 				h_n = read_count();
 				if (h_n == 0) any_large = false;
 			}
@@ -921,12 +948,12 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		} else {
 		// ---- which slots belong to groups too large for a tile ----
 		uint64_t nL = u;
+		const uint32_t *hix_large = hid;
 		if (tiles_ok) {
 			nL = 0;
 			if (any_large) {
-				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
-				inclusive_max_u32(hid, u, scan_ws, s);
-				hipLaunchKernelGGL(k_tie_large_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, gid, u, flag);
+				hix_large = head_index();
+				hipLaunchKernelGGL(k_tie_large_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hix_large, (const uint32_t *)gid, u, flag);
 				exclusive_sum_u32(flag, u + 1, scan_ws, s);
 				uint32_t h_nl = 0;
 				B3M_HIP(hipMemcpyAsync(&h_nl, flag + u, 4, hipMemcpyDeviceToHost, s));
@@ -936,19 +963,21 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			}
 			if (nL > u / 2) nL = u;                      // mostly large groups: the radix sorts take the whole list
 		}
+		used_lsd = nL > 0;
 		if (nL == u) tie_round_lsd(T, idx, idx_hi, tmp_hi, U, gid, u, kx, ky, vx, vy, hid, nullptr, isa, h, off, gbits, radix, s);
 		else {
 			// the sub-list of the large groups (nL <= u/2 slots) and its sort buffers share the round's buffers: kx/ky hold u keys each
 			const uint64_t hu = (u + 1) / 2;
 			uint32_t *U_L = reinterpret_cast<uint32_t *>(kx + hu), *gid_L = U_L + nL, *lpos = reinterpret_cast<uint32_t *>(ky + hu);
-			if (nL) hipLaunchKernelGGL(k_tie_large_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hid, gid, U, u, U_L, gid_L, lpos);
+			if (nL) hipLaunchKernelGGL(k_tie_large_compact, dim3(nblk(u)), dim3(256), 0, s, flag, hix_large, (const uint32_t *)gid, U, u, U_L, gid_L, lpos);
 			if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 			else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 			if (nL) tie_round_lsd(T, idx, nullptr, nullptr, U_L, gid_L, nL, kx, ky, vx, vy, hid, lpos, isa, h, off, gbits, radix, s);
 			if (dbg >= 3) fprintf(stderr, "[b3m]   tiles: %u, %llu slots of large groups through the radix sorts\n", ntile, (unsigned long long)nL);
 		}
 		}
-		inclusive_max_u32(hid, u, scan_ws, s);
+		// the tiles and the pieces of one key wrote every slot's head index; the radix-sort path wrote it at the heads only: one max-scan spreads it
+		if (used_lsd) inclusive_max_u32(hid, u, scan_ws, s);
 		if (isa) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, hid, idx, u, isa);   // every key of this round has been read
 		hipLaunchKernelGGL(k_tie_flags, dim3(nblk(u + 1)), dim3(256), 0, s, hid, u, flag);
 		exclusive_sum_u32(flag, u + 1, scan_ws, s);
@@ -961,6 +990,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), (unsigned long long)u, ms_splits,
 		                      dbg >= 3 ? "; includes the census" : "", h_u);
 		vx = U; vy = gid; U = U2; gid = gid2;
+		heads = true;                                    // (k_tie_compact: the new labels are the heads' new list indices)
 		u = h_u;
 		h *= 2;
 	}

@@ -2333,7 +2333,7 @@ __global__ void k_ovf_split(const uint64_t *pairs, uint32_t nov, uint32_t *sizes
 	sizes[j] = (uint32_t)(p >> 32) & size_mask; b0[j] = (uint32_t)p;
 }
 
-// list of the suffix-array slots of the overflow buckets: U[s] = slot, gid[s] = bucket start
+// list of the suffix-array slots of the overflow buckets: U[s] = slot, gid[s] = list index of the bucket's first slot
 __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, uint32_t nov, uint64_t total, uint32_t *U, uint32_t *gid)
 {
 	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2341,7 +2341,7 @@ __global__ void k_fill_overflow_list(const uint32_t *off, const uint32_t *b0, ui
 	uint32_t lo = 0, hi = nov;          // last j with off[j] <= s
 	while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= s) lo = mid; else hi = mid; }
 	U[s] = b0[lo] + (uint32_t)(s - off[lo]);
-	if (gid) gid[s] = b0[lo];
+	if (gid) gid[s] = off[lo];                 // (label: the list index of the range's first slot, see tie_rounds: labels_are_heads)
 }
 
 // the same with one wave per range (a repeat-rich genome: a million ranges of a few hundred slots): consecutive lanes write consecutive slots, no search
@@ -2350,7 +2350,7 @@ __global__ __launch_bounds__(256) void k_fill_overflow_ranges(const uint32_t *of
 	const uint32_t lane = threadIdx.x & 63u, nw = gridDim.x * 4u;
 	for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < nov; j += nw) {
 		const uint32_t o = off[j], sz = off[j + 1] - o, b = b0[j];
-		for (uint32_t t = lane; t < sz; t += 64u) { U[o + t] = b + t; if (gid) gid[o + t] = b; }
+		for (uint32_t t = lane; t < sz; t += 64u) { U[o + t] = b + t; if (gid) gid[o + t] = o; }      // (label: the list index of the range's first slot)
 	}
 }
 
@@ -3061,14 +3061,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// ... unless the plan that runs the shards one after the other keeps a list of what they leave tied (ws.sparse_room): then the shard stops after the
 		// usual few rounds, as every other sort does, and the plan finishes the union of those lists by prefix doubling ON THE LIST (engine.hip: sparse_tie_finish)
 		const bool sdefer = nshards > 1 && start == 0 && len_in == T.n && ws.no_defer && ws.sparse_room > 0;
-		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, sdefer ? R0 : 0, nullptr, 0, sa.hi, ws.tie_hi, off0);
+		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, sdefer ? R0 : 0, nullptr, 0, sa.hi, ws.tie_hi, off0, false, true);
 		else
-		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree || sdefer) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0);
+		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree || sdefer) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0, false, true);
 		if (sdefer && left && out.tie_rounds >= R0) {
 			if (left <= ws.sparse_room) { out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1]; out.tie_depth = off0 + R0 * (uint64_t)key_symbols(T.type); }
 			else {         // no room on the plan's list: to the end here, as without it
 				out.tie_refused = true;
-				out.tie_rounds += tie_rounds(T, sa.lo, left, R0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, big ? sa.hi : nullptr, big ? ws.tie_hi : nullptr, off0);
+				out.tie_rounds += tie_rounds(T, sa.lo, left, R0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, nullptr, 0, big ? sa.hi : nullptr, big ? ws.tie_hi : nullptr, off0, false, true);
 			}
 		}
 		if (big || sdefer) { /* finished above, or handed over */ }
@@ -3095,7 +3095,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				slots_again(Bf[4]);
 				isa_sparse_from_slots(sa.lo, len, Bf[4], total, ws.t[5], s);
 			} else isa_from_sa(sa.lo, len, ws.t[5], s);
-			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0, nullptr, nullptr, 0, sparse);
+			out.tie_rounds += tie_rounds(T, sa.lo, left, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 0, ws.t[5], h0, nullptr, nullptr, 0, sparse, true);
 		}
 		// BWT symbols (and p0) of the slots finished here
 		// (into a buffer the rounds only use as scratch: a shard's deferred list lives on in two of the others)
