@@ -3061,8 +3061,21 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// ... unless the plan that runs the shards one after the other keeps a list of what they leave tied (ws.sparse_room): then the shard stops after the
 		// usual few rounds, as every other sort does, and the plan finishes the union of those lists by prefix doubling ON THE LIST (engine.hip: sparse_tie_finish)
 		const bool sdefer = nshards > 1 && start == 0 && len_in == T.n && ws.no_defer && ws.sparse_room > 0;
+		uint64_t h0_whole = 1; while (2 * h0_whole <= R0 * (uint64_t)key_symbols(T.type)) h0_whole *= 2;
+		uint32_t *U1_keep = U_keep ? U_keep + total + 16 : nullptr; uint64_t u1 = 0;
+		const bool keep_first = whole && !big && U_keep && 16 * total + 256 <= 8 * ws.cap && (R0 - 1) * (uint64_t)key_symbols(T.type) >= h0_whole &&
+		                        !(getenv("B3M_ISA_EVER_LISTED") && atoi(getenv("B3M_ISA_EVER_LISTED")));      // (measurement switch: ranks for every slot ever listed, as before)
 		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, sdefer ? R0 : 0, nullptr, 0, sa.hi, ws.tie_hi, off0, false, true);
-		else
+		else if (keep_first) {
+			// (a whole-text block) the list as the first round leaves it is kept: the doubling rounds behind the R0 key rounds ask for the ranks of suffixes that agree
+			// with another one on (R0 - 1) K symbols or more, i.e. of suffixes on THAT list -- ranks for those 163 M instead of all 332 M ever listed (genome-like text at C3 size)
+			out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, 1, nullptr, 0, nullptr, nullptr, off0, false, true);
+			if (left) {
+				u1 = left;
+				B3M_HIP(hipMemcpyAsync(U1_keep, Bf[0], 4 * u1, hipMemcpyDeviceToDevice, s));
+				out.tie_rounds += tie_rounds(T, sa.lo, left, 1, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, R0 - 1, nullptr, 0, nullptr, nullptr, off0, false, true);
+			}
+		} else
 		out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, (whole || defer || tree || sdefer) ? R0 : 0, nullptr, 0, nullptr, nullptr, off0, false, true);
 		if (sdefer && left && out.tie_rounds >= R0) {
 			if (left <= ws.sparse_room) { out.tie_left = left; out.tie_U = Bf[0]; out.tie_gid = Bf[1]; out.tie_depth = off0 + R0 * (uint64_t)key_symbols(T.type); }
@@ -3091,7 +3104,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
 			// ranks for the suffixes that were ever listed; the few others doubling asks for are searched (B3M_ISA_FULL=1: all n entries, as before)
 			const bool sparse = !(getenv("B3M_ISA_FULL") && atoi(getenv("B3M_ISA_FULL")));
-			if (sparse) {
+			if (sparse && u1) isa_sparse_from_slots(sa.lo, len, U1_keep, u1, ws.t[5], s);
+			else if (sparse) {
 				slots_again(Bf[4]);
 				isa_sparse_from_slots(sa.lo, len, Bf[4], total, ws.t[5], s);
 			} else isa_from_sa(sa.lo, len, ws.t[5], s);
