@@ -2354,6 +2354,7 @@ __global__ __launch_bounds__(256) void k_fill_overflow_ranges(const uint32_t *of
 	}
 }
 
+static uint32_t big_grid() { const char *e = getenv("B3M_BIG_GRID"); const int v = e ? atoi(e) : 2048; return (uint32_t)(v < 64 ? 64 : v); }      // (measurement switch: workgroups that stride over the listed buckets)
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                     uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own, bool allow_ext)
 {
@@ -2912,7 +2913,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				if (need_sa) hipLaunchKernelGGL((k_finish_lds<true, 1024>), dim3(gmid2), dim3(1024), 0, s, F2, fbits2, 0u, (const uint32_t *)M.mid2, (uint32_t)M.list2_cap, dl + 3, O);
 				else hipLaunchKernelGGL((k_finish_lds<false, 1024>), dim3(gmid2), dim3(1024), 0, s, F2, fbits2, 0u, (const uint32_t *)M.mid2, (uint32_t)M.list2_cap, dl + 3, O);
 				hipLaunchKernelGGL(k_huge_spill, dim3(2048), dim3(256), 0, s, (const uint64_t *)ws.keyA, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.huge2, (uint32_t)M.huge_cap, sa, pb);
-				const uint32_t gbig2 = (uint32_t)std::min<uint64_t>(nbF2, 2048);
+				const uint32_t gbig2 = (uint32_t)std::min<uint64_t>(nbF2, big_grid());
 				if (fbits2 > 8) {
 					bucket_finish_chain((const uint64_t *)ws.keyA, ws.keyB, (const uint32_t *)d_st2, (const uint32_t *)d_en2, M.big2, (uint32_t)M.list2_cap, consumed + d2, fbits2, gbig2);
 				} else {
@@ -2931,7 +2932,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		}
 		if (!gather || nbig1) {
 		// one workgroup per listed bucket: the listed buckets up to LVL2_MIN records (and all of them where there is no level 2: small blocks without a level 1)
-		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 2048);
+		const uint32_t gbig = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, big_grid());
 		bucket_finish_chain(cur, other, (const uint32_t *)M.lvl_start, (const uint32_t *)nullptr, M.biglist, (uint32_t)M.big_cap, consumed, fbits, gbig);
 		}
 		stage("big / huge finish");
