@@ -2215,6 +2215,22 @@ __device__ __forceinline__ void tie_group(const TextView &T, const uint32_t *tie
 		uint32_t g = 2;
 		for (uint64_t z = q + 1; z < len && g <= (uint32_t)LS_TIE_CAP && ((tiebits[z >> 5] >> (z & 31)) & 1u); ++z) ++g;
 		if (g > (uint32_t)LS_TIE_CAP) return;     // cannot happen (see above)
+		if (g == 2 && !X.keys) {
+			// two records (nearly every group of a text without repeats): both positions, both symbols and both windows are fetched side by side, not as the
+			// chain of loads the insertion below makes of them (ties of C3: 1.06 -> 0.93 ms)
+			const uint64_t y = sa_get(sa, pos), x = sa_get(sa, pos + 1);
+			const uint8_t by = bwt[pos], bx = bwt[pos + 1];
+			const bool ey = y + eq_syms + 32 <= T.nbases, ex = x + eq_syms + 32 <= T.nbases;
+			const uint64_t dy = ey ? window32(T, y + eq_syms) >> 2 : 0, dx = ex ? window32(T, x + eq_syms) >> 2 : 0;
+			const bool y_le_x = (ex && ey && dx != dy) ? dy < dx : compare_rotations(T, y, x) <= 0;
+			if (!y_le_x) { sa_set(sa, pos, x); sa_set(sa, pos + 1, y); bwt[pos] = bx; bwt[pos + 1] = by; }
+			const uint64_t f = y_le_x ? y : x, l2 = y_le_x ? x : y;
+			if (f == start) *p0 = (uint32_t)pos;
+			if (l2 == start) *p0 = (uint32_t)(pos + 1);
+			if (sample_hit(smp, (uint32_t)f)) sample_put(smp, pos, f);
+			if (sample_hit(smp, (uint32_t)l2)) sample_put(smp, pos + 1, l2);
+			return;
+		}
 		for (uint32_t a = 1; a < g; ++a) {
 			uint64_t x = sa_get(sa, pos + a); uint8_t bx = bwt[pos + a];
 			bool ex = (uint64_t)x + eq_syms + 32 <= T.nbases;
