@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <exception>
 #include <functional>
+#include <map>
+#include <mutex>
 
 namespace b3m {
 
@@ -200,6 +202,98 @@ struct b3m_plan {
 };
 
 static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
+
+// The arena of a plan.  One hipMalloc of 91 GB (C3) lands on physical pages that put level 1 of the record sort -- the gather between the two 24 GB record buffers -- into one
+// of two modes, 10.8 or 11.4 ms, for as long as the arena lives (same virtual address either way; in a fresh process about three allocations in five get the slow one:
+// profiles/NOTES_r04.md, tools/l1_mode.py).  Backed by separate physical allocations of 1 GB each, mapped into one reserved address range (hipMemCreate / hipMemMap), the
+// first arena of a process runs it in 10.3-10.5 ms (seven fresh processes of seven; tools/arena_chunks.py) and nothing else gets slower.  256 MB pieces do the same for level 1
+// but cost the list rounds of a repeat-rich text 1 % (random access likes large pieces); pieces for the record buffers alone do NOT give the fast mode; and a merge tree's
+// gap walk loses 5 % on any mapped arena (95 instead of 91 ms), so only one-block, unsharded plans of 1 GB and more take this form.  B3M_ARENA_CHUNK_MB=c: pieces of c MB
+// (0: one hipMalloc, as before).  Any failure of the mapping calls falls back to hipMalloc.
+struct ArenaVmm { std::vector<hipMemGenericAllocationHandle_t> handles; uint64_t chunk = 0, size = 0; void *va = nullptr; };
+static std::map<const void *, ArenaVmm> g_arena_vmm;        // (per plan)
+static std::mutex g_arena_mu;
+static ArenaVmm &arena_vmm_of(const void *plan) { std::lock_guard<std::mutex> g(g_arena_mu); return g_arena_vmm[plan]; }
+static void arena_vmm_drop(const void *plan) { std::lock_guard<std::mutex> g(g_arena_mu); g_arena_vmm.erase(plan); }
+static void arena_vmm_undo(ArenaVmm &V, uint64_t mapped)
+{
+	if (mapped) (void)hipMemUnmap(V.va, mapped);
+	for (auto h : V.handles) (void)hipMemRelease(h);
+	if (V.va) (void)hipMemAddressFree(V.va, V.size);
+	(void)hipGetLastError();
+	V = ArenaVmm{};
+}
+// rec_off / rec_len: the part of the arena that gets the pieces (all of it, as plan_create_impl calls this; in front of it and behind it: one physical allocation each)
+static uint8_t *arena_alloc(uint64_t bytes, ArenaVmm &V, bool chunked_ok, uint64_t rec_off, uint64_t rec_len)
+{
+	const char *e = getenv("B3M_ARENA_CHUNK_MB");
+	const uint64_t chunk = (e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
+	uint8_t *ptr = nullptr;
+	if (chunk && chunked_ok && bytes >= (1ull << 30) && rec_len >= 2 * chunk) {
+		int dev = 0; B3M_HIP(hipGetDevice(&dev));
+		hipMemAllocationProp prop{};
+		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+		size_t gran = 0;
+		bool ok = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran && chunk % gran == 0;
+		uint64_t size = 0, r0 = 0, r1 = 0;
+		if (ok) {
+			size = (bytes + gran - 1) / gran * gran;
+			r0 = (rec_off + gran - 1) / gran * gran;                       // the pieces start at the first granule inside the record buffers ...
+			r1 = r0 + (rec_off + rec_len - r0) / chunk * chunk;            // ... and cover whole pieces of them
+			V.chunk = chunk; V.size = size;
+			ok = hipMemAddressReserve(&V.va, size, chunk, nullptr, 0) == hipSuccess;
+		}
+		uint64_t mapped = 0;
+		auto back = [&](uint64_t o, uint64_t len) {                      // one physical allocation for [o, o + len) (in 8 GB pieces if the driver will not give it whole)
+			if (!ok || !len) return;
+			hipMemGenericAllocationHandle_t h;
+			if (hipMemCreate(&h, len, &prop, 0) == hipSuccess) {
+				V.handles.push_back(h);
+				ok = hipMemMap((uint8_t *)V.va + o, len, 0, h, 0) == hipSuccess;
+				if (ok) mapped = o + len;
+				return;
+			}
+			(void)hipGetLastError();
+			const uint64_t big = 8ull << 30;
+			for (uint64_t q = 0; ok && q < len; q += big) {
+				const uint64_t l = std::min(big, len - q);
+				ok = hipMemCreate(&h, l, &prop, 0) == hipSuccess;
+				if (!ok) break;
+				V.handles.push_back(h);
+				ok = hipMemMap((uint8_t *)V.va + o + q, l, 0, h, 0) == hipSuccess;
+				if (ok) mapped = o + q + l;
+			}
+		};
+		back(0, r0);
+		for (uint64_t o = r0; ok && o < r1; o += chunk) {
+			hipMemGenericAllocationHandle_t h;
+			ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
+			if (!ok) break;
+			V.handles.push_back(h);
+			ok = hipMemMap((uint8_t *)V.va + o, chunk, 0, h, 0) == hipSuccess;
+			if (ok) mapped = o + chunk;
+		}
+		back(r1, size - r1);
+		if (ok) {
+			hipMemAccessDesc acc{};
+			acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+			ok = hipMemSetAccess(V.va, size, &acc, 1) == hipSuccess;
+		}
+		if (ok) return (uint8_t *)V.va;
+		arena_vmm_undo(V, mapped);                  // (the mapping calls are not available, or memory is short in pieces: one hipMalloc says so in the usual way)
+	}
+	B3M_HIP(hipMalloc((void **)&ptr, bytes));
+	return ptr;
+}
+static void arena_free(uint8_t *ptr, ArenaVmm &V)
+{
+	if (!ptr) return;
+	if (!V.chunk) { (void)hipFree(ptr); return; }
+	(void)hipMemUnmap(ptr, V.size);
+	for (auto h : V.handles) (void)hipMemRelease(h);
+	(void)hipMemAddressFree(ptr, V.size);
+	V = ArenaVmm{};
+}
 
 // entries of each kind a plan of sequential shards keeps for the long repeats of its text (b3m_plan::SparseTies): a tenth of a shard's sort (the finish works in the
 // sort's buffers: 2 + 3 * 2 tenths of its record buffers), i.e. 2 bytes per suffix of a shard beside the ~50 of its sort.  B3M_SPARSE_TIES=c: at most c entries (test
@@ -451,7 +545,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 		         (unsigned long long)p->blocksize);
 		throw Error(buf);
 	}
-	B3M_HIP(hipMalloc((void **)&p->arena, off));
+	p->arena = arena_alloc(off, arena_vmm_of(p), nshards <= 1 && B == 1, 0, off);
 	uint8_t *A = p->arena;
 	p->d_text = A + o_text; p->d_bwt[0] = A + o_bwt0; p->d_bwt[1] = A + o_bwt1;
 	p->d_gt[0] = (uint32_t *)(A + o_gt0); p->d_gt[1] = (uint32_t *)(A + o_gt1);
@@ -510,7 +604,7 @@ void b3m_plan_destroy(b3m_plan *p)
 	if (p->d_pack) (void)hipFree(p->d_pack);
 	if (p->d_isa_cache) (void)hipFree(p->d_isa_cache);
 	blocksort_release(p->bs);
-	if (p->arena) (void)hipFree(p->arena);
+	arena_free(p->arena, arena_vmm_of(p)); arena_vmm_drop(p);
 	delete p;
 }
 uint64_t b3m_plan_num_blocks(const b3m_plan *p) { return p ? p->leaves.size() : 0; }
