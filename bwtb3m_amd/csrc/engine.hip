@@ -206,7 +206,7 @@ static inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ull; }
 // The arena of a plan.  One hipMalloc of 91 GB (C3) lands on physical pages that put level 1 of the record sort -- the gather between the two 24 GB record buffers -- into one
 // of two modes, 10.8 or 11.4 ms, for as long as the arena lives (same virtual address either way; in a fresh process about three allocations in five get the slow one:
 // profiles/NOTES_r04.md, tools/l1_mode.py).  Backed by separate physical allocations of 1 GB each, mapped into one reserved address range (hipMemCreate / hipMemMap), the
-// first arena of a process runs it in 10.3-10.5 ms (seven fresh processes of seven; tools/arena_chunks.py) and nothing else gets slower.  256 MB pieces do the same for level 1
+// first arena of a process runs it in 10.3-10.9 ms (fourteen fresh processes of fourteen, pieces of 64 MB to 4 GB; tools/arena_chunks.py) and nothing else gets slower.  256 MB pieces do the same for level 1
 // but cost the list rounds of a repeat-rich text 1 % (random access likes large pieces); pieces for the record buffers alone do NOT give the fast mode; and a merge tree's
 // gap walk loses 5 % on any mapped arena (95 instead of 91 ms), so only one-block, unsharded plans of 1 GB and more take this form.  B3M_ARENA_CHUNK_MB=c: pieces of c MB
 // (0: one hipMalloc, as before).  Any failure of the mapping calls falls back to hipMalloc.
