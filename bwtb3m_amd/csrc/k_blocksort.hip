@@ -240,7 +240,7 @@ constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512
 #else
 constexpr int TT_STRIDE = 1024, TT_GROUP = 1024, TT_CAP = 2048, TT_THREADS = 256, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
 #endif
-static int tt_count_max() { const char *e = getenv("B3M_TT_COUNT"); const int v = e ? atoi(e) : TT_COUNT; return v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v); }      // measurement switch
+static int tt_count_max() { const char *e = getenv("B3M_TT_COUNT"); const int v = e ? atoi(e) : TT_COUNT; const char *x = getenv("B3M_TT_EXPERIMENT"); return (v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v)) | ((x ? atoi(x) : 0) << 16); }      // measurement switch
 static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
 
 // flag[s] = 1 if the group of slot s has more than TT_GROUP members (hid[s] = list index of the group's head); flag[u] = 0
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 {
 	// kshift = 12 where the key leaves room (pacterm: 48 bits, ranks: 32): the slot inside the tile rides in the low bits, every key of the tile is
 	// distinct and one 64-bit compare per pair orders them (0: 64-bit keys, ties are broken by the slot in a second compare)
+	const int xflags = count_max >> 16; count_max &= 0xFFFF;      // (experiment flags: 1 = no ordering, 2 = no write-back, 4 = leave after the fetch)
 	constexpr bool ISA = MODE == 1;
 	constexpr uint32_t GROUP = MODE == 2 ? MP_GROUP : TT_GROUP;       // (MODE 2: a group above MP_GROUP is a piece of one key, k_msd_leftover's)
 	__shared__ uint64_t sk[TT_CAP];                  // keys
@@ -354,7 +355,9 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 	}
 	__syncthreads();
 	const uint32_t gmax = red[3];
-	if (gmax <= (uint32_t)count_max) {
+	if (xflags & 4) return;
+	if (xflags & 1) { /* timing only: the keys stay as they were fetched */ }
+	else if (gmax <= (uint32_t)count_max) {
 		// ---- every member counts the members of its group in front of it in (key, slot) order ----
 		uint64_t mk[TT_PER]; uint32_t mv[TT_PER]; uint32_t dst[TT_PER];
 		#pragma unroll
@@ -364,8 +367,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 			if (p < m) {
 				const uint32_t g = sg[p], b = gs[g], en = gs[g + 1];
 				const uint64_t my = sk[p];
-				uint32_t less = 0;
-				for (uint32_t j = b; j < en; ++j) less += sk[j] < my ? 1u : 0u;
+				// (eight keys per step: the loads of a step are in flight together; one key per step waited for the LDS at every member -- 10 of the 22 ms the tiles of
+				// a genome-like text's first round took, tools/tt_experiment.py)
+				uint32_t less = 0, j = b;
+				for (; j + 8u <= en; j += 8u) {
+					uint64_t kk[8];
+					#pragma unroll
+					for (int q = 0; q < 8; ++q) kk[q] = sk[j + q];
+					#pragma unroll
+					for (int q = 0; q < 8; ++q) less += kk[q] < my ? 1u : 0u;
+				}
+				for (; j < en; ++j) less += sk[j] < my ? 1u : 0u;
 				mk[k] = my; mv[k] = sv[p]; dst[k] = b + less;
 			}
 		}
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 		#pragma unroll
 		for (int k = 0; k < TT_PER; ++k) {
 			const uint32_t p = tid * TT_PER + k;
-			if (p < m) {
+			if (p < m && !(xflags & 2)) {
 				const uint64_t s = (uint64_t)a + p;
 				idx[U[s]] = sv[p];
 				hid[s] = a + (hl[k] ? hl[k] : carry) - 1u;
@@ -989,6 +1001,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		if (dbg >= 2) fprintf(stderr, "[b3m]   round %llu: %.2f ms on %llu slots (%.2f ms until the splits were through%s), %u left\n", (unsigned long long)rounds,
 		                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), (unsigned long long)u, ms_splits,
 		                      dbg >= 3 ? "; includes the census" : "", h_u);
+		if (getenv("B3M_TT_EXPERIMENT") && atoi(getenv("B3M_TT_EXPERIMENT"))) throw Error("B3M_TT_EXPERIMENT: timing-only round done");
 		vx = U; vy = gid; U = U2; gid = gid2;
 		heads = true;                                    // (k_tie_compact: the new labels are the heads' new list indices)
 		u = h_u;
