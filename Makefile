@@ -41,8 +41,16 @@ $(OBJDIR)/dbg_%.o: $(CSRC)/%.hip $(HDRS)
 debug: $(DBG_OBJS) $(HOST_OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o bwtb3m_amd/libb3m_dbg.so $^ -pthread
 
+# experiment build: k_finish_v3 can be left after each of its phases (B3M_FINISH_EXPERIMENT=1..5, timing only): tools/finish_experiment.py loads it with B3M_LIB
+EXP_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/exp_%.o,$(HIP_SRCS))
+$(OBJDIR)/exp_%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DB3M_PHASE_EXPERIMENT -c $< -o $@
+experiment: $(EXP_OBJS) $(HOST_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o bwtb3m_amd/libb3m_exp.so $^ -pthread
+
 clean:
 	rm -rf $(OBJDIR) $(LIB) bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean debug
+.PHONY: all oracle clean debug experiment

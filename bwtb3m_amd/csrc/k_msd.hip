@@ -1649,7 +1649,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	__shared__ uint16_t bl[V3_BL];                                    // bins above eight entries
 	__shared__ uint32_t s_slow, s_wl, s_tl, s_sp, s_bl;
 	__shared__ uint32_t lds_pad[WPC == 2 ? 6144 : 1];                 // (WPC = 2, the A/B form: enough LDS to keep a third workgroup off the CU)
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + (S.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x);
+#ifdef B3M_PHASE_EXPERIMENT
+	const uint32_t xf = S.xcd >> 8;             // (`make experiment`, timing only: B3M_FINISH_EXPERIMENT = leave after the records are loaded (1), the count (2), the scan (3), the entries are placed (4), the listed bins (5))
+#else
+	constexpr uint32_t xf = 0u;                  // (the exits below cost the kernel 0.15 ms when they are compiled in: 11.31 vs 11.16 ms)
+#endif
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = b_first + ((S.xcd & 1u) ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x);
 	const uint32_t b0 = b >> S.D1;
 	const uint32_t nch = S.btab[2 * S.nb0 + b0], tab_off = S.btab[S.nb0 + b0], bstart0 = S.btab[b0];
 	const uint32_t s0 = S.bstart[b], m = bucket_end(S, b) - s0;
@@ -1756,6 +1761,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 			}
 		}
 	}
+	if (xf == 1u) { if (ev[0] == 0xFFFFFFFFu && bs[1] == 0xFFFFFFFFu) O.bwt[s0] = 0; return; }
 	// ---- count: arrival slot of every record inside its bin (16-bit counters, two per word) ----
 	#pragma unroll
 	for (int k = 0; k < F_PER; ++k) {
@@ -1767,6 +1773,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 		}
 	}
 	__syncthreads();
+	if (xf == 2u) { if (bs[0] == 0xFFFFFFFFu) O.bwt[s0] = (uint8_t)ev[1]; return; }
 	// ---- scan: thread = 16 consecutive bins = 8 words; half-word = start | min(count, 7) << 13; the bins with two entries or more go on the
 	// work list (their number rides in the high half of the scanned sum) ----
 	{
@@ -1819,6 +1826,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	}
 	__syncthreads();
 	const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(tabw);
+	if (xf == 3u) { if (bs[0] == 0xFFFFFFFFu && tab16[tid] == 0xFFFFu) O.bwt[s0] = (uint8_t)ev[1]; return; }
 	// ---- entries into bin order (arrival order inside a bin) ----
 	uint32_t tid_again = tid;
 	asm volatile("" : "+v"(tid_again));                             // (the "slot inside the bucket" masks of the count phase are computed again, not kept: they were spilled)
@@ -1837,6 +1845,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 		}
 	}
 	__syncthreads();
+	if (xf == 4u) { if (ent[tid] == 0xFFFFFFFFu) O.bwt[s0] = 1; return; }
 	// ---- the listed bins: in order, in place; key ties noted ----
 	// the entry x at place p ties with a neighbour; returns what to OR into the entry (no room on the list: its position is fetched when the bucket leaves,
 	// by whoever writes its byte -- a bucket of an A+T-rich prefix ties a third of its records, and fetching them here, one after the other, cost 100 us per bucket)
@@ -1967,6 +1976,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	const uint32_t ntl = s_tl < (uint32_t)V3_TL ? s_tl : (uint32_t)V3_TL;
 	uint64_t trec = 0; uint32_t tplace = 0;
 	if (tid < ntl) { const uint32_t it = tl[tid]; tplace = it >> 13; trec = S.rec[rec_adr(it & 0x1FFFu)]; }
+	if (xf == 5u) { if (ent[tid] == 0xFFFFFFFFu) O.bwt[s0] = 1; return; }
 	// ---- the bucket leaves: four entries = four BWT bytes = one dword (partial first / last dword bytewise) ----
 	{
 		uint8_t *gb = O.bwt + ((ptrdiff_t)s0 - (ptrdiff_t)apad);      // 4-byte aligned (may point before the block's first byte: never written)
@@ -2621,7 +2631,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	const int l1_order = getenv("B3M_L1_ORDER") ? atoi(getenv("B3M_L1_ORDER")) : 0;
 	const int xcd_on = getenv("B3M_XCD_ORDER") ? atoi(getenv("B3M_XCD_ORDER")) : 1;       // measurement switch: 0 = workgroups take their items in launch order
 	FinishSrc FS{};                     // where the finish finds the records of a final bucket
-	FS.bstart = M.lvl_start; FS.xcd = xcd_on ? 1u : 0u;
+	FS.bstart = M.lvl_start; FS.xcd = (xcd_on ? 1u : 0u) | ((getenv("B3M_FINISH_EXPERIMENT") ? (uint32_t)atoi(getenv("B3M_FINISH_EXPERIMENT")) : 0u) << 8);
 	bool gather = false;
 	if (dg.D1 == 0) {
 		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.lvl_start);
