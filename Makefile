@@ -46,7 +46,10 @@ EXP_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/exp_%.o,$(HIP_SRCS))
 $(OBJDIR)/exp_%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DB3M_PHASE_EXPERIMENT -c $< -o $@
-experiment: $(EXP_OBJS) $(HOST_OBJS)
+$(OBJDIR)/exp_host_switches.o: $(CSRC)/host/switches.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS_H) -x c++ -D__HIP_PLATFORM_AMD__ -DB3M_PHASE_EXPERIMENT -I/opt/rocm/include -c $< -o $@
+experiment: $(EXP_OBJS) $(filter-out $(OBJDIR)/host_switches.o,$(HOST_OBJS)) $(OBJDIR)/exp_host_switches.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o bwtb3m_amd/libb3m_exp.so $^ -pthread
 
 clean:

@@ -56,6 +56,8 @@ _u64, _p, _i, _cp = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_cha
 SYMBOLS = [
     ("b3m_version", _i, []),
     ("b3m_last_error", _cp, []),
+    ("b3m_switch_name", _cp, [_i]),
+    ("b3m_switch_doc", _cp, [_i]),
     ("b3m_parse_input_type", _i, [_cp]),
     ("b3m_input_type_name", _cp, [_i]),
     ("b3m_options_init", None, [ctypes.POINTER(Options)]),

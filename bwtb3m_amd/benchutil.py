@@ -7,8 +7,18 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
 KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true, 0>",
-             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3, 512>", "ties": "b3m::k_tie_fix",
+             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3, 512, false>", "ties": "b3m::k_tie_fix",
              "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk4"}
+
+
+def pmc_kernel_name(name, kernels):
+    """the entry of a PMC file's `kernels` for `name`: the exact instantiation, else the instantiation of the same kernel template that
+    moved the most bytes (a template parameter added later must not turn `roofline.traffic` into null: round 4 did)"""
+    if name in kernels:
+        return name
+    base = name.split("<")[0]
+    same = [k for k in kernels if k.split("<")[0] == base]
+    return max(same, key=lambda k: kernels[k].get("hbm_bytes_per_launch", 0)) if same else None
 
 
 def add_kernel_times(fam, kernel_times):
@@ -34,8 +44,8 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1, 
         import glob
         files = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))      # the latest round's PMC passes
         tj = json.load(open(files[-1])) if files else {}
-        kn = KERNEL_OF_.get(dname, dname)
-        if pmc_n and tj.get("workload_n") == pmc_n and kn in tj.get("kernels", {}):
+        kn = pmc_kernel_name(KERNEL_OF_.get(dname, dname), tj.get("kernels", {}))
+        if pmc_n and tj.get("workload_n") == pmc_n and kn is not None:
             traffic = int(tj["kernels"][kn]["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         traffic = None

@@ -6,6 +6,7 @@
 #include <vector>
 #include <stdexcept>
 #include "../../include/b3m.h"
+#include "switches.h"
 
 namespace b3m {
 

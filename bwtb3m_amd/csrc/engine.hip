@@ -226,8 +226,7 @@ static void arena_vmm_undo(ArenaVmm &V, uint64_t mapped)
 // rec_off / rec_len: the part of the arena that gets the pieces (all of it, as plan_create_impl calls this; in front of it and behind it: one physical allocation each)
 static uint8_t *arena_alloc(uint64_t bytes, ArenaVmm &V, bool chunked_ok, uint64_t rec_off, uint64_t rec_len)
 {
-	const char *e = getenv("B3M_ARENA_CHUNK_MB");
-	const uint64_t chunk = (e ? strtoull(e, nullptr, 10) : 1024ull) << 20;
+	const uint64_t chunk = (uint64_t)sw().ARENA_CHUNK_MB.get(1024) << 20;
 	uint8_t *ptr = nullptr;
 	if (chunk && chunked_ok && bytes >= (1ull << 30) && rec_len >= 2 * chunk) {
 		int dev = 0; B3M_HIP(hipGetDevice(&dev));
@@ -300,9 +299,8 @@ static void arena_free(uint8_t *ptr, ArenaVmm &V)
 // switch; 0: the shards finish their repeats themselves, as before round 4)
 static uint64_t sparse_ties_cap(uint64_t n, uint64_t shard_cap)
 {
-	const char *e = getenv("B3M_SPARSE_TIES");
 	uint64_t c = shard_cap / 10;
-	if (e) c = std::min<uint64_t>(c, strtoull(e, nullptr, 10));
+	if (sw().SPARSE_TIES.set) c = std::min<uint64_t>(c, (uint64_t)sw().SPARSE_TIES.v);
 	return c;
 }
 static void chains_for(uint64_t mr, uint64_t &chain_len, uint64_t &num_chains)
@@ -377,6 +375,8 @@ extern "C" {
 
 int b3m_version(void) { return B3M_VERSION; }
 const char *b3m_last_error(void) { return g_err.c_str(); }
+const char *b3m_switch_name(int i) { const SwitchDoc *d; const int n = switches_describe(&d); return i >= 0 && i < n ? d[i].name : nullptr; }
+const char *b3m_switch_doc(int i) { const SwitchDoc *d; const int n = switches_describe(&d); return i >= 0 && i < n ? d[i].doc : nullptr; }
 
 static const char *type_names[7] = {"bytestream", "compactstream", "pac", "pacterm", "lz4", "utf-8", "symbols32"};
 int b3m_parse_input_type(const char *name)
@@ -400,6 +400,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 {
 	b3m_plan *p = nullptr;
 	B3M_TRY
+	switches_load();
 	B3M_REQUIRE(inputtype == B3M_INPUT_BYTESTREAM || inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM || inputtype == B3M_INPUT_SYMBOLS32,
 	            std::string("input type ") + b3m_input_type_name(inputtype) + " is not supported by the GPU engine yet");
 	B3M_REQUIRE(n >= 1, "empty input");
@@ -439,8 +440,7 @@ static b3m_plan *plan_create_impl(uint64_t n, int inputtype, uint64_t blocksize,
 	// shards need the text (0.25 B/symbol) and ONE shard's sort; their slices of the BWT are final when the shard is through and leave for pinned host memory
 	// (b3m_plan_run_host: two slice buffers, the copy of one behind the sort of the next).  Taken when no merge tree fits the target (B3M_FORCE_SPILL=S: test switch).
 	if (nshards == 1 && p->seq_shards == 1 && blocksize == 0 && (inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM) && n >= (1ull << 18)) {
-		const char *fe = getenv("B3M_FORCE_SPILL");
-		int S = fe ? atoi(fe) : 0;
+		int S = (int)sw().FORCE_SPILL.get(0);
 		if (S < 2 && mem) {
 			const uint64_t fixed_tree = packed_text_bytes(n, inputtype) + 2 * n + n / 2 + (64ull << 20);
 			const uint64_t bmin = std::max<uint64_t>(1024, n / 1024);
@@ -746,7 +746,7 @@ static void sparse_finish_core(b3m_plan *p, const TextView &T, uint64_t Tn, uint
 	const uint64_t M = Tn + Ex;
 	BlockSortWs &ws = p->bs;
 	const bool big = p->n >= (1ull << 32);
-	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	const int dbg = (int)sw().DEBUG.get(0);
 	blocksort_ensure_ties(ws, Tn);
 	uint32_t *Bf[6] = {ws.t[0], ws.t[1], ws.idxB, ws.t[2], ws.t[3], ws.t[4]};
 	if (big) { Bf[0] = ws.t[1]; Bf[1] = ws.t[2]; Bf[2] = ws.t[3]; Bf[3] = ws.t[4]; Bf[4] = ws.t[5]; Bf[5] = ws.idxB; }
@@ -856,6 +856,7 @@ static const std::vector<uint64_t> &samples_of(b3m_plan *p)
 static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_in, uint8_t *d_bwt_out, uint8_t *h_bwt_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	const bool host = h_text_in != nullptr;
 	B3M_REQUIRE(p && (host ? (h_bwt_out != nullptr) : (d_text_in && d_bwt_out)), "b3m_plan_run: null argument");
 	hipStream_t s = (hipStream_t)stream;
@@ -885,7 +886,7 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 	}
 	const uint64_t n = p->n, B = p->leaves.size();
 	Timeline *tl = &p->tl;
-	tl->reset(); tl->stream = s; tl->enabled = !(getenv("B3M_NO_TIMELINE") && atoi(getenv("B3M_NO_TIMELINE")));      // (measurement switch: no per-family HIP events)
+	tl->reset(); tl->stream = s; tl->enabled = !sw().NO_TIMELINE.on();      // (measurement switch: no per-family HIP events)
 	hipEvent_t ev0 = tl->get(), ev1 = tl->get();
 	TextArrival arrival{}; bool streaming_text = false;
 	if (host) {
@@ -1283,6 +1284,7 @@ int b3m_plan_tie_export(b3m_plan *p, uint32_t *d_sa_slice_out, uint32_t *d_pairs
 int b3m_plan_tie_finish(b3m_plan *p, uint32_t *d_sa_global, const uint32_t *d_pairs_all, uint64_t total, uint64_t my_first, uint8_t *d_bwt_slice, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	B3M_REQUIRE(p && d_sa_global && d_pairs_all && (d_bwt_slice || p->slice_len == 0), "b3m_plan_tie_finish: null argument");      // (an empty shard takes part with an empty slice)
 	B3M_REQUIRE(p->nshards > 1 && p->n < (1ull << 32), "tie finish: suffix-range shards of a text below 2^32 symbols only");
 	hipStream_t s = (hipStream_t)stream;
@@ -1378,6 +1380,7 @@ int b3m_plan_list_finish(b3m_plan *p, const uint64_t *d_tied_all, uint64_t tied_
                          int complete, uint8_t *d_bwt_slice, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	B3M_REQUIRE(p && p->nshards > 1 && p->tie_mode == B3M_TIES_LIST, "b3m_plan_list_finish: a suffix-range shard in list mode (b3m_plan_set_tie_mode) is needed");
 	B3M_REQUIRE((d_tied_all || !tied_total) && (d_placed_all || !placed_total) && (d_bwt_slice || p->slice_len == 0), "b3m_plan_list_finish: null argument");
 	if (tied_total == 0) return 0;
@@ -1446,6 +1449,7 @@ int b3m_plan_kernel_times(const b3m_plan *p, b3m_kernel_time *out, int cap)
 int b3m_histogram(const void *d_text, uint64_t n, int inputtype, uint64_t start, uint64_t len, uint64_t *hist_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(start + len <= n, "range out of bounds");
@@ -1463,6 +1467,7 @@ int b3m_block_sort(const void *d_text, uint64_t n, int inputtype, uint64_t start
                    uint8_t *d_bwt_out, uint32_t *d_gt_out, uint64_t *p0_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
@@ -1512,6 +1517,7 @@ int b3m_rank_of(const void *d_text, uint64_t n, int inputtype, const uint32_t *d
                 uint64_t count, uint64_t *ranks_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	PaddedText pt(d_text, n, inputtype, s);
@@ -1532,6 +1538,7 @@ int b3m_gap(const void *d_text, uint64_t n, int inputtype, uint64_t a, uint64_t 
             uint32_t *d_G_dense, uint32_t *d_gtP, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
@@ -1604,6 +1611,7 @@ int b3m_interleave(const uint32_t *d_sorted_ranks, const uint8_t *d_bwtL, uint64
                    uint64_t p0L, uint64_t *p0P_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(m + mr < (1ull << 32), "block too large");
@@ -1633,6 +1641,7 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
                    uint32_t *d_sorted_ranks, uint64_t *count_out, uint32_t *d_gt_abs_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM, "gap merge needs a 2-bit alphabet (pac/pacterm)");
@@ -1686,6 +1695,7 @@ int b3m_gap_chains(const void *d_text, uint64_t n, int inputtype, uint64_t a, ui
 int b3m_sort_u32(const uint32_t *d_keys, uint64_t count, int nbits, uint32_t *d_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	if (count == 0) return 0;
@@ -1721,6 +1731,7 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
                        uint8_t *d_bwt_out, uint32_t *d_gt_abs, uint64_t *p0_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	hipStream_t s = (hipStream_t)stream;
 	B3M_REQUIRE(start + len <= n && len >= 1, "range out of bounds");
@@ -1825,6 +1836,7 @@ static void lf_walk_bytes_any(const TextView &T, const uint8_t *d_bwt, const uin
 int b3m_lf_walk_job(const b3m_lf_job *j, uint64_t *mismatches_out, void *stream)
 {
 	B3M_TRY
+	switches_load();
 	require_device();
 	B3M_REQUIRE(j && j->d_bwt && j->hist256 && j->sample_pairs && mismatches_out && j->num_samples >= 1, "b3m_lf_walk_job: null argument");
 	B3M_REQUIRE(j->inputtype == B3M_INPUT_PAC || j->inputtype == B3M_INPUT_PACTERM || j->inputtype == B3M_INPUT_BYTESTREAM, "b3m_lf_walk_job: bytestream, pac and pacterm texts");
@@ -1984,6 +1996,7 @@ b3m_dist_plan *b3m_dist_create(uint64_t n, int inputtype, uint64_t max_leaf, uin
 {
 	b3m_dist_plan *p = nullptr;
 	B3M_TRY
+	switches_load();
 	require_device();
 	B3M_REQUIRE(inputtype == B3M_INPUT_PAC || inputtype == B3M_INPUT_PACTERM || inputtype == B3M_INPUT_BYTESTREAM, "the multi-GPU block merge takes pac, pacterm and bytestream texts");
 	B3M_REQUIRE(n >= 1 && n < (1ull << 32), "n out of range for the block-merge mode (use suffix-range shards above 2^32)");

@@ -4,6 +4,7 @@
 // are ALL pairs of X.preisa (or the ranks of X.isa where only that exists: bwtonly=0), one chain per anchor (b3m_lf_walk: every symbol and every
 // chain closure checked).
 #include "formats.h"
+#include "../switches.h"
 #include "parfile.h"
 #include "../../../include/b3m.h"
 #include <hip/hip_runtime.h>
@@ -32,6 +33,7 @@ void logf(int fd, const char *fmt, ...)
 
 extern "C" int b3m_check_bwt(const char *bwt_fn, const char *text_fn, const char *inputtype, int log_fd, uint64_t *mismatches_out)
 {
+	b3m::switches_load();
 	void *d_text = nullptr; uint8_t *d_bwt = nullptr;
 	auto cleanup = [&]() { if (d_text) (void)hipFree(d_text); if (d_bwt) (void)hipFree(d_bwt); b3m::staging_release(); };
 	try {
@@ -123,6 +125,7 @@ extern "C" int b3m_check_bwt(const char *bwt_fn, const char *text_fn, const char
 // circular 2-bit text, anything else the byte LF array (fewer than 2^32 symbols).
 extern "C" int b3m_compute_ssa(const char *bwt_fn, uint64_t sasamplingrate, uint64_t isasamplingrate, int log_fd)
 {
+	b3m::switches_load();
 	uint8_t *d_bwt = nullptr;
 	auto cleanup = [&]() { if (d_bwt) (void)hipFree(d_bwt); b3m::staging_release(); };
 	try {

@@ -12,6 +12,7 @@
 //          stream of their own, the samples streamed from HBM) or X.preisa (the plan's pinned sample image, written in place).
 #include "formats.h"
 #include "parfile.h"
+#include "../switches.h"
 #include "../../../include/b3m.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -83,7 +84,7 @@ std::vector<int> device_list(int N)
 	int ndev = 0;
 	HIPCHK(hipGetDeviceCount(&ndev));
 	std::vector<int> d;
-	if (const char *e = getenv("B3M_DEVICES")) {
+	if (const char *e = b3m::sw().DEVICES[0] ? b3m::sw().DEVICES : nullptr) {
 		for (const char *p = e; *p;) { char *q; long v = strtol(p, &q, 10); if (q == p) break; d.push_back((int)v); p = *q == ',' ? q + 1 : q; }
 		if ((int)d.size() != N) throw std::runtime_error("B3M_DEVICES must list exactly numgpus devices");
 		for (int v : d) if (v < 0 || v >= ndev) throw std::runtime_error("B3M_DEVICES names a device this machine does not have");
@@ -248,6 +249,7 @@ extern "C" uint64_t b3m_plan_sampling_rate(uint64_t isasamplingrate, int bwtonly
 
 extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 {
+	b3m::switches_load();
 	void *d_text = nullptr; Built B; std::vector<Shard> shards; int dev0 = 0; bool own_bwt = false;
 	void *h_text = nullptr; uint8_t *h_bwt = nullptr;      // host tier: the text comes from, the BWT goes to pinned host memory
 	auto cleanup = [&]() {
@@ -482,11 +484,11 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				} else if (!B.d_bwt && h_bwt) {
 					// host tier, bwtonly=1: the BWT is in pinned host memory; the device encoder takes it one segment at a time (a sixteenth of the memory target)
 					const uint64_t seg = std::max<uint64_t>(1ull << 24, mem / 16);
-					if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device_from_host(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap, s, seg))
+					if (b3m::sw().HOST_RL.set || !b3m::rl_encode_device_from_host(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap, s, seg))
 						b3m::rl_encode_file(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap);
 					b3m::write_hist(prefix + ".hist", B.hist, symmap);
 				} else {
-					if (getenv("B3M_HOST_RL") || !b3m::rl_encode_device(outfn, B.d_bwt, n, 64 * 1024, enc_threads, symmap, s)) {
+					if (b3m::sw().HOST_RL.set || !b3m::rl_encode_device(outfn, B.d_bwt, n, 64 * 1024, enc_threads, symmap, s)) {
 						std::vector<uint8_t> bwt(n);
 						HIPCHK(hipMemcpy(bwt.data(), B.d_bwt, n, hipMemcpyDeviceToHost));
 						b3m::rl_encode_file(outfn, bwt.data(), n, 64 * 1024, enc_threads, symmap);

@@ -1,5 +1,6 @@
 // parfile.cpp -- see parfile.h
 #include "parfile.h"
+#include "../switches.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -95,8 +96,7 @@ void ParFile::reserve(uint64_t total_bytes)
 {
 	// measured at C3 (tools/e2e_c3.py --mmap-ab, 0.94 GB .bwt + 0.75 GB .sa): the mapping is SLOWER than pwrite from 8 threads (0.72-0.96 s against
 	// 0.38-0.48 s for the .bwt: a page fault per 4 KB costs more than the inode lock): off unless B3M_FILE_MMAP=1 asks for it
-	const char *e = getenv("B3M_FILE_MMAP");
-	if (!(e && atoi(e) == 1) || total_bytes < (64ull << 20) || map_) return;
+	if (b3m::sw().FILE_MMAP.get(0) != 1 || total_bytes < (64ull << 20) || map_) return;
 	if (ftruncate(fd_, (off_t)total_bytes) != 0) return;
 	void *m = mmap(nullptr, total_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
 	if (m == MAP_FAILED) return;                                                  // (a file system without shared mappings: pwrite it is)

@@ -240,7 +240,11 @@ constexpr int TT_STRIDE = 2048, TT_GROUP = 2048, TT_CAP = 4096, TT_THREADS = 512
 #else
 constexpr int TT_STRIDE = 1024, TT_GROUP = 1024, TT_CAP = 2048, TT_THREADS = 256, TT_PER = TT_CAP / TT_THREADS, TT_COUNT = 512;
 #endif
-static int tt_count_max() { const char *e = getenv("B3M_TT_COUNT"); const int v = e ? atoi(e) : TT_COUNT; const char *x = getenv("B3M_TT_EXPERIMENT"); return (v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v)) | ((x ? atoi(x) : 0) << 16); }      // measurement switch
+static int tt_count_max()      // measurement switch (+ the experiment build's timing-only flags in the high half: never set in the product library)
+{
+	const int v = (int)sw().TT_COUNT.get(TT_COUNT);
+	return (v < 8 ? 8 : (v > TT_COUNT ? TT_COUNT : v)) | ((int)sw().TT_EXPERIMENT.get(0) << 16);
+}
 static_assert(TT_STRIDE - 1 + TT_GROUP <= TT_CAP, "a tile holds the groups of its stride");
 
 // flag[s] = 1 if the group of slot s has more than TT_GROUP members (hid[s] = list index of the group's head); flag[u] = 0
@@ -279,7 +283,11 @@ __global__ __launch_bounds__(TT_THREADS) void k_tie_tile(TextView T, const uint3
 {
 	// kshift = 12 where the key leaves room (pacterm: 48 bits, ranks: 32): the slot inside the tile rides in the low bits, every key of the tile is
 	// distinct and one 64-bit compare per pair orders them (0: 64-bit keys, ties are broken by the slot in a second compare)
-	const int xflags = count_max >> 16; count_max &= 0xFFFF;      // (experiment flags: 1 = no ordering, 2 = no write-back, 4 = leave after the fetch)
+#ifdef B3M_PHASE_EXPERIMENT
+	const int xflags = count_max >> 16; count_max &= 0xFFFF;      // (`make experiment`, timing only, WRONG results: 1 = no ordering, 2 = no write-back, 4 = leave after the fetch)
+#else
+	constexpr int xflags = 0;
+#endif
 	constexpr bool ISA = MODE == 1;
 	constexpr uint32_t GROUP = MODE == 2 ? MP_GROUP : TT_GROUP;       // (MODE 2: a group above MP_GROUP is a piece of one key, k_msd_leftover's)
 	__shared__ uint64_t sk[TT_CAP];                  // keys
@@ -870,11 +878,11 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		return hid;
 	};
 	if (isa && u) hipLaunchKernelGGL(k_isa_list, dim3(nblk(u)), dim3(256), 0, s, U, head_index(), idx, u, isa);
-	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	const int dbg = (int)sw().DEBUG.get(0);
 	// tiles (k_tie_tile): 32-bit positions; B3M_NO_TIE_TILES=1 keeps every round on the radix sorts
-	const bool tiles_ok = !idx_hi && !(getenv("B3M_NO_TIE_TILES") && atoi(getenv("B3M_NO_TIE_TILES")));
+	const bool tiles_ok = !idx_hi && !sw().NO_TIE_TILES.on();
 	// large groups split inside the round (k_msd_*); B3M_NO_TIE_MSD=1: through the radix sorts as a sub-list
-	const bool msd_on = !(getenv("B3M_NO_TIE_MSD") && atoi(getenv("B3M_NO_TIE_MSD")));
+	const bool msd_on = !sw().NO_TIE_MSD.on();
 	bool any_large = true;                             // (groups only shrink: once none is large, none will be)
 	for (uint64_t depth = depth0; u > 0; ++depth) {
 		const uint64_t off = sym_off + depth * K;       // symbols in front of this round's key
@@ -901,7 +909,7 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			B3M_HIP(hipMemcpyAsync(&nq, qcnt, 4, hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipStreamSynchronize(s));
 			if (dbg >= 3) fprintf(stderr, "[b3m]   doubling by %llu: %u of %llu targets have no rank yet\n", (unsigned long long)h, nq, (unsigned long long)u);
-			const uint64_t nq_max = getenv("B3M_ISA_SEARCH_MAX") ? strtoull(getenv("B3M_ISA_SEARCH_MAX"), nullptr, 10) : T.n / 64;      // (switch: 0 = fill the array as soon as one target is unset)
+			const uint64_t nq_max = sw().ISA_SEARCH_MAX.set ? (uint64_t)sw().ISA_SEARCH_MAX.v : T.n / 64;      // (switch: 0 = fill the array as soon as one target is unset)
 			if (nq > nq_max) {
 				isa_from_sa(idx, len_for_labels, isa, s);
 				hipLaunchKernelGGL(k_heads_from_gid, dim3(nblk(u)), dim3(256), 0, s, gid, u, hid);
@@ -1001,7 +1009,9 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 		if (dbg >= 2) fprintf(stderr, "[b3m]   round %llu: %.2f ms on %llu slots (%.2f ms until the splits were through%s), %u left\n", (unsigned long long)rounds,
 		                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count(), (unsigned long long)u, ms_splits,
 		                      dbg >= 3 ? "; includes the census" : "", h_u);
-		if (getenv("B3M_TT_EXPERIMENT") && atoi(getenv("B3M_TT_EXPERIMENT"))) throw Error("B3M_TT_EXPERIMENT: timing-only round done");
+#ifdef B3M_PHASE_EXPERIMENT
+		if (sw().TT_EXPERIMENT.on()) throw Error("TT_EXPERIMENT: timing-only round done");
+#endif
 		vx = U; vy = gid; U = U2; gid = gid2;
 		heads = true;                                    // (k_tie_compact: the new labels are the heads' new list indices)
 		u = h_u;
@@ -1097,7 +1107,7 @@ uint64_t tie_rounds_sparse(const TextView &T, uint32_t *idx, uint8_t *idx_hi, ui
 	uint32_t *U = B[0], *gid = B[1], *vx = B[2], *vy = B[3], *hid = B[4], *flag = B[5];
 	SparseRanks R{pos, rank, cnt, gslot, d_missing};
 	B3M_HIP(hipMemsetAsync(d_missing, 0, 4, s));
-	const int dbg = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	const int dbg = (int)sw().DEBUG.get(0);
 	uint64_t rounds = 0, d = d0;
 	uint32_t h_u = 0;
 	if (u) {
@@ -1317,8 +1327,8 @@ void isa_sparse_from_slots(const uint32_t *d_sa, uint64_t len, const uint32_t *d
 	if (total) hipLaunchKernelGGL(k_isa_slots, dim3(nblk(total)), dim3(256), 0, s, d_slots, total, d_sa, d_isa);
 }
 
-bool no_tree_doubling() { const char *e = getenv("B3M_NO_TREE_DOUBLING"); return e && atoi(e) != 0; }
-uint64_t block_overhang() { const char *e = getenv("B3M_OVERHANG"); return e ? strtoull(e, nullptr, 10) : (1ull << 20); }
+bool no_tree_doubling() { return sw().NO_TREE_DOUBLING.on(); }
+uint64_t block_overhang() { return sw().OVERHANG.set ? (uint64_t)sw().OVERHANG.v : (1ull << 20); }
 
 void block_sort_lsd(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out, uint64_t own, bool allow_ext)
 {

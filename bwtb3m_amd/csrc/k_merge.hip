@@ -213,8 +213,7 @@ __global__ void k_rank_headers_sb(uint32_t *blocks, const uint32_t *cnt, uint64_
 int rank_sb_shift()
 {
 	// (test switch: small superblocks put texts the oracle can sort across many of them)
-	const char *e = getenv("B3M_RANK_SB_SHIFT");
-	const int v = e ? atoi(e) : 16;
+	const int v = (int)sw().RANK_SB_SHIFT.get(16);
 	return v < 1 ? 1 : (v > 24 ? 24 : v);
 }
 uint64_t rank_superblocks(uint64_t m) { return (rank_blocks(m) >> rank_sb_shift()) + 1; }
@@ -417,7 +416,7 @@ uint64_t gap_walk_slots(uint64_t num_chains, uint64_t chain_len) { return num_ch
 void gap_walk(const GapWalkArgs &A, hipStream_t s)
 {
 	if (!A.num_chains) return;
-	const int one_lane = getenv("B3M_WALK_ONE_LANE") ? atoi(getenv("B3M_WALK_ONE_LANE")) : 0;   // measurement switch
+	const int one_lane = (int)sw().WALK_ONE_LANE.get(0);   // measurement switch
 	if (one_lane) {
 		// the one-lane kernel fills [chain_len][num_chains]; the rest of the padded table must read as unused
 		const uint64_t used = A.num_chains * A.chain_len, all = gap_walk_slots(A.num_chains, A.chain_len);

@@ -96,13 +96,13 @@ static MsdDigits msd_digits(uint64_t len)
 	else { d.D0 = 11; d.D1 = t - d.D0; if (d.D1 > MSD_MAXBITS) { d.D1 = MSD_MAXBITS; d.D0 = std::min(W0_MAXBITS, t - d.D1); } }
 	// test switch: B3M_MSD_D1=k gives level 1 k bits whatever the size, so that small inputs (which the oracle can check) run the
 	// kernels of the large geometries (k_l1_local, the gathering finishes, k_finish_fast from 4 bits on)
-	if (const char *e = getenv("B3M_MSD_D1")) {
-		const int k = atoi(e);
+	if (sw().MSD_D1.set) {
+		const int k = (int)sw().MSD_D1.v;
 		if (k >= 1 && k <= MSD_MAXBITS && t > k) { d.D1 = k; d.D0 = std::min(W0_MAXBITS, t - k); }
 	}
 	// test switch: B3M_MSD_D0=k caps level 0 at k bits (with B3M_MSD_D1: fewer partition bits than the size asks for, which is
 	// what a 30 Gbase text has; a suffix-range shard then takes the fine level 0 of block_sort_msd on an input the oracle can check)
-	if (const char *e = getenv("B3M_MSD_D0")) { const int k = atoi(e); if (k >= 1 && k < d.D0) d.D0 = k; }
+	if (sw().MSD_D0.set) { const int k = (int)sw().MSD_D0.v; if (k >= 1 && k < d.D0) d.D0 = k; }
 	return d;
 }
 
@@ -2380,14 +2380,14 @@ __global__ __launch_bounds__(256) void k_fill_overflow_ranges(const uint32_t *of
 	}
 }
 
-static uint32_t big_grid() { const char *e = getenv("B3M_BIG_GRID"); const int v = e ? atoi(e) : 2048; return (uint32_t)(v < 64 ? 64 : v); }      // (measurement switch: workgroups that stride over the listed buckets)
+static uint32_t big_grid() { const int v = (int)sw().BIG_GRID.get(2048); return (uint32_t)(v < 64 ? 64 : v); }      // (measurement switch: workgroups that stride over the listed buckets)
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                     uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own, bool allow_ext)
 {
 	uint64_t len = len_in;           // becomes the number of KEPT suffixes after level 0 (suffix-range shard)
 	MsdWs &M = ws.msd;
 	// B3M_DEBUG=2: the stream is drained after every stage and the stage is named on stderr (which kernel a fault belongs to)
-	const int dbg_stages = getenv("B3M_DEBUG") ? atoi(getenv("B3M_DEBUG")) : 0;
+	const int dbg_stages = (int)sw().DEBUG.get(0);
 	// (a GPU memory fault ends the process inside the runtime: the last "stage done" line then names the stage BEFORE the faulting one)
 	auto stage = [&](const char *name) {
 		if (dbg_stages < 2) return;
@@ -2422,7 +2422,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	A.keep_lo = 0; A.keep_hi = bins0; A.pb = pb;
 	// Chunk-local level 0 (unsharded blocks with a level 1, 32-bit positions): no counting pass, the records of a chunk stay in the
 	// chunk's own index range, level 1 gathers (k_l0_pass<.., LOCAL>, k_l1_gather).  B3M_L0_LOCAL=0: the scattering form.
-	const int l0_local_on = getenv("B3M_L0_LOCAL") ? atoi(getenv("B3M_L0_LOCAL")) : 1;
+	const int l0_local_on = (int)sw().L0_LOCAL.get(1);
 	const uint32_t nchunks0 = (uint32_t)((span + W0A_CHUNK - 1) / W0A_CHUNK);
 	bool local0 = l0_local_on && nshards <= 1 && geoA && dg.D1 > 0 && !big && span <= ws.cap && M.tab0 != nullptr
 	              && (uint64_t)bins0 * ((uint64_t)ntA * W0A_TCH) <= M.tab0_cap && span < (1ull << 32);
@@ -2439,7 +2439,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// (cbase[column]); level 1 gathers through the run table as for a whole block.
 	bool shard1 = false, borders_fixed = false; uint32_t fixed_lo = 0, fixed_hi = 0;
 	{
-		const int onepass_on = getenv("B3M_SHARD_ONEPASS") ? atoi(getenv("B3M_SHARD_ONEPASS")) : 1;
+		const int onepass_on = (int)sw().SHARD_ONEPASS.get(1);
 		int tfin = 0; while ((len_in >> tfin) > (uint64_t)F_AVG) ++tfin;
 		if (nshards > 1 && onepass_on && l0_local_on && geoA && dg.D1 > 0 && !big && M.tab0 != nullptr && M.cbase0 != nullptr && span < (1ull << 32)
 		    && ncol0 <= M.cbase0_cap && !allow_ext && own == 0 && tfin - dg.D0 - dg.D1 <= 0) {
@@ -2467,7 +2467,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			borders_fixed = true; fixed_lo = lo; fixed_hi = hi;
 			const double est = cum[bins0] ? (double)(cum[hi] - cum[lo]) / (double)cum[bins0] * (double)len_in : 0.0;
 			const uint64_t capr = std::min<uint64_t>(ws.cap, 0xFFFFFFFFull);
-			const unsigned two_mask = getenv("B3M_SHARD_TWO_PASS") ? (unsigned)strtoul(getenv("B3M_SHARD_TWO_PASS"), nullptr, 0) : 0u;      // test switch: these shards (bit k = shard k) take the two passes, the others one
+			const unsigned two_mask = (unsigned)sw().SHARD_TWO_PASS.get(0);      // test switch: these shards (bit k = shard k) take the two passes, the others one
 			if (hi > lo && (uint64_t)(hi - lo) * ncol0 <= M.tab0_cap && est <= 0.97 * (double)capr && !((two_mask >> (shard & 31)) & 1u)) {
 				uint32_t *d_alloc = M.cbase0 + M.cbase0_cap;
 				unsigned long long *d_below = reinterpret_cast<unsigned long long *>(d_alloc + 2);
@@ -2481,7 +2481,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				B.symhist = want_hist ? d_h5 : nullptr;
 				// three shards and more: 512-thread workgroups with a third of the index array, two to a CU (B3M_SHARD_WG2=0: always the 1024-thread form);
 				// a chunk that keeps more than that array holds raises the flag and the pass is repeated in the other form
-				const int wg2_on = getenv("B3M_SHARD_WG2") ? atoi(getenv("B3M_SHARD_WG2")) : 1;
+				const int wg2_on = (int)sw().SHARD_WG2.get(1);
 				uint32_t h_sc[4] = {0, 0, 0, 0};
 				for (int form = (wg2_on && est <= 0.30 * (double)len_in) ? 2 : 1; form >= 1; --form) {
 					if (form == 1 && h_sc[1]) B3M_HIP(hipMemsetAsync(d_alloc, 0, 32 + 64, s));      // (the flagged attempt's counts start over)
@@ -2585,9 +2585,9 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		int t = 0; while ((len_in >> t) > (uint64_t)F_AVG) ++t;
 		int S = 0;
 		while (hi > lo && S < t - dg.D0 - dg.D1 && dg.D0 + S < 15 && ((uint64_t)(hi - lo) << (S + 1)) <= (uint64_t)W0_MAXBINS) ++S;
-		const int no_fine = getenv("B3M_NO_FINE_SHARDS") ? atoi(getenv("B3M_NO_FINE_SHARDS")) : 0;      // measurement switch
+		const int no_fine = (int)sw().NO_FINE_SHARDS.get(0);      // measurement switch
 		if (no_fine) S = 0;
-		{ const char *e = getenv("B3M_FINE_MAXS"); if (e && S > atoi(e)) S = atoi(e); }
+		if (sw().FINE_MAXS.set && S > (int)sw().FINE_MAXS.v) S = (int)sw().FINE_MAXS.v;
 		A.keep_lo = lo << S; A.keep_hi = hi << S; A.D = dg.D0 + S; D0e = dg.D0 + S;
 		bins0 = (hi - lo) << S;
 		if (S == 0) hist0 = M.hist + (uint64_t)lo * ntA;      // the rows of the first count serve
@@ -2628,10 +2628,10 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// B3M_L1_ORDER=1 (measurement switch): level 1's tiles listed tile-major (tile j of every bucket, then j + 1) and taken in XCD-aware order, so that tile j of
 	// buckets d and d + 1 -- neighbouring runs of the same level-0 chunks -- run side by side on one XCD.  It takes the reads from 36.1 to 25.4 GB (PMC) and
 	// the kernel from 11.31 to 11.52 ms: level 1 is not waiting for those bytes (profiles/NOTES_r03.md).  Default: bucket by bucket, launch order.
-	const int l1_order = getenv("B3M_L1_ORDER") ? atoi(getenv("B3M_L1_ORDER")) : 0;
-	const int xcd_on = getenv("B3M_XCD_ORDER") ? atoi(getenv("B3M_XCD_ORDER")) : 1;       // measurement switch: 0 = workgroups take their items in launch order
+	const int l1_order = (int)sw().L1_ORDER.get(0);
+	const int xcd_on = (int)sw().XCD_ORDER.get(1);       // measurement switch: 0 = workgroups take their items in launch order
 	FinishSrc FS{};                     // where the finish finds the records of a final bucket
-	FS.bstart = M.lvl_start; FS.xcd = (xcd_on ? 1u : 0u) | ((getenv("B3M_FINISH_EXPERIMENT") ? (uint32_t)atoi(getenv("B3M_FINISH_EXPERIMENT")) : 0u) << 8);
+	FS.bstart = M.lvl_start; FS.xcd = (xcd_on ? 1u : 0u) | ((uint32_t)sw().FINISH_EXPERIMENT.get(0) << 8);      // (the experiment field is only ever set in the experiment build)
 	bool gather = false;
 	if (dg.D1 == 0) {
 		hipLaunchKernelGGL(k_l0_starts, dim3(nblk((uint64_t)bins0 + 1)), dim3(256), 0, s, hist0, ntA, bins0, (uint32_t)len, M.lvl_start);
@@ -2752,7 +2752,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		B3M_HIP(hipMemsetAsync(M.midlist, 0, 4, s));
 		const uint32_t gmid = (uint32_t)std::min<uint64_t>(len / F_CAP + 1, 1024);
 		// (buckets up to F_HUGE2 records go through level 2 where there is one: tiles in parallel; without it one workgroup partitions a listed bucket: F_HUGE)
-		const uint32_t huge_min = (gather && !getenv("B3M_NO_LEVEL2")) ? F_HUGE2 : F_HUGE;
+		const uint32_t huge_min = (gather && !sw().NO_LEVEL2.set) ? F_HUGE2 : F_HUGE;
 		const FinishLists hl[2] = {{M.midlist, (uint32_t)M.mid_cap, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, huge_min},
 		                           {nullptr, 0u, M.biglist, (uint32_t)M.big_cap, M.hugelist, (uint32_t)M.huge_cap, huge_min}};
 		FinishLists *dl = reinterpret_cast<FinishLists *>(M.lists);       // [0]: first launch (lists mid / big / huge), [1]: the mid launch
@@ -2770,7 +2770,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_HIP(hipStreamSynchronize(s));
 			for (uint32_t i = 0; i <= nsl; ++i) lvl0[i] = hs[(uint64_t)bins0 * i / nsl];
 		}
-		const int no_fast = getenv("B3M_NO_FAST_FINISH") ? atoi(getenv("B3M_NO_FAST_FINISH")) : 0;      // measurement switch
+		const int no_fast = (int)sw().NO_FAST_FINISH.get(0);      // measurement switch
 		for (uint32_t sl = 0; sl < nsl; ++sl) {
 			const uint32_t l0a = (uint32_t)((uint64_t)bins0 * sl / nsl), l0b = (uint32_t)((uint64_t)bins0 * (sl + 1) / nsl);
 			const uint32_t bfa = nsl > 1 ? l0a << dg.D1 : 0u, bfb = nsl > 1 ? l0b << dg.D1 : nbF;
@@ -2779,12 +2779,14 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			if (gather && !no_fast && fbits >= F_BINBITS && fbits - F_BINBITS <= 12) {
 				// sorts that keep no suffix array take k_finish_v3 (32-bit positions; sampling off or sparse enough for its list of special records).
 				// B3M_FINISH_V3 (measurement switch): 0 = k_finish_fast<false> instead, 2 = k_finish_v3 held at two workgroups per CU
-				int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;
+				int v3 = (int)sw().FINISH_V3.get(1);
 				if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
 				if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3 == 2) hipLaunchKernelGGL(k_finish_v3<2>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else if (v3 == 4) hipLaunchKernelGGL((k_finish_v3<3, 1024>), dim3(bfb - bfa), dim3(1024), 0, s, FS, fbits, bfa, dl, O);
-				else if (v3 == 5) hipLaunchKernelGGL((k_finish_v3<3, 512, true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
+#ifdef B3M_PHASE_EXPERIMENT
+				else if (sw().FINISH_NOMAP.on()) hipLaunchKernelGGL((k_finish_v3<3, 512, true>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);      // timing only, WRONG results
+#endif
 				else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 				else hipLaunchKernelGGL((k_finish_fast<false>), dim3(bfb - bfa), dim3(512), 0, s, FS, fbits, bfa, dl, O);
 			} else if (gather) {
@@ -2807,7 +2809,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		auto bucket_finish_chain = [&](const uint64_t *rin, uint64_t *rtmp, const uint32_t *bst, const uint32_t *ben, const uint32_t *list, uint32_t list_cap,
 		                               int cons, int bits, uint32_t grid) {
 			const int kb_main = consumed + std::min(fbits, F_BINBITS);      // key bits a bin of the main finish knows: what "one bin" promises the list rounds
-			const int no_chain = getenv("B3M_NO_FINISH_CHAIN") ? atoi(getenv("B3M_NO_FINISH_CHAIN")) : 0;      // measurement switch: one pass, as before
+			const int no_chain = (int)sw().NO_FINISH_CHAIN.get(0);      // measurement switch: one pass, as before
 			for (int pass = 0; pass < 3; ++pass) {
 				const int D = pass == 0 ? 8 : std::min(8, bits);
 				const int sortbits = bits - D, shift = 64 - cons - D;
@@ -2851,18 +2853,18 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// workgroup of its own.  (Before: one workgroup per listed bucket partitioned it alone, chunk by chunk, and sub-buckets above 512 records
 		// went to the list-based rounds: 80 % A+T cost 10x the uniform text.)  What is still too large after it takes the old paths.
 		bool lvl2_done = false; (void)lvl2_done;
-		const int no_lvl2 = getenv("B3M_NO_LEVEL2") ? atoi(getenv("B3M_NO_LEVEL2")) : 0;      // measurement switch
+		const int no_lvl2 = (int)sw().NO_LEVEL2.get(0);      // measurement switch
 		uint32_t nbig1 = lc1[1];                                          // listed buckets left to k_bucket_finish
 		if (gather && lc1[1] && !no_lvl2 && fbits > 8 && lc1[1] <= M.big_cap) {
 			std::vector<uint32_t> all(lc1[1]), ids, small, ls((size_t)nbF + 1);
 			B3M_HIP(hipMemcpyAsync(all.data(), M.biglist + 1, 4ull * lc1[1], hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipMemcpyAsync(ls.data(), M.lvl_start, 4ull * (nbF + 1), hipMemcpyDeviceToHost, s));
 			B3M_HIP(hipStreamSynchronize(s));
-			const uint32_t lvl2_min = getenv("B3M_LVL2_MIN") ? (uint32_t)atoi(getenv("B3M_LVL2_MIN")) : LVL2_MIN;      // test switch: small inputs through level 2
+			const uint32_t lvl2_min = (uint32_t)sw().LVL2_MIN.get(LVL2_MIN);      // test switch: small inputs through level 2
 			// a bucket's fan-out is chosen from its own size: the sub-buckets are to average LVL2_AVG records (half a finish workgroup's capacity: on
 			// skewed text the heaviest is a few times the average), so a class of buckets per digit width D2 = 1 .. 8, one after the other.  (With 8 bits
 			// for all of them a 65 K bucket made 256 sub-buckets of 256 records: 1.3 M workgroups, 24 ms of the 80 a Gbase at 80 % A+T took.)
-			const uint32_t lvl2_avg = getenv("B3M_LVL2_AVG") ? std::min<uint32_t>(LVL2_AVG, (uint32_t)atoi(getenv("B3M_LVL2_AVG"))) : LVL2_AVG;      // (measurement switch: smaller only, the tables are sized for LVL2_AVG)
+			const uint32_t lvl2_avg = sw().LVL2_AVG.set ? std::min<uint32_t>(LVL2_AVG, (uint32_t)sw().LVL2_AVG.v) : LVL2_AVG;      // (measurement switch: smaller only, the tables are sized for LVL2_AVG)
 			std::vector<uint32_t> cls[MSD_MAXBITS + 1];
 			const int d2_max = std::min(MSD_MAXBITS, fbits - 1);
 			for (uint32_t b : all) {
@@ -2922,7 +2924,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				F2.chunk = (uint32_t)L1_CHUNK; F2.nbF = nbF2; F2.nrec = (uint32_t)len;
 				const int fbits2 = fbits - d2;
 				if (!no_fast && fbits2 >= F_BINBITS && fbits2 - F_BINBITS <= 12) {
-					int v3 = getenv("B3M_FINISH_V3") ? atoi(getenv("B3M_FINISH_V3")) : 1;
+					int v3 = (int)sw().FINISH_V3.get(1);
 					if (big || (O.smp.pairs && O.smp.rate < V3_MIN_RATE)) v3 = 0;
 					if (need_sa) hipLaunchKernelGGL((k_finish_fast<true>), dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
 					else if (v3) hipLaunchKernelGGL(k_finish_v3<3>, dim3(nbF2), dim3(512), 0, s, F2, fbits2, 0u, dl + 2, O);
@@ -2952,7 +2954,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				B3M_HIP(hipMemcpyAsync(&l2[0], M.mid2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[1], M.big2, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipMemcpyAsync(&l2[2], M.huge2, 4, hipMemcpyDeviceToHost, s));
 				B3M_HIP(hipStreamSynchronize(s));
 				B3M_REQUIRE(l2[0] <= M.list2_cap && l2[1] <= M.list2_cap && l2[2] <= M.huge_cap, "internal: a bucket list of level 2 ran over");
-				if (getenv("B3M_DEBUG"))
+				if (sw().DEBUG.set)
 					fprintf(stderr, "[b3m] level 2: %u buckets by %d bits, %zu tiles, fbits %d; listed again: mid %u big %u huge %u\n", nb2, d2, c.tiles.size(), fbits2, l2[0], l2[1], l2[2]);
 			}
 		}
@@ -2979,7 +2981,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	}
 	if (!sliced || out.late_writes) {
 		Scope sc(tl, KF_TIES, len / 8);
-		const int tie_two_step = getenv("B3M_TIE_TWO_STEP") ? atoi(getenv("B3M_TIE_TWO_STEP")) : 1;      // measurement switch
+		const int tie_two_step = (int)sw().TIE_TWO_STEP.get(1);      // measurement switch
 		// (sequential shards of a plan that keeps a list of tied suffixes: what the direct comparisons place among long repeats is listed too, TieExtras)
 		TieExtras xtra{};
 		if (nshards > 1 && start == 0 && len_in == T.n && ws.no_defer && ws.sparse_room > 0 && ws.extras.cnt) { xtra = ws.extras; xtra.keys = 4; }      // (4 = R0, the key rounds a shard runs before it hands over)
@@ -2990,7 +2992,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_HIP(hipMemsetAsync(gcnt, 0, 4, s));
 			hipLaunchKernelGGL(k_tie_collect, dim3(nblk((len + 31) / 32, 256 * TIE_WPT)), dim3(256), 0, s, ws.t[0], len, glist, gcap, gcnt);
 			hipLaunchKernelGGL(k_tie_fix_list, dim3(8192), dim3(256), 0, s, T, ws.t[0], len, glist, gcnt, gcap, eq_syms, sa, d_bwt, start, d_p0, O.smp, xtra);
-			if (getenv("B3M_DEBUG")) {
+			if (sw().DEBUG.set) {
 				uint32_t ng = 0; B3M_HIP(hipMemcpyAsync(&ng, gcnt, 4, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
 				fprintf(stderr, "[b3m] tie fix: %u groups of records with equal key fields\n", ng);
 			}
@@ -3008,7 +3010,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// what every range of the overflow list shares: the bits of its bucket, and those of its bin when every range is one bin of a finish (a repeated
 	// 16-mer at the usual geometry).  The rounds on the list start behind it (in the record sort's reading of the text: key_at_off)
 	const uint64_t ovf_syms = (uint64_t)(D0e + consumed + ((novw[1] & 1u) ? 0 : std::min(fbits, F_BINBITS))) / 2;
-	if (getenv("B3M_DEBUG")) fprintf(stderr, "[b3m] block_sort_msd len %llu D0 %d D1 %d: listed mid %u big %u huge %u (caps %llu %llu %llu), overflow ranges %u\n",
+	if (sw().DEBUG.set) fprintf(stderr, "[b3m] block_sort_msd len %llu D0 %d D1 %d: listed mid %u big %u huge %u (caps %llu %llu %llu), overflow ranges %u\n",
 	                                 (unsigned long long)len, D0e, dg.D1, nlist[0], nlist[1], nlist[2], (unsigned long long)M.mid_cap, (unsigned long long)M.big_cap, (unsigned long long)M.huge_cap, nov);
 	// a list that ran over would have dropped buckets silently
 	B3M_REQUIRE(nlist[0] <= M.mid_cap && nlist[1] <= M.big_cap && nlist[2] <= M.huge_cap, "internal: a bucket list of the MSD finish ran over");
@@ -3025,7 +3027,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		uint64_t *pk = reinterpret_cast<uint64_t *>(M.overflow + 2), *rk = nullptr;
 		radix_sort_u64(pk, nullptr, ws.keyA, nullptr, nov, 32, ws.radix, s, nullptr, &rk, nullptr);
 		if (rk == pk) { B3M_HIP(hipMemcpyAsync(ws.keyA, pk, 8ull * nov, hipMemcpyDeviceToDevice, s)); rk = ws.keyA; }
-		if (getenv("B3M_DEBUG") && atoi(getenv("B3M_DEBUG")) >= 3) {
+		if (sw().DEBUG.get(0) >= 3) {
 			std::vector<uint64_t> hp(nov);
 			B3M_HIP(hipMemcpyAsync(hp.data(), rk, 8ull * nov, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s));
 			uint64_t nb = 0, eb = 0, no = 0, eo = 0, big_o = 0;
@@ -3051,7 +3053,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			B3M_REQUIRE(total <= ws.tie_cap, "repeat-rich input of 2^32 symbols and more: " + std::to_string(total) + " suffixes are left to the list-based rounds, whose buffers hold " +
 			            std::to_string(ws.tie_cap) + ": use more shards");
 		}
-		const bool by_range = total / nov >= 16 && !(getenv("B3M_FILL_BY_SLOT") && atoi(getenv("B3M_FILL_BY_SLOT")));      // (few slots per range: one thread per slot and a search keep the lanes busy)
+		const bool by_range = total / nov >= 16 && !sw().FILL_BY_SLOT.on();      // (few slots per range: one thread per slot and a search keep the lanes busy)
 		auto fill_list = [&](uint32_t *U, uint32_t *gid) {
 			if (by_range) hipLaunchKernelGGL(k_fill_overflow_ranges, dim3(std::min<uint32_t>((nov + 3) / 4, 32768u)), dim3(256), 0, s, (const uint32_t *)d_off, (const uint32_t *)d_b0, nov, U, gid);
 			else hipLaunchKernelGGL(k_fill_overflow_list, dim3(nblk(total)), dim3(256), 0, s, d_off, d_b0, nov, total, U, gid);
@@ -3079,7 +3081,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		// (b3m_plan_tie_export / b3m_plan_tie_finish): O(log longest repeat) rounds there too
 		const bool defer = nshards > 1 && start == 0 && len_in == T.n && !ws.no_defer;
 		const uint64_t R0 = 4;
-		const uint64_t off0 = getenv("B3M_TIE_FROM_0") ? 0 : ovf_syms;      // (switch: the rounds start at symbol 0, as they did before)
+		const uint64_t off0 = sw().TIE_FROM_0.set ? 0 : ovf_syms;      // (switch: the rounds start at symbol 0, as they did before)
 		// a block of a merge tree: the same few rounds, then prefix doubling inside the block and its overhang (tie_rounds_domain):
 		// the first time round the caller is asked to sort the block again with the overhang behind it (out.want_ext)
 		const bool tree = !whole && !defer && !no_tree_doubling() && !(nshards > 1 && ws.no_defer);      // (a sequential shard holds a rank range of the text, not a block: key extension to the end)
@@ -3091,7 +3093,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		uint64_t h0_whole = 1; while (2 * h0_whole <= R0 * (uint64_t)key_symbols(T.type)) h0_whole *= 2;
 		uint32_t *U1_keep = U_keep ? U_keep + total + 16 : nullptr; uint64_t u1 = 0;
 		const bool keep_first = whole && !big && U_keep && 16 * total + 256 <= 8 * ws.cap && (R0 - 1) * (uint64_t)key_symbols(T.type) >= h0_whole &&
-		                        !(getenv("B3M_ISA_EVER_LISTED") && atoi(getenv("B3M_ISA_EVER_LISTED")));      // (measurement switch: ranks for every slot ever listed, as before)
+		                        !sw().ISA_EVER_LISTED.on();      // (measurement switch: ranks for every slot ever listed, as before)
 		if (big) out.tie_rounds = tie_rounds(T, sa.lo, total, 0, ws.keyA, ws.keyB, Bf, ws.scan_ws, ws.radix, len, s, &left, sdefer ? R0 : 0, nullptr, 0, sa.hi, ws.tie_hi, off0, false, true);
 		else if (keep_first) {
 			// (a whole-text block) the list as the first round leaves it is kept: the doubling rounds behind the R0 key rounds ask for the ranks of suffixes that agree
@@ -3130,7 +3132,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			if (!need_sa) { rerun_with_sa = true; goto leave_fallback; }
 			uint64_t h0 = 1; while (2 * h0 <= R0 * (uint64_t)key_symbols(T.type)) h0 *= 2;
 			// ranks for the suffixes that were ever listed; the few others doubling asks for are searched (B3M_ISA_FULL=1: all n entries, as before)
-			const bool sparse = !(getenv("B3M_ISA_FULL") && atoi(getenv("B3M_ISA_FULL")));
+			const bool sparse = !sw().ISA_FULL.on();
 			if (sparse && u1) isa_sparse_from_slots(sa.lo, len, U1_keep, u1, ws.t[5], s);
 			else if (sparse) {
 				slots_again(Bf[4]);

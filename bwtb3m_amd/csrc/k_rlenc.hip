@@ -202,7 +202,7 @@ static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, cons
 	const uint32_t rpb = (uint32_t)runs_per_block;
 	uint64_t seg_max = 1ull << 31;
 	if (seg_limit >= 1024 && seg_limit < seg_max) seg_max = seg_limit;
-	if (const char *e = getenv("B3M_RL_SEG")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024 && v < seg_max) seg_max = v; }
+	if (sw().RL_SEG.set) { const uint64_t v = (uint64_t)sw().RL_SEG.v; if (v >= 1024 && v < seg_max) seg_max = v; }
 	std::unique_ptr<Buf> stage;                           // host source: the segment's symbols in HBM
 	if (h_symbols) stage.reset(new Buf(std::min(seg_max, n) + 16));
 	int dev = 0;
@@ -313,6 +313,7 @@ static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, cons
 extern "C" int b3m_rl_write_device(const char *fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, void *stream)
 {
 	try {
+		b3m::switches_load();
 		int cnt = 0;
 		if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) throw b3m::Error("no HIP device: this library has no CPU fallback");
 		if (!fn || !d_symbols) throw b3m::Error("b3m_rl_write_device: null argument");

@@ -50,6 +50,11 @@ enum {
 
 int         b3m_version(void);
 const char *b3m_last_error(void);
+/* The library's environment switches (csrc/switches.h is the one place that reads the environment: at plan creation, at the start of a run and at the stage entry
+   points, never per kernel launch): name / description of switch i, NULL behind the last one.  None of them changes a result; timing-only experiments that do are
+   compiled into the experiment build alone (`make experiment`). */
+const char *b3m_switch_name(int i);
+const char *b3m_switch_doc(int i);
 
 /* parseInputType: name -> enum, -1 (and error text of /root/reference/src/checkbwt.cpp:274) if unknown */
 int         b3m_parse_input_type(const char *name);

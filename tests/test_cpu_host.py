@@ -32,6 +32,40 @@ def test_header_symbols_all_exported(L):
         assert hasattr(L, name), name
 
 
+def test_environment_switches_live_in_one_place(L):
+    # csrc/switches.h: one list, read by host/switches.cpp alone; tools/README.md names every one of them
+    names = []
+    i = 0
+    while True:
+        nm = L.b3m_switch_name(i)
+        if not nm:
+            break
+        assert L.b3m_switch_doc(i)
+        names.append(nm.decode()); i += 1
+    assert len(names) >= 35 and len(set(names)) == len(names) and all(n.startswith("B3M_") for n in names)
+    csrc = os.path.join(ROOT, "bwtb3m_amd", "csrc")
+    for d, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".h", ".cpp")) and f != "switches.cpp":
+                assert "getenv" not in open(os.path.join(d, f)).read(), "%s reads the environment itself" % f
+    readme = open(os.path.join(ROOT, "tools", "README.md")).read()
+    for n in names:
+        assert n in readme, "%s is not listed in tools/README.md" % n
+
+
+def test_wrong_result_switches_are_not_in_the_product_library():
+    # timing-only experiments that skip work (and return wrong results) are compiled into `make experiment` alone: the product
+    # library and programs do not even hold the names of their variables
+    blobs = [os.path.join(ROOT, "bwtb3m_amd", "libb3m.so")] + [os.path.join(ROOT, "bin", f) for f in sorted(os.listdir(os.path.join(ROOT, "bin")))]
+    for b in blobs:
+        data = open(b, "rb").read()
+        for name in (b"B3M_FINISH_EXPERIMENT", b"B3M_TT_EXPERIMENT", b"B3M_FINISH_NOMAP", b"timing only"):
+            assert name not in data, (b, name)
+    # (B3M_FINISH_V3=5 was the NOMAP form until round 4: the value no longer selects anything)
+    src = open(os.path.join(ROOT, "bwtb3m_amd", "csrc", "k_msd.hip")).read()
+    assert "v3 == 5" not in src
+
+
 def test_no_cpu_fallback(L):
     import torch
     if torch.cuda.is_available():
@@ -204,3 +238,17 @@ def test_bench_roofline_helper():
     assert r["launches_per_step"] == 1 and r["alg_bytes_per_launch"] == 48_000_000_016
     assert abs(r["job_frac"] - 28.5e9 / 0.052 / 1e9 / 8000.0) < 1e-4
     assert set(r["families_ms_per_step"]) == {"msd_scatter", "bucket_finish", "scan"}
+    # the committed PMC passes name the kernels by their full instantiation: every family that can be the dominant one of the
+    # one-block C3 step must be found EXACTLY in the newest file (round 4's line had `traffic: null` after a template parameter was added)
+    import glob, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r0*_pmc_traffic.json")))[-1]
+    tj = json.load(open(newest))
+    for f in ("msd_scatter", "msd_scatter_text", "bucket_finish"):
+        assert benchutil.KERNEL_OF[f] in tj["kernels"], (f, benchutil.KERNEL_OF[f], newest)
+    fam2 = {"bucket_finish": {"ms": 11.0, "launches": 1, "alg_bytes": 27_000_000_009}, "scan": {"ms": 0.3, "launches": 6, "alg_bytes": 1000}}
+    r2 = benchutil.dominant_roofline(fam2, 1, 0.030, 3_000_000_000, 0, tj["workload_n"], root)
+    assert r2["traffic"] is not None and r2["traffic"] > 20e9
+    # a kernel whose template arguments changed since the passes were taken still resolves (same template, most bytes)
+    assert benchutil.pmc_kernel_name("b3m::k_finish_v3<3, 512, false, 7>", tj["kernels"]) == benchutil.KERNEL_OF["bucket_finish"]
+    assert benchutil.pmc_kernel_name("b3m::k_no_such_kernel<1>", tj["kernels"]) is None

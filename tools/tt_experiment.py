@@ -1,4 +1,5 @@
 import os, sys
+assert "libb3m_exp" in os.environ.get("B3M_LIB", ""), "timing-only switches exist in the experiment build alone: make experiment; B3M_LIB=bwtb3m_amd/libb3m_exp.so"
 sys.path.insert(0, "/root/repo")
 import torch
 from bwtb3m_amd import engine, synth, _lib
