@@ -153,16 +153,23 @@ __device__ __forceinline__ void sample_put(const SampleOut &S, uint64_t rank, ui
 // ---- wave helpers (64 lanes) -----------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Inclusive scans over the 64 lanes through DPP (cross-lane operands of the VALU itself): row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 (lane 15 of rows 0 and 2 into rows 1 and 3) and row_bcast:31 (lane 31 into rows 2 and 3): six vector instructions, no LDS
+// pipe (the `__shfl_up` form is six ds_bpermute round trips; every phase that scans -- level 0, level 1, the finish, the scan kernels -- sits
+// between two barriers and waits for exactly that chain).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }     // lanes without a source (or outside the row mask) read 0
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 {
-	#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o, 64); if ((int)lane_id() >= o) v += u; }
+	v += dpp_or0<0x111, 0xf>(v); v += dpp_or0<0x112, 0xf>(v); v += dpp_or0<0x114, 0xf>(v); v += dpp_or0<0x118, 0xf>(v);
+	v += dpp_or0<0x142, 0xa>(v); v += dpp_or0<0x143, 0xc>(v);
 	return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)      // (unsigned: 0 is the neutral element)
 {
-	#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o, 64); if ((int)lane_id() >= o) v = v > u ? v : u; }
+	uint32_t u;
+	u = dpp_or0<0x111, 0xf>(v); v = v > u ? v : u; u = dpp_or0<0x112, 0xf>(v); v = v > u ? v : u; u = dpp_or0<0x114, 0xf>(v); v = v > u ? v : u; u = dpp_or0<0x118, 0xf>(v); v = v > u ? v : u;
+	u = dpp_or0<0x142, 0xa>(v); v = v > u ? v : u; u = dpp_or0<0x143, 0xc>(v); v = v > u ? v : u;
 	return v;
 }
 

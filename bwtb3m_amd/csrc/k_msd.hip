@@ -670,6 +670,42 @@ __global__ __launch_bounds__(256) void k_rows0_prefix(const uint32_t *tab0, uint
 // (group descriptors of up to four runs per 64 slots; a lane of a group with more searches the run list), and written contiguously
 // to the bucket's own range of the output buffer.
 // ------------------------------------------------------------------------------------------------
+// ---- slot -> run map of a gathering kernel, held in REGISTERS (round 5) ----
+// A thread's item s is slot s * THREADS + tid of its chunk, so the 64-slot group of item s is the same for all lanes of a wave: group s * W + wave (W waves).
+// The descriptor of that group -- up to four runs: where the second, third and fourth begin inside the 64 slots, the address of the group's slot 0 and what to
+// add from each run border on -- is built by LANE s of the wave and fetched by v_readlane with a constant lane: five scalar registers per item instead of two
+// 16-byte LDS broadcasts per record (level 1 and the finish issue ~6 LDS instructions per record; these two were a third of them).
+struct GDesc { uint32_t pk, A, d1, d2, d3; };      // pk = o1 | o2 << 8 | o3 << 16 | (more than four runs) << 24; address of slot x = A + x + [x >= o1] d1 + [x >= o2] d2 + [x >= o3] d3
+// built from the run list of the chunk: rr[j] = {first slot of run j inside the chunk, index of its first record taken}, rr[nr], rr[nr + 1] = {nv, 0};
+// gfirst[g] = last run that begins at or before slot 64 g (the list is written by the threads that own the runs)
+__device__ __forceinline__ GDesc gdesc_build(const uint2 *rr, const uint16_t *gfirst, const uint32_t g, const uint32_t nr)
+{
+	const uint32_t sl = g << 6;
+	const uint32_t j0 = gfirst[g], j1 = gfirst[g + 1];
+	const uint2 q0 = rr[j0];
+	uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
+	const uint32_t b0 = q0.y + (sl - q0.x);
+	for (uint32_t i = j0 + 1; i <= j1 && i < nr; ++i) {
+		const uint2 qi = rr[i];
+		if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
+		const uint32_t oo = qi.x - sl, bb = qi.y - oo;
+		if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
+		++found;
+	}
+	GDesc d;
+	d.pk = o1 | (o2 << 8) | (o3 << 16) | (found > 3 ? 1u << 24 : 0u);
+	d.A = b0; d.d1 = b1 - b0; d.d2 = b2 - b1; d.d3 = b3 - b2;      // (absent runs: border 64, never reached)
+	return d;
+}
+// the descriptor lane `s` of this wave holds, in scalar registers; address of slot x (< 64) of that group
+#define GDESC_LANE(D, s, pk_, A_, d1_, d2_, d3_) \
+	const uint32_t pk_ = (uint32_t)__builtin_amdgcn_readlane((int)(D).pk, s), A_ = (uint32_t)__builtin_amdgcn_readlane((int)(D).A, s), d1_ = (uint32_t)__builtin_amdgcn_readlane((int)(D).d1, s), \
+	               d2_ = (uint32_t)__builtin_amdgcn_readlane((int)(D).d2, s), d3_ = (uint32_t)__builtin_amdgcn_readlane((int)(D).d3, s);
+__device__ __forceinline__ uint32_t gdesc_adr(const uint32_t pk, const uint32_t A, const uint32_t d1, const uint32_t d2, const uint32_t d3, const uint32_t x)
+{
+	return A + x + (x >= (pk & 0xFFu) ? d1 : 0u) + (x >= ((pk >> 8) & 0xFFu) ? d2 : 0u) + (x >= ((pk >> 16) & 0xFFu) ? d3 : 0u);
+}
+
 struct L1GTile { uint32_t out_off, count, hist_base, stride, d, tfr, slot0, pad; };    // tfr: index into tile_fr of the tile's first chunk; slot0: its first slot in the bucket
 struct L1GArgs {
 	const uint64_t *rec_in; uint64_t *rec_out;
@@ -685,25 +721,25 @@ constexpr int L1G_RUNS = 1536;       // runs of one chunk kept in LDS (uniform i
 template <int THREADS, int TCH>
 __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 {
-	constexpr int CHUNK = THREADS * MSD_ITEMS;
+	constexpr int CHUNK = THREADS * MSD_ITEMS, W = THREADS / 64;
 	constexpr int NG = CHUNK / 64;
 	__shared__ uint32_t cnt[MSD_MAXBINS];
 	__shared__ uint32_t binstart[MSD_MAXBINS];
 	__shared__ uint32_t tabst[TCH][MSD_MAXBINS];
-	__shared__ __attribute__((aligned(16))) uint64_t srec[CHUNK];
+	__shared__ __attribute__((aligned(16))) uint64_t srec[CHUNK + 2];
 	__shared__ uint32_t wsum[THREADS / 64];
 	__shared__ __attribute__((aligned(8))) uint2 rr[L1G_RUNS + 2];       // x = first slot of the run inside the chunk, y = index of its first record taken
 	__shared__ uint16_t gfirst[NG + 2];
-	__shared__ __attribute__((aligned(16))) uint4 gda[NG], gdb[NG];      // {o1, o2, o3, A} and {B - o1, C - o2, D - o3, more than four runs}
-	static_assert(THREADS >= MSD_MAXBINS && NG <= THREADS, "one bin / one group per thread");
-	const uint32_t tid = threadIdx.x, wave = tid >> 6;
+	__shared__ uint32_t any_w;
+	static_assert(THREADS >= MSD_MAXBINS && MSD_ITEMS <= 64, "one bin per thread; one descriptor per lane");
+	const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
 	const int bins = 1 << A.D;
 	const L1GTile tile = A.tiles[A.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x];
 	const uint32_t nchunks = (tile.count + CHUNK - 1) / CHUNK;       // <= TCH
 	const uint32_t *row0 = A.tab0 + (uint64_t)tile.d * A.nchunks0, *prow = A.pre0 + (uint64_t)tile.d * A.nchunks0;
 	uint64_t rec[MSD_ITEMS];
 	// the 16 records of a thread = slots s * THREADS + tid of chunk c of the tile (all loads back to back, clamped slot).  Barriers inside:
-	// every thread calls it.  The map (rr, gfirst, gda, gdb) is only needed until the loads are issued.
+	// every thread calls it.  The run list (rr, gfirst) is only needed until the loads are issued; the slot -> run map itself lives in registers (GDesc).
 	auto load_chunk = [&](const uint32_t c) {
 		const uint32_t cbase = c * CHUNK;
 		const uint32_t nv = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
@@ -711,7 +747,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 		const uint32_t fr = A.tile_fr[tile.tfr + c];
 		uint32_t fre = A.tile_fr[tile.tfr + c + 1]; if (fre >= A.nchunks0) fre = A.nchunks0 - 1;
 		const uint32_t nr = fre - fr + 1;
-		const uint32_t glast = (nv - 1) >> 6;
+		const uint32_t glast = (nv - 1) >> 6, xlast = (nv - 1) & 63u;
 		if (nr > (uint32_t)L1G_RUNS) {
 			// (skew: the bucket is rare, its chunk spans more level-0 chunks than the list holds) every lane searches the row's prefixes in HBM
 			#pragma unroll                                          // (a loop with a dynamic index would put rec[] into scratch memory)
@@ -724,7 +760,7 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 			}
 			return;
 		}
-		__syncthreads();                                              // (the map of the chunk before is no longer read)
+		__syncthreads();                                              // (the list of the chunk before is no longer read)
 		for (uint32_t j = tid; j < nr; j += THREADS) {
 			const uint32_t e = row0[fr + j], pre = prow[fr + j], len = e >> 16;
 			const uint32_t lo = pre > S0 ? pre - S0 : 0u, skip = S0 > pre ? S0 - pre : 0u;
@@ -732,42 +768,38 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 			rr[j] = make_uint2(lo < nv ? lo : nv, (A.cbase ? A.cbase[fr + j] : (fr + j) * A.chunk0) + (e & 0xFFFFu) + skip);
 			for (uint32_t g = (lo + 63) >> 6; (g << 6) < hi; ++g) gfirst[g] = (uint16_t)j;
 		}
-		if (tid == 0) { rr[nr] = make_uint2(nv, 0u); rr[nr + 1] = make_uint2(nv, 0u); gfirst[glast + 1] = (uint16_t)(nr - 1); }
+		if (tid == 0) { rr[nr] = make_uint2(nv, 0u); rr[nr + 1] = make_uint2(nv, 0u); gfirst[glast + 1] = (uint16_t)(nr - 1); any_w = 0u; }
 		__syncthreads();
-		if (tid <= glast) {
-			const uint32_t sl = tid << 6;
-			const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
-			const uint2 q0 = rr[j0];
-			uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
-			for (uint32_t i = j0 + 1; i <= j1 && i < nr; ++i) {
-				const uint2 qi = rr[i];
-				if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
-				const uint32_t oo = qi.x - sl, bb = qi.y - oo;
-				if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
-				++found;
-			}
-			gda[tid] = make_uint4(o1, o2, o3, q0.y + (sl - q0.x));
-			gdb[tid] = make_uint4(b1, b2, b3, found > 3 ? 1u : 0u);
+		GDesc D{0u, 0u, 0u, 0u, 0u};
+		{
+			const uint32_t g = lane * W + wave;                         // lane s holds the descriptor of this wave's item s
+			if (lane < (uint32_t)MSD_ITEMS && g <= glast) { D = gdesc_build(rr, gfirst, g, nr); if (D.pk >> 24) any_w = 1u; }
 		}
-		__syncthreads();
 		#pragma unroll
 		for (int s = 0; s < MSD_ITEMS; ++s) {
-			uint32_t e = s * THREADS + tid; e = e < nv ? e : nv - 1;
-			const uint32_t g = e >> 6, x = e & 63u;
-			const uint4 da = gda[g], db = gdb[g];
-			uint32_t adr = (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
-			if (db.w) {                                             // more than four runs in these 64 slots: search the list
-				uint32_t lo = gfirst[g], hi = nr;                   // largest j with rr[j].x <= e
+			GDESC_LANE(D, s, pk, A0, d1, d2, d3)
+			const uint32_t g = (uint32_t)s * W + wave;                  // (the same for the whole wave)
+			rec[s] = 0;
+			if (g <= glast) rec[s] = A.rec_in[gdesc_adr(pk, A0, d1, d2, d3, g == glast && lane > xlast ? xlast : lane)];
+		}
+		__syncthreads();
+		if (any_w) {
+			// groups that meet more than four runs (3e-4 of them on uniform text): their lanes search the list
+			#pragma unroll
+			for (int s = 0; s < MSD_ITEMS; ++s) {
+				if (((uint32_t)__builtin_amdgcn_readlane((int)D.pk, s) >> 24) == 0u) continue;
+				uint32_t e = s * THREADS + tid; e = e < nv ? e : nv - 1;
+				uint32_t lo = gfirst[e >> 6], hi = nr;                    // largest j with rr[j].x <= e
 				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rr[mid].x <= e) lo = mid; else hi = mid; }
-				adr = rr[lo].y + (e - rr[lo].x);
+				rec[s] = A.rec_in[rr[lo].y + (e - rr[lo].x)];
 			}
-			rec[s] = A.rec_in[adr];
 		}
 	};
 	load_chunk(0);
 	for (uint32_t c = 0; c < nchunks; ++c) {
 		const uint32_t cbase = c * CHUNK;
 		const uint32_t nvalid = tile.count - cbase < (uint32_t)CHUNK ? tile.count - cbase : (uint32_t)CHUNK;
+		const uint32_t oidx = tile.out_off + cbase, a = oidx & 1u;   // staging index = place + the parity of the output index: pairs of records are 16-byte aligned on both sides
 		for (int b = tid; b < bins; b += THREADS) cnt[b] = 0;
 		__syncthreads();
 		uint32_t dg[MSD_ITEMS]; uint32_t slot[MSD_ITEMS];
@@ -788,14 +820,194 @@ __global__ __launch_bounds__(THREADS) void k_l1_gather(L1GArgs A)
 		}
 		__syncthreads();
 		#pragma unroll
-		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) srec[binstart[dg[s]] + slot[s]] = rec[s];
+		for (int s = 0; s < MSD_ITEMS; ++s) if ((uint32_t)(s * THREADS) + tid < nvalid) srec[binstart[dg[s]] + slot[s] + a] = rec[s];
 		if (c + 1 < nchunks) load_chunk(c + 1);                       // issued before this chunk is copied out: read and write streams overlap
 		__syncthreads();
-		uint64_t *out = A.rec_out + (uint64_t)tile.out_off + cbase;
-		for (uint32_t p = tid; p < nvalid; p += THREADS) __builtin_nontemporal_store(srec[p], &out[p]);
+		uint64_t *o0 = A.rec_out + ((uint64_t)oidx - a);              // even index: element j of the staging array goes to o0[j], j in [a, a + nvalid)
+		for (uint32_t p = tid; 2 * p < a + nvalid; p += THREADS) {
+			const uint32_t j = 2 * p;
+			if (j >= a && j + 2 <= a + nvalid) {
+				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&srec[j]);
+				__builtin_nontemporal_store(v.x, &o0[j]); __builtin_nontemporal_store(v.y, &o0[j + 1]);
+			} else {
+				if (j >= a) __builtin_nontemporal_store(srec[j], &o0[j]);
+				if (j + 1 >= a && j + 1 < a + nvalid) __builtin_nontemporal_store(srec[j + 1], &o0[j + 1]);
+			}
+		}
 	}
 	__syncthreads();
 	for (int d = tid; d < bins; d += THREADS) {
+		uint32_t *row = A.runtab + (uint64_t)tile.hist_base + (uint64_t)d * tile.stride;
+		for (uint32_t c = 0; c < nchunks; ++c) row[c] = tabst[c][d];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same level 1 with TWO workgroups per CU (round 5).  k_l1_gather is one 1024-thread workgroup per CU (its 16 Ki records staged in 128 KB of
+// LDS): the chain load -> count -> scan -> place -> store of a chunk is what paces it, and nothing of one chunk overlaps anything of the next.  Two
+// smaller workgroups per CU overlap their chains (chunks of 8 Ki records: 11.3 -> 10.05 ms in round 3), but halving the chunk halves the runs the
+// finish gathers.  Here the chunk stays 16 Ki records and the STAGING shrinks instead: a 512-thread workgroup keeps its 32 records per thread in
+// registers, learns every record's place inside the sorted chunk from the counting sort (an arrival slot per record, 14 bits), and sends the chunk out
+// in PASSES of L1M_CAP places through a 64-KB staging array (which the run list of the gather shares: it is dead by then): pass k takes the records whose
+// place lies in [k CAP, (k + 1) CAP).  70 KB of LDS, at most 128 registers: two workgroups per CU; same input, same output, same run table as k_l1_gather.
+// ------------------------------------------------------------------------------------------------
+constexpr int L1M_THREADS = 512, L1M_ITEMS = L1_CHUNK / L1M_THREADS, L1M_CAP = 8192;
+static_assert(L1M_ITEMS * L1M_THREADS == L1_CHUNK && L1M_ITEMS % 2 == 0, "k_l1_gather_mp: the chunk is level 1's");
+
+// one chunk of k_l1_gather_mp.  FULL: all CHUNK slots hold records (every chunk of a bucket but its last): no per-item guards
+struct L1MShared {
+	uint32_t cnt[MSD_MAXBINS];                                            // arrival counters, then the first place of every digit
+	uint32_t wsum[L1M_THREADS / 64];
+	uint32_t any_w;                                                       // a 64-slot group of this chunk meets more than four runs
+	union {                                                               // the run list is dead once the records are requested; the staging array is first written two barriers later
+		struct { __attribute__((aligned(8))) uint2 rr[L1G_RUNS + 2]; uint16_t gfirst[L1_CHUNK / 64 + 2]; } map;
+		__attribute__((aligned(16))) uint64_t srec[L1M_CAP + 2];
+	} u;
+};
+template <bool FULL>
+__device__ __forceinline__ void l1m_chunk(const L1GArgs &A, const L1GTile &tile, const uint32_t c, L1MShared &S, uint32_t *tabst_c, const uint32_t *row0, const uint32_t *prow)
+{
+	constexpr int THREADS = L1M_THREADS, ITEMS = L1M_ITEMS, CHUNK = L1_CHUNK, CAP = L1M_CAP, W = THREADS / 64;
+	uint32_t tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));                                         // (opaque per chunk: the 32 slot numbers, group indices and LDS addresses derived from it were hoisted out of the chunk loop and spilled)
+	const uint32_t wave = tid >> 6, lane = tid & 63u;
+	const int bins = 1 << A.D;
+	const uint32_t cbase = c * CHUNK;
+	const uint32_t nv = FULL ? (uint32_t)CHUNK : tile.count - cbase;
+	const uint32_t glast = (nv - 1) >> 6, xlast = (nv - 1) & 63u;
+	uint64_t rec[ITEMS];
+	// ---- the chunk's records: slots s * THREADS + tid, through the slot -> run map ----
+	{
+		const uint32_t S0 = tile.slot0 + cbase;
+		const uint32_t fr = A.tile_fr[tile.tfr + c];
+		uint32_t fre = A.tile_fr[tile.tfr + c + 1]; if (fre >= A.nchunks0) fre = A.nchunks0 - 1;
+		const uint32_t nr = fre - fr + 1;
+		if (nr > (uint32_t)L1G_RUNS) {
+			// (skew: the bucket is rare, its chunk spans more level-0 chunks than the list holds) every lane searches the row's prefixes in HBM
+			#pragma unroll
+			for (int s = 0; s < ITEMS; ++s) {
+				uint32_t e = s * THREADS + tid; if (!FULL) e = e < nv ? e : nv - 1;
+				const uint32_t slot = S0 + e;
+				uint32_t lo = fr, hi = fre + 1;                           // largest i in [fr, fre] with prow[i] <= slot
+				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prow[mid] <= slot) lo = mid; else hi = mid; }
+				rec[s] = A.rec_in[(A.cbase ? (uint64_t)A.cbase[lo] : (uint64_t)lo * A.chunk0) + (row0[lo] & 0xFFFFu) + (slot - prow[lo])];
+			}
+			for (int b = tid; b < bins; b += THREADS) S.cnt[b] = 0;
+		} else {
+			for (uint32_t j = tid; j < nr; j += THREADS) {
+				const uint32_t e = row0[fr + j], pre = prow[fr + j], len = e >> 16;
+				const uint32_t lo = pre > S0 ? pre - S0 : 0u, skip = S0 > pre ? S0 - pre : 0u;
+				uint32_t hi = pre + len > S0 ? pre + len - S0 : 0u; hi = hi < nv ? hi : nv;
+				S.u.map.rr[j] = make_uint2(lo < nv ? lo : nv, (A.cbase ? A.cbase[fr + j] : (fr + j) * A.chunk0) + (e & 0xFFFFu) + skip);
+				for (uint32_t g = (lo + 63) >> 6; (g << 6) < hi; ++g) S.u.map.gfirst[g] = (uint16_t)j;
+			}
+			if (tid == 0) { S.u.map.rr[nr] = make_uint2(nv, 0u); S.u.map.rr[nr + 1] = make_uint2(nv, 0u); S.u.map.gfirst[glast + 1] = (uint16_t)(nr - 1); S.any_w = 0u; }
+			for (int b = tid; b < bins; b += THREADS) S.cnt[b] = 0;
+			__syncthreads();
+			GDesc D{0u, 0u, 0u, 0u, 0u};
+			{
+				const uint32_t g = lane * W + wave;                         // lane s holds the descriptor of this wave's item s
+				if (lane < (uint32_t)ITEMS && g <= glast) { D = gdesc_build(S.u.map.rr, S.u.map.gfirst, g, nr); if (D.pk >> 24) S.any_w = 1u; }
+			}
+			#pragma unroll
+			for (int s = 0; s < ITEMS; ++s) {
+				GDESC_LANE(D, s, pk, A0, d1, d2, d3)
+				if (FULL) rec[s] = A.rec_in[gdesc_adr(pk, A0, d1, d2, d3, lane)];
+				else {
+					const uint32_t g = (uint32_t)s * W + wave;              // (the same for the whole wave: a group behind the chunk's last record is skipped by all its lanes)
+					rec[s] = 0;
+					if (g <= glast) rec[s] = A.rec_in[gdesc_adr(pk, A0, d1, d2, d3, g == glast && lane > xlast ? xlast : lane)];
+				}
+			}
+			__syncthreads();                                              // (any_w is set; the list stays in place until the barrier behind the loads)
+			if (S.any_w) {
+				// groups that meet more than four runs (3e-4 of them on uniform text): their lanes search the list
+				#pragma unroll
+				for (int s = 0; s < ITEMS; ++s) {
+					if (((uint32_t)__builtin_amdgcn_readlane((int)D.pk, s) >> 24) == 0u) continue;
+					uint32_t e = s * THREADS + tid; if (!FULL) e = e < nv ? e : nv - 1;
+					uint32_t lo = S.u.map.gfirst[e >> 6], hi = nr;                // largest j with rr[j].x <= e
+					while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (S.u.map.rr[mid].x <= e) lo = mid; else hi = mid; }
+					rec[s] = A.rec_in[S.u.map.rr[lo].y + (e - S.u.map.rr[lo].x)];
+				}
+			}
+		}
+	}
+	__syncthreads();                                                      // (the counters are zero; the staging array of the chunk before has left; the run list is dead)
+	// ---- count: arrival slot of every record inside its digit (two per register) ----
+	uint32_t place[ITEMS / 2];
+	#pragma unroll
+	for (int s = 0; s < ITEMS; s += 2) {
+		uint32_t p0 = 0u, p1 = 0u;
+		if (FULL || (uint32_t)(s * THREADS) + tid < nv) p0 = atomicAdd(&S.cnt[(uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1)], 1u);
+		if (FULL || (uint32_t)((s + 1) * THREADS) + tid < nv) p1 = atomicAdd(&S.cnt[(uint32_t)(rec[s + 1] >> A.shift) & (uint32_t)(bins - 1)], 1u);
+		place[s >> 1] = p0 | (p1 << 16);
+	}
+	__syncthreads();
+	{
+		const uint32_t v = (int)tid < bins ? S.cnt[tid] : 0u;
+		const uint32_t inc = wave_incl_sum(v);
+		if ((tid & 63u) == 63u) S.wsum[wave] = inc;
+		__syncthreads();
+		uint32_t pre = 0;
+		for (uint32_t i = 0; i < wave; ++i) pre += S.wsum[i];
+		if ((int)tid < bins) { S.cnt[tid] = pre + inc - v; tabst_c[tid] = (pre + inc - v) | (v << 16); }
+	}
+	__syncthreads();
+	// ---- every record's place inside the sorted chunk = first place of its digit + arrival slot (0xFFFF: no record) ----
+	// (the counters' addresses are computed again, not kept from the count phase: 32 registers held across the scan were 22 records spilled)
+	#pragma unroll
+	for (int s = 0; s < ITEMS; ++s) { uint32_t h = (uint32_t)(rec[s] >> 32); asm volatile("" : "+v"(h)); rec[s] = (rec[s] & 0xFFFFFFFFull) | ((uint64_t)h << 32); }
+	#pragma unroll
+	for (int s = 0; s < ITEMS; s += 2) {
+		uint32_t p0 = (place[s >> 1] & 0xFFFFu) + S.cnt[(uint32_t)(rec[s] >> A.shift) & (uint32_t)(bins - 1)];
+		uint32_t p1 = (place[s >> 1] >> 16) + S.cnt[(uint32_t)(rec[s + 1] >> A.shift) & (uint32_t)(bins - 1)];
+		if (!FULL) { if ((uint32_t)(s * THREADS) + tid >= nv) p0 = 0xFFFFu; if ((uint32_t)((s + 1) * THREADS) + tid >= nv) p1 = 0xFFFFu; }
+		place[s >> 1] = p0 | (p1 << 16);
+	}
+	// ---- the chunk leaves in passes of CAP places; staging index = place + the parity of the output index, so that pairs of records are 16-byte aligned on both sides ----
+	for (uint32_t k0 = 0; k0 < nv; k0 += CAP) {
+		if (k0) __syncthreads();                                          // (the pass before has been read out of the staging array)
+		const uint32_t oidx = tile.out_off + cbase + k0, a = oidx & 1u;
+		#pragma unroll
+		for (int s = 0; s < ITEMS; s += 2) {
+			const uint32_t q0 = (place[s >> 1] & 0xFFFFu) - k0, q1 = (place[s >> 1] >> 16) - k0;      // (no record: 0xFFFF - k0 >= CAP)
+			if (q0 < (uint32_t)CAP) S.u.srec[q0 + a] = rec[s];
+			if (q1 < (uint32_t)CAP) S.u.srec[q1 + a] = rec[s + 1];
+		}
+		__syncthreads();
+		const uint32_t nk = nv - k0 < (uint32_t)CAP ? nv - k0 : (uint32_t)CAP;
+		uint64_t *o0 = A.rec_out + ((uint64_t)oidx - a);                  // even index: 16-byte aligned; element j of the staging array goes to o0[j], j in [a, a + nk)
+		for (uint32_t p = tid; 2 * p < a + nk; p += THREADS) {
+			const uint32_t j = 2 * p;
+			if (j >= a && j + 2 <= a + nk) {
+				const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&S.u.srec[j]);
+				__builtin_nontemporal_store(v.x, &o0[j]); __builtin_nontemporal_store(v.y, &o0[j + 1]);
+			} else {
+				if (j >= a) __builtin_nontemporal_store(S.u.srec[j], &o0[j]);
+				if (j + 1 >= a && j + 1 < a + nk) __builtin_nontemporal_store(S.u.srec[j + 1], &o0[j + 1]);
+			}
+		}
+	}
+}
+
+template <int TCH>
+__global__ __launch_bounds__(L1M_THREADS, 4) void k_l1_gather_mp(L1GArgs A)
+{
+	__shared__ L1MShared S;
+	__shared__ uint32_t tabst[TCH][MSD_MAXBINS];
+	static_assert(L1M_THREADS >= MSD_MAXBINS && L1_CHUNK / 64 <= L1M_THREADS && 0xFFFF - (L1_CHUNK - 1) >= L1M_CAP, "one bin / one group per thread; the 'no record' place is in no pass");
+	const uint32_t tid = threadIdx.x;
+	const int bins = 1 << A.D;
+	const L1GTile tile = A.tiles[A.xcd ? xcd_order(blockIdx.x, gridDim.x) : blockIdx.x];
+	const uint32_t nchunks = (tile.count + L1_CHUNK - 1) / L1_CHUNK;       // <= TCH
+	const uint32_t *row0 = A.tab0 + (uint64_t)tile.d * A.nchunks0, *prow = A.pre0 + (uint64_t)tile.d * A.nchunks0;
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		if (tile.count - c * L1_CHUNK >= (uint32_t)L1_CHUNK) l1m_chunk<true>(A, tile, c, S, tabst[c], row0, prow);
+		else l1m_chunk<false>(A, tile, c, S, tabst[c], row0, prow);
+	}
+	__syncthreads();
+	for (int d = tid; d < bins; d += L1M_THREADS) {
 		uint32_t *row = A.runtab + (uint64_t)tile.hist_base + (uint64_t)d * tile.stride;
 		for (uint32_t c = 0; c < nchunks; ++c) row[c] = tabst[c][d];
 	}
@@ -1671,56 +1883,48 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	}
 	if (WPC == 2 && fbits < 0) lds_pad[tid] = 0;                 // (never: keeps the padding array alive)
 	const uint32_t apad = (uint32_t)((reinterpret_cast<uintptr_t>(O.bwt) + s0) & 3u);
-	// ---- slots -> runs (see finish_bucket) ----
-	const uint32_t glast = (m - 1) >> 6;
+	// ---- slots -> runs (see finish_bucket).  The map a thread needs for its OWN records lives in registers (GDesc: lane k of a wave builds the descriptor of the
+	// 64-slot group of the wave's item k, every lane fetches it with v_readlane): the records are requested before the barrier that publishes the LDS copy of the
+	// map, which only the rare re-fetches use (tied records, dense samples) ----
+	const uint32_t glast = (m - 1) >> 6, xlast = (m - 1) & 63u;
+	GDesc D{64u | (64u << 8) | (64u << 16), 0u, 0u, 0u, 0u};
 	if (NOMAP) {
 		if (tid <= glast) { gda[tid] = make_uint4(64u, 64u, 64u, s0 + (tid << 6)); gdb[tid] = make_uint4(0u, 0u, 0u, 0u); }
+		{ const uint32_t g = lane * F_WAVES + wave; D.A = s0 + ((g < glast ? g : glast) << 6); }
 		if (tid == 0) { s_slow = 0u; s_tl = 0u; s_sp = 0u; s_bl = 0u; }
 		#pragma unroll
 		for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
 		if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }
 		if (tid < 12) ent[apad + m + tid] = 0u;
-		__syncthreads();
 	} else {
-	{
-		const uint32_t *row = S.runpre + tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
-		const uint32_t tc = tid < nch ? tid : nch - 1, tn = tc + 1 < nch ? tc + 1 : tc;
-		const uint32_t v = row[tc], vn = tid + 1 < nch ? row[tn] : (m << 14);
-		const uint32_t pre = v >> 14, end = vn >> 14;
-		if (tid < nch) {
-			rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
-			for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
+		{
+			const uint32_t *row = S.runpre + tab_off + (uint64_t)(b & ((1u << S.D1) - 1u)) * nch;
+			const uint32_t tc = tid < nch ? tid : nch - 1, tn = tc + 1 < nch ? tc + 1 : tc;
+			const uint32_t v = row[tc], vn = tid + 1 < nch ? row[tn] : (m << 14);
+			const uint32_t pre = v >> 14, end = vn >> 14;
+			if (tid < nch) {
+				rr[tid] = make_uint2(pre, bstart0 + tid * S.chunk + (v & 0x3FFFu));
+				for (uint32_t g = (pre + 63) >> 6; (g << 6) < end; ++g) gfirst[g] = (uint16_t)tid;
+			}
+			if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; s_tl = 0u; s_sp = 0u; s_bl = 0u; }
+			#pragma unroll
+			for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
+			if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }      // the places in front of the bucket's first and behind its last entry: no symbol, not special
+			if (tid < 12) ent[apad + m + tid] = 0u;
 		}
-		if (tid == 0) { rr[nch] = make_uint2(m, 0u); gfirst[glast + 1] = (uint16_t)(nch - 1); s_slow = 0u; s_tl = 0u; s_sp = 0u; s_bl = 0u; }
-		#pragma unroll
-		for (int k = 0; k < (F_BINS / 2) / F_THREADS; ++k) tabw[k * F_THREADS + tid] = 0;
-		if (tid < 4) { ent[tid] = 0u; tabw[F_BINS / 2 + tid] = 0u; }      // the places in front of the bucket's first and behind its last entry: no symbol, not special
-		if (tid < 12) ent[apad + m + tid] = 0u;
-	}
-	__syncthreads();
-	if (tid <= glast) {
-		const uint32_t sl = tid << 6;
-		const uint32_t j0 = gfirst[tid], j1 = gfirst[tid + 1];
-		const uint2 q0 = rr[j0];
-		uint32_t o1 = 64u, o2 = 64u, o3 = 64u, b1 = 0u, b2 = 0u, b3 = 0u, found = 0;
-		for (uint32_t i = j0 + 1; i <= j1 && i < nch; ++i) {
-			const uint2 qi = rr[i];
-			if (rr[i + 1].x == qi.x || qi.x >= sl + 64u) continue;
-			const uint32_t oo = qi.x - sl, bb = qi.y - oo;
-			if (found == 0) { o1 = oo; b1 = bb; } else if (found == 1) { o2 = oo; b2 = bb; } else if (found == 2) { o3 = oo; b3 = bb; }
-			++found;
+		__syncthreads();
+		if (lane < (uint32_t)F_PER) {
+			const uint32_t g = lane * F_WAVES + wave;                   // (a group behind the bucket's last one: its lanes fetch the last record again)
+			D = gdesc_build(rr, gfirst, g < glast ? g : glast, nch);
+			if (D.pk >> 24) s_slow = 1u;                                // more than four runs in 64 slots: the bucket is listed
+			if (g <= glast) {
+				const uint32_t b1 = D.A + D.d1, b2 = b1 + D.d2, b3 = b2 + D.d3;
+				gda[g] = make_uint4(D.pk & 0xFFu, (D.pk >> 8) & 0xFFu, (D.pk >> 16) & 0xFFu, D.A);
+				gdb[g] = make_uint4(b1, b2, b3, 0u);
+			}
 		}
-		if (found > 3) s_slow = 1u;
-		gda[tid] = make_uint4(o1, o2, o3, q0.y + (sl - q0.x));
-		gdb[tid] = make_uint4(b1, b2, b3, 0u);
 	}
-	__syncthreads();
-	if (s_slow) {
-		if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
-		return;
-	}
-	}
-	// the record of index e of the bucket (slot e of its rank range before sorting), through the slot -> run map
+	// the record of index e of the bucket (slot e of its rank range before sorting), through the LDS copy of the slot -> run map
 	auto rec_adr = [&](const uint32_t e) -> uint32_t {
 		const uint32_t g = e >> 6, x = e & 63u;
 		const uint4 da = gda[g], db = gdb[g];
@@ -1732,18 +1936,18 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 2 * WPC : 8) void k_finis
 	uint32_t ev[F_PER], bs[F_PER];
 	{
 		uint64_t r[F_PER];
-		uint32_t adr[F_PER];
 		#pragma unroll
 		for (int k = 0; k < F_PER; ++k) {
-			const uint32_t eu = k * F_THREADS + tid;
-			const uint32_t e = eu < m ? eu : m - 1;
-			uint32_t g = (uint32_t)(k * F_WAVES) + wave; g = g < glast ? g : glast;
-			const uint4 da = gda[g], db = gdb[g];
-			const uint32_t x = e - (g << 6);
-			adr[k] = (x >= da.z ? db.z : x >= da.y ? db.y : x >= da.x ? db.x : da.w) + x;
+			GDESC_LANE(D, k, pk, A0, d1, d2, d3)
+			const uint32_t g = (uint32_t)(k * F_WAVES) + wave;       // (the same for the whole wave)
+			const uint32_t x = g > glast || (g == glast && lane > xlast) ? xlast : lane;
+			r[k] = S.rec[(pk >> 24) ? A0 : gdesc_adr(pk, A0, d1, d2, d3, x)];
 		}
-		#pragma unroll
-		for (int k = 0; k < F_PER; ++k) r[k] = S.rec[adr[k]];
+		__syncthreads();                                             // (the loads are in flight; s_slow and the LDS copy of the map are published)
+		if (s_slow) {
+			if (tid == 0) { const FinishLists L = *Lp; uint32_t k = atomicAdd(&L.midlist[0], 1u); if (k < L.mid_cap) L.midlist[1 + k] = b; }
+			return;
+		}
 		const int lowbits = fbits - F_BINBITS;                   // <= 12
 		const int hks = rec_key_shift(O.pb) - 32, hps = O.pb - 32;
 		const int bsh = hks + lowbits;
@@ -2709,7 +2913,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			Gq.cbase = shard1 ? M.cbase0 : nullptr; Gq.xcd = l1_order ? 1u : 0u;
 			ntB = (uint32_t)gtiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-			hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
+			if (sw().L1_MP.get(1)) hipLaunchKernelGGL((k_l1_gather_mp<L1_TCH>), dim3(ntB), dim3(L1M_THREADS), 0, s, Gq);
+			else hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
 			stage("level 1 (gather)");
 		} else {
 			B3M_HIP(hipMemcpyAsync(M.tiles, tiles.data(), sizeof(MsdTile) * tiles.size(), hipMemcpyHostToDevice, s));

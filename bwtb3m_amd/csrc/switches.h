@@ -55,7 +55,8 @@ struct Sw {
 	X(WALK_ONE_LANE,    "measurement: 1 = the gap walk with one lane per chain")                                                        \
 	X(RL_SEG,           "test: segment length of the device RL encoder (default 2^31 symbols)")                                         \
 	X(HOST_RL,          "measurement: present = the RL container is coded on the host")                                                 \
-	X(FILE_MMAP,        "measurement: 1 = output files through a shared mapping instead of pwrite")
+	X(FILE_MMAP,        "measurement: 1 = output files through a shared mapping instead of pwrite")                                     \
+	X(L1_MP,            "measurement: 0 = level 1's gather as one 1024-thread workgroup per CU (k_l1_gather, the form before round 5)")
 
 struct Switches {
 #define B3M_SW_FIELD(name, doc) Sw name;
