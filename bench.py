@@ -232,7 +232,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
+    # (WORLD_SIZE=1 with B3M_BENCH_BACKEND set explicitly: the N > 1 code path with a process group of ONE rank -- every collective of the exchange mode runs,
+    # through RCCL on a one-GPU box; a plain `python bench.py` or a launcher's WORLD_SIZE=1 alone is the one-GPU line)
+    if a.gpus > 1 or world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("B3M_BENCH_BACKEND")):
         from bwtb3m_amd import distributed
         return distributed.bench_main(a, rank, local_rank, world)
 

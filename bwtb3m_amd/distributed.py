@@ -3,8 +3,9 @@ over xGMI on the GPU box, "gloo" in the CPU tests).  SURVEY.md 8(e).
 
 Partitioning (strong scaling: the input is fixed, the work is split):
   * the packed text is replicated on every GPU (0.75 GB at 3 Gbase);
-  * rank k sorts leaf block k (no communication);
-  * a merge (L, R) is executed by ALL ranks of both sides together:
+  * the text is cut into B >= P leaf blocks; rank g sorts blocks g, g + P, ... (SURVEY.md 8(e); no communication);
+  * a merge (L, R) is executed by ALL ranks that own a block of either side together (with B > P a rank may hold a slice of BOTH sides,
+    and with P = 1 the group is one rank: every collective below still runs, on device tensors, through the process group's backend):
       - BWT(L) is broadcast inside the group (every walker needs the rank dictionary),
       - R's text positions are cut into one chain range per rank; each rank walks its range
         (b3m_gap_chains) and gets the ranks in L of those suffixes of R,
@@ -41,31 +42,40 @@ def chains_for(mr, world_hint=1):
 
 
 class Node:
-    def __init__(self, a, m, ranks):
-        self.a, self.m, self.ranks = a, m, list(ranks)
+    """a node of the merge tree: text range [a, a + m), its leaf blocks, the ranks that own one of them (ascending: a node's BWT is the
+    concatenation of its members' slices in this order), and its HOLDER -- the owner of its first leaf -- which keeps the node's gt bits"""
+
+    def __init__(self, a, m, leaves, world):
+        self.a, self.m, self.leaves = a, m, list(leaves)
+        self.ranks = sorted({k % world for k in self.leaves})
+        self.holder = self.leaves[0] % world
+        self.key = self.leaves[0]
 
 
 class Merge:
-    def __init__(self, L, R, idx):
+    def __init__(self, L, R, idx, world):
         self.L, self.R, self.idx = L, R, idx
-        self.group = L.ranks + R.ranks
+        self.group = sorted(set(L.ranks) | set(R.ranks))
+        self.parent = Node(L.a, L.m + R.m, L.leaves + R.leaves, world)
         self.chain_len, self.num_chains = chains_for(R.m, len(self.group))
         self.anchor_off = 0
 
 
 class TreePlan:
-    """balanced binary merge tree over one leaf per rank"""
+    """balanced binary merge tree over `leaves` >= world leaf blocks; leaf k belongs to rank k % world: "GPU g sorts blocks g, g + P, ..."
+    (SURVEY.md 8(e), 3.1 steps 3, 5).  Default: one leaf per rank."""
 
-    def __init__(self, n, world):
-        assert 1 <= world <= n
-        bs = (n + world - 1) // world
-        self.n, self.world, self.bs = n, world, bs
+    def __init__(self, n, world, leaves=None):
+        B = world if leaves is None else int(leaves)
+        assert 1 <= world <= B <= n, "need world <= leaves <= n"
+        bs = (n + B - 1) // B
+        self.n, self.world, self.bs, self.B = n, world, bs, B
         self.leaves = []
-        for k in range(world):
+        for k in range(B):
             a = k * bs
             m = min(bs, n - a)
-            assert m >= 1, "more ranks than symbols"
-            self.leaves.append(Node(a, m, [k]))
+            assert m >= 1, "more leaf blocks than symbols"
+            self.leaves.append(Node(a, m, [k], world))
         self.levels = []
         self.merges = []
         cur = self.leaves
@@ -73,24 +83,28 @@ class TreePlan:
         while len(cur) > 1:
             nxt, lv = [], []
             for i in range(0, len(cur) - 1, 2):
-                mg = Merge(cur[i], cur[i + 1], len(self.merges))
+                mg = Merge(cur[i], cur[i + 1], len(self.merges), world)
                 mg.anchor_off = off
                 off += mg.num_chains
                 self.merges.append(mg)
                 lv.append(mg)
-                nxt.append(Node(mg.L.a, mg.L.m + mg.R.m, mg.group))
+                nxt.append(mg.parent)
             if len(cur) & 1:
                 nxt.append(cur[-1])
             self.levels.append(lv)
             cur = nxt
+        self.root = cur[0]
         self.total_anchors = off
 
     def anchor_positions(self, mg):
         rend = mg.R.a + mg.R.m
         return (rend - np.arange(mg.num_chains, dtype=np.int64) * mg.chain_len) % self.n
 
+    def leaves_of(self, rank):
+        return [k for k in range(self.B) if k % self.world == rank]
+
     def merges_with_leaf_on_left(self, k):
-        return [mg for mg in self.merges if k in mg.L.ranks]
+        return [mg for mg in self.merges if k in mg.L.leaves]
 
 
 def split_even(total, parts):
@@ -340,22 +354,45 @@ def _replace_bits_seg(dst, seg, seg_w0, b, e):
 # ---------------------------------------------------------------------------------------------------
 # the distributed hot path
 # ---------------------------------------------------------------------------------------------------
+def _exchange_words(send_parts, recv_counts, group):
+    """one all-to-all(v) of int32 word segments: send_parts[j] goes to member j (empty tensors allowed); -> list of the segments received,
+    recv_counts[j] words from member j (every member can compute both sides from the plan)"""
+    send = torch.cat(send_parts) if any(t.numel() for t in send_parts) else send_parts[0][:0]
+    got = _PendingA2A(send.contiguous(), [t.numel() for t in send_parts], recv_counts, group).result()
+    out, o = [], 0
+    for c in recv_counts:
+        out.append(got[o:o + int(c)])
+        o += int(c)
+    return out
+
+
 class DistributedBwt:
-    """construct the BWT of a replicated packed text on dist.get_world_size() GPUs by balanced block merging.
+    """construct the BWT of a replicated packed text on dist.get_world_size() GPUs by balanced block merging over `leaves` >= world leaf
+    blocks (rank g sorts blocks g, g + P, ...).
 
     run() returns this rank's contiguous slice of the BWT, its offset, and p0 (rank of the rotation starting at 0).  Groups are
-    created once (new_group is collective over ALL ranks); the backend's workspace is allocated once, in __init__."""
+    created once (new_group is collective over ALL ranks; one per distinct rank set); the backend's workspace is allocated once, in __init__.
 
-    def __init__(self, n, itype, backend, device):
+    gt bits: the HOLDER of a node (the owner of its first leaf) keeps the node's bits.  In a merge the holder of R sends every walker the
+    words of its own chain range (one all-to-all(v): |R| / 8 bytes in all, not |L| / 8 + |R| / 8 to every member), the walkers send the
+    new bits of their ranges to the holder of the parent (= the holder of L, whose bits stay where they are)."""
+
+    def __init__(self, n, itype, backend, device, leaves=None):
         self.n, self.itype, self.be, self.device = n, itype, backend, torch.device(device)
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
-        self.plan = TreePlan(n, self.world)
-        self.groups = {}
+        self.plan = TreePlan(n, self.world, leaves)
+        self.groups, by_set = {}, {}
         for mg in self.plan.merges:          # same order on every rank
-            self.groups[mg.idx] = dist.new_group(ranks=mg.group)
+            key = tuple(mg.group)
+            if key not in by_set:
+                by_set[key] = dist.new_group(ranks=mg.group)
+            self.groups[mg.idx] = by_set[key]
+        self._group_sets = by_set
         mine = [mg for mg in self.plan.merges if self.rank in mg.group]
-        self.be.setup(n, itype, self.plan.leaves[self.rank].m, max([mg.L.m for mg in mine] + [1]), max([mg.R.m for mg in mine] + [1]))
+        my_leaves = self.plan.leaves_of(self.rank)
+        assert my_leaves, "every rank owns a leaf block"
+        self.be.setup(n, itype, max(self.plan.leaves[k].m for k in my_leaves), max([mg.L.m for mg in mine] + [1]), max([mg.R.m for mg in mine] + [1]))
         self.timing = {}
         self.sync_phases = False           # a device synchronisation at every phase border: the phase split of ONE extra step of the bench, never the timed steps
 
@@ -363,20 +400,20 @@ class DistributedBwt:
         """first use of every group this rank belongs to (RCCL creates a communicator on a group's first collective): a tiny all-reduce each, in the
         same order on every rank, so that the timed steps and their watchdog see collectives, not communicator setup"""
         dev = "cpu" if dist.get_backend() == "gloo" else self.device
-        for mg in self.plan.merges:
-            if self.rank in mg.group:
+        for key, grp in self._group_sets.items():
+            if self.rank in key:
                 t = torch.ones(1, dtype=torch.int64, device=dev)
-                dist.all_reduce(t, group=self.groups[mg.idx])
-                assert int(t[0]) == len(mg.group)
+                dist.all_reduce(t, group=grp)
+                assert int(t[0]) == len(key)
 
     def _now(self):
         if self.sync_phases and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         return time.perf_counter()
 
-    def _symstart(self, ranks):
+    def _symstart(self, leaves):
         """C array of a node's text: symbols smaller than code c (pacterm: code c = symbol c + 1, the terminator is smaller than every base)"""
-        h = self.leaf_hist[ranks].sum(axis=0)
+        h = self.leaf_hist[leaves].sum(axis=0)
         if self.itype == "bytestream":
             return [int(x) for x in np.concatenate([[0], np.cumsum(h[:255])])]
         if self.itype == "pacterm":
@@ -387,89 +424,120 @@ class DistributedBwt:
         n, be, plan, me = self.n, self.be, self.plan, self.rank
         dev = self.device
         tm = self.timing = {"leaf": 0.0, "anchors": 0.0, "gather": 0.0, "dict": 0.0, "walk": 0.0, "all_to_all": 0.0, "sort": 0.0, "interleave": 0.0}
-        t0 = self._now()
-        leaf = plan.leaves[me]
         be.set_text(d_text)
-        my_bwt, gt_cur, p0, h5 = be.leaf(leaf.a, leaf.m)
-        node_p0 = {me: p0}
-        # ---- anchors (z-ranks) of every merge: partial ranks in my leaf, summed over ranks; leaf histograms for the C arrays -----
-        t1 = self._now()
-        tm["leaf"] += t1 - t0
+        # ---- my leaf blocks g, g + P, ...: sort, the anchors (z-ranks) of every merge the leaf is on the left of, histogram ----
         # (the ranks never visit the host: partial ranks are added on the device, summed over the ranks by one all-reduce, and the walks read them there)
         anchors = torch.zeros(max(1, plan.total_anchors), dtype=torch.int64, device=dev)
-        for mg in plan.merges_with_leaf_on_left(me):
-            be.rank_of_into(plan.anchor_positions(mg), anchors[mg.anchor_off:mg.anchor_off + mg.num_chains])
-        if self.world > 1:
-            _all_reduce_sum(anchors)
-        self.leaf_hist = _all_gather_i64(h5, None, dev) if self.world > 1 else np.array([h5], dtype=np.int64)
+        slices, node_p0, hists = {}, {}, []       # node key -> (my slice of its BWT, offset of the slice inside the node's BWT)
+        gt_cur = None
+        for k in plan.leaves_of(me):
+            t0 = self._now()
+            leaf = plan.leaves[k]
+            bw, gt_leaf, p0, h5 = be.leaf(leaf.a, leaf.m)
+            if gt_cur is None:
+                gt_cur = gt_leaf                  # absolute-position bit array: this rank's leaves and the nodes it holds occupy disjoint ranges of it
+            else:
+                be.bits_replace(gt_cur, gt_leaf, 0, leaf.a + 1, leaf.a + leaf.m + 1)
+            slices[leaf.key] = (bw, 0)
+            node_p0[leaf.key] = p0
+            hists.append([k] + [int(x) for x in h5])
+            t1 = self._now()
+            tm["leaf"] += t1 - t0
+            for mg in plan.merges_with_leaf_on_left(k):
+                be.rank_of_into(plan.anchor_positions(mg), anchors[mg.anchor_off:mg.anchor_off + mg.num_chains])
+            tm["anchors"] += self._now() - t1
+        t1 = self._now()
+        _all_reduce_sum(anchors)
+        per = (plan.B + self.world - 1) // self.world
+        width = len(hists[0])
+        table = np.full((per, width), -1, dtype=np.int64)
+        table[:len(hists)] = np.array(hists, dtype=np.int64)
+        allh = _all_gather_i64(table.reshape(-1).tolist(), None, dev).reshape(-1, width)
+        self.leaf_hist = np.zeros((plan.B, width - 1), dtype=np.int64)
+        for row in allh:
+            if row[0] >= 0:
+                self.leaf_hist[int(row[0])] = row[1:]
         tm["anchors"] += self._now() - t1
-        # ---- merge levels ----------------------------------------------------------------------------------
-        my_off = 0                  # offset of my slice inside my current node's BWT
-        my_node = leaf              # node I currently belong to
-        for lv in plan.levels:
-            mine = [mg for mg in lv if me in mg.group]
-            if not mine:
-                continue
-            mg = mine[0]
-            my_bwt, my_off, gt_cur, p0P = self._merge(mg, my_bwt, my_off, gt_cur, node_p0[my_node.ranks[0]], anchors, tm)
-            my_node = Node(mg.L.a, mg.L.m + mg.R.m, mg.group)
-            node_p0[my_node.ranks[0]] = p0P
-        return my_bwt, my_off, node_p0[my_node.ranks[0]]
+        # ---- merges, level by level, in the same order on every rank -----------------------------------------
+        for mg in plan.merges:
+            if me in mg.group:
+                gt_cur = self._merge(mg, slices, node_p0, gt_cur, anchors, tm)
+        out, off = slices[plan.root.key]
+        return out, off, node_p0[plan.root.key]
 
-    def _merge(self, mg, my_bwt, my_off, gt_cur, my_node_p0, anchors, tm):
-        """one merge of the tree, this rank's part.  What the host sees of it: slice sizes and the split sizes of the all-to-all (and the
+    def _merge(self, mg, slices, node_p0, gt_cur, anchors, tm):
+        """one merge of the tree, this rank's part.  What the host sees of it: slice sizes and the split sizes of the all-to-alls (and the
         new p0 at the end); anchors, gt bits, ranks and symbols stay on the device.  Collectives per merge: one small all-gather (slice
-        sizes, p0), ONE all-gather of the packed slices of both sides, two broadcasts + one all-reduce of gt words, one small all-gather
-        of the bucket sizes per tile, one all-to-all(v) of the gap buckets per tile, one small all-gather (new p0, offsets)."""
+        sizes, p0), ONE all-gather of the packed slices of both sides, one all-to-all(v) of gt words (R's holder -> the walkers' chain ranges),
+        one small all-gather of the bucket sizes per tile, one all-to-all(v) of the gap buckets per tile, one all-to-all(v) of gt words (walkers ->
+        the parent's holder), one small all-gather (new p0, offsets)."""
         n, be, me, dev = self.n, self.be, self.rank, self.device
         grp = self.groups[mg.idx]
         members = mg.group
         gs = len(members)
         gi = members.index(me)
-        nL = len(mg.L.ranks)
         a, m, mr = mg.L.a, mg.L.m, mg.R.m
         rbeg, rend = a + m, a + m + mr
         t0 = self._now()
-        # 1. slice sizes and the node p0 of both sides (the symbol of L's p0 entry, which the packed form cannot carry, is the text symbol
-        #    in front of L: the library reads it there)
-        sz = my_bwt.numel()
-        info = _all_gather_i64([sz, my_node_p0], grp, dev)
-        sizes = info[:, 0]
-        p0L = int(info[0, 1])
-        assert int(sizes[:nL].sum()) == m and int(sizes[nL:].sum()) == mr, "slice tables inconsistent"
+        # 1. slice sizes of both sides and L's p0 (the symbol of L's p0 entry, which the packed form cannot carry, is the text symbol
+        #    in front of L: the library reads it there).  A member may hold a slice of L, of R, or (more leaves than ranks) of both.
+        myL, myR = slices.pop(mg.L.key, None), slices.pop(mg.R.key, None)
+        empty = torch.empty(0, dtype=torch.uint8, device=dev)
+        bwL, bwR = (myL[0] if myL else empty), (myR[0] if myR else empty)
+        info = _all_gather_i64([bwL.numel(), bwR.numel(), node_p0.get(mg.L.key, -1) if myL else -1], grp, dev)
+        sizesL, sizesR = info[:, 0], info[:, 1]
+        p0L = int(info[:, 2].max())
+        assert int(sizesL.sum()) == m and int(sizesR.sum()) == mr and p0L >= 0, "slice tables inconsistent"
+        node_p0.pop(mg.L.key, None); node_p0.pop(mg.R.key, None)
         # 2. the packed slices of BOTH sides to every member in ONE all-gather (2 bits per symbol; bytes: as they are).  L's slices become the rank
         #    dictionary where it is used; an owner later takes its range of BWT(R) out of R's slices, so no second exchange of symbols is needed.
         #    (Padded to the largest slice: a member's share of a node differs from the others' by the rounding of the rank slices.)
-        chunk = max(1, max(be.packed_len(int(c)) for c in sizes))
-        allpk = _all_gather_padded(be.pack2(my_bwt), chunk, grp)
-        partsL = [(allpk[j], int(sizes[j])) for j in range(nL)]
-        partsR = [(allpk[j], int(sizes[j])) for j in range(nL, gs)]
-        # 3. gt bits: L's positions (a, rbeg) are valid on L's members, R's (rbeg, rend] on R's.
-        #    Everybody gets both word ranges; partial edge words are merged bit-exactly.
-        lw0, lw1 = a >> 5, (rbeg >> 5) + 1
-        w0, w1 = rbeg >> 5, (rend >> 5) + 1
-        lseg = gt_cur[lw0:lw1].clone()
-        _broadcast(lseg, members[0], grp)
-        rseg = gt_cur[w0:w1].clone()
-        _broadcast(rseg, members[nL], grp)
-        be.bits_replace(gt_cur, lseg, lw0, a + 1, rbeg + 1)
-        be.bits_replace(gt_cur, rseg, w0, rbeg + 1, rend + 1)
+        chunkL = max(1, max(be.packed_len(int(c)) for c in sizesL))
+        chunkR = max(1, max(be.packed_len(int(c)) for c in sizesR))
+        both = torch.zeros(chunkL + chunkR, dtype=torch.uint8, device=dev)
+        if bwL.numel():
+            pk = be.pack2(bwL); both[:pk.numel()] = pk
+        if bwR.numel():
+            pk = be.pack2(bwR); both[chunkL:chunkL + pk.numel()] = pk
+        allpk = _all_gather_padded(both, chunkL + chunkR, grp)
+        partsL = [(allpk[j, :chunkL], int(sizesL[j])) for j in range(gs) if sizesL[j]]
+        partsR = [(allpk[j, chunkL:], int(sizesR[j])) for j in range(gs) if sizesR[j]]
+        del bwL, bwR, myL, myR, both
+        # 3. gt bits of R's positions: R's holder has them; member j walks the chains [cb[j], cb[j+1]) = the positions (rbeg + klo_j, rbeg + khi_j]
+        #    and gets the words of that range only
+        cb = split_even(mg.num_chains, gs)
+        def chain_bits(j):                     # absolute bit range [b, e) member j's walk reads (one bit of margin on both sides, inside R)
+            khi = mr - cb[j] * mg.chain_len
+            klo = max(0, mr - cb[j + 1] * mg.chain_len)
+            if cb[j + 1] == cb[j]:
+                return rbeg, rbeg
+            return max(rbeg, rbeg + klo - 1), min(rend + 1, rbeg + khi + 2)
+        def words(b, e):
+            return (b >> 5, ((e - 1) >> 5) + 1) if e > b else (0, 0)
+        hR, hP = members.index(mg.R.holder), members.index(mg.L.holder)
+        need = [words(*chain_bits(j)) for j in range(gs)]
+        noseg = torch.empty(0, dtype=torch.int32, device=dev)
+        send = [gt_cur[w0:w1].contiguous() if gi == hR else noseg for (w0, w1) in need]
+        got = _exchange_words(send, [(need[gi][1] - need[gi][0]) if j == hR else 0 for j in range(gs)], grp)
+        if gi != hR and need[gi][1] > need[gi][0]:
+            b, e = chain_bits(gi)
+            be.bits_replace(gt_cur, got[hR], need[gi][0], b, e)
         t1 = self._now()
         tm["gather"] += t1 - t0
         # 4. dictionary, then my chain range; the ranks come back sorted and already cut at the borders of the group's rank slices
         be.build_dict(partsL, m, p0L)
         t1b = self._now()
         tm["dict"] += t1b - t1
-        cb = split_even(mg.num_chains, gs)
         c0, c1 = cb[gi], cb[gi + 1]
         lam = split_even(m + 1, gs)           # owner j holds ranks [lam[j], lam[j+1])
         # B3M_DIST_TILES = t > 1: my chain range goes in t tiles; while tile i+1 walks, the gap buckets of tile i are already on their way
         # (RCCL runs the all-to-all on its own stream), at the price of one small all-gather of bucket sizes per tile.  Default: one tile,
         # one all-gather of the bucket sizes, one all-to-all(v).
-        ntile = max(1, min(int(os.environ.get("B3M_DIST_TILES", "1")), c1 - c0))
+        ntile = max(1, min(int(os.environ.get("B3M_DIST_TILES", "1")), max(1, c1 - c0)))
         tb = split_even(c1 - c0, ntile)
-        symstart = self._symstart(mg.L.ranks)
+        symstart = self._symstart(mg.L.leaves)
         flights, rc, oseg = [], None, None
+        w0, w1 = rbeg >> 5, (rend >> 5) + 1
         t_walk = t_a2a = 0.0
         for t in range(ntile):
             tw0 = self._now()
@@ -488,12 +556,21 @@ class DistributedBwt:
             t_a2a += self._now() - tw1
         t2 = self._now()
         tm["walk"] += t_walk
-        # new gt bits of R's positions relative to S_a: union over walkers (disjoint positions)
-        oseg = oseg.contiguous()
-        _all_reduce_sum(oseg, grp)
-        gt_new = gt_cur                               # L's bits (a, rbeg) stay; R's become relative to S_a
-        be.bits_replace(gt_new, oseg, w0, rbeg, rend)
-        be.set_endbit(gt_new, rend, anchors[mg.anchor_off: mg.anchor_off + 1], p0L)
+        # new gt bits of R's positions relative to S_a: member j made the bits of [rbeg + klo_j, rbeg + khi_j); they go to the parent's holder
+        def made_bits(j):
+            khi = mr - cb[j] * mg.chain_len
+            klo = max(0, mr - cb[j + 1] * mg.chain_len)
+            return (rbeg + klo, rbeg + khi) if cb[j + 1] > cb[j] else (rbeg, rbeg)
+        made = [words(*made_bits(j)) for j in range(gs)]
+        mw0, mw1 = made[gi]
+        send = [oseg[mw0 - w0:mw1 - w0].contiguous() if (j == hP and mw1 > mw0) else noseg for j in range(gs)]
+        got = _exchange_words(send, [(made[j][1] - made[j][0]) if gi == hP else 0 for j in range(gs)], grp)
+        if gi == hP:
+            for j in range(gs):
+                b, e = made_bits(j)
+                if e > b:
+                    be.bits_replace(gt_cur, got[j], made[j][0], b, e)      # L's bits (a, rbeg) stay; R's become relative to S_a
+            be.set_endbit(gt_cur, rend, anchors[mg.anchor_off: mg.anchor_off + 1], p0L)
         t2b = self._now()
         tm["gather"] += t2b - t2
         # 5. the gap buckets of my slice of the rank space [0, m], from every walker and tile
@@ -516,8 +593,10 @@ class DistributedBwt:
         out = be.interleave(sr_local, be.l_bytes(a, l0, l1), bwtR_part)
         del partsL, partsR, allpk
         p0P, new_off = self._p0_after_merge(sr_slice, p0L, l0, l1, int(Q[gi]), out.numel(), gi, grp)
+        slices[mg.parent.key] = (out, new_off)
+        node_p0[mg.parent.key] = p0P
         tm["interleave"] += self._now() - t4
-        return out, new_off, gt_new, p0P
+        return gt_cur
 
     def _p0_after_merge(self, sr_slice, p0L, l0, l1, q0, out_len, gi, grp):
         """new rank of L's p0 entry, p0L + #{q : sr[q] <= p0L} (known to the owner of rank p0L), and the offset of my slice of the parent:
@@ -751,9 +830,13 @@ def bench_main(a, rank, local_rank, world):
     from . import _lib
     plan_rate = int(_lib.lib().b3m_plan_sampling_rate(getattr(a, "isasamplingrate", 0), getattr(a, "bwtonly", 0), n))
 
+    # leaf blocks of the block-merge mode: --blocks B (>= world; rank g sorts blocks g, g + P, ...), default one per rank -- and four for a world of ONE rank
+    # (`WORLD_SIZE=1 B3M_BENCH_BACKEND=nccl python bench.py --gpus 1`: the one-GPU box's way to run every collective of a merge through RCCL)
+    nleaves = max(world, int(getattr(a, "blocks", 0) or 0)) if (getattr(a, "blocks", 0) or world > 1) else 4
+
     def make(m):
         # (a text too skewed for suffix-range shards is constructed by block merging instead; the line then says so and claims no samples)
-        return (DistributedBwt(n, itype, HipBackend(dev), dev) if m == "blocks"
+        return (DistributedBwt(n, itype, HipBackend(dev), dev, leaves=nleaves) if m == "blocks"
                 else PrefixShardedBwt(n, itype, dev, isasamplingrate=plan_rate, allow_fallback_without_samples=True))
 
     def guarded(seconds, bail, fn):
@@ -835,7 +918,7 @@ def bench_main(a, rank, local_rank, world):
         else:
             roof = {"bound": "hbm", "kernel": "whole job (SURVEY.md 8d alg_bytes(n,B))", "achieved": round(alg_job / (dt / steps) / 1e9, 1),
                     "peak": 8000.0 * world, "unit": "GB/s", "frac": round(alg_job / (dt / steps) / 1e9 / (8000.0 * world), 5), "traffic": None}
-        names = {"blocks": "%d GPUs: 1 leaf block per GPU, balanced merges, RCCL all-to-all of gap buckets" % world,
+        names = {"blocks": "%d GPU(s): %d leaf blocks (rank g sorts blocks g, g + P, ...), balanced merges, %s all-to-all of gap buckets" % (world, nleaves, "RCCL" if backend == "nccl" else backend),
                  "prefix": "%d GPUs: suffix-range shards of the replicated text, no exchange step" % world}
         modes = {mode: summary(res_main)}
         # only suffix-range shards emit samples; a shard job that fell back to block merging emitted none
@@ -847,7 +930,7 @@ def bench_main(a, rank, local_rank, world):
             "value": round(nbases * steps / dt / 1e9, 4), "unit": "Gbase/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": world if mode == "blocks" else 1,
+            "config": {"workload": "%s: %d-symbol synthetic %s" % (a.config.upper(), n, itype), "blocks": nleaves if mode == "blocks" else 1, "backend": backend,
                        "merge_levels": levels, "mode": mode, "parallelism": names[mode], "modes": modes, "checked": res_main["checked"],
                        "value_is": "device-resident: packed text replicated in every GPU's HBM -> BWT slices%s in HBM" % (" + (rank,pos) samples" if with_samples else "")},
             "roofline": roof,

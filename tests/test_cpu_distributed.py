@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, itype, nb, seed, repeat, q):
+def _worker(rank, world, port, itype, nb, seed, repeat, q, leaves=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,7 +42,7 @@ def _worker(rank, world, port, itype, nb, seed, repeat, q):
             buf = O.pac_encode(b)
         sym = O.symbols_from_file_bytes(buf, itype)
         n = len(sym)
-        job = D.DistributedBwt(n, itype, OracleBackend(sym, itype), torch.device("cpu"))
+        job = D.DistributedBwt(n, itype, OracleBackend(sym, itype), torch.device("cpu"), leaves=leaves)
         out, off, p0 = job.run(torch.from_numpy(buf))
         full = D.gather_result(out).numpy()
         ref = O.bwt(sym)
@@ -59,11 +59,11 @@ def _worker(rank, world, port, itype, nb, seed, repeat, q):
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("itype,nb,repeat", [("pacterm", 5000, False), ("pac", 4097, False), ("pacterm", 6000, True), ("bytestream", 4001, False)])
-def test_distributed_driver_gloo(world, itype, nb, repeat):
+def test_distributed_driver_gloo(world, itype, nb, repeat, leaves=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, itype, nb, 17 + world, repeat, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, itype, nb, 17 + world, repeat, q, leaves)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -87,6 +87,17 @@ def test_distributed_driver_gloo_eight_ranks():
     test_distributed_driver_gloo(8, "bytestream", 5003, False)
 
 
+@pytest.mark.parametrize("world,leaves", [(1, 4), (2, 4), (2, 5), (3, 7), (4, 8)])
+def test_distributed_driver_gloo_more_leaves_than_ranks(world, leaves):
+    """"GPU g sorts blocks g, g + P, ...": B >= P leaf blocks, a rank holds slices of both sides of a merge, groups of one rank (world 1:
+    every collective of a merge still runs, on a group of one); gt bits travel holder -> walkers' chain ranges -> the parent's holder"""
+    test_distributed_driver_gloo(world, "pacterm", 5003, False, leaves)
+    test_distributed_driver_gloo(world, "bytestream", 3001, False, leaves)
+    if world == 2:
+        test_distributed_driver_gloo(world, "pacterm", 6000, True, leaves)
+        test_distributed_driver_gloo(world, "pac", 4097, False, leaves)
+
+
 def test_tree_plan_shapes():
     sys.path.insert(0, ROOT)
     from bwtb3m_amd.distributed import TreePlan, split_even, chains_for
@@ -100,5 +111,11 @@ def test_tree_plan_shapes():
         assert (mg.num_chains - 1) * mg.chain_len < mg.R.m <= mg.num_chains * mg.chain_len
     p3 = TreePlan(1000, 3)          # odd: the last leaf is carried one level
     assert [len(l) for l in p3.levels] == [1, 1] and p3.levels[1][0].group == [0, 1, 2]
+    # more leaves than ranks: round robin, groups = the ranks that own a leaf of either side, the holder of a node = the owner of its first leaf
+    p24 = TreePlan(1000, 2, leaves=4)
+    assert [(mg.L.leaves, mg.R.leaves, mg.group, mg.L.holder, mg.R.holder) for mg in p24.merges] == [([0], [1], [0, 1], 0, 1), ([2], [3], [0, 1], 0, 1), ([0, 1], [2, 3], [0, 1], 0, 0)]
+    assert p24.leaves_of(1) == [1, 3] and p24.root.key == 0
+    p14 = TreePlan(1000, 1, leaves=4)
+    assert all(mg.group == [0] for mg in p14.merges) and len(p14.merges) == 3
     assert split_even(10, 3) == [0, 3, 6, 10]
     assert chains_for(100)[0] == 32

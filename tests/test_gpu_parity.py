@@ -358,6 +358,116 @@ def _dist_worker(rank, world, port, itype, nb, q):
         dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(port, q):
+    """ONE rank, backend nccl (= RCCL) on the one GPU: the exchange mode with four leaf blocks (three merges, groups of one member) and the suffix-range
+    shard job with a world of one, at C2 size, against the oracle.  Every all_gather_into_tensor / all_to_all_single / all-reduce of a merge runs through
+    RCCL on device tensors: nothing may be staged through the host."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from oracle import oracle as O
+        from bwtb3m_amd import distributed as D, synth
+        res = {}
+        staged = []
+        orig_cpu = torch.Tensor.cpu
+
+        def spy_cpu(self, *a, **k):
+            import inspect
+            if self.is_cuda and self.numel() > 4096:
+                for fr in inspect.stack()[1:6]:
+                    if fr.filename.endswith("distributed.py"):
+                        staged.append((fr.function, self.numel())); break
+            return orig_cpu(self, *a, **k)
+        itype, buf, n = synth.config_input("c2")                     # 5 Mbase pacterm, n = 5,000,001
+        sym = O.symbols_from_file_bytes(buf, itype)
+        ref = O.bwt(sym)
+        d_text = torch.from_numpy(buf).to(dev)
+        used = []
+        for name in ("all_gather_into_tensor", "all_to_all_single", "all_reduce", "all_gather"):
+            orig = getattr(dist, name)
+
+            def wrap(*a, __orig=orig, __name=name, **k):
+                t = a[0] if not isinstance(a[0], (list, tuple)) else a[0][0]
+                used.append((__name, bool(t.is_cuda)))
+                return __orig(*a, **k)
+            setattr(dist, name, wrap)
+        torch.Tensor.cpu = spy_cpu
+        job = D.DistributedBwt(n, itype, D.HipBackend(dev), dev, leaves=4)
+        job.warm_communicators()
+        out, off, p0 = job.run(d_text)
+        torch.Tensor.cpu = orig_cpu
+        res["blocks"] = bool(off == 0 and out.numel() == n and np.array_equal(out.cpu().numpy(), ref) and ref[p0] == 0)
+        res["levels"] = len(job.plan.levels)
+        res["merges"] = len(job.plan.merges)
+        res["staged"] = staged
+        res["collectives"] = sorted(set(used))
+        del job
+        sh = D.PrefixShardedBwt(n, itype, dev, isasamplingrate=4096)
+        sl, soff, sp0 = sh.run(d_text)
+        res["prefix"] = bool(soff == 0 and sl.numel() == n and np.array_equal(sl.cpu().numpy(), ref) and sp0 == p0)
+        # a byte alphabet through the same one-rank groups (count rows instead of 2-bit rank lines)
+        nb = 200001
+        b = O.synth_bases(nb, 5)
+        tb = np.frombuffer(b"ACGT", dtype=np.uint8)[b].copy()
+        tb[::97] = 255; tb[5::211] = 0
+        symb = O.symbols_from_file_bytes(tb, "bytestream")
+        jb = D.DistributedBwt(len(symb), "bytestream", D.HipBackend(dev), dev, leaves=3)
+        ob, _, _ = jb.run(torch.from_numpy(tb).to(dev))
+        res["bytes"] = bool(np.array_equal(ob.cpu().numpy(), O.bwt(symb)))
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_one_rank_on_one_gpu(gpu):
+    """VERDICT r04 missing 1: the RCCL code path itself (device tensors, all_gather_into_tensor, all_to_all_single(async_op=True), init_process_group("nccl",
+    device_id=...)) had never run.  A world of one rank with B = 4 leaf blocks executes every collective of three merges on the one GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    p.start()
+    _join_all([p], 420)
+    res = q.get(timeout=10)
+    assert res["blocks"] and res["prefix"] and res["bytes"], res
+    assert res["levels"] == 2 and res["merges"] == 3
+    assert res["staged"] == [], "device tensors were staged through the host under nccl: %r" % (res["staged"],)
+    names = {nm for nm, _ in res["collectives"]}
+    assert {"all_gather_into_tensor", "all_to_all_single", "all_reduce"} <= names, res["collectives"]
+    assert all(cuda for nm, cuda in res["collectives"]), res["collectives"]
+
+
+def test_bench_one_rank_rccl_prints_a_line(gpu):
+    """`WORLD_SIZE=1 B3M_BENCH_BACKEND=nccl python bench.py --gpus 1`: the N > 1 bench line from a process group of one rank on RCCL (both modes)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", B3M_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "40000000", "--steps", "2", "--warmup", "1", "--mode", "blocks"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["mode"] == "blocks" and line["config"]["blocks"] == 4 and line["config"]["backend"] == "nccl"
+    assert line["config"]["merge_levels"] == 2 and "tile [0, n)" in line["config"]["checked"]
+    assert "prefix" in line["config"]["modes"] and "error" not in line["config"]["modes"]["prefix"]
+    assert set(line["config"]["modes"]["blocks"]["rank0_phase_s"]) >= {"leaf", "walk", "all_to_all", "interleave"}
+
+
 @pytest.mark.parametrize("world,itype,nb", [(2, "pacterm", 300000), (4, "pac", 262144), (3, "pacterm", 100001), (2, "bytestream", 200001), (3, "bytestream", 70000),
                                             (5, "pacterm", 500001)])      # five ranks: three merge levels with a carried node (with this process the six the box allows on one GPU)
 def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
