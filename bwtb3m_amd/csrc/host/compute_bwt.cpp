@@ -214,11 +214,12 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 		B.ms_sort = std::max(B.ms_sort, s.res.ms_sort);
 	}
 	if (have_p0 != 1) throw std::runtime_error("internal: the rotation starting at position 0 was placed by " + std::to_string(have_p0) + " shards");
+	HIPCHK(hipSetDevice(sh[0].dev));
 	B3MCHK(b3m_plan_histogram(sh[0].plan, B.hist));          // (every shard's level 0 sees the whole text: any shard has the text's histogram)
 	// samples: every sampled position got its rank from exactly one shard (slot i of each shard's pinned image = position i * rate)
 	if (rate) {
 		uint64_t nslots = 0; std::vector<const uint64_t *> raw((size_t)N, nullptr);
-		for (int k = 0; k < N; ++k) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(sh[(size_t)k].plan, &raw[(size_t)k], &c)); if (k && c != nslots) throw std::runtime_error("internal: sample tables differ"); nslots = c; }
+		for (int k = 0; k < N; ++k) { uint64_t c = 0; HIPCHK(hipSetDevice(sh[(size_t)k].dev)); B3MCHK(b3m_plan_samples_raw(sh[(size_t)k].plan, &raw[(size_t)k], &c)); if (k && c != nslots) throw std::runtime_error("internal: sample tables differ"); nslots = c; }
 		B.pairs_store.assign(2 * nslots, ~0ull);
 		for (int k = 0; k < N; ++k)
 			for (uint64_t i = 0; i < nslots; ++i) if (raw[(size_t)k][2 * i] != ~0ull) {
@@ -228,6 +229,7 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 		for (uint64_t i = 0; i < nslots; ++i) if (B.pairs_store[2 * i] == ~0ull) throw std::runtime_error("internal: the (rank,pos) sample of position " + std::to_string(i * rate) + " was written by no shard");
 		B.pairs = B.pairs_store.data(); B.npairs = nslots;
 	}
+	HIPCHK(hipSetDevice(B.dev));
 	std::map<int, int> distinct;
 	for (int d : devs) distinct[d] = 1;
 	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu tied + %llu placed suffixes on the shards' lists%s), gather %.3f s\n", N,
@@ -411,7 +413,31 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		const double tp1 = now();
 		// ---- sort -------------------------------------------------------------------------------------------------------------------
 		double t1 = now(), t2 = t1;
-		if (!sharded) {
+		// a shard that refuses its range (one 32-base window holds more suffixes than a shard's workspace: borders fall inside level-0 digits, but never inside a
+		// window) must not end the job -- the reference never fails because of mem= or its thread count (/root/reference/src/bwtb3m.cpp:48-55)
+		const auto refusal = [](const std::string &why) { return why.find("suffix-range shard larger than the workspace") != std::string::npos; };
+		bool run_sharded = sharded;
+		if (run_sharded) {
+			log("[V] input read into HBM in %.3f s\n", tp1 - tp0);
+			t1 = now();
+			own_bwt = true;
+			try { construct_sharded(devs, type, n, mem, anchor_rate, d_text, tb, B, shards, log); }
+			catch (const std::exception &e) {
+				const std::string why = e.what();
+				if (!refusal(why) || n >= (1ull << 32)) throw;
+				free_shards(shards);
+				HIPCHK(hipSetDevice(dev0));
+				if (B.d_bwt) (void)hipFree(B.d_bwt);
+				B = Built{}; own_bwt = false;
+				Log{log_fd}("[W] numgpus=%d: %s -- constructing on one device instead\n", ngpus, why.c_str());
+				B.plan = b3m_plan_create(n, type, 0, mem, anchor_rate);
+				if (B.plan && b3m_plan_host_tier(B.plan)) { b3m_plan_destroy(B.plan); B.plan = b3m_plan_create(n, type, 0, 0, anchor_rate); }      // (the text is in HBM already)
+				if (!B.plan) throw std::runtime_error(b3m_last_error());
+				run_sharded = false;
+			}
+			t2 = now();
+		}
+		if (!run_sharded) {
 			b3m_plan *plan = B.plan;
 			if (*b3m_plan_warning(plan)) Log{log_fd}("[W] %s\n", b3m_plan_warning(plan));       // (whatever verbose= says)
 			if (spill) log("[V] blocks %llu workspace %.2f GB; plan created, %.3f GB of text read into pinned host memory (%.3f s) and %.3f GB pinned for the BWT: %.3f s\n",
@@ -424,9 +450,24 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				log("[V] host tier: mem=%llu is below what a merge tree needs (7.25 bytes per symbol whatever the blocks): %d sequential suffix-range shards, the text from and the "
 				    "BWT to pinned host memory\n", (unsigned long long)mem, spill);
 				t1 = now();
-				if (b3m_plan_run_host(plan, h_text, h_bwt, nullptr, nullptr)) throw std::runtime_error(b3m_last_error());
+				if (b3m_plan_run_host(plan, h_text, h_bwt, nullptr, nullptr)) {
+					const std::string why = b3m_last_error();
+					if (!refusal(why)) throw std::runtime_error(why);
+					// the host tier cannot hold this text's heaviest window in a shard: the smallest-block merge tree instead, above the target (as before the host tier existed)
+					const uint64_t bmin = std::max<uint64_t>(1024, n / 1024);
+					Log{log_fd}("[W] mem=%llu: %s -- constructing by block merging with %llu-symbol blocks instead, above the memory target\n", (unsigned long long)mem, why.c_str(),
+					            (unsigned long long)bmin);
+					b3m_plan_destroy(plan); B.plan = plan = nullptr;
+					HIPCHK(hipMalloc(&d_text, tb + 64));
+					HIPCHK(hipMemset((uint8_t *)d_text + (tb & ~63ull), 0, tb + 64 - (tb & ~63ull)));
+					HIPCHK(hipMemcpy(d_text, h_text, tb, hipMemcpyHostToDevice));
+					b3m_host_free(h_text); h_text = nullptr; b3m_host_free(h_bwt); h_bwt = nullptr;
+					B.plan = plan = b3m_plan_create(n, type, bmin, 0, anchor_rate);
+					if (!plan) throw std::runtime_error(b3m_last_error());
+					spill = 0;
+				}
 				t2 = now();
-				if (want_sa) {
+				if (spill && want_sa) {
 					// the LF walks that make X.sa / X.isa read the whole BWT and a rank dictionary of it: 1.7 bytes per symbol of HBM beside the plan
 					const uint64_t need = b3m_plan_workspace_bytes(plan) + n + 2 * (n / 3) + 8 * ((n + sarate - 1) / sarate);
 					if (need > mem) Log{log_fd}("[W] mem=%llu is exceeded by the LF walks of bwtonly=0 (the whole BWT and its rank dictionary in HBM: %.2f GB with the plan); "
@@ -434,7 +475,8 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 					HIPCHK(hipMalloc((void **)&B.d_bwt, n + 16)); own_bwt = true;
 					HIPCHK(hipMemcpy(B.d_bwt, h_bwt, n, hipMemcpyHostToDevice));
 				}
-			} else {
+			}
+			if (!spill) {
 			HIPCHK(hipMalloc((void **)&B.d_bwt, (wide ? 4 * n : n) + 16)); own_bwt = true;
 			t1 = now();
 			if (b3m_plan_run(plan, d_text, B.d_bwt, nullptr)) throw std::runtime_error(b3m_last_error());
@@ -451,12 +493,6 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 				if (empty) throw std::runtime_error("internal: " + std::to_string(empty) + " (rank,pos) samples were not written by the sort");
 				B.npairs = c;
 			} else if (res.num_samples) { uint64_t c = 0; B3MCHK(b3m_plan_samples_raw(plan, &B.pairs, &c)); B.npairs = c; }
-		} else {
-			log("[V] input read into HBM in %.3f s\n", tp1 - tp0);
-			t1 = now();
-			construct_sharded(devs, type, n, mem, anchor_rate, d_text, tb, B, shards, log);
-			own_bwt = true;
-			t2 = now();
 		}
 		// (this process launches every kernel for the first time: `sort` includes the loading of their code objects, 3-14 ms at 3 Gbase; with
 		// HIP_ENABLE_DEFERRED_LOADING=0 the figure is bench.py's ms_per_step and the 2.4 s of loading move in front of the plan: tools/cli_sort_time.py)

@@ -253,7 +253,27 @@ struct L0Args {
 	uint32_t *cbase; uint32_t *alloc; uint32_t cap;
 	unsigned long long *below;   // += positions of the block with a digit below keep_lo: the global rank of the shard's first suffix
 	unsigned long long *symhist; // SHARD, may be null: += the block's symbol histogram (256 entries; every position is looked at anyway)
+	// EDGE (a suffix-range shard whose borders fall INSIDE a level-0 digit: skewed text): of the digit keep_lo only the positions whose 64-bit window (32 bases,
+	// window_safe) is >= key_lo take part (edge & 1), of the digit keep_hi - 1 only those below key_hi (edge & 2); `below` then also counts the positions of digit
+	// keep_lo in front of key_lo (COUNT_ONLY passes count it too: the two-pass form gets the shard's first rank from there)
+	uint64_t key_lo, key_hi; uint32_t edge;
 };
+
+// EDGE: does the position with digit dg0 and window x (fetched on demand: only the two edge digits need it) belong to the shard?  *blw: it lies in front of the shard
+template <typename F>
+__device__ __forceinline__ bool l0_edge_keep(const L0Args &A, const uint32_t dg0, const uint32_t klo, const uint32_t nbin, F window, bool *blw)
+{
+	const uint32_t bin = dg0 - klo;
+	bool in = bin < nbin;
+	*blw = dg0 < klo;
+	const bool at_lo = (A.edge & 1u) && dg0 == klo, at_hi = (A.edge & 2u) && in && bin == nbin - 1u;
+	if (at_lo || at_hi) {
+		const uint64_t x = window();
+		if (at_lo && x < A.key_lo) { in = false; *blw = true; }
+		if (at_hi && x >= A.key_hi) in = false;
+	}
+	return in;
+}
 
 // window / predecessor of an arbitrary position (chunks at the block edges or near the text end)
 __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t start, uint64_t end, uint64_t *x, uint32_t *pr)
@@ -275,10 +295,11 @@ __device__ __forceinline__ bool l0_slow(const TextView &T, uint64_t i, uint64_t 
 // workgroups share a CU: what paces this pass is the chain of latencies per chunk (text load, barriers, the reservation, the stores), not the
 // atomics of the few positions kept.  (Two workgroups of 1024 threads need 64 registers per thread: 161 spilled, the pass went from 3.0 to 7.5 ms.)
 constexpr int W0S_SIDX = 24576, W0S_THREADS = 512;
-template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false, int SHARD = 0>
+template <bool COUNT_ONLY, int CHUNK, int TCH, int MAXBINS, bool LOCAL = false, int SHARD = 0, bool EDGE = false>
 __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ? 4 : 1) void k_l0_pass(L0Args A)
 {
 	static_assert(!SHARD || (LOCAL && !COUNT_ONLY), "a one-pass shard is a chunk-local level 0");
+	static_assert(!EDGE || COUNT_ONLY || !LOCAL || SHARD, "borders inside a digit belong to suffix-range shards");
 	constexpr int TH = SHARD == 2 ? W0S_THREADS : W0_THREADS;
 	constexpr int WORDS = CHUNK / 16;
 	static_assert(CHUNK % 16 == 0 && CHUNK <= 65536, "chunk-local positions are 16-bit");
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 		constexpr int NJ = (WORDS + TH - 1) / TH;
 		constexpr bool KM = !COUNT_ONLY && (!LOCAL || SHARD);
 		uint32_t km[KM ? (NJ + 1) / 2 : 1];
-		const bool sparse = KM && 2u * nbin <= (1u << A.D);
+		const bool sparse = KM && (EDGE || 2u * nbin <= (1u << A.D));      // (EDGE: the count's verdict on every position is kept, the place phase does not test again)
 		if (KM) { for (int j = 0; j < (NJ + 1) / 2; ++j) km[j] = 0u; }
 		if (fast) {
 			#pragma unroll
@@ -352,8 +373,16 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 				}
 				#pragma unroll
 				for (int s = 0; s < 16; ++s) {
-					const uint32_t dg0 = (s ? __funnelshift_l(w1, w0, 2 * s) : w0) >> dsh32;
+					const uint32_t xh = s ? __funnelshift_l(w1, w0, 2 * s) : w0;
+					const uint32_t dg0 = xh >> dsh32;
 					const uint32_t bin = dg0 - klo;
+					if (EDGE) {
+						bool blw;
+						const bool in = l0_edge_keep(A, dg0, klo, nbin, [&]() { const uint32_t w2 = stext[w + 3]; return ((uint64_t)xh << 32) | (s ? __funnelshift_l(w2, w1, 2 * s) : w1); }, &blw);
+						n_below += blw ? 1u : 0u;
+						if (in) { atomicAdd(&cur[bin], 1u); mk |= 1u << s; }
+						continue;
+					}
 					if (SHARD) n_below += dg0 < klo ? 1u : 0u;
 					if (bin < nbin) { atomicAdd(&cur[bin], 1u); mk |= 1u << s; }
 				}
@@ -365,13 +394,15 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
+					bool blw = (uint32_t)(x >> dsh) < klo, in = bin < nbin;
+					if (EDGE) { in = l0_edge_keep(A, (uint32_t)(x >> dsh), klo, nbin, [&]() { return x; }, &blw); if (!SHARD) n_below += blw ? 1u : 0u; }
 					if (SHARD) {
-						n_below += (uint32_t)(x >> dsh) < klo ? 1u : 0u;
+						n_below += blw ? 1u : 0u;
 						const uint64_t ap = cpos + li;
 						if (A.T.type == B3M_INPUT_PACTERM && ap == A.T.n - 1) n_term += 1u;
 						else { const uint32_t bs = base_at(A.T, ap); n_s1 += bs == 1u; n_s2 += bs == 2u; n_s3 += bs == 3u; n_all += 1u; }
 					}
-					if (bin < nbin) atomicAdd(&cur[bin], 1u);
+					if (in) atomicAdd(&cur[bin], 1u);
 				}
 			}
 		}
@@ -440,7 +471,9 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 				uint64_t x; uint32_t pr;
 				if (l0_slow(A.T, cpos + li, A.start, end, &x, &pr)) {
 					const uint32_t bin = (uint32_t)(x >> dsh) - klo;
-					if (bin < nbin) sidx[atomicAdd(&cur[bin], 1u)] = (uint16_t)li;
+					bool in = bin < nbin, blw;
+					if (EDGE) in = l0_edge_keep(A, (uint32_t)(x >> dsh), klo, nbin, [&]() { return x; }, &blw);
+					if (in) sidx[atomicAdd(&cur[bin], 1u)] = (uint16_t)li;
 				}
 			}
 		}
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(SHARD == 2 ? W0S_THREADS : W0_THREADS, SHARD == 2 ?
 		__syncthreads();
 		for (int b = tid; b < bins; b += TH) A.hist[tcol + (uint64_t)b * ntiles] = cur[b];
 	}
-	if (SHARD) {
+	if (SHARD || (COUNT_ONLY && EDGE)) {
 		#pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
 			n_below += __shfl_xor(n_below, o, 64);
@@ -2584,6 +2617,62 @@ __global__ __launch_bounds__(256) void k_fill_overflow_ranges(const uint32_t *of
 	}
 }
 
+// ---- suffix-range shards whose borders fall INSIDE a level-0 digit (skewed text) ----
+// A shard is a range of 64-bit windows [key_lo, key_hi) (32 bases, the record sort's reading of the text: window_safe) instead of a range of whole digits.  The
+// borders are quantiles of a fixed sample of the block's positions (every stride-th one: the same sample, hence the same borders, on every rank); what must be exact --
+// a shard's size and the rank of its first suffix -- is counted by the level-0 passes themselves (k_l0_pass<.., EDGE>).  A window is a prefix of its suffix under a
+// reading in which the terminator and what follows are the smallest base, so window order never contradicts suffix order and equal windows share a shard.
+__global__ __launch_bounds__(256) void k_sample_windows(TextView T, uint64_t start, uint64_t stride, uint32_t ns, uint64_t *out)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < ns) out[i] = window_safe(T, start + (uint64_t)i * stride);
+}
+constexpr uint32_t SHARD_KEY_SAMPLES = 1u << 17;
+struct ShardKeys {
+	bool on = false;
+	std::vector<uint64_t> sorted;          // the sample, ascending
+	int nshards = 1;
+	uint64_t border(int k) const { return k <= 0 ? 0 : sorted[(size_t)((uint64_t)sorted.size() * (unsigned)k / (unsigned)nshards)]; }      // key_lo of shard k (k < nshards)
+	bool edge_lo(int k) const { return k > 0 && border(k) != 0; }
+	bool edge_hi(int k) const { return k + 1 < nshards; }
+	bool empty(int k) const { return edge_hi(k) && border(k + 1) <= border(k); }
+	// the shard's range of D-bit digits: [lo, hi), hi = one behind the digit of the last window it may hold
+	uint32_t dig_lo(int k, int D) const { return (uint32_t)(border(k) >> (64 - D)); }
+	uint32_t dig_hi(int k, int D) const { if (empty(k)) return dig_lo(k, D); return edge_hi(k) ? (uint32_t)((border(k + 1) - 1) >> (64 - D)) + 1u : (1u << D); }
+	double fraction(int k) const          // of the block's suffixes, by the sample
+	{
+		const auto lb = [&](uint64_t key) { return (double)(std::lower_bound(sorted.begin(), sorted.end(), key) - sorted.begin()); };
+		const double a = k > 0 ? lb(border(k)) : 0.0, b = edge_hi(k) ? lb(border(k + 1)) : (double)sorted.size();
+		return b > a ? (b - a) / (double)sorted.size() : 0.0;
+	}
+};
+static void shard_keys_sample(ShardKeys &K, const TextView &T, uint64_t start, uint64_t len, int nshards, uint64_t *d_scratch, hipStream_t s)
+{
+	const uint32_t ns = (uint32_t)std::min<uint64_t>(len, SHARD_KEY_SAMPLES);
+	const uint64_t stride = len / ns;
+	hipLaunchKernelGGL(k_sample_windows, dim3((ns + 255) / 256), dim3(256), 0, s, T, start, stride, ns, d_scratch);
+	K.sorted.resize(ns);
+	B3M_HIP(hipMemcpyAsync(K.sorted.data(), d_scratch, 8ull * ns, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	std::sort(K.sorted.begin(), K.sorted.end());
+	K.nshards = nshards; K.on = true;
+}
+// do whole-digit borders leave a shard above its share by more than half the slack a plan gives it (n / 64: engine.hip, shard_cap)?  cum: digit totals (any scale)
+static bool digit_borders_unbalanced(const std::vector<uint64_t> &cum, uint32_t bins0, int nshards, uint64_t len_in)
+{
+	if (sw().SHARD_KEYS.set) return sw().SHARD_KEYS.v != 0;      // test switch: 1 = always borders by window, 0 = never
+	if (!cum[bins0]) return false;
+	uint32_t prev = 0;
+	for (int k = 1; k <= nshards; ++k) {
+		uint32_t d = bins0;
+		if (k < nshards) { const uint64_t target = (uint64_t)((unsigned __int128)cum[bins0] * (unsigned)k / (unsigned)nshards); d = 0; while (d < bins0 && cum[d] < target) ++d; }
+		const double est = (double)(cum[d] - cum[prev]) / (double)cum[bins0] * (double)len_in;
+		if (est > (double)len_in / nshards + (double)len_in / 128.0) return true;
+		prev = d;
+	}
+	return false;
+}
+
 static uint32_t big_grid() { const int v = (int)sw().BIG_GRID.get(2048); return (uint32_t)(v < 64 ? 64 : v); }      // (measurement switch: workgroups that stride over the listed buckets)
 void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSortWs &ws, hipStream_t s, Timeline *tl, BlockSortOut &out,
                     uint8_t *d_bwt, uint32_t *d_p0, int shard, int nshards, bool need_sa, uint64_t own, bool allow_ext)
@@ -2642,6 +2731,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	// restricted to the shard's digits: a chunk sorts the 1/N of its positions it keeps and puts them behind what earlier chunks reserved
 	// (cbase[column]); level 1 gathers through the run table as for a whole block.
 	bool shard1 = false, borders_fixed = false; uint32_t fixed_lo = 0, fixed_hi = 0;
+	ShardKeys SK;                          // borders inside digits (skewed text), once either form of the shard's level 0 has asked for them
 	{
 		const int onepass_on = (int)sw().SHARD_ONEPASS.get(1);
 		int tfin = 0; while ((len_in >> tfin) > (uint64_t)F_AVG) ++tfin;
@@ -2666,10 +2756,17 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				uint32_t d = 0; while (d < bins0 && cum[d] < target) ++d;
 				return d;
 			};
-			const uint32_t lo = bound(shard), hi = bound(shard + 1);
+			uint32_t lo = bound(shard), hi = bound(shard + 1);
+			double est = cum[bins0] ? (double)(cum[hi] - cum[lo]) / (double)cum[bins0] * (double)len_in : 0.0;
+			if (digit_borders_unbalanced(cum, bins0, nshards, len_in)) {
+				// skewed text: whole digits do not balance the shards; borders by 64-bit window instead (the same decision and the same sample on every rank)
+				shard_keys_sample(SK, T, start, len_in, nshards, ws.keyB, s);
+				lo = SK.dig_lo(shard, dg.D0); hi = SK.dig_hi(shard, dg.D0); est = SK.fraction(shard) * (double)len_in;
+				if (dbg_stages >= 1) fprintf(stderr, "[b3m] shard %d of %d: borders by window: [%016llx, %016llx) = digits %u..%u, ~%.0f suffixes\n", shard, nshards,
+				                             (unsigned long long)SK.border(shard), (unsigned long long)(SK.edge_hi(shard) ? SK.border(shard + 1) : ~0ull), lo, hi, est);
+			}
 			// (whether THIS shard then takes the one pass or, for want of room, the two: its borders are these -- the other shards' are)
 			borders_fixed = true; fixed_lo = lo; fixed_hi = hi;
-			const double est = cum[bins0] ? (double)(cum[hi] - cum[lo]) / (double)cum[bins0] * (double)len_in : 0.0;
 			const uint64_t capr = std::min<uint64_t>(ws.cap, 0xFFFFFFFFull);
 			const unsigned two_mask = (unsigned)sw().SHARD_TWO_PASS.get(0);      // test switch: these shards (bit k = shard k) take the two passes, the others one
 			if (hi > lo && (uint64_t)(hi - lo) * ncol0 <= M.tab0_cap && est <= 0.97 * (double)capr && !((two_mask >> (shard & 31)) & 1u)) {
@@ -2679,6 +2776,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				L0Args B = A;
 				B.keep_lo = lo; B.keep_hi = hi; B.runtab0 = M.tab0; B.nchunks0 = ncol0; B.tile_base = 0;
 				B.cbase = M.cbase0; B.alloc = d_alloc; B.below = d_below; B.cap = (uint32_t)capr;
+				if (SK.on) { B.key_lo = SK.border(shard); B.key_hi = SK.edge_hi(shard) ? SK.border(shard + 1) : 0; B.edge = (SK.edge_lo(shard) ? 1u : 0u) | (SK.edge_hi(shard) ? 2u : 0u); }
 				// the block's symbol histogram rides along (no second pass over the text for it); a fallback to the two passes must not count twice
 				const bool want_hist = ws.d_symhist_out != nullptr;
 				unsigned long long *d_h5 = reinterpret_cast<unsigned long long *>(d_alloc + 8);      // five counters behind the scalars, added to the caller's array on success
@@ -2690,7 +2788,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 				for (int form = (wg2_on && est <= 0.30 * (double)len_in) ? 2 : 1; form >= 1; --form) {
 					if (form == 1 && h_sc[1]) B3M_HIP(hipMemsetAsync(d_alloc, 0, 32 + 64, s));      // (the flagged attempt's counts start over)
 					Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * (uint64_t)est);
-					if (form == 2) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 2>), dim3(ntA), dim3(W0S_THREADS), 0, s, B);
+					if (SK.on) {
+						if (form == 2) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 2, true>), dim3(ntA), dim3(W0S_THREADS), 0, s, B);
+						else hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 1, true>), dim3(ntA), dim3(W0_THREADS), 0, s, B);
+					}
+					else if (form == 2) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 2>), dim3(ntA), dim3(W0S_THREADS), 0, s, B);
 					else hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, true, 1>), dim3(ntA), dim3(W0_THREADS), 0, s, B);
 					B3M_HIP(hipMemcpyAsync(h_sc, d_alloc, 16, hipMemcpyDeviceToHost, s));
 					B3M_HIP(hipStreamSynchronize(s));
@@ -2772,9 +2874,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		};
 		uint32_t lo = bound(shard), hi = bound(shard + 1);
 		if (borders_fixed) { lo = fixed_lo; hi = fixed_hi; }      // the borders every shard of this text uses (from the sampled count above); sizes and offsets below are exact
+		else if (digit_borders_unbalanced(cum, bins0, nshards, len_in)) shard_keys_sample(SK, T, start, len_in, nshards, ws.keyB, s);      // skewed text: borders by 64-bit window
+		if (SK.on) { lo = SK.dig_lo(shard, dg.D0); hi = SK.dig_hi(shard, dg.D0); }
 		out.slice_offset = cum[lo];
-		len = cum[hi] - cum[lo];
-		if (!(len <= ws.cap && len < (1ull << 32))) {
+		len = cum[hi] - cum[lo];             // (borders by window: an upper bound until the count below)
+		if (!SK.on && !(len <= ws.cap && len < (1ull << 32))) {
 			uint64_t mx = 0; for (uint32_t d = lo; d < hi; ++d) mx = std::max<uint64_t>(mx, tot[d]);
 			throw Error("suffix-range shard larger than the workspace (skewed input): shard " + std::to_string(shard) + " of " + std::to_string(nshards) + " would hold " +
 			            std::to_string(len) + " suffixes (level-0 digits " + std::to_string(lo) + ".." + std::to_string(hi) + ", the heaviest has " + std::to_string(mx) +
@@ -2793,8 +2897,41 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 		if (no_fine) S = 0;
 		if (sw().FINE_MAXS.set && S > (int)sw().FINE_MAXS.v) S = (int)sw().FINE_MAXS.v;
 		A.keep_lo = lo << S; A.keep_hi = hi << S; A.D = dg.D0 + S; D0e = dg.D0 + S;
-		bins0 = (hi - lo) << S;
-		if (S == 0) hist0 = M.hist + (uint64_t)lo * ntA;      // the rows of the first count serve
+		if (SK.on) {
+			// the window borders cut finer than (lo, hi) << S: the digits that can hold a window of the shard, and the two edge tests inside the first and the last
+			A.keep_lo = SK.dig_lo(shard, D0e); A.keep_hi = SK.dig_hi(shard, D0e);
+			A.key_lo = SK.border(shard); A.key_hi = SK.edge_hi(shard) ? SK.border(shard + 1) : 0; A.edge = (SK.edge_lo(shard) ? 1u : 0u) | (SK.edge_hi(shard) ? 2u : 0u);
+		}
+		bins0 = A.keep_hi - A.keep_lo;
+		if (SK.on) {
+			// always counted again: the rows of the first count hold whole digits.  The pass also counts what lies in front of the shard (its first rank), an empty shard's too
+			geoA = bins0 <= (uint32_t)W0A_BINS;
+			tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
+			ntA = (uint32_t)((span + tile0 - 1) / tile0);
+			B3M_REQUIRE((uint64_t)std::max(bins0, 1u) * ntA <= M.hist_cap, "MSD histogram workspace too small");
+			unsigned long long *d_below = d_tot + W0_MAXBINS;      // (behind the totals of at most W0_MAXBINS rows)
+			B3M_HIP(hipMemsetAsync(d_below, 0, 8, s));
+			A.below = d_below;
+			{
+				Scope sc(tl, KF_MSD_HIST, span / 4);
+				if (geoA) hipLaunchKernelGGL((k_l0_pass<true, W0A_CHUNK, W0A_TCH, W0A_BINS, false, 0, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+				else hipLaunchKernelGGL((k_l0_pass<true, W0B_CHUNK, W0B_TCH, W0B_BINS, false, 0, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+				if (bins0) hipLaunchKernelGGL(k_row_totals, dim3(bins0), dim3(256), 0, s, M.hist, ntA, d_tot);
+			}
+			std::vector<unsigned long long> kt(bins0); unsigned long long below = 0;
+			if (bins0) B3M_HIP(hipMemcpyAsync(kt.data(), d_tot, 8ull * bins0, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipMemcpyAsync(&below, d_below, 8, hipMemcpyDeviceToHost, s));
+			B3M_HIP(hipStreamSynchronize(s));
+			len = 0; for (uint32_t d = 0; d < bins0; ++d) len += kt[d];
+			out.slice_offset = below;
+			if (dbg_stages >= 1) fprintf(stderr, "[b3m] shard %d of %d: borders by window: [%016llx, %016llx) = %u digits of %d bits, %llu suffixes behind %llu\n", shard, nshards,
+			                             (unsigned long long)A.key_lo, (unsigned long long)(SK.edge_hi(shard) ? A.key_hi : ~0ull), bins0, D0e, (unsigned long long)len, below);
+			if (!(len <= ws.cap && len < (1ull << 32)))
+				throw Error("suffix-range shard larger than the workspace (skewed input): shard " + std::to_string(shard) + " of " + std::to_string(nshards) + " would hold " +
+				            std::to_string(len) + " suffixes between two 32-base windows, the workspace " + std::to_string(ws.cap) +
+				            (ws.no_defer ? ": raise mem= or leave it out" : ": use block mode or fewer shards"));
+		}
+		else if (S == 0) hist0 = M.hist + (uint64_t)lo * ntA;      // the rows of the first count serve
 		else if (bins0) {
 			geoA = bins0 <= (uint32_t)W0A_BINS;
 			tile0 = geoA ? (uint64_t)W0A_CHUNK * W0A_TCH : (uint64_t)W0B_CHUNK * W0B_TCH;
@@ -2815,7 +2952,11 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			exclusive_sum_u32(hist0, (uint64_t)bins0 * ntA, M.scan_ws, s);
 		}
 		Scope sc(tl, KF_MSD_SCATTER_TEXT, span / 4 + 8 * len);
-		if (geoA) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		if (SK.on) {
+			if (geoA) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS, false, 0, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+			else hipLaunchKernelGGL((k_l0_pass<false, W0B_CHUNK, W0B_TCH, W0B_BINS, false, 0, true>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
+		}
+		else if (geoA) hipLaunchKernelGGL((k_l0_pass<false, W0A_CHUNK, W0A_TCH, W0A_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 		else hipLaunchKernelGGL((k_l0_pass<false, W0B_CHUNK, W0B_TCH, W0B_BINS>), dim3(ntA), dim3(W0_THREADS), 0, s, A);
 	}
 	{

@@ -29,6 +29,7 @@ struct Sw {
 	X(L0_LOCAL,         "measurement: 0 = the scattering level 0 (counting pass + [digit][tile] scan) instead of the chunk-local one")   \
 	X(SHARD_ONEPASS,    "measurement: 0 = suffix-range shards take the two-pass level 0")                                                \
 	X(SHARD_TWO_PASS,   "test: bit k set = shard k takes the two-pass level 0 (mixed sets of shards must agree on their borders)")       \
+	X(SHARD_KEYS,       "test: 1 = suffix-range shards always take borders by 64-bit window (inside level-0 digits), 0 = never (default: skewed text only)") \
 	X(SHARD_WG2,        "measurement: 0 = one-pass shards never take the 512-thread form")                                               \
 	X(NO_FINE_SHARDS,   "measurement: 1 = shards do not split their digit range further")                                                \
 	X(FINE_MAXS,        "measurement: cap on the extra bits of a shard's fine level 0")                                                  \

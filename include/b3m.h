@@ -80,9 +80,10 @@ typedef struct b3m_options {
 	uint32_t    copyinputtomemory; /* accepted; the packed input is always HBM-resident */
 	uint32_t    verbose;
 	int32_t     num_gpus;          /* extension (CLI key numgpus=): GPUs of this node to construct on, devices 0 .. num_gpus-1 (default 1).  > 1: one host thread
-	                                  per device, each with one suffix-range shard of the text (pac / pacterm, n >= 2^18; no exchange step; long repeats are
-	                                  finished over the gathered suffix array slices); the slices are gathered on device 0, which writes the same files as
-	                                  num_gpus = 1.  (One process per GPU over RCCL instead: bwtb3m_amd.distributed.) */
+	                                  per device, each with one suffix-range shard of the text (pac / pacterm, n >= 2^18; no exchange step; a shard is a range of
+	                                  32-base windows, so its borders may fall inside a level-0 digit of a skewed text; long repeats are finished over the
+	                                  gathered LISTS of tied suffixes, b3m_plan_list_*); the slices are gathered on device 0, which writes the same files as
+	                                  num_gpus = 1.  A shard that still refuses its range (one window above a shard's workspace) sends the job to one device with a [W] line.  (One process per GPU over RCCL instead: bwtb3m_amd.distributed.) */
 	uint64_t    blocksize;         /* extension: leaf block size in symbols, 0 = derive from mem */
 } b3m_options;
 

@@ -446,6 +446,49 @@ def test_host_tier_sequential_shards_against_the_oracle(gpu, oracle, kind, monke
     plan.close()
 
 
+@pytest.mark.parametrize("how", ["numgpus", "mem"])
+def test_cli_refusing_shards_fall_back_with_a_warning(gpu, oracle, tmp_path, how):
+    """a suffix-range shard that refuses its range must not end `bwtb3m numgpus=N` or `bwtb3m mem=...` (the reference never fails because of
+    mem= or its thread count, /root/reference/src/bwtb3m.cpp:48-55).  85 % A with whole-digit borders forced (B3M_SHARD_KEYS=0: one level-0 digit holds 41 % of the
+    suffixes; by default the borders fall inside the digit and nothing refuses -- second half): the job falls back to one device / to block merging with a [W] line
+    and writes the files of an unconstrained run."""
+    from bwtb3m_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    nb = 8_000_001          # (large enough that the plan's fixed slack of 2^20 suffixes does not hide the skew: a shard of four may hold 3.2 M, the digit holds 3.3 M)
+    b = (rng.random(nb) >= 0.85).astype(np.uint8) * rng.integers(1, 4, nb).astype(np.uint8)
+    buf = oracle.pac_encode(b)
+    inp = tmp_path / "skew.pac"
+    inp.write_bytes(np.asarray(buf, dtype=np.uint8).tobytes())
+    exe = os.path.join(ROOT, "bin", "bwtb3m")
+    common = ["inputtype=pacterm", "bwtonly=1", "verbose=1", "isasamplingrate=2048"]
+    free = str(tmp_path / "free.bwt")
+    r = subprocess.run([exe] + common + ["outputfilename=" + free, str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    want = _files(free[:-4])
+    s = oracle.symbols_from_file_bytes(np.asarray(buf, dtype=np.uint8), "pacterm")
+    ref = oracle.bwt(s)
+    assert np.array_equal(_decode(L, free), ref)
+    extra, env = (["numgpus=4"], dict(os.environ, B3M_DEVICES="0,0,0,0")) if how == "numgpus" else (["mem=64m"], dict(os.environ, B3M_FORCE_SPILL="4"))
+    for keys in ("0", None):
+        e = dict(env)
+        if keys is not None:
+            e["B3M_SHARD_KEYS"] = keys
+        out = str(tmp_path / ("k%s.bwt" % keys))
+        r = subprocess.run([exe] + common + extra + ["outputfilename=" + out, str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert r.returncode == 0, r.stderr.decode()
+        fell = b"[W]" in r.stderr and b"suffix-range shard larger than the workspace" in r.stderr
+        assert fell == (keys == "0"), r.stderr.decode()
+        if fell:
+            assert (b"constructing on one device instead" if how == "numgpus" else b"constructing by block merging") in r.stderr
+        got = _files(out[:-4])
+        assert set(got) == set(want)
+        for suf in want:
+            if suf in (".bwt", ".hist") or not (fell and how == "mem"):          # (.meta names the blocks of the tree that ran; its .preisa is checked by its own tests)
+                assert got[suf] == want[suf], (keys, suf)
+        assert np.array_equal(_decode(L, out), ref)
+
+
 def _long_repeat_bases(oracle, nb, seed):
     """random bases with planted long repeats of both kinds: families above 32 copies (their suffixes reach the list-based rounds: a 16-mer above 32 records) -- a 2-kb
     segment 40 times, a tandem array, a homopolymer run -- and two-copy repeats (finished by the record sort's direct comparisons) that the copies of a family run into."""
