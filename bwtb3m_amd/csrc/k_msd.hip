@@ -3054,7 +3054,7 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 			Gq.cbase = shard1 ? M.cbase0 : nullptr; Gq.xcd = l1_order ? 1u : 0u;
 			ntB = (uint32_t)gtiles.size();
 			Scope sc(tl, KF_MSD_SCATTER, 16 * len);
-			if (sw().L1_MP.get(1)) hipLaunchKernelGGL((k_l1_gather_mp<L1_TCH>), dim3(ntB), dim3(L1M_THREADS), 0, s, Gq);
+			if (sw().L1_MP.get(0)) hipLaunchKernelGGL((k_l1_gather_mp<L1_TCH>), dim3(ntB), dim3(L1M_THREADS), 0, s, Gq);
 			else hipLaunchKernelGGL((k_l1_gather<L1_THREADS, L1_TCH>), dim3(ntB), dim3(L1_THREADS), 0, s, Gq);
 			stage("level 1 (gather)");
 		} else {

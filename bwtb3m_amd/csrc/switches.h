@@ -57,7 +57,7 @@ struct Sw {
 	X(RL_SEG,           "test: segment length of the device RL encoder (default 2^31 symbols)")                                         \
 	X(HOST_RL,          "measurement: present = the RL container is coded on the host")                                                 \
 	X(FILE_MMAP,        "measurement: 1 = output files through a shared mapping instead of pwrite")                                     \
-	X(L1_MP,            "measurement: 0 = level 1's gather as one 1024-thread workgroup per CU (k_l1_gather, the form before round 5)")
+	X(L1_MP,            "measurement: 1 = level 1's gather as two 512-thread workgroups per CU that send the chunk out in passes (k_l1_gather_mp: slower)")
 
 struct Switches {
 #define B3M_SW_FIELD(name, doc) Sw name;

@@ -490,11 +490,13 @@ def test_distributed_driver_hip_backend_shared_gpu(gpu, world, itype, nb):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("itype", ["pac", "pacterm"])
 @pytest.mark.parametrize("kind", ["uniform", "repeat", "polyA", "periodic", "twosym"])
-@pytest.mark.parametrize("d1", [0, 4, 6, 8])
+@pytest.mark.parametrize("d1", [0, 4, 6, 8, "6mp"])
 def test_msd_block_sort_paths(gpu, oracle, itype, kind, d1, monkeypatch):
     """d1 > 0: B3M_MSD_D1 gives level 1 that many bits whatever the size, so that these half-megabase inputs, which the oracle can check, run
     the kernels of the large geometries: chunk-local level 1, the gathering finishes and (from 4 bits on) k_finish_fast, with their
     listed-bucket, hot-bin and tie paths.  (At their natural size those kernels are only reached by inputs the oracle cannot sort.)"""
+    if d1 == "6mp":                                  # level 1's measurement form (two 512-thread workgroups per CU, the chunk sent out in passes: k_l1_gather_mp) stays exact
+        monkeypatch.setenv("B3M_L1_MP", "1"); d1 = 6
     if d1:
         monkeypatch.setenv("B3M_MSD_D1", str(d1))
         monkeypatch.setenv("B3M_LVL2_MIN", "0")      # every bucket above twice the finish's capacity through level 2 (at its natural threshold: buckets above 98,304 records)
