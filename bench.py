@@ -19,6 +19,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# GPU time of every leg of this run, from the engine's own HIP events (the per-family times of each plan run) plus the wall time of the LF walks that
+# verify: `config.gpu_seconds`.  A sampler that looks at the GPU every few seconds sees little of a run whose bulk is the CPU baseline; this figure says
+# how long the GPU worked.
+GPU_MS = {"sort": 0.0, "lf_walk": 0.0, "runs": 0}
+
+
+def gpu_acc(plan):
+    GPU_MS["sort"] += sum(k["ms"] for k in plan.kernel_times())
+    GPU_MS["runs"] += 1
+
+
+def lf_walk_timed(torch, plan, d_out):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = plan.lf_walk(d_out, sarate=0)
+    torch.cuda.synchronize()
+    GPU_MS["lf_walk"] += (time.perf_counter() - t0) * 1e3
+    return r
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -42,6 +61,8 @@ def parse():
                     help="skip the extra leg that times a plan without (rank,pos) samples (`config.bwt_only`)")
     ap.add_argument("--no-genome-like", dest="genome_like", action="store_false",
                     help="skip the extra leg on a repeat-rich text of the same size (`config.genome_like`: what a real genome costs; never the headline)")
+    ap.add_argument("--genome-repeats", type=float, default=0.5,
+                    help="second repeat-rich leg (`config.genome_like_harsh`): fraction of the text in interspersed repeats, 0.5 = nearer to a human genome; 0 = skip")
     ap.add_argument("--no-check", dest="check", action="store_false",
                     help="skip the verification after the timed loop (default: the timed output is LF-walked on the device against the "
                          "text from the timed plan's own (rank,pos) samples, checkbwt semantics)")
@@ -91,7 +112,7 @@ def verify_timed_result(torch, plan, d_text, d_out, n, itype):
     from bwtb3m_amd import benchutil
     hist_text = benchutil.text_histogram(d_text, n, itype)          # torch only, independent of the engine
     assert plan.histogram().astype("int64").tolist() == hist_text, "bench check: the engine's symbol histogram (.hist) differs from the text's"
-    m0, m1, _ = plan.lf_walk(d_out, sarate=0)
+    m0, m1, _ = lf_walk_timed(torch, plan, d_out)
     assert (m0, m1) == (0, 0), "bench check: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
     if itype == "pacterm":
         assert int(d_out[res0["p0"]]) == 0, "bench check: BWT[p0] is not the terminator"
@@ -113,11 +134,14 @@ def time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, steps):
     d0 = torch.empty(n, dtype=torch.uint8, device=d_out.device)
     plan0.run(buf, d0)
     torch.cuda.synchronize()
+    gpu_acc(plan0)
     t0 = time.perf_counter()
     for _ in range(steps):
         plan0.run(buf, d0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for _ in range(steps):
+        gpu_acc(plan0)                       # (every step ran the same kernels: the last step's times, once per step)
     same = bool(torch.equal(d0, d_out))
     assert same, "bench: the isasamplingrate=0 plan's output differs from the shipped plan's"
     del buf
@@ -127,33 +151,38 @@ def time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, steps):
             "equals_shipped_output": same, "what": "plan without (rank,pos) samples: BWT bytes only, not what b3m_compute_bwt runs"}
 
 
-def time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate):
+def time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate, repeats=0.15):
     """the same size and plan, on a text with the repeat structure of a genome (synth.genome_like_device: interspersed repeats at 3-10 %
     divergence, segmental duplications, microsatellites, a satellite array) instead of uniform bases: BASELINE.json's metric is quoted on
     uniform text, every real .pac is on this side.  LF-verified from the plan's own samples; two timed steps."""
     nb = n - 1 if itype == "pacterm" else n
     t0 = time.perf_counter()
-    d_text = synth.genome_like_device(nb, 7, "cuda")
+    d_text = synth.genome_like_device(nb, 7, "cuda", repeats=repeats)
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     plan = engine.Plan(n, itype, blocksize=blocksize, isasamplingrate=plan_rate)
     out = torch.empty(n, dtype=torch.uint8, device="cuda")
     plan.run(d_text, out)                                   # (the first run of a plan on repeat-rich text sorts twice: BWT only, then with the suffix array kept)
     torch.cuda.synchronize()
+    gpu_acc(plan)
     steps = 2
     t0 = time.perf_counter()
     for _ in range(steps):
         plan.run(d_text, out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    for _ in range(steps):
+        gpu_acc(plan)
     r = plan.result()
-    m0, m1, _ = plan.lf_walk(out, sarate=0)
+    m0, m1, _ = lf_walk_timed(torch, plan, out)
     assert (m0, m1) == (0, 0), "bench genome_like: LF walk found %d symbol and %d chain mismatches" % (m0, m1)
     fam = {k["name"]: round(k["ms"], 2) for k in plan.kernel_times() if k["ms"] > 0.05}
     plan.close()
     return {"ms_per_step": round(dt * 1e3, 2), "value": round(nb / dt / 1e9, 3), "unit": "Gbase/s", "steps": steps, "tie_rounds": r["tie_rounds"],
             "tie_elements": r["tie_elements"], "families_ms": fam, "lf_verified": True, "input_gen_s": round(gen_s, 2),
-            "what": "same size, same plan, genome-like repeat-rich text (bwtb3m_amd.synth.genome_like_device): not the metric's input"}
+            "repeats": repeats,
+            "what": "same size, same plan, genome-like repeat-rich text (bwtb3m_amd.synth.genome_like_device%s): not the metric's input"
+                    % (", the harsher recipe: ~45 %% of the positions in interspersed repeats at 8-16 %% divergence" if repeats >= 0.3 else ": ~15 % of the positions planted")}
 
 
 def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
@@ -167,13 +196,20 @@ def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
         nbytes = (n + 3) // 4 if packed else n
         h_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         plan.run_host(h_text, h_out, packed=packed)    # warm-up (first touch of the pinned pages)
+        gpu_acc(plan)
         acc = {"h2d_ms": 0.0, "construct_ms": 0.0, "d2h_tail_ms": 0.0, "total_ms": 0.0}
         streamed = 0
+        per_step = []
         for _ in range(steps):
             t = plan.run_host(h_text, h_out, packed=packed)
+            gpu_acc(plan)
             for k in acc:
                 acc[k] += t[k]
             streamed = t["streamed_bytes"]
+            # every step on its own (round 4 saw ONE host-to-host step of 56 ms, construct 41 instead of 26 ms, that left no record of which family grew): a
+            # step whose construct time is a quarter above the fastest keeps the engine's family times
+            per_step.append({"total_ms": round(t["total_ms"], 2), "construct_ms": round(t["construct_ms"], 2),
+                             "families_ms": {k["name"]: round(k["ms"], 2) for k in plan.kernel_times() if k["ms"] > 0.05}})
         torch.cuda.synchronize()
         if packed:
             want = torch.cat([engine.Plan.pack_pac(c, itype == "pacterm") for c in torch.split(d_out, 1 << 28)]).cpu()   # (1 << 28 is a multiple of 4)
@@ -182,6 +218,11 @@ def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
         ok = bool(torch.equal(h_out, want))
         assert ok, "bench e2e: the BWT that arrived in host memory differs from the device-resident result"
         res = {k: round(v / steps, 3) for k, v in acc.items()}
+        fastest = min(p["construct_ms"] for p in per_step)
+        res["per_step_total_ms"] = [p["total_ms"] for p in per_step]
+        slow = [p for p in per_step if p["construct_ms"] > 1.25 * fastest]
+        if slow:
+            res["slow_steps"] = slow
         res.update({"value_e2e": round(nbases / (acc["total_ms"] / steps) / 1e6, 4), "unit": "Gbase/s", "steps": steps,
                     "bytes_in": int(h_text.numel()), "bytes_out": int(nbytes), "streamed_bytes": int(streamed), "equals_device_result": ok})
         out["packed" if packed else "bytes"] = res
@@ -196,17 +237,39 @@ def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
     return res
 
 
+def benchutil_count_gpus():
+    """GPUs of this machine without any HIP call: the KFD topology nodes with SIMDs (CPU nodes have simd_count 0); HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow it"""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                with open(os.path.join(base, d, "properties")) as f:
+                    props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(a):
     """`python3 bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): this process starts the N ranks itself --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`,
     the form the driver uses -- BEFORE anything here has touched a GPU (it never does: no HIP call, no torch.cuda.is_available()), lets
-    rank 0's ONE JSON line through on the inherited stdout and returns the ranks' status.  One rank per GPU over RCCL; with
+    rank 0's ONE JSON line through on the inherited stdout and returns the ranks' status.  (Do not profile an N > 1 run through this launcher: under
+    `rocprofv3 ... -- python3 bench.py --gpus N` the profiler's library has initialised the GPU in this parent before it starts the ranks; profile one rank directly.)  One rank per GPU over RCCL; with
     B3M_BENCH_BACKEND=gloo the ranks share the GPUs that exist (rehearsal on a one-GPU box, collectives staged through host memory)."""
     import socket
     import subprocess
-    import torch
-    ndev = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
-    if os.environ.get("B3M_BENCH_BACKEND", "nccl") == "nccl" and a.gpus > max(1, ndev):
+    ndev = benchutil_count_gpus()               # (from sysfs: nothing of HIP / torch.cuda is touched in the launcher, whatever torch's device count falls back to)
+    if os.environ.get("B3M_BENCH_BACKEND", "nccl") == "nccl" and ndev > 0 and a.gpus > ndev:      # (0: the topology could not be read -- the ranks will say)
         sys.stderr.write("bench.py: --gpus %d but this machine shows %d GPU(s); RCCL needs one GPU per rank "
                          "(B3M_BENCH_BACKEND=gloo rehearses the N>1 flow with the ranks sharing a GPU)\n" % (a.gpus, ndev))
         return 2
@@ -269,12 +332,14 @@ def main():
         d_text = buf
     for _ in range(a.warmup):
         plan.run(d_text, d_out)
+        gpu_acc(plan)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fam = {}
     for _ in range(a.steps):
         plan.run(d_text, d_out)
         benchutil.add_kernel_times(fam, plan.kernel_times())
+        gpu_acc(plan)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     d_text = d_text_gen                                   # (the view into the plan's buffer dies with the plan)
@@ -314,11 +379,15 @@ def main():
         out["config"]["bwt_only"] = time_bwt_only(torch, engine, d_text, d_out, n, itype, blocksize, max(1, min(a.steps, 10)))
     if a.genome_like and itype in ("pac", "pacterm") and n >= (1 << 22):
         out["config"]["genome_like"] = time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate)
+        if a.genome_repeats > 0:
+            out["config"]["genome_like_harsh"] = time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate, repeats=a.genome_repeats)
     if not a.no_cpu_baseline:
         sample = int(min(a.cpu_sample, n))
         # host copy of the prefix the CPU baseline works on (same bytes as the GPU workload)
         _, buf, _ = synth.config_input(a.config, size=min(want, sample + 64))
         out["cpu_baseline"] = cpu_baseline(buf, itype, sample, B)
+    out["config"]["gpu_seconds"] = {"sort_kernels": round(GPU_MS["sort"] / 1e3, 3), "lf_walks": round(GPU_MS["lf_walk"] / 1e3, 3), "plan_runs": GPU_MS["runs"],
+                                    "what": "GPU time of all legs of this run: the engine's HIP-event family times of every plan run + the wall time of the verifying LF walks"}
     print(json.dumps(out))
 
 

@@ -112,11 +112,14 @@ def config_input_device(name, size=None, device="cuda"):
     return itype, pac_file_bytes_torch(n, seed, device), n + (1 if itype == "pacterm" else 0)
 
 
-def genome_like_device(nb, seed=7, device="cuda"):
+def genome_like_device(nb, seed=7, device="cuda", repeats=0.15):
     """nb bases with the repeat structure of a genome, on the device (the recipe of tools/repeat_test.py, vectorised): uniform background;
     a 300-bp element at 10 % divergence over ~10 % of the text; a 6-kb element at 3 % over ~5 %; six 200-kb segmental duplications at
     0.1 %; microsatellites (unit 1-6, 20-200 copies) every 100 kb; one satellite array of 171 bp x 3000 at 1 %.  Returns the .pac image
-    (uint8 tensor, padded) for inputtype pac / pacterm.  NOT the timed metric (BASELINE: uniform); reported beside it."""
+    (uint8 tensor, padded) for inputtype pac / pacterm.  NOT the timed metric (BASELINE: uniform); reported beside it.
+    repeats=0.5: the harsher recipe, nearer to a human genome (about half of it interspersed repeats): the 300-bp element at 12 % over 10 % of the text (Alu-like) and an
+    older family of it at 16 % over 8 %, a 6-kb element at 8 % over 17 % (L1-like; truncated copies: a random stretch of 0.5-6 kb of it), a 2-kb element at 12 % over
+    8 %, then the duplications, microsatellites and the satellite array as above: ~45 % of the positions planted."""
     import torch
     g = torch.Generator(device=device); g.manual_seed(seed)
     b = torch.empty(nb, dtype=torch.uint8, device=device)
@@ -124,18 +127,32 @@ def genome_like_device(nb, seed=7, device="cuda"):
         m_ = min(1 << 28, nb - o)
         b[o:o + m_] = torch.randint(0, 4, (m_,), device=device, dtype=torch.uint8, generator=g)
 
-    def plant(unit, copies, rate):
+    def plant(unit, copies, rate, truncated=False):
         ln = unit.numel()
-        for c0 in range(0, copies, 1 << 16):
-            c = min(1 << 16, copies - c0)
+        per = max(1, min(1 << 16, (1 << 27) // ln)) if repeats >= 0.3 else 1 << 16       # (copies at a time; the default recipe keeps round 4's sequence of draws: the same text)
+        for c0 in range(0, copies, per):
+            c = min(per, copies - c0)
             p = torch.randint(0, nb - ln, (c,), device=device, generator=g)
             seg = unit.repeat(c, 1)
             mut = torch.rand((c, ln), device=device, generator=g) < rate
             seg = torch.where(mut, (seg + torch.randint(1, 4, (c, ln), device=device, dtype=torch.uint8, generator=g)) & 3, seg)
-            b[(p[:, None] + torch.arange(ln, device=device)[None, :]).reshape(-1)] = seg.reshape(-1)
+            at = p[:, None] + torch.arange(ln, device=device)[None, :]
+            if truncated:               # a copy is a random stretch of the element (its 3' part, as L1 copies are): columns [first, ln)
+                first = torch.randint(0, ln - ln // 12, (c,), device=device, generator=g)
+                keep = torch.arange(ln, device=device)[None, :] >= first[:, None]
+                b[at[keep]] = seg[keep]
+            else:
+                b[at.reshape(-1)] = seg.reshape(-1)
 
-    plant(torch.randint(0, 4, (300,), device=device, dtype=torch.uint8, generator=g), nb // 3000, 0.10)
-    plant(torch.randint(0, 4, (6000,), device=device, dtype=torch.uint8, generator=g), nb // 120000, 0.03)
+    if repeats >= 0.3:
+        alu = torch.randint(0, 4, (300,), device=device, dtype=torch.uint8, generator=g)
+        plant(alu, nb // 3750, 0.16)                                      # the older family first: younger copies land on top of it
+        plant(torch.randint(0, 4, (6000,), device=device, dtype=torch.uint8, generator=g), int(nb * 0.17 / 3250), 0.08, truncated=True)
+        plant(torch.randint(0, 4, (2000,), device=device, dtype=torch.uint8, generator=g), nb // 25000, 0.12)
+        plant(alu, nb // 3000, 0.12)
+    else:
+        plant(torch.randint(0, 4, (300,), device=device, dtype=torch.uint8, generator=g), nb // 3000, 0.10)
+        plant(torch.randint(0, 4, (6000,), device=device, dtype=torch.uint8, generator=g), nb // 120000, 0.03)
     if nb > 400000:
         plant(torch.randint(0, 4, (200000,), device=device, dtype=torch.uint8, generator=g), 6, 0.001)
     nms = nb // 100000                                           # microsatellites: unit u, c copies, as a masked (nms, 1200) block
