@@ -182,7 +182,7 @@ def time_genome_like(torch, engine, synth, n, itype, blocksize, plan_rate, repea
             "tie_elements": r["tie_elements"], "families_ms": fam, "lf_verified": True, "input_gen_s": round(gen_s, 2),
             "repeats": repeats,
             "what": "same size, same plan, genome-like repeat-rich text (bwtb3m_amd.synth.genome_like_device%s): not the metric's input"
-                    % (", the harsher recipe: ~45 %% of the positions in interspersed repeats at 8-16 %% divergence" if repeats >= 0.3 else ": ~15 % of the positions planted")}
+                    % (", the harsher recipe: ~45 % of the positions in interspersed repeats at 8-16 % divergence" if repeats >= 0.3 else ": ~15 % of the positions planted")}
 
 
 def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):

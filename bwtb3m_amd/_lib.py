@@ -100,6 +100,9 @@ SYMBOLS = [
     ("b3m_lf_walk", _i, [_p, _u64, _i, _p, _u64, _p, _p, _u64, _u64, _p, _p, _p, _p]),
     ("b3m_check_bwt", _i, [_cp, _cp, _cp, _i, _p]),
     ("b3m_lf_walk_job", _i, [_p, _p, _p]),
+    ("b3m_lf_walk_chains", _i, [_p, _u64, _u64, _p, _p]),
+    ("b3m_merge_samples", _i, [_p, _p, _u64, _p]),
+    ("b3m_merge_sample_pairs", _i, [_p, _p, _u64, _p, _p]),
     ("b3m_compute_ssa", _i, [_cp, _u64, _u64, _i]),
     ("b3m_plan_kernel_times", _i, [_p, ctypes.POINTER(KernelTime), _i]),
     ("b3m_histogram", _i, [_p, _u64, _i, _u64, _u64, _p, _p]),

@@ -315,7 +315,8 @@ uint64_t rank_superblocks(uint64_t m);
 void rank_build64(const uint8_t *d_bwt, uint64_t m, const uint64_t *d_p0, int type, uint32_t *d_blocks, uint32_t *d_scratch, uint32_t *scan_ws, uint64_t *d_sb, hipStream_t s);
 // extras of a walk: ISA samples (isa_out[p / isarate] = rank of the rotation at p, for the multiples of isarate: bwtcomputessa makes X.isa from a sparser X.preisa this way) and
 // nocheck (no text to compare the symbols with: T.b is not read; the chain closures are still checked)
-struct LfExtra { uint64_t isarate = 0; uint64_t *d_isa_out = nullptr; bool nocheck = false; };
+struct LfExtra { uint64_t isarate = 0; uint64_t *d_isa_out = nullptr; bool nocheck = false;
+                 uint64_t chain_first = 0, chain_count = 0; };      // chain_count > 0: only the chains [chain_first, chain_first + chain_count) (2-bit walk: one device's share of a run over several)
 void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, uint64_t p0, const uint64_t C[4], const uint64_t *d_anchors, uint64_t nanchors, uint64_t sarate,
              uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s, const LfExtra &X = LfExtra());
 void lf_walk_bytes(const TextView &T, const uint8_t *d_bwt, uint64_t *d_keys, uint64_t *d_keys2, uint32_t *d_vals, uint32_t *d_vals2, uint32_t *d_lf,

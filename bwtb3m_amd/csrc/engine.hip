@@ -1775,7 +1775,8 @@ int b3m_block_sort_abs(const void *d_text, uint64_t n, int inputtype, uint64_t s
  * terminator, [1..4] the bases; pac: [0..3]); anchors: K (rank,pos) pairs in position order, the first at position 0 (host); p0 = rank of the terminator entry
  * (~0: none).  SA samples go to sa_out (host) and/or stay in d_sa_keep (device, ceil(n/sarate) u64) for a caller that streams them out itself. */
 static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, const uint64_t *hist, const uint64_t *anchors, uint64_t K, uint64_t sarate,
-                         uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, hipStream_t s, uint64_t isarate = 0, uint64_t *isa_out = nullptr, bool nocheck = false)
+                         uint64_t *sa_out, uint64_t *d_sa_keep, uint64_t *mismatches_out, hipStream_t s, uint64_t isarate = 0, uint64_t *isa_out = nullptr, bool nocheck = false,
+                         uint64_t chain_first = 0, uint64_t chain_count = 0)
 {
 	const uint64_t n = T.n;
 	B3M_REQUIRE(K >= 1 && anchors[1] == 0, "anchor at position 0 missing");
@@ -1785,7 +1786,7 @@ static void lf_walk_2bit(const TextView &T, const uint8_t *d_bwt, uint64_t p0, c
 	DevBuf blocks(64 * nb), scratch(64 * nb + 64), sws(4 * scan_ws_elems(nb) + 64), sb(32 * nsb + 64), p0d(16), danc(16 * K), dsa(d_sa_keep ? 16 : 8 * (nsa + 1)), dmis(16), disa(8 * (nisa + 1));
 	uint64_t *d_sa = d_sa_keep ? d_sa_keep : dsa.as<uint64_t>();
 	if (nisa) B3M_HIP(hipMemsetAsync(disa.p, 0xFF, 8 * nisa, s));
-	LfExtra X; X.isarate = nisa ? isarate : 0; X.d_isa_out = disa.as<uint64_t>(); X.nocheck = nocheck;
+	LfExtra X; X.isarate = nisa ? isarate : 0; X.d_isa_out = disa.as<uint64_t>(); X.nocheck = nocheck; X.chain_first = chain_first; X.chain_count = chain_count;
 	B3M_HIP(hipMemcpyAsync(p0d.p, &p0, 8, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemcpyAsync(danc.p, anchors, 16 * K, hipMemcpyHostToDevice, s));
 	B3M_HIP(hipMemsetAsync(dmis.p, 0, 16, s));
@@ -1850,6 +1851,70 @@ int b3m_lf_walk_job(const b3m_lf_job *j, uint64_t *mismatches_out, void *stream)
 	}
 	lf_walk_2bit(T, j->d_bwt, j->inputtype == B3M_INPUT_PACTERM ? j->p0 : ~0ull, j->hist256, j->sample_pairs, j->num_samples, j->sarate, j->sa_out, j->d_sa_out, mismatches_out,
 	             (hipStream_t)stream, j->isarate, j->isa_out, nocheck);
+	return 0;
+	B3M_CATCH(1)
+}
+
+/* ONE DEVICE'S SHARE of the walks of a run over several devices (b3m_compute_bwt with num_gpus > 1): the chains [chain_first, chain_first + chain_count) of the job
+ * (chain k runs from sample k + 1 back to sample k), over the whole BWT on the current device; d_sa_out (device, ceil(n / sarate) u64, required when sarate > 0) is
+ * filled with ~0 first and receives the SA samples these chains meet: the shares of all devices together hold every sample once.  pac / pacterm. */
+int b3m_lf_walk_chains(const b3m_lf_job *j, uint64_t chain_first, uint64_t chain_count, uint64_t *mismatches_out, void *stream)
+{
+	B3M_TRY
+	switches_load();
+	require_device();
+	B3M_REQUIRE(j && j->d_bwt && j->d_text && j->hist256 && j->sample_pairs && mismatches_out && j->num_samples >= 1, "b3m_lf_walk_chains: null argument");
+	B3M_REQUIRE(j->inputtype == B3M_INPUT_PAC || j->inputtype == B3M_INPUT_PACTERM, "b3m_lf_walk_chains: pac and pacterm texts");
+	B3M_REQUIRE(chain_count >= 1 && chain_first + chain_count <= j->num_samples, "b3m_lf_walk_chains: chain range out of range");
+	B3M_REQUIRE(!j->sarate || j->d_sa_out, "b3m_lf_walk_chains: the SA samples of a share stay on the device (d_sa_out)");
+	B3M_REQUIRE(!j->sa_out && !j->isa_out, "b3m_lf_walk_chains: host outputs belong to the whole job (b3m_lf_walk_job)");
+	TextView T{(const uint8_t *)j->d_text, j->n, num_bases(j->n, j->inputtype), j->inputtype};
+	lf_walk_2bit(T, j->d_bwt, j->inputtype == B3M_INPUT_PACTERM ? j->p0 : ~0ull, j->hist256, j->sample_pairs, j->num_samples, j->sarate, nullptr, j->d_sa_out, mismatches_out,
+	             (hipStream_t)stream, 0, nullptr, false, chain_first, chain_count);
+	return 0;
+	B3M_CATCH(1)
+}
+/* d_dst[i] = d_src[i] where d_src[i] != ~0 (count u64 on the current device): the shares of b3m_lf_walk_chains put together */
+__global__ void k_merge_set_u64(uint64_t *dst, const uint64_t *src, uint64_t count)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count && src[i] != ~0ull) dst[i] = src[i];
+}
+/* (rank,pos) sample tables of suffix-range shards put together on the device: slot i of d_src with a rank != ~0 goes to slot i of d_dst; stats_out[0] += slots both
+ * tables had ranked, stats_out[1] = slots of d_dst that are still empty afterwards (host memory) */
+__global__ void k_merge_pairs(uint64_t *dst, const uint64_t *src, uint64_t npairs, unsigned long long *stats)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= npairs) return;
+	const uint64_t r = src[2 * i];
+	if (r != ~0ull) {
+		if (dst[2 * i] != ~0ull) atomicAdd(&stats[0], 1ull);
+		dst[2 * i] = r; dst[2 * i + 1] = src[2 * i + 1];
+	} else if (dst[2 * i] == ~0ull) atomicAdd(&stats[1], 1ull);
+}
+int b3m_merge_sample_pairs(uint64_t *d_dst, const uint64_t *d_src, uint64_t npairs, uint64_t *stats_out, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(d_dst && d_src && stats_out, "b3m_merge_sample_pairs: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	DevBuf st(16);
+	B3M_HIP(hipMemsetAsync(st.p, 0, 16, s));
+	if (npairs) hipLaunchKernelGGL(k_merge_pairs, dim3((uint32_t)((npairs + 255) / 256)), dim3(256), 0, s, d_dst, d_src, npairs, st.as<unsigned long long>());
+	unsigned long long h[2] = {0, 0};
+	B3M_HIP(hipMemcpyAsync(h, st.p, 16, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	stats_out[0] += h[0]; stats_out[1] = h[1];
+	return 0;
+	B3M_CATCH(1)
+}
+int b3m_merge_samples(uint64_t *d_dst, const uint64_t *d_src, uint64_t count, void *stream)
+{
+	B3M_TRY
+	require_device();
+	B3M_REQUIRE(d_dst && d_src, "b3m_merge_samples: null argument");
+	if (count) hipLaunchKernelGGL(k_merge_set_u64, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_dst, d_src, count);
+	B3M_HIP(hipStreamSynchronize((hipStream_t)stream));
 	return 0;
 	B3M_CATCH(1)
 }

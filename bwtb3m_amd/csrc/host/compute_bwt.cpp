@@ -65,7 +65,8 @@ struct Built {
 	uint64_t p0 = 0, num_blocks = 1, levels = 0;
 	uint64_t hist[256] = {0};
 	const uint64_t *pairs = nullptr; uint64_t npairs = 0;     // (rank,pos) samples in position order, host memory
-	const uint64_t *d_pairs = nullptr;                        // or (one GPU, X.preisa only) their image in HBM
+	const uint64_t *d_pairs = nullptr;                        // or (X.preisa only) their image in HBM
+	uint64_t *d_pairs_own = nullptr;                          // ... which this struct owns (several GPUs: the shards' tables put together on the first device)
 	std::vector<uint64_t> pairs_store;
 	double ms_sort = 0, ms_gap = 0, ms_interleave = 0;
 };
@@ -75,6 +76,7 @@ struct Shard {
 	uint64_t tied = 0, placed = 0, depth = 0;                // what the shard's run left on its list (b3m_plan_list_counts)
 	uint64_t *d_tied = nullptr, *d_placed = nullptr;         // its records (b3m_plan_list_export)
 	uint64_t *d_tied_all = nullptr, *d_placed_all = nullptr; // the union on this shard's device (b3m_plan_list_finish)
+	uint8_t *d_full = nullptr;                               // the whole BWT on this shard's device (bwtonly=0: every device walks its share of the LF chains)
 };
 
 // the devices of an N-GPU run: 0 .. N-1, or what B3M_DEVICES lists (test switch: "0,0,0,0" runs four shards' worth of host threads, plans and peer
@@ -100,14 +102,16 @@ void free_shards(std::vector<Shard> &sh)
 	for (auto &s : sh) {
 		(void)hipSetDevice(s.dev);
 		if (s.plan) b3m_plan_destroy(s.plan);
-		for (void *p : {(void *)s.d_out, (void *)s.d_tied, (void *)s.d_placed, (void *)s.d_tied_all, (void *)s.d_placed_all}) if (p) (void)hipFree(p);
+		for (void *p : {(void *)s.d_out, (void *)s.d_tied, (void *)s.d_placed, (void *)s.d_tied_all, (void *)s.d_placed_all, (void *)s.d_full}) if (p) (void)hipFree(p);
 		s = Shard{};
 	}
 }
 
 // N suffix-range shards, one host thread and one device each; d_text0: the packed text on devs[0].  Leaves the whole BWT on devs[0].
+// gather: 0 = the slices stay where they are (bwtonly=1: every device codes its own part of X.bwt), 1 = the whole BWT on the first device (the form before round 5),
+// 2 = on EVERY device (bwtonly=0: every device also walks its share of the LF chains)
 void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint64_t mem, uint64_t rate, const void *d_text0, uint64_t tb, Built &B, std::vector<Shard> &sh,
-                       const Log &log)
+                       const Log &log, int gather)
 {
 	const int N = (int)devs.size();
 	sh.assign((size_t)N, Shard{});
@@ -198,13 +202,15 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	}
 	if (pos != n) throw std::runtime_error("internal: the shards' slices do not cover the rank space");
 	B.dev = devs[0];
-	HIPCHK(hipSetDevice(B.dev));
-	HIPCHK(hipMalloc((void **)&B.d_bwt, n + 16));
-	on_threads(N, [&](int k) {
-		Shard &s = sh[(size_t)k];
-		HIPCHK(hipSetDevice(B.dev));
-		if (s.res.slice_len) HIPCHK(hipMemcpyPeer(B.d_bwt + s.res.slice_offset, B.dev, s.d_out, s.dev, s.res.slice_len));
+	if (gather) on_threads(N, [&](int k) {
+		Shard &d = sh[(size_t)k];
+		if (gather == 1 && k) return;
+		HIPCHK(hipSetDevice(d.dev));
+		HIPCHK(hipMalloc((void **)&d.d_full, n + 16));
+		for (const Shard &s : sh) if (s.res.slice_len) HIPCHK(hipMemcpyPeer(d.d_full + s.res.slice_offset, d.dev, s.d_out, s.dev, s.res.slice_len));
+		HIPCHK(hipDeviceSynchronize());                   // (device-to-device copies return before they are done; the readers use streams that do not wait for the null stream)
 	});
+	B.d_bwt = sh[0].d_full;                              // (null without a gather; owned by the shard)
 	HIPCHK(hipSetDevice(B.dev));
 	B.d_text = b3m_plan_text_buffer(sh[0].plan);
 	B.num_blocks = 1; B.levels = 0;
@@ -217,7 +223,37 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	HIPCHK(hipSetDevice(sh[0].dev));
 	B3MCHK(b3m_plan_histogram(sh[0].plan, B.hist));          // (every shard's level 0 sees the whole text: any shard has the text's histogram)
 	// samples: every sampled position got its rank from exactly one shard (slot i of each shard's pinned image = position i * rate)
-	if (rate) {
+	if (rate && gather != 2 && 16 * ((n + rate - 1) / rate) > (64ull << 20)) {      // (gather 2 = bwtonly=0: the LF walks read the pairs from host memory)
+		// a large table (bwtonly=1 samples every 64th position: 750 MB at 3 Gbase) never comes to the host: the shards' device images are put together on the first
+		// device and X.preisa is streamed from there, as on one GPU
+		const uint64_t nslots = (n + rate - 1) / rate;
+		HIPCHK(hipSetDevice(B.dev));
+		HIPCHK(hipMalloc((void **)&B.d_pairs_own, 16 * nslots + 16));
+		HIPCHK(hipMemset(B.d_pairs_own, 0xFF, 16 * nslots));
+		uint64_t *tmp = nullptr;
+		uint64_t stats[2] = {0, nslots};
+		try {
+			for (int k = 0; k < N; ++k) {
+				const uint64_t *d_slots = nullptr; uint64_t c = 0;
+				HIPCHK(hipSetDevice(sh[(size_t)k].dev));
+				B3MCHK(b3m_plan_samples_device(sh[(size_t)k].plan, &d_slots, &c, nullptr, nullptr));
+				if (c != nslots) throw std::runtime_error("internal: sample tables differ");
+				HIPCHK(hipDeviceSynchronize());
+				HIPCHK(hipSetDevice(B.dev));
+				const uint64_t *src = d_slots;
+				if (sh[(size_t)k].dev != B.dev) {
+					if (!tmp) HIPCHK(hipMalloc((void **)&tmp, 16 * nslots + 16));
+					HIPCHK(hipMemcpyPeer(tmp, B.dev, d_slots, sh[(size_t)k].dev, 16 * nslots));
+					src = tmp;
+				}
+				B3MCHK(b3m_merge_sample_pairs(B.d_pairs_own, src, nslots, stats, nullptr));
+			}
+		} catch (...) { if (tmp) { (void)hipSetDevice(B.dev); (void)hipFree(tmp); } throw; }
+		if (tmp) (void)hipFree(tmp);
+		if (stats[0]) throw std::runtime_error("internal: " + std::to_string(stats[0]) + " sampled positions were ranked by two shards");
+		if (stats[1]) throw std::runtime_error("internal: the (rank,pos) samples of " + std::to_string(stats[1]) + " positions were written by no shard");
+		B.d_pairs = B.d_pairs_own; B.npairs = nslots;
+	} else if (rate) {
 		uint64_t nslots = 0; std::vector<const uint64_t *> raw((size_t)N, nullptr);
 		for (int k = 0; k < N; ++k) { uint64_t c = 0; HIPCHK(hipSetDevice(sh[(size_t)k].dev)); B3MCHK(b3m_plan_samples_raw(sh[(size_t)k].plan, &raw[(size_t)k], &c)); if (k && c != nslots) throw std::runtime_error("internal: sample tables differ"); nslots = c; }
 		B.pairs_store.assign(2 * nslots, ~0ull);
@@ -232,8 +268,167 @@ void construct_sharded(const std::vector<int> &devs, int type, uint64_t n, uint6
 	HIPCHK(hipSetDevice(B.dev));
 	std::map<int, int> distinct;
 	for (int d : devs) distinct[d] = 1;
-	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu tied + %llu placed suffixes on the shards' lists%s), gather %.3f s\n", N,
-	    (int)distinct.size(), t1 - t0, t2 - t1, (unsigned long long)total, (unsigned long long)placed, local ? ": too many for a shard's workspace, finished shard by shard" : "", now() - t2);
+	log("[V] %d suffix-range shards on %d device(s): plans + sort %.3f s, tie finish %.3f s (%llu tied + %llu placed suffixes on the shards' lists%s), %s %.3f s\n", N,
+	    (int)distinct.size(), t1 - t0, t2 - t1, (unsigned long long)total, (unsigned long long)placed, local ? ": too many for a shard's workspace, finished shard by shard" : "",
+	    gather == 2 ? "BWT gathered on every device" : gather == 1 ? "gather" : "slices stay on their devices, samples merged", now() - t2);
+}
+
+// the whole BWT on the first device after all (a part of the distributed output stage could not be used)
+void gather_on_first(std::vector<Shard> &sh, uint64_t n, Built &B)
+{
+	Shard &d = sh[0];
+	HIPCHK(hipSetDevice(d.dev));
+	if (!d.d_full) {
+		HIPCHK(hipMalloc((void **)&d.d_full, n + 16));
+		for (const Shard &s : sh) if (s.res.slice_len) HIPCHK(hipMemcpyPeer(d.d_full + s.res.slice_offset, d.dev, s.d_out, s.dev, s.res.slice_len));
+		HIPCHK(hipDeviceSynchronize());
+	}
+	B.d_bwt = d.d_full;
+}
+
+// X.bwt from the slices where they lie: a block of the container is runs_per_block runs counted from the start of the BWT, so the devices first count the run heads of
+// their slices (one small exchange of counts through this host process: the role of an all-gather), every device finds where the first block that BEGINS in its slice
+// starts, takes the symbols from there to the next device's first block (its own slice and the head of the following one, by peer copy) and codes them -- runs,
+// frequencies, both code streams on the device, tables on its share of the host threads -- and writes its image at the offset the sizes in front of it give.  The
+// file is the one-device file byte for byte.  false: not an input for the device encoder (see rl_encode_device); nothing usable was written.
+bool encode_sharded(const std::string &fn, std::vector<Shard> &sh, uint64_t n, uint64_t rpb, unsigned numthreads, const int64_t *symmap, const Log &log)
+{
+	const int N = (int)sh.size();
+	const double t0 = now();
+	struct Part { std::vector<uint32_t> tile_first; uint8_t first = 0, last = 0; bool cont = false; uint64_t heads = 0, G = 0, b0 = 0, P = 0, Pend = 0; bool starts = false;
+	              std::unique_ptr<b3m::RLPart> img; bool ok = true; uint64_t base = 0; };
+	std::vector<Part> pt((size_t)N);
+	std::vector<hipStream_t> st((size_t)N, nullptr);
+	struct Streams { std::vector<Shard> &sh; std::vector<hipStream_t> &st; ~Streams() { for (size_t k = 0; k < st.size(); ++k) if (st[k]) { (void)hipSetDevice(sh[k].dev); (void)hipStreamDestroy(st[k]); } } } guard{sh, st};
+	on_threads(N, [&](int k) {
+		Shard &s = sh[(size_t)k];
+		HIPCHK(hipSetDevice(s.dev));
+		HIPCHK(hipStreamCreateWithFlags(&st[(size_t)k], hipStreamNonBlocking));
+		b3m::rl_slice_scan(s.d_out, s.res.slice_len, st[(size_t)k], pt[(size_t)k].tile_first, &pt[(size_t)k].first, &pt[(size_t)k].last);
+	});
+	// run heads in front of every slice; the first block that begins inside it
+	uint64_t G = 0; int prev = -1;
+	for (int k = 0; k < N; ++k) {
+		Part &p = pt[(size_t)k];
+		if (!sh[(size_t)k].res.slice_len) continue;
+		p.cont = prev >= 0 && pt[(size_t)prev].last == p.first;          // the slice goes on with its neighbour's last run: its position 0 is no head
+		p.heads = (uint64_t)p.tile_first.back() - (p.cont ? 1 : 0);
+		p.G = G; p.b0 = (G + rpb - 1) / rpb;
+		p.starts = p.b0 * rpb < G + p.heads;
+		G += p.heads; prev = k;
+	}
+	const uint64_t runs = G;
+	on_threads(N, [&](int k) {
+		Part &p = pt[(size_t)k]; Shard &s = sh[(size_t)k];
+		if (!p.starts) return;
+		HIPCHK(hipSetDevice(s.dev));
+		p.P = s.res.slice_offset + b3m::rl_head_position(s.d_out, s.res.slice_len, p.tile_first, p.b0 * rpb - p.G + (p.cont ? 1 : 0), st[(size_t)k]);
+	});
+	{
+		uint64_t end = n;
+		for (int k = N - 1; k >= 0; --k) if (pt[(size_t)k].starts) { pt[(size_t)k].Pend = end; end = pt[(size_t)k].P; }
+		if (end != 0) throw std::runtime_error("internal: the first block of the run-length container does not begin at symbol 0");
+	}
+	int nparts = 0;
+	for (auto &p : pt) nparts += p.starts ? 1 : 0;
+	const unsigned thr = std::max(1u, numthreads / (unsigned)std::max(1, nparts));
+	on_threads(N, [&](int k) {
+		Part &p = pt[(size_t)k]; Shard &d = sh[(size_t)k];
+		if (!p.starts) return;
+		HIPCHK(hipSetDevice(d.dev));
+		const uint64_t len = p.Pend - p.P;
+		uint8_t *buf = nullptr;
+		HIPCHK(hipMalloc((void **)&buf, len + 16));
+		try {
+			for (const Shard &s : sh) {
+				const uint64_t lo = std::max(p.P, s.res.slice_offset), hi = std::min(p.Pend, s.res.slice_offset + s.res.slice_len);
+				if (lo < hi) HIPCHK(hipMemcpyPeerAsync(buf + (lo - p.P), d.dev, s.d_out + (lo - s.res.slice_offset), s.dev, hi - lo, st[(size_t)k]));
+			}
+			HIPCHK(hipStreamSynchronize(st[(size_t)k]));
+			p.img.reset(new b3m::RLPart());
+			p.ok = b3m::rl_encode_part(buf, len, rpb, thr, symmap, st[(size_t)k], *p.img);
+		} catch (...) { (void)hipFree(buf); throw; }
+		(void)hipFree(buf);
+	});
+	for (auto &p : pt) if (p.starts && !p.ok) return false;
+	// offsets; every part holds whole blocks: as many as lie between its first block and the next part's
+	std::vector<b3m::RLIndexEntry> index;
+	uint64_t fpos = 8, nextb = (runs + rpb - 1) / rpb;
+	for (int k = N - 1; k >= 0; --k) {
+		Part &p = pt[(size_t)k];
+		if (!p.starts) continue;
+		if (p.img->index.size() != nextb - p.b0) throw std::runtime_error("internal: a device's part of the run-length container holds " + std::to_string(p.img->index.size()) +
+		                                                                  " blocks, " + std::to_string(nextb - p.b0) + " begin in its range");
+		nextb = p.b0;
+	}
+	for (int k = 0; k < N; ++k) {
+		Part &p = pt[(size_t)k];
+		if (!p.starts) continue;
+		p.base = fpos;
+		for (const b3m::RLIndexEntry &e : p.img->index) index.push_back({fpos + e.pos, e.runs, e.syms});
+		fpos += p.img->bytes;
+	}
+	const double t1 = now();
+	b3m::ParFile pf(fn);
+	on_threads(N, [&](int k) {
+		Part &p = pt[(size_t)k];
+		if (!p.starts) return;
+		uint64_t at = p.base;
+		for (auto &im : p.img->images) { pf.put_device(at, im.first, im.second, p.img->dev, std::min(thr, 8u)); at += im.second; }
+	});
+	std::vector<uint8_t> head, tail;
+	b3m::rl_container_ends(n, fpos - 8, index, head, tail);
+	pf.put(0, head.data(), head.size());
+	pf.put(fpos, tail.data(), tail.size());
+	pf.close();
+	log("[V] X.bwt coded by %d of %d devices, each the blocks that begin in its slice (%llu runs, %llu blocks): run heads + coding %.3f s, images to the file %.3f s\n", nparts, N,
+	    (unsigned long long)runs, (unsigned long long)index.size(), t1 - t0, now() - t1);
+	return true;
+}
+
+// X.sa's samples from the LF walks, every device its share of the chains over its own copy of the BWT (Shard::d_full) and the packed text of its plan; the shares are put
+// together on the first device (d_sa: ceil(n / sarate) u64 there).  Every symbol and every chain is verified on the way, as on one device.
+void walk_sharded(std::vector<Shard> &sh, uint64_t n, int type, const Built &B, uint64_t sarate, uint64_t *d_sa, uint64_t mm[2], const Log &log)
+{
+	const int N = (int)sh.size();
+	const uint64_t nsa = (n + sarate - 1) / sarate, K = B.npairs;
+	const double t0 = now();
+	std::vector<uint64_t *> part((size_t)N, nullptr);
+	std::vector<uint64_t> m0((size_t)N, 0), m1((size_t)N, 0);
+	struct Free { std::vector<Shard> &sh; std::vector<uint64_t *> &p; ~Free() { for (size_t k = 1; k < p.size(); ++k) if (p[k]) { (void)hipSetDevice(sh[k].dev); (void)hipFree(p[k]); } } } guard{sh, part};
+	part[0] = d_sa;
+	on_threads(N, [&](int k) {
+		Shard &s = sh[(size_t)k];
+		const uint64_t c0 = K * (uint64_t)k / (uint64_t)N, c1 = K * (uint64_t)(k + 1) / (uint64_t)N;
+		HIPCHK(hipSetDevice(s.dev));
+		if (k) HIPCHK(hipMalloc((void **)&part[(size_t)k], 8 * nsa + 16));
+		hipStream_t st = nullptr;
+		HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		b3m_lf_job j{};
+		j.d_text = b3m_plan_text_buffer(s.plan); j.n = n; j.inputtype = type; j.d_bwt = s.d_full; j.p0 = B.p0; j.hist256 = B.hist;
+		j.sample_pairs = B.pairs; j.num_samples = K; j.sarate = sarate; j.d_sa_out = part[(size_t)k];
+		uint64_t m[2] = {0, 0};
+		int rc = 0;
+		if (c1 > c0) rc = b3m_lf_walk_chains(&j, c0, c1 - c0, m, st);
+		else HIPCHK(hipMemset(part[(size_t)k], 0xFF, 8 * nsa));
+		(void)hipStreamDestroy(st);
+		if (rc) throw std::runtime_error(b3m_last_error());
+		m0[(size_t)k] = m[0]; m1[(size_t)k] = m[1];
+	});
+	const double t1 = now();
+	mm[0] = mm[1] = 0;
+	for (int k = 0; k < N; ++k) { mm[0] += m0[(size_t)k]; mm[1] += m1[(size_t)k]; }
+	HIPCHK(hipSetDevice(sh[0].dev));
+	uint64_t *tmp = nullptr;
+	if (N > 1) HIPCHK(hipMalloc((void **)&tmp, 8 * nsa + 16));
+	try {
+		for (int k = 1; k < N; ++k) {
+			HIPCHK(hipMemcpyPeer(tmp, sh[0].dev, part[(size_t)k], sh[(size_t)k].dev, 8 * nsa));
+			B3MCHK(b3m_merge_samples(d_sa, tmp, nsa, nullptr));
+		}
+	} catch (...) { if (tmp) (void)hipFree(tmp); throw; }
+	if (tmp) (void)hipFree(tmp);
+	log("[V] LF walks on %d devices, %llu chains each: %.3f s; SA samples put together on the first: %.3f s\n", N, (unsigned long long)(K / (uint64_t)N), t1 - t0, now() - t1);
 }
 }  // namespace
 
@@ -260,6 +455,7 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (B.plan) b3m_plan_destroy(B.plan);
 		if (d_text) (void)hipFree(d_text);
 		if (own_bwt && B.d_bwt) (void)hipFree(B.d_bwt);
+		if (B.d_pairs_own) (void)hipFree(B.d_pairs_own);
 		if (h_text) b3m_host_free(h_text);
 		if (h_bwt) b3m_host_free(h_bwt);
 		b3m::staging_release();
@@ -420,15 +616,15 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 		if (run_sharded) {
 			log("[V] input read into HBM in %.3f s\n", tp1 - tp0);
 			t1 = now();
-			own_bwt = true;
-			try { construct_sharded(devs, type, n, mem, anchor_rate, d_text, tb, B, shards, log); }
+			// (the whole BWT on every device for the LF walks of bwtonly=0; bwtonly=1 needs it nowhere: the slices are coded where they lie)
+			try { construct_sharded(devs, type, n, mem, anchor_rate, d_text, tb, B, shards, log, want_sa ? 2 : 0); own_bwt = false; }
 			catch (const std::exception &e) {
 				const std::string why = e.what();
 				if (!refusal(why) || n >= (1ull << 32)) throw;
 				free_shards(shards);
 				HIPCHK(hipSetDevice(dev0));
-				if (B.d_bwt) (void)hipFree(B.d_bwt);
-				B = Built{}; own_bwt = false;
+				if (B.d_pairs_own) (void)hipFree(B.d_pairs_own);
+				B = Built{}; own_bwt = false;          // (the shards owned their copies of the BWT)
 				Log{log_fd}("[W] numgpus=%d: %s -- constructing on one device instead\n", ngpus, why.c_str());
 				B.plan = b3m_plan_create(n, type, 0, mem, anchor_rate);
 				if (B.plan && b3m_plan_host_tier(B.plan)) { b3m_plan_destroy(B.plan); B.plan = b3m_plan_create(n, type, 0, 0, anchor_rate); }      // (the text is in HBM already)
@@ -517,6 +713,9 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 					std::map<int64_t, uint64_t> hm;
 					for (uint64_t i = 0; i < n; ++i) hm[wide_map[bw[i]]]++;
 					b3m::write_hist_map(prefix + ".hist", hm);
+				} else if (run_sharded && !b3m::sw().HOST_RL.set && encode_sharded(outfn, shards, n, 64 * 1024, enc_threads, symmap, log)) {
+					HIPCHK(hipSetDevice(B.dev));
+					b3m::write_hist(prefix + ".hist", B.hist, symmap);
 				} else if (!B.d_bwt && h_bwt) {
 					// host tier, bwtonly=1: the BWT is in pinned host memory; the device encoder takes it one segment at a time (a sixteenth of the memory target)
 					const uint64_t seg = std::max<uint64_t>(1ull << 24, mem / 16);
@@ -524,6 +723,8 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 						b3m::rl_encode_file(outfn, h_bwt, n, 64 * 1024, enc_threads, symmap);
 					b3m::write_hist(prefix + ".hist", B.hist, symmap);
 				} else {
+					if (run_sharded && !B.d_bwt) gather_on_first(shards, n, B);       // (the slices could not be coded where they lie: a text for the host encoder)
+					HIPCHK(hipSetDevice(B.dev));
 					if (b3m::sw().HOST_RL.set || !b3m::rl_encode_device(outfn, B.d_bwt, n, 64 * 1024, enc_threads, symmap, s)) {
 						std::vector<uint8_t> bwt(n);
 						HIPCHK(hipMemcpy(bwt.data(), B.d_bwt, n, hipMemcpyDeviceToHost));
@@ -553,8 +754,13 @@ extern "C" int b3m_compute_bwt(const b3m_options *o, int log_fd)
 					// the SA samples stay in HBM and leave for the file in pieces (0.75 GB at 3 Gbase and rate 32)
 					uint64_t *d_sa = nullptr;
 					HIPCHK(hipMalloc((void **)&d_sa, 8 * nsa + 16));
-					int rc = B.plan ? b3m_plan_lf_walk_dev(B.plan, B.d_bwt, sarate, d_sa, mm, s)
-					                : b3m_lf_walk(B.d_text, n, type, B.d_bwt, B.p0, B.hist, B.pairs, B.npairs, sarate, nullptr, d_sa, mm, s);
+					int rc = 0;
+					if (run_sharded && shards.size() > 1 && B.npairs >= shards.size()) {
+						try { walk_sharded(shards, n, type, B, sarate, d_sa, mm, log); } catch (...) { (void)hipFree(d_sa); throw; }
+						HIPCHK(hipSetDevice(B.dev));
+					}
+					else rc = B.plan ? b3m_plan_lf_walk_dev(B.plan, B.d_bwt, sarate, d_sa, mm, s)
+					                 : b3m_lf_walk(B.d_text, n, type, B.d_bwt, B.p0, B.hist, B.pairs, B.npairs, sarate, nullptr, d_sa, mm, s);
 					if (rc) { (void)hipFree(d_sa); throw std::runtime_error(b3m_last_error()); }
 					if (!(mm[0] || mm[1])) pf.put_device(16, d_sa, 8 * nsa, B.dev, io_threads);
 					(void)hipFree(d_sa);

@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace b3m {
@@ -43,6 +44,17 @@ bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t 
 // the same from a BWT in (pinned) host memory, brought to HBM one segment of at most seg_limit symbols at a time (host tier)
 bool rl_encode_device_from_host(const std::string &fn, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream,
                                 uint64_t seg_limit);
+// one file from several devices: every device codes the blocks that BEGIN in its slice of the BWT (csrc/k_rlenc.hip, used by b3m_compute_bwt with num_gpus > 1)
+struct RLPart {
+	int dev = 0; uint64_t bytes = 0;
+	std::vector<std::pair<void *, uint64_t>> images;     // device pointers (owned) and their sizes, in file order
+	std::vector<RLIndexEntry> index;                      // the part's blocks; pos relative to the part's first byte
+	RLPart() = default; ~RLPart();
+	RLPart(const RLPart &) = delete; RLPart &operator=(const RLPart &) = delete;
+};
+void rl_slice_scan(const uint8_t *d_symbols, uint64_t len, void *hip_stream, std::vector<uint32_t> &tile_first, uint8_t *first_sym, uint8_t *last_sym);
+uint64_t rl_head_position(const uint8_t *d_symbols, uint64_t len, const std::vector<uint32_t> &tile_first, uint64_t ordinal, void *hip_stream);
+bool rl_encode_part(const uint8_t *d_symbols, uint64_t len, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream, RLPart &out);
 void rl_container_ends(uint64_t n, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index, std::vector<uint8_t> &head, std::vector<uint8_t> &tail);
 void rl_write_container(const std::string &fn, uint64_t n, const uint8_t *blocks, uint64_t blocks_bytes, const std::vector<RLIndexEntry> &index);
 std::vector<RLIndexEntry> rl_index(const std::string &fn);

@@ -592,11 +592,13 @@ struct LfWalkArgs {
 	uint64_t *sa_out;               // ceil(n / sarate) positions
 	unsigned long long *mismatch;   // [0] symbol mismatches, [1] chain closure mismatches
 	uint64_t isarate; uint64_t *isa_out; int nocheck;      // LfExtra
+	uint64_t kfirst, kcount;        // the chains this launch walks
 };
 __global__ __launch_bounds__(256) void k_lf_walk(LfWalkArgs A)
 {
 	uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= A.nanchors) return;
+	if (k >= A.kcount) return;
+	k += A.kfirst;
 	const TextView &T = A.T;
 	const bool term = T.type == B3M_INPUT_PACTERM;
 	const uint64_t p0 = A.rd.p0;
@@ -639,8 +641,9 @@ void lf_walk(const TextView &T, const uint32_t *d_blocks, const uint64_t *d_sb, 
              uint64_t *d_sa_out, unsigned long long *d_mismatch, hipStream_t s, const LfExtra &X)
 {
 	LfWalkArgs A{T, RankDict64{d_blocks, d_sb, rank_sb_shift(), T.n, p0, {C[0], C[1], C[2], C[3]}}, d_anchors, nanchors, sarate, d_sa_out, d_mismatch,
-	             X.isarate, X.d_isa_out, X.nocheck ? 1 : 0};
-	if (nanchors) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(nanchors)), dim3(256), 0, s, A);
+	             X.isarate, X.d_isa_out, X.nocheck ? 1 : 0, 0, nanchors};
+	if (X.chain_count) { A.kfirst = std::min(X.chain_first, nanchors); A.kcount = std::min(X.chain_count, nanchors - A.kfirst); }
+	if (A.kcount) hipLaunchKernelGGL(k_lf_walk, dim3(nblk(A.kcount)), dim3(256), 0, s, A);
 }
 
 // Byte alphabets (byte LF walk): no rank dictionary -- the whole LF array is built by ONE

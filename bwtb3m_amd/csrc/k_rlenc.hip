@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <thread>
 
@@ -181,8 +182,33 @@ __global__ __launch_bounds__(64) void k_rl_headers(const uint8_t *blob, const ui
 // begins at a run head, encodes the whole blocks of runs_per_block runs that lie inside it -- never its last run, which may go on behind the
 // segment's end -- and the next segment begins where its last block ended.  The blocks of the file are the same ones, whatever the segments.
 // h_symbols != null: the BWT lies in host memory (host tier: it never was in HBM as a whole) and every segment is brought to a staging buffer of seg_max bytes first
+// The encoder proper hands every segment's image (in HBM, freed when the sink returns unless the sink takes the pointer) and its blocks (positions relative to the image)
+// to a sink: the file writer below puts it at the next file offset; the encoder of ONE PART of a file (several devices, each with a range of whole blocks) keeps it.
+using RLSink = std::function<void(Buf &image, uint64_t bytes, std::vector<RLIndexEntry> &blocks)>;
+static bool rl_encode_stream(const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
+                             void *hip_stream, uint64_t seg_limit, const RLSink &sink);
 static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
-                           void *hip_stream, uint64_t seg_limit);
+                           void *hip_stream, uint64_t seg_limit)
+{
+	int dev = 0;
+	B3M_HIP(hipGetDevice(&dev));
+	std::unique_ptr<ParFile> pf;
+	std::vector<RLIndexEntry> index;
+	uint64_t fpos = 8;                                    // file offset of the next block (8 bytes of n in front)
+	const bool ok = rl_encode_stream(d_symbols, h_symbols, n, runs_per_block, numthreads, symmap, hip_stream, seg_limit, [&](Buf &image, uint64_t bytes, std::vector<RLIndexEntry> &blocks) {
+		if (!pf) pf.reset(new ParFile(fn));
+		pf->put_device(fpos, image.p, bytes, dev, std::min(numthreads ? numthreads : 1u, 8u));
+		for (const RLIndexEntry &e : blocks) index.push_back({fpos + e.pos, e.runs, e.syms});
+		fpos += bytes;
+	});
+	if (!ok) return false;
+	std::vector<uint8_t> head, tail;
+	rl_container_ends(n, fpos - 8, index, head, tail);
+	pf->put(0, head.data(), head.size());
+	pf->put(fpos, tail.data(), tail.size());
+	pf->close();
+	return true;
+}
 bool rl_encode_device(const std::string &fn, const uint8_t *d_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream)
 {
 	return rl_encode_impl(fn, d_symbols, nullptr, n, runs_per_block, numthreads, symmap, hip_stream, 0);
@@ -192,8 +218,8 @@ bool rl_encode_device_from_host(const std::string &fn, const uint8_t *h_symbols,
 {
 	return rl_encode_impl(fn, nullptr, h_symbols, n, runs_per_block, numthreads, symmap, hip_stream, seg_limit);
 }
-static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
-                           void *hip_stream, uint64_t seg_limit)
+static bool rl_encode_stream(const uint8_t *d_symbols, const uint8_t *h_symbols, uint64_t n, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap,
+                             void *hip_stream, uint64_t seg_limit, const RLSink &sink)
 {
 	hipStream_t s = (hipStream_t)hip_stream;
 	if (!runs_per_block) runs_per_block = 64 * 1024;
@@ -205,11 +231,6 @@ static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, cons
 	if (sw().RL_SEG.set) { const uint64_t v = (uint64_t)sw().RL_SEG.v; if (v >= 1024 && v < seg_max) seg_max = v; }
 	std::unique_ptr<Buf> stage;                           // host source: the segment's symbols in HBM
 	if (h_symbols) stage.reset(new Buf(std::min(seg_max, n) + 16));
-	int dev = 0;
-	B3M_HIP(hipGetDevice(&dev));
-	std::unique_ptr<ParFile> pf;
-	std::vector<RLIndexEntry> index;
-	uint64_t fpos = 8;                                    // file offset of the next block (8 bytes of n in front)
 	for (uint64_t a = 0; a < n;) {
 		const uint64_t len = std::min<uint64_t>(seg_max, n - a);
 		const bool last = a + len == n;
@@ -267,9 +288,10 @@ static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, cons
 		if (too_long) return false;
 		uint64_t pos = 0;                                   // offsets inside this segment's image
 		std::vector<uint64_t> hdst(nblocks);
+		std::vector<RLIndexEntry> index;                    // this segment's blocks, positions relative to its image
 		for (uint64_t b = 0; b < nblocks; ++b) {
 			const uint32_t *hb = h.data() + (size_t)RL_HIST * b;
-			index.push_back({fpos + pos, std::min<uint64_t>(rpb, R - b * rpb), (uint64_t)hb[514] | ((uint64_t)hb[515] << 32)});
+			index.push_back({pos, std::min<uint64_t>(rpb, R - b * rpb), (uint64_t)hb[514] | ((uint64_t)hb[515] << 32)});
 			hdst[b] = pos;
 			off_sym[b] = pos + headers[b].size();
 			off_len[b] = off_sym[b] + bytes1[b];
@@ -295,17 +317,62 @@ static bool rl_encode_impl(const std::string &fn, const uint8_t *d_symbols, cons
 		hipLaunchKernelGGL(k_rl_headers, dim3((uint32_t)nblocks), dim3(64), 0, s, d_blob.as<uint8_t>(), d_hs.as<uint64_t>(), d_hd.as<uint64_t>(), d_out.as<uint8_t>());
 		B3M_HIP(hipStreamSynchronize(s));
 		B3M_HIP(hipGetLastError());
-		if (!pf) pf.reset(new ParFile(fn));
-		pf->put_device(fpos, d_out.p, total, dev, std::min(numthreads, 8u));
-		fpos += total;
+		sink(d_out, total, index);
 		a += used;
 	}
-	std::vector<uint8_t> head, tail;
-	rl_container_ends(n, fpos - 8, index, head, tail);
-	pf->put(0, head.data(), head.size());
-	pf->put(fpos, tail.data(), tail.size());
-	pf->close();
 	return true;
+}
+
+// ---- one file from SEVERAL devices (b3m_compute_bwt with num_gpus > 1: every device codes the blocks that begin in its slice of the BWT) ----
+// A block is rpb runs, counted from the start of the whole BWT, so a device must know how many run heads lie in front of its slice and where the first block of its
+// own begins.  rl_slice_scan: heads per tile of the slice, scanned (position 0 counts as a head: the caller takes it back when the slice continues its neighbour's
+// last run), with the slice's first and last symbol; rl_head_position: the position of the slice's ordinal-th head.  Current device.
+void rl_slice_scan(const uint8_t *d_symbols, uint64_t len, void *hip_stream, std::vector<uint32_t> &tile_first, uint8_t *first_sym, uint8_t *last_sym)
+{
+	hipStream_t s = (hipStream_t)hip_stream;
+	tile_first.assign(1, 0u);
+	*first_sym = *last_sym = 0;
+	if (!len) return;
+	B3M_REQUIRE(len < (1ull << 32), "internal: a slice of 2^32 symbols and more in the run-length encoder");
+	const uint64_t ntiles = (len + RL_TILE - 1) / RL_TILE;
+	Buf tiles(4 * (ntiles + 1)), scan_ws(4 * scan_ws_elems(ntiles + 1));
+	hipLaunchKernelGGL(k_rl_count, dim3((uint32_t)ntiles), dim3(256), 0, s, d_symbols, len, tiles.as<uint32_t>());
+	B3M_HIP(hipMemsetAsync(tiles.as<uint32_t>() + ntiles, 0, 4, s));
+	exclusive_sum_u32(tiles.as<uint32_t>(), ntiles + 1, scan_ws.as<uint32_t>(), s);
+	tile_first.resize(ntiles + 1);
+	B3M_HIP(hipMemcpyAsync(tile_first.data(), tiles.p, 4 * (ntiles + 1), hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(first_sym, d_symbols, 1, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipMemcpyAsync(last_sym, d_symbols + len - 1, 1, hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+}
+uint64_t rl_head_position(const uint8_t *d_symbols, uint64_t len, const std::vector<uint32_t> &tile_first, uint64_t ordinal, void *hip_stream)
+{
+	hipStream_t s = (hipStream_t)hip_stream;
+	const uint64_t ntiles = tile_first.size() - 1;
+	B3M_REQUIRE(ntiles >= 1 && ordinal < tile_first[ntiles], "internal: run head out of range");
+	const uint64_t t = (uint64_t)(std::upper_bound(tile_first.begin(), tile_first.end(), (uint32_t)ordinal) - tile_first.begin()) - 1;      // last tile whose first head is <= ordinal
+	const uint64_t base = t * RL_TILE, cnt = std::min<uint64_t>(RL_TILE, len - base);
+	std::vector<uint8_t> sym(cnt + 1);
+	B3M_HIP(hipMemcpyAsync(sym.data() + (base ? 0 : 1), d_symbols + (base ? base - 1 : 0), cnt + (base ? 1 : 0), hipMemcpyDeviceToHost, s));
+	B3M_HIP(hipStreamSynchronize(s));
+	if (!base) sym[0] = (uint8_t)~sym[1];                  // (position 0 is a head: the kernel's convention)
+	uint64_t want = ordinal - tile_first[t];
+	for (uint64_t i = 0; i < cnt; ++i) if (sym[i + 1] != sym[i]) { if (!want) return base + i; --want; }
+	throw Error("internal: run head not found in its tile");
+}
+RLPart::~RLPart() { if (!images.empty()) { (void)hipSetDevice(dev); for (auto &im : images) if (im.first) (void)hipFree(im.first); } }
+// every run of d_symbols[0, len) -- a range that begins at a block's first run and ends where another block begins (or at the end of the BWT) -- coded into images that stay
+// in HBM (current device); false: not an input for the device encoder (as rl_encode_device)
+bool rl_encode_part(const uint8_t *d_symbols, uint64_t len, uint64_t runs_per_block, unsigned numthreads, const int64_t *symmap, void *hip_stream, RLPart &out)
+{
+	B3M_HIP(hipGetDevice(&out.dev));
+	out.bytes = 0; out.index.clear();
+	return rl_encode_stream(d_symbols, nullptr, len, runs_per_block, numthreads, symmap, hip_stream, 0, [&](Buf &image, uint64_t bytes, std::vector<RLIndexEntry> &blocks) {
+		out.images.emplace_back(image.p, bytes);
+		image.p = nullptr;                                  // (the part owns it now)
+		for (const RLIndexEntry &e : blocks) out.index.push_back({out.bytes + e.pos, e.runs, e.syms});
+		out.bytes += bytes;
+	});
 }
 
 }  // namespace b3m

@@ -256,6 +256,17 @@ typedef struct b3m_lf_job {
 	uint64_t       isarate; uint64_t *isa_out;
 } b3m_lf_job;
 int b3m_lf_walk_job(const b3m_lf_job *job, uint64_t *mismatches_out, void *stream);
+
+/* One device's share of the same job (b3m_compute_bwt with num_gpus > 1 splits the LF walks that make X.sa over its devices: /root/reference/src/bwtb3m.cpp:48-50,
+ * numthreads= is the reference's knob for the same stage): the chains [chain_first, chain_first + chain_count) -- chain k runs from sample k + 1 back to sample k --
+ * over the whole BWT on the current device.  job->d_sa_out (device, ceil(n/sarate) u64) is set to ~0 and receives the SA samples these chains meet; job->sa_out and
+ * job->isa_out must be NULL, job->d_text is required.  b3m_merge_samples puts shares together: d_dst[i] = d_src[i] where d_src[i] != ~0. */
+int b3m_lf_walk_chains(const b3m_lf_job *job, uint64_t chain_first, uint64_t chain_count, uint64_t *mismatches_out, void *stream);
+int b3m_merge_samples(uint64_t *d_dst, const uint64_t *d_src, uint64_t count, void *stream);
+/* the (rank,pos) sample tables of suffix-range shards (b3m_plan_samples_device: slot i = position i * rate, rank ~0 = another shard's) put together on the device:
+ * slots of d_src that hold a rank go to d_dst (npairs slots of 16 bytes each, current device); stats_out (host): [0] += slots both had ranked (must stay 0),
+ * [1] = slots of d_dst still empty afterwards. */
+int b3m_merge_sample_pairs(uint64_t *d_dst, const uint64_t *d_src, uint64_t npairs, uint64_t *stats_out, void *stream);
 /* bwtcomputessa as one call (/root/reference/README.md:63-67: after bwtonly=1, X.preisa is the hint file for "the bwtcomputessa program to compute a sampled suffix array
  * and sampled inverse suffix array"): X.bwt is decoded, the chains between the pairs of X.preisa are walked on the device, X.sa and X.isa are written (layout of
  * /root/reference/src/sasubsample.cpp:34-57).  Defaults of the reference's program: both rates 32.  bin/bwtcomputessa is the program. */

@@ -97,6 +97,9 @@ def test_cli_numgpus_writes_the_files_of_one_gpu(gpu, oracle, tmp_path, kind, ng
         assert r.returncode == 0, r.stderr.decode()
         if N > 1:
             assert ("%d suffix-range shards" % N).encode() in r.stderr
+            # the output stage is distributed too (round 5): every device codes the blocks of X.bwt that begin in its slice, and walks its share of the LF chains of X.sa
+            assert b"X.bwt coded by" in r.stderr, r.stderr.decode()
+            assert (b"LF walks on %d devices" % N in r.stderr) == (bwtonly == 0), r.stderr.decode()
             if kind == "repeat":
                 assert b"tie finish" in r.stderr and b"(0 tied" not in r.stderr, r.stderr.decode()
         outs[N] = _files(out[:-4])
