@@ -494,14 +494,34 @@ __device__ __forceinline__ void msd_block_count(uint32_t mine, uint32_t *total, 
 	__syncthreads();
 	if (threadIdx.x == 0) { act[blockIdx.x] = acc ? 1 : 0; if (acc) atomicAdd(total + (blockIdx.x & 63u), acc); }      // (64 counters, summed by the host)
 }
-__global__ __launch_bounds__(MP_THREADS) void k_msd_init(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint32_t *pid, uint32_t *nlarge, uint8_t *act)
+// PIECES OF MIDDLE SIZE (above MP_GROUP, up to 8192 slots) leave the split passes: on repeat families a pass by one byte of the key sheds a third of a piece at best
+// (copies at 10 % divergence agree on the next four symbols two times in three), so a piece of a few thousand slots took all eight passes over the list before
+// (genome-like 3 Gbase: 47 M of the 163 M slots of the second key round, 8 x (count + scatter + relabel)).  Such a piece is listed (first slot | size << 32, the
+// buffer its pairs are in) and ONE workgroup orders it completely in LDS (k_msd_piece_sort).
+struct PieceList { unsigned long long *rec; uint32_t *cnt; uint32_t cap; uint32_t maxsize; };      // maxsize: the largest piece the sorter takes (2048, 4096 or 8192)
+__device__ __forceinline__ void piece_put(const PieceList &P, uint64_t start, uint32_t size, uint32_t loc)
+{
+	const uint32_t at = atomicAdd(P.cnt, 1u);
+	if (at < P.cap) P.rec[at] = (unsigned long long)start | ((unsigned long long)size << 32) | (loc ? 1ull << 63 : 0ull);      // (more than the list holds: the host sees cnt > cap and takes the passes for all)
+}
+__global__ __launch_bounds__(MP_THREADS) void k_msd_init(const uint32_t *hid, const uint32_t *gid, uint64_t u, uint32_t *pid, uint32_t *nlarge, uint8_t *act, PieceList PL)
 {
 	uint32_t mine = 0;
 	#pragma unroll
 	for (int k = 0; k < MP_PER; ++k) {
 		const uint64_t s = (uint64_t)blockIdx.x * MP_CHUNK + threadIdx.x + (uint64_t)k * MP_THREADS;
 		if (s >= u) continue;
-		const bool large = tie_large(hid, gid, u, s, MP_GROUP);
+		bool large = tie_large(hid, gid, u, s, MP_GROUP);
+		if (large && PL.cap && !tie_large(hid, gid, u, s, PL.maxsize)) {
+			// a group of middle size: its head lists it (the size by bisection between MP_GROUP and maxsize members), nobody takes part in the passes
+			large = false;
+			if (hid[s] == (uint32_t)s) {
+				const uint32_t g = gid[s];
+				uint64_t lo = s + MP_GROUP, hi = s + PL.maxsize < u ? s + PL.maxsize : u;      // gid[lo] == g; hi: first slot known to be outside (or u)
+				while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; if (gid[mid] == g) lo = mid; else hi = mid; }
+				piece_put(PL, s, (uint32_t)(hi - s), 0u);
+			}
+		}
 		pid[s] = large ? hid[s] + 1u : 0u;
 		mine += large ? 1u : 0u;
 	}
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(MP_THREADS) void k_msd_scatter(const uint64_t *K, c
 }
 // after the scatter the table holds the END of every byte's range (= the start of the next byte's): the new pieces are the ranges above TT_GROUP
 // (K: where this split wrote; loc: MSD_LOC if that is the second pair of buffers)
-__global__ __launch_bounds__(MP_THREADS) void k_msd_repid(const uint64_t *K, uint32_t *pid, uint64_t u, int shift, const uint32_t *tab, uint32_t loc, uint32_t *nleft, uint8_t *act)
+__global__ __launch_bounds__(MP_THREADS) void k_msd_repid(const uint64_t *K, uint32_t *pid, uint64_t u, int shift, const uint32_t *tab, uint32_t loc, uint32_t *nleft, uint8_t *act, PieceList PL)
 {
 	if (!act[blockIdx.x]) return;
 	uint32_t mine = 0;
@@ -607,11 +627,74 @@ __global__ __launch_bounds__(MP_THREADS) void k_msd_repid(const uint64_t *K, uin
 		const uint32_t st = q - 1u, d = (uint32_t)((K[s] >> shift) & 255u);
 		const uint32_t *row = tab + (uint64_t)(st >> MP_ROW) * 256u;
 		const uint32_t e = row[d], b = d ? row[d - 1] : 0u;
-		const bool large = e - b > (uint32_t)MP_GROUP;
+		bool large = e - b > (uint32_t)MP_GROUP;
+		if (large && shift > 0 && PL.cap && e - b <= PL.maxsize) {      // a new piece of middle size: listed by its first slot, out of the passes (after the key's last byte a piece holds one key: it stays)
+			large = false;
+			if (s == (uint64_t)st + b) piece_put(PL, s, e - b, loc);
+		}
 		pid[s] = (large ? st + b + 1u : 0u) | (p & MSD_BND) | (s == (uint64_t)st + b ? MSD_BND : 0u) | loc;
 		mine += large ? 1u : 0u;
 	}
 	msd_block_count(mine, nleft, act);
+}
+// one workgroup per listed piece: its pairs ordered by the whole key in LDS (bitonic network over the next power of two, padded with keys above every real one),
+// written back where they were; then the labels the passes would have left: a boundary where the key changes, and a run of one key above MP_GROUP slots keeps
+// its first slot as its piece (k_msd_leftover makes it a group; k_tie_tile<2> takes the rest)
+constexpr uint32_t PS_PAD = 0xFFFFFFFFu;               // the suffix of a padding entry (positions are below 2^32 - 1): orders it behind a real entry with the same key (pac keys use all 64 bits)
+template <int CAP, int PS_THREADS>
+__global__ __launch_bounds__(PS_THREADS) void k_msd_piece_sort(PieceList PL, uint32_t npieces, uint64_t *K0, uint32_t *V0, uint64_t *K1, uint32_t *V1, uint32_t *pid)
+{
+	__shared__ uint64_t sk[CAP];
+	__shared__ uint32_t sv[CAP];
+	const uint32_t tid = threadIdx.x;
+	for (uint32_t pi = blockIdx.x; pi < npieces; pi += gridDim.x) {
+		const unsigned long long rec = PL.rec[pi];
+		const uint64_t st = rec & 0xFFFFFFFFull;
+		const uint32_t m = (uint32_t)(rec >> 32) & 0x7FFFFFFFu, loc = (uint32_t)(rec >> 63);
+		uint64_t *K = loc ? K1 : K0; uint32_t *V = loc ? V1 : V0;
+		uint32_t P = 2 * PS_THREADS; while (P < m) P <<= 1;
+		for (uint32_t j = tid; j < P; j += PS_THREADS) { sk[j] = j < m ? K[st + j] : ~0ull; sv[j] = j < m ? V[st + j] : PS_PAD; }
+		__syncthreads();
+		for (uint32_t k = 2; k <= P; k <<= 1)
+			for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+				for (uint32_t t = tid; t < (P >> 1); t += PS_THREADS) {
+					const uint32_t i = ((t & ~(jj - 1u)) << 1) | (t & (jj - 1u)), l = i | jj;      // i: bit jj clear; partner l
+					const bool up = (i & k) == 0u;
+					const uint64_t a = sk[i], b = sk[l];
+					const uint32_t va = sv[i], vb = sv[l];
+					const bool gt = a > b || (a == b && va == PS_PAD && vb != PS_PAD);      // (padding behind everything real)
+					if (gt == up && (a != b || va == PS_PAD || vb == PS_PAD)) { sk[i] = b; sk[l] = a; sv[i] = vb; sv[l] = va; }
+				}
+				__syncthreads();
+			}
+		// runs of one key: the first slot of slot j's run by a backward look (runs are short unless the repeat goes on: bounded by a scan over 64-slot blocks)
+		for (uint32_t j = tid; j < m; j += PS_THREADS) { K[st + j] = sk[j]; V[st + j] = sv[j]; }
+		__syncthreads();
+		// sv is free now: sv[j] = j where a run begins, else 0 -> inclusive max-scan = the run's first slot
+		for (uint32_t j = tid; j < P; j += PS_THREADS) sv[j] = (j < m && (j == 0 || sk[j] != sk[j - 1])) ? j : 0u;
+		__syncthreads();
+		for (uint32_t d = 1; d < P; d <<= 1) {
+			uint32_t tmp[CAP / PS_THREADS];
+			#pragma unroll
+			for (uint32_t q = 0; q < (uint32_t)(CAP / PS_THREADS); ++q) { const uint32_t j = tid + q * PS_THREADS; tmp[q] = (j < P && j >= d) ? max(sv[j], sv[j - d]) : (j < P ? sv[j] : 0u); }
+			__syncthreads();
+			#pragma unroll
+			for (uint32_t q = 0; q < (uint32_t)(CAP / PS_THREADS); ++q) { const uint32_t j = tid + q * PS_THREADS; if (j < P) sv[j] = tmp[q]; }
+			__syncthreads();
+		}
+		// the run's end: the next run's first slot, found from the run starts (a run start j knows its predecessor run ended at j): sk reused as "end of the run that starts here"
+		for (uint32_t j = tid; j < m; j += PS_THREADS) {
+			const bool last_of_run = j + 1 == m || sv[j + 1] != sv[j];
+			if (last_of_run) reinterpret_cast<uint32_t *>(sk)[sv[j]] = j + 1u;      // (32-bit view of the key array: the keys have left)
+		}
+		__syncthreads();
+		for (uint32_t j = tid; j < m; j += PS_THREADS) {
+			const uint32_t rs = sv[j], re = reinterpret_cast<uint32_t *>(sk)[rs];
+			const bool big = re - rs > (uint32_t)MP_GROUP;
+			pid[st + j] = (big ? (uint32_t)(st + rs) + 1u : 0u) | (j == rs ? MSD_BND : 0u) | (loc ? MSD_LOC : 0u);
+		}
+		__syncthreads();
+	}
 }
 // pieces still large after the key's last byte hold one key each: they stay groups
 __global__ void k_msd_leftover(const uint32_t *U, const uint32_t *gid, const uint32_t *pid, const uint32_t *V, const uint32_t *V1, uint64_t u, uint32_t *idx, uint32_t *hid)
@@ -927,17 +1010,27 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 			uint32_t *cnt = radix.tile_hist;                 // 64 words (the radix sorts' tile histograms: 256 words per 4096 keys, idle in such a round)
 			const uint64_t rows = (u >> MP_ROW) + 2;
 			const uint32_t nchunk = (uint32_t)((u + MP_CHUNK - 1) / MP_CHUNK);
-			uint8_t *act = reinterpret_cast<uint8_t *>(radix.tile_hist + 64);   // a byte per chunk
-			uint32_t h_n = 0, h_c[64];
-			auto read_count = [&]() { B3M_HIP(hipMemcpyAsync(h_c, cnt, 256, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s)); uint64_t t = 0; for (int i = 0; i < 64; ++i) t += h_c[i]; return (uint32_t)std::min<uint64_t>(t, 0xFFFFFFFFull); };
+			uint8_t *act = reinterpret_cast<uint8_t *>(radix.tile_hist + 66);   // a byte per chunk
+			// the list of middle-sized pieces (k_msd_piece_sort) behind the chunk flags: at most one piece per MP_GROUP slots
+			PieceList PL{};
+			PL.cnt = cnt + 64;
+			PL.rec = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(act) + (((uint64_t)nchunk + 15) & ~15ull) + 8);
+			PL.rec = reinterpret_cast<unsigned long long *>(((uintptr_t)PL.rec + 7) & ~(uintptr_t)7);
+			PL.cap = sw().NO_PIECE_SORT.on() ? 0u : (uint32_t)(u / MP_GROUP + 2);
+			PL.maxsize = 4096;      // (genome-like 3 Gbase, one process: no piece sort 179.1 ms, 8192 slots / 1024 threads 182.2, 4096 / 512 172.3, 2048 / 256 173.9: profiles/r05_ab_piece.log)
+			if (sw().PIECE_CAP.set) PL.maxsize = sw().PIECE_CAP.v <= 2048 ? 2048u : sw().PIECE_CAP.v <= 4096 ? 4096u : 8192u;
+			uint32_t h_n = 0, h_c[65], n_pieces = 0;
+			auto read_count = [&]() { B3M_HIP(hipMemcpyAsync(h_c, cnt, 260, hipMemcpyDeviceToHost, s)); B3M_HIP(hipStreamSynchronize(s)); uint64_t t = 0; for (int i = 0; i < 64; ++i) t += h_c[i];
+			                          n_pieces = h_c[64]; return (uint32_t)std::min<uint64_t>(t, 0xFFFFFFFFull); };
 			if (any_large) {
 				const uint32_t *hix = head_index();
-				B3M_HIP(hipMemsetAsync(cnt, 0, 256, s));
-				hipLaunchKernelGGL(k_msd_init, dim3(nchunk), dim3(MP_THREADS), 0, s, hix, (const uint32_t *)gid, u, pid, cnt, act);
+				B3M_HIP(hipMemsetAsync(cnt, 0, 260, s));
+				hipLaunchKernelGGL(k_msd_init, dim3(nchunk), dim3(MP_THREADS), 0, s, hix, (const uint32_t *)gid, u, pid, cnt, act, PL);
 				h_n = read_count();
-				if (h_n == 0) any_large = false;
+				B3M_REQUIRE(n_pieces <= PL.cap, "internal: more pieces of middle size than slots allow");
+				if (h_n == 0 && n_pieces == 0) any_large = false;
 			}
-			if (h_n == 0) {
+			if (h_n == 0 && n_pieces == 0) {
 				if (isa) hipLaunchKernelGGL(k_tie_tile<1>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)isa, h, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 				else hipLaunchKernelGGL(k_tie_tile<0>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, kshift, tt_count_max());
 			} else {
@@ -954,16 +1047,23 @@ uint64_t tie_rounds(const TextView &T, uint32_t *idx, uint64_t u, uint64_t depth
 					hipLaunchKernelGGL(k_msd_scatter, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K0, (const uint32_t *)V0, (const uint32_t *)pid, u, shift, tab, K1, V1, (const uint8_t *)act);
 					cur ^= 1;
 					B3M_HIP(hipMemsetAsync(cnt, 0, 256, s));
-					hipLaunchKernelGGL(k_msd_repid, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K1, pid, u, shift, (const uint32_t *)tab, cur ? MSD_LOC : 0u, cnt, act);
+					hipLaunchKernelGGL(k_msd_repid, dim3(nchunk), dim3(MP_THREADS), 0, s, (const uint64_t *)K1, pid, u, shift, (const uint32_t *)tab, cur ? MSD_LOC : 0u, cnt, act, PL);
 					h_n = read_count();
+					B3M_REQUIRE(n_pieces <= PL.cap, "internal: more pieces of middle size than slots allow");
 					++passes;
 				}
+				if (n_pieces) {
+					const dim3 grid(std::min<uint32_t>(n_pieces, 16384u));
+					if (PL.maxsize <= 2048) hipLaunchKernelGGL((k_msd_piece_sort<2048, 256>), grid, dim3(256), 0, s, PL, n_pieces, kx, vx, ky, vy, pid);
+					else if (PL.maxsize <= 4096) hipLaunchKernelGGL((k_msd_piece_sort<4096, 512>), grid, dim3(512), 0, s, PL, n_pieces, kx, vx, ky, vy, pid);
+					else hipLaunchKernelGGL((k_msd_piece_sort<8192, 1024>), grid, dim3(1024), 0, s, PL, n_pieces, kx, vx, ky, vy, pid);
+				}
 				ms_splits = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
-				if (dbg >= 3) fprintf(stderr, "[b3m]   large groups: %u split passes, %u slots in pieces of one key\n", passes, h_n);
+				if (dbg >= 3) fprintf(stderr, "[b3m]   large groups: %u split passes, %u slots in pieces of one key, %u pieces of middle size ordered in LDS\n", passes, h_n, n_pieces);
 				// (the table in hid is dead: the tiles and the pieces of one key write the heads there)
 				hipLaunchKernelGGL(k_tie_tile<2>, dim3(ntile), dim3(TT_THREADS), 0, s, T, U, gid, u, idx, (const uint32_t *)nullptr, off, hid, (const uint64_t *)kx, (const uint32_t *)vx, (const uint32_t *)pid,
 				                   (const uint64_t *)ky, (const uint32_t *)vy, kshift, tt_count_max());
-				if (h_n) hipLaunchKernelGGL(k_msd_leftover, dim3(nblk(u)), dim3(256), 0, s, (const uint32_t *)U, (const uint32_t *)gid, (const uint32_t *)pid, (const uint32_t *)vx, (const uint32_t *)vy, u, idx, hid);
+				if (h_n || n_pieces) hipLaunchKernelGGL(k_msd_leftover, dim3(nblk(u)), dim3(256), 0, s, (const uint32_t *)U, (const uint32_t *)gid, (const uint32_t *)pid, (const uint32_t *)vx, (const uint32_t *)vy, u, idx, hid);
 			}
 		} else {
 		// ---- which slots belong to groups too large for a tile ----

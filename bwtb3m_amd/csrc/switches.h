@@ -49,6 +49,8 @@ struct Sw {
 	X(ISA_SEARCH_MAX,   "measurement: unset targets above which the inverse suffix array is filled whole (default n / 64)")             \
 	X(TT_COUNT,         "measurement: groups above this many members send a tile of the list rounds to the bitonic network")            \
 	X(NO_TIE_TILES,     "measurement: 1 = no LDS tiles in the list-based rounds (radix sorts only)")                                    \
+	X(NO_PIECE_SORT,    "measurement: 1 = pieces of 513..8192 slots go through the byte-split passes like larger ones (the form before round 5)")       \
+	X(PIECE_CAP,        "measurement: largest piece ordered by one workgroup in LDS: 2048, 4096 (default) or 8192 slots")                             \
 	X(NO_TIE_MSD,       "measurement: 1 = large groups through the LSD radix sorts")                                                    \
 	X(NO_TREE_DOUBLING, "measurement: 1 = blocks of a merge tree finish long repeats by key extension only")                            \
 	X(OVERHANG,         "test: symbols of overhang behind a block of a merge tree (default 2^20)")                                      \
