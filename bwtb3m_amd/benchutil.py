@@ -6,8 +6,8 @@ import os
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # rocprof kernel name of each family's main kernel (profiles/*kernel_stats.csv)
-KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true, 0>",
-             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0>", "bucket_finish": "b3m::k_finish_v3<3, 512, false>", "ties": "b3m::k_tie_fix",
+KERNEL_OF = {"msd_scatter": "b3m::k_l1_gather<1024, 4>", "msd_scatter_text": "b3m::k_l0_pass<false, 65280, 4, 2048, true, 0, false>",
+             "msd_hist": "b3m::k_l0_pass<true, 65280, 4, 2048, false, 0, false>", "bucket_finish": "b3m::k_finish_v3<3, 512, false>", "ties": "b3m::k_tie_fix",
              "radix_scatter": "b3m::k_scatter<unsigned int, false, 512>", "gap_walk": "b3m::k_gap_walk4"}
 
 
@@ -33,7 +33,7 @@ def dominant_roofline(fam, steps, dt, nbases, levels, pmc_n, root, peak_gpus=1, 
     one-pass instantiation of k_l0_pass: 512-thread workgroups from three shards on)."""
     dname, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     if shards > 1 and dname == "msd_scatter_text":
-        KERNEL_OF_ = dict(KERNEL_OF, msd_scatter_text="b3m::k_l0_pass<false, 65280, 4, 2048, true, %d>" % (2 if shards >= 3 else 1))
+        KERNEL_OF_ = dict(KERNEL_OF, msd_scatter_text="b3m::k_l0_pass<false, 65280, 4, 2048, true, %d, false>" % (2 if shards >= 3 else 1))
     else:
         KERNEL_OF_ = KERNEL_OF
     achieved = d["alg_bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0

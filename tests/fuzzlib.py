@@ -21,14 +21,15 @@ def _set_env(**kv):
 def clear_switches():
     _set_env(B3M_MSD_D0=None, B3M_MSD_D1=None, B3M_L0_LOCAL=None, B3M_NO_FAST_FINISH=None, B3M_TIE_TWO_STEP=None, B3M_LVL2_MIN=None, B3M_NO_LEVEL2=None, B3M_FINISH_V3=None,
              B3M_NO_TIE_TILES=None, B3M_TIE_FROM_0=None, B3M_ISA_FULL=None, B3M_ISA_SEARCH_MAX=None, B3M_NO_TIE_MSD=None,
-             B3M_SHARD_ONEPASS=None, B3M_SHARD_TWO_PASS=None, B3M_SHARD_WG2=None, B3M_XCD_ORDER=None, B3M_L1_ORDER=None)
+             B3M_SHARD_ONEPASS=None, B3M_SHARD_TWO_PASS=None, B3M_SHARD_WG2=None, B3M_XCD_ORDER=None, B3M_L1_ORDER=None, B3M_SHARD_KEYS=None, B3M_PIECE_CAP=None,
+             B3M_NO_PIECE_SORT=None, B3M_L1_MP=None)
 
 
 def _tie_switches(rng):
     """the list-based rounds' alternatives: radix sorts only / from symbol 0 with the whole inverse suffix array (the forms before the LDS tiles)"""
-    t = int(rng.integers(0, 6))
+    t = int(rng.integers(0, 8))
     _set_env(B3M_NO_TIE_TILES=1 if t == 2 else None, B3M_TIE_FROM_0=1 if t == 3 else None, B3M_ISA_FULL=1 if t == 3 else None, B3M_ISA_SEARCH_MAX=0 if t == 4 else None,
-             B3M_NO_TIE_MSD=1 if t == 5 else None)
+             B3M_NO_TIE_MSD=1 if t == 5 else None, B3M_NO_PIECE_SORT=1 if t == 6 else None, B3M_PIECE_CAP=[2048, 8192][int(rng.integers(0, 2))] if t == 7 else None)      # (6, 7: middle-sized pieces through the split passes / the other capacities of the LDS piece sorter)
     return t
 
 
@@ -140,10 +141,13 @@ def case_shards(rng, O, engine, torch):
     """2..8 suffix-range shards of a 0.26..0.9 Mbase text must tile the oracle's BWT (forced digit widths: the large geometries, the fine level 0)"""
     itype = ["pac", "pacterm"][int(rng.integers(0, 2))]
     nb = int(rng.integers(262200, 900000))
-    kind = int(rng.integers(0, 3))
-    b = rng.integers(0, [4, 4, 2][kind], nb, dtype=np.uint8)
+    kind = int(rng.integers(0, 4))
+    b = rng.integers(0, [4, 4, 2, 4][kind], nb, dtype=np.uint8)
     if kind == 1:
         k = int(rng.integers(1, nb // 3)); p = int(rng.integers(0, nb - k)); b[p:p + k] = b[:k]
+    if kind == 3:       # skewed composition: the shards' borders fall inside a level-0 digit (32-base windows)
+        pa = [0.7, 0.85, 0.95][int(rng.integers(0, 3))]
+        b = np.where(rng.random(nb) < pa, 0, np.maximum(b, 1)).astype(np.uint8)
     buf = O.pac_encode(b); s = O.symbols_from_file_bytes(buf, itype); n = len(s)
     ns = int(rng.integers(2, 9))
     geo = int(rng.integers(0, 4))
@@ -153,7 +157,9 @@ def case_shards(rng, O, engine, torch):
     alt = int(rng.integers(0, 5))
     _set_env(B3M_SHARD_ONEPASS=0 if alt == 1 else None, B3M_SHARD_TWO_PASS=int(rng.integers(1, 255)) if alt == 2 else None, B3M_SHARD_WG2=0 if alt == 3 else None,
              B3M_XCD_ORDER=0 if alt == 4 else None)
-    desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d alt=%d" % (itype, nb, kind, ns, geo, isar, alt)
+    wk = int(rng.integers(0, 3))          # borders by window forced on any text (1), as the text asks (0, 2)
+    _set_env(B3M_SHARD_KEYS=1 if wk == 1 else None)
+    desc = "shards type=%s nb=%d kind=%d shards=%d geo=%d isar=%d alt=%d windows=%d" % (itype, nb, kind, ns, geo, isar, alt, wk)
     try:
         d_text = torch.from_numpy(np.asarray(buf)).cuda()
         plans, slices, _ = run_shards(torch, engine, d_text, n, itype, ns, isar, lists=True if (ns & 1) else None)      # (odd shard counts: the list form of the tie finish)
