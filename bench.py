@@ -192,7 +192,9 @@ def measure_e2e(torch, plan, d_text, d_out, n, nbases, steps, itype):
     from bwtb3m_amd import engine
     h_text = d_text.cpu().pin_memory()
     out = {}
-    for packed in ((False, True) if itype in ("pac", "pacterm") else (False,)):
+    # (a plan that runs sequential shards -- texts of 2^32 symbols and more, the host tier -- hands the BWT over one byte per symbol: b3m_plan_run_host refuses the packed form there)
+    can_pack = itype in ("pac", "pacterm") and n < (1 << 32) and not getattr(plan, "host_tier", 0)
+    for packed in ((False, True) if can_pack else (False,)):
         nbytes = (n + 3) // 4 if packed else n
         h_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         plan.run_host(h_text, h_out, packed=packed)    # warm-up (first touch of the pinned pages)
