@@ -252,3 +252,42 @@ def test_bench_roofline_helper():
     # a kernel whose template arguments changed since the passes were taken still resolves (same template, most bytes)
     assert benchutil.pmc_kernel_name("b3m::k_finish_v3<3, 512, false, 7>", tj["kernels"]) == benchutil.KERNEL_OF["bucket_finish"]
     assert benchutil.pmc_kernel_name("b3m::k_no_such_kernel<1>", tj["kernels"]) is None
+
+
+def test_bench_launcher_counts_gpus_without_touching_hip(monkeypatch):
+    """the self-launching parent of `bench.py --gpus N` must not initialise the GPU; it counts devices from the KFD topology in sysfs (0 where that is
+    absent, as in this container: the launcher then lets the ranks decide) and honours HIP_VISIBLE_DEVICES"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    n = bench.benchutil_count_gpus()
+    assert isinstance(n, int) and n >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.benchutil_count_gpus() <= 1
+    src = open(os.path.join(root, "bench.py")).read()
+    launcher = src[src.index("def launch_ranks"):src.index("def main")]
+    code = "\n".join(l.split("#")[0] for l in launcher.split('"""')[2].splitlines())      # the body behind the docstring, comments cut
+    assert "import torch" not in code and "torch.cuda" not in code, "the launcher must not import torch or touch torch.cuda"
+
+
+def test_genome_like_recipes_on_the_cpu():
+    """both recipes of the repeat-rich bench legs (synth.genome_like_device): deterministic, the right size, and the harsher one plants more"""
+    import torch
+    from bwtb3m_amd import synth
+    nb = 2_000_000
+    a = synth.genome_like_device(nb, 7, "cpu")
+    b = synth.genome_like_device(nb, 7, "cpu")
+    h = synth.genome_like_device(nb, 7, "cpu", repeats=0.5)
+    assert a.numel() == nb // 4 + 1 + 64 + (1 if nb % 4 == 0 else 0) and torch.equal(a, b) and h.numel() == a.numel()
+    assert not torch.equal(a, h)
+    # repeat content: distinct 16-mers among the first 1 M bases (2-bit unpacked) -- fewer where more of the text is copies
+    def distinct(pac):
+        x = pac[: 250_000].to(torch.int64)
+        bases = torch.stack([(x >> 6) & 3, (x >> 4) & 3, (x >> 2) & 3, x & 3], 1).reshape(-1)
+        k = torch.zeros(bases.numel() - 15, dtype=torch.int64)
+        for i in range(16):
+            k = k * 4 + bases[i: i + k.numel()]
+        return int(torch.unique(k).numel())
+    assert distinct(h) < distinct(a)
