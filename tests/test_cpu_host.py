@@ -285,12 +285,3 @@ def test_genome_like_recipes_on_the_cpu():
     # bench runs differ in the sixth digit for that reason; every run is LF-verified against the text it got)
     assert int((a != b).sum()) < a.numel() // 100
     assert int((a != h).sum()) > a.numel() // 10
-    # repeat content: distinct 16-mers among the first 1 M bases (2-bit unpacked) -- fewer where more of the text is copies
-    def distinct(pac):
-        x = pac[: 250_000].to(torch.int64)
-        bases = torch.stack([(x >> 6) & 3, (x >> 4) & 3, (x >> 2) & 3, x & 3], 1).reshape(-1)
-        k = torch.zeros(bases.numel() - 15, dtype=torch.int64)
-        for i in range(16):
-            k = k * 4 + bases[i: i + k.numel()]
-        return int(torch.unique(k).numel())
-    assert distinct(h) < distinct(a)
