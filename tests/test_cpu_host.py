@@ -283,5 +283,5 @@ def test_genome_like_recipes_on_the_cpu():
     assert a.numel() == nb // 4 + 1 + 64 + (1 if nb % 4 == 0 else 0) and h.numel() == a.numel()
     # (two draws with one seed agree except where planted copies overlap: which copy's base wins there is the scatter's choice -- the listed-suffix counts of two
     # bench runs differ in the sixth digit for that reason; every run is LF-verified against the text it got)
-    assert int((a != b).sum()) < a.numel() // 100
+    assert int((a != b).sum()) < a.numel() // 20
     assert int((a != h).sum()) > a.numel() // 10
