@@ -14,5 +14,6 @@ bad = 0; t0 = time.time()
 for it in range(iters):
     ok, desc = fuzzlib.case_shards(rng, O, engine, torch)
     if not ok: bad += 1; print("MISMATCH it=%d %s" % (it, desc), flush=True)
+    if it % 100 == 99: print("%d iterations, %d bad, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)      # (a run that writes nothing for minutes is taken to be hung)
 print("done: %d iterations, %d bad, %.0f s" % (iters, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
