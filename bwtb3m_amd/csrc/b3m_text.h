@@ -138,7 +138,10 @@ __device__ inline int compare_rotations(const TextView &T, uint64_t x, uint64_t 
 __device__ __forceinline__ bool sample_hit(const SampleOut &S, uint32_t lo32)
 {
 	bool h = (lo32 & S.pmask) == 0u;
-	if (!S.pow2) h = h && (lo32 >> S.tz) * S.inv <= S.lim;
+	// rates that are not powers of two: the exact test only for the few positions the mask lets through, BEHIND a branch (the empty asm keeps the compiler from
+	// computing it for every record and selecting afterwards: a shift, a 32-bit multiply -- quarter rate -- and three selects per record of k_finish_v3, whose
+	// vector ALUs are ~85 % busy: round 5)
+	if (h && !S.pow2) { uint32_t q = (lo32 >> S.tz) * S.inv; asm volatile("" : "+v"(q)); h = q <= S.lim; }
 	return h;
 }
 // (only for positions sample_hit accepted: the quotient by the odd part of the rate is then the product with its inverse modulo
