@@ -492,6 +492,35 @@ def test_cli_refusing_shards_fall_back_with_a_warning(gpu, oracle, tmp_path, how
         assert np.array_equal(_decode(L, out), ref)
 
 
+@pytest.mark.parametrize("ngpus,bwtonly", [(3, 1), (5, 0)])
+def test_cli_numgpus_with_an_empty_shard(gpu, oracle, tmp_path, ngpus, bwtonly):
+    """97 % A: the all-A window holds more than a shard's share, so two borders coincide and a shard is EMPTY; the tie finish over the shards' lists, the split coder (one block:
+    one device codes it, the others have no block that begins in their slice) and the split LF walks must cope, and the files are those of one GPU."""
+    from bwtb3m_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    nb = 900_001
+    b = (rng.random(nb) >= 0.97).astype(np.uint8) * rng.integers(1, 4, nb).astype(np.uint8)
+    buf = oracle.pac_encode(b)
+    inp = tmp_path / "a.pac"
+    inp.write_bytes(np.asarray(buf, dtype=np.uint8).tobytes())
+    outs = {}
+    for N in (1, ngpus):
+        out = str(tmp_path / ("g%d.bwt" % N))
+        env = dict(os.environ, B3M_DEBUG="1")
+        if N > 1:
+            env["B3M_DEVICES"] = ",".join(["0"] * N)
+        r = subprocess.run([os.path.join(ROOT, "bin", "bwtb3m"), "inputtype=pacterm", "bwtonly=%d" % bwtonly, "verbose=1", "numgpus=%d" % N, "isasamplingrate=4096",
+                            "outputfilename=" + out, str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        if N > 1:
+            assert b"0 suffixes behind" in r.stderr and b"X.bwt coded by" in r.stderr, r.stderr.decode()
+        outs[N] = _files(out[:-4])
+    assert outs[1] == outs[ngpus]
+    s = oracle.symbols_from_file_bytes(np.asarray(buf, dtype=np.uint8), "pacterm")
+    assert np.array_equal(_decode(L, str(tmp_path / ("g%d.bwt" % ngpus))), oracle.bwt(s))
+
+
 def _long_repeat_bases(oracle, nb, seed):
     """random bases with planted long repeats of both kinds: families above 32 copies (their suffixes reach the list-based rounds: a 16-mer above 32 records) -- a 2-kb
     segment 40 times, a tandem array, a homopolymer run -- and two-copy repeats (finished by the record sort's direct comparisons) that the copies of a family run into."""
