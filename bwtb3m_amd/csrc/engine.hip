@@ -941,15 +941,17 @@ static int plan_run_impl(b3m_plan *p, const void *d_text_in, const void *h_text_
 		const Leaf &lf = p->leaves[k];
 		BlockSortOut so;
 		// (rank,pos) samples of a whole-text block (or its shards) are written by the sort itself, where each suffix is finally placed
-		// (SampleOut): no suffix array is kept for them.  Blocks of a merge tree keep theirs anyway (anchors), the LSD path always has one.
-		const bool smp_in_kernel = B == 1 && p->isarate != 0 && sample_in_kernel_ok(p->isarate, n);
+		// (SampleOut): no suffix array is kept for them.  Blocks of a merge tree keep theirs anyway (anchors), the LSD path always has one; since round 5 their record
+		// sort writes the samples too (leaf-local ranks, carried through the merges as before) instead of a pass over the leaf's suffix array afterwards
+		// (k_emit_samples: 3.9 ms per step of C3 in 8 blocks); a leaf that is sorted again with an overhang (long repeats) still takes that pass.
+		const bool smp_in_kernel = p->isarate != 0 && sample_in_kernel_ok(p->isarate, n);
 		const bool need_sa = B > 1 || p->keep_sa || p->sa_hint || (p->isarate != 0 && !smp_in_kernel);       // anchors / the tie export / samples the kernels cannot test for read the suffix array
 		SampleOut smp_cfg;
 		if (smp_in_kernel) smp_cfg = make_sample_out(p->d_samples + 2 * p->sample_off[k], p->isarate, (lf.a + p->isarate - 1) / p->isarate, p->sample_off[k + 1] - p->sample_off[k]);
 		const int nsh = p->seq_shards > 1 ? p->seq_shards : p->nshards;
 		uint64_t acc = 0;                                    // suffixes sorted by the earlier shards of this run = global rank of this shard's first
 		// slots of other shards stay "empty"; samples written by the sort itself: a slot nobody wrote is found by samples_of
-		if (p->isarate && (nsh > 1 || smp_in_kernel)) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
+		if (p->isarate && (nsh > 1 || smp_in_kernel) && k == 0) B3M_HIP(hipMemsetAsync(p->d_samples, 0xFF, 16 * (p->total_samples + 1), s));
 		const bool seq_host = host && p->seq_shards > 1;         // the slices leave for host memory one by one: two slice buffers in d_bwt[0]
 		std::vector<hipEvent_t> gone;                            // gone[sh]: slice sh has left its buffer
 		p->bs.no_defer = p->seq_shards > 1 || (p->nshards > 1 && p->tie_mode != B3M_TIES_SA);

@@ -1526,8 +1526,10 @@ void block_sort(const TextView &T, uint64_t start, uint64_t len, BlockSortWs &ws
 		uint64_t *hist_keep = ws.d_symhist_out; ws.d_symhist_out = nullptr;      // the histogram of the block was added by the first pass (MSD) or is the caller's business
 		const bool hist_done = out.symhist_done;
 		BlockSortOut o2;
+		const SampleOut *smp_keep = ws.samples; ws.samples = nullptr;            // (ranks inside the extended domain are not the block's: the caller samples the filtered suffix array)
 		if (msd) block_sort_msd(T, start, len + H, ws, s, tl, o2, reinterpret_cast<uint8_t *>(ws.t[1]), d_p0, 0, 1, true, len, false);
 		else block_sort_lsd(T, start, len + H, ws, s, tl, o2, len, false);
+		ws.samples = smp_keep;
 		ws.d_symhist_out = hist_keep;
 		Scope sc(tl, KF_EMIT, 14 * (len + H));
 		uint32_t *flag = ws.t[3], *sa_own = ws.t[2];

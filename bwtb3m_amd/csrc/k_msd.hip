@@ -3090,7 +3090,8 @@ void block_sort_msd(const TextView &T, uint64_t start, uint64_t len_in, BlockSor
 	SortOut O{sa, d_bwt, start, d_p0, M.overflow, ovf_cap, d_tiebits, pb, SampleOut()};
 	if (ws.samples) {
 		// (rank,pos) samples leave with the records: only sorts of the whole text (or of a suffix-range shard of it) know global ranks
-		B3M_REQUIRE(start == 0 && len_in == T.n && !allow_ext && own == 0, "internal: in-kernel samples need a whole-text block");
+		// (... or leaf-local ones: a block of a merge tree, sorted as it stands; not the second sort of a block with its overhang, whose ranks count the overhang's suffixes)
+		B3M_REQUIRE(own == 0, "internal: in-kernel samples need a block sorted as it stands");
 		B3M_REQUIRE(sample_in_kernel_ok(ws.samples->rate, T.n), "internal: sampling rate the kernels cannot test");
 		O.smp = *ws.samples; O.smp.rank_off = out.slice_offset;
 		out.samples_done = true;
