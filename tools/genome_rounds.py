@@ -1,5 +1,5 @@
 """The genome-like text of bench.py's `config.genome_like` leg (same size, same plan) with the per-round log of the list-based rounds (B3M_DEBUG=2: one line per
-round with its time and slots; =3 adds the census of group sizes).  python tools/genome_rounds.py [nbases] [debug level] [steps]"""
+round with its time and slots; =3 adds the census of group sizes).  python tools/genome_rounds.py [nbases] [debug level] [steps] [repeats: 0.15 | 0.5 = the harsher recipe]"""
 import os, sys, time
 dbg = sys.argv[2] if len(sys.argv) > 2 else "2"
 import torch
@@ -7,8 +7,9 @@ sys.path.insert(0, "/root/repo")
 from bwtb3m_amd import engine, synth, _lib
 nb = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+repeats = float(sys.argv[4]) if len(sys.argv) > 4 else 0.15
 n = nb + 1
-d_text = synth.genome_like_device(nb, 7, "cuda")
+d_text = synth.genome_like_device(nb, 7, "cuda", repeats=repeats)
 rate = int(_lib.lib().b3m_plan_sampling_rate(0, 0, n))
 plan = engine.Plan(n, "pacterm", isasamplingrate=rate)
 out = torch.empty(n, dtype=torch.uint8, device="cuda")
